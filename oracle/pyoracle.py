@@ -1,0 +1,170 @@
+"""ctypes binding of the CPU oracle (oracle/libvdl2oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libvdl2oracle.so")
+
+COUNTER_NAMES = [
+    "demod.sync.good", "decoder.crc.good", "decoder.crc.bad", "decoder.errors.no_header",
+    "decoder.errors.too_long", "decoder.errors.no_fec", "decoder.errors.data_truncated",
+    "decoder.errors.fec_truncated", "decoder.errors.deinterleave_data",
+    "decoder.errors.deinterleave_fec", "decoder.errors.fec_bad", "decoder.errors.bitstream",
+    "decoder.errors.truncated_octets", "decoder.errors.unstuff", "decoder.blocks.processed",
+    "decoder.blocks.fec_ok", "decoder.msg.good", "decoder.msg.good_loud",
+    "demod.ppm_reject", "demod.slicer_neg_idx",
+]
+NUM_COUNTERS = len(COUNTER_NAMES)
+FMT_U8, FMT_S16LE = 0, 1
+
+
+class Frame(C.Structure):
+    _fields_ = [
+        ("chan", C.c_int32), ("freq", C.c_uint32), ("idx", C.c_int32), ("len", C.c_uint32),
+        ("octets_off", C.c_uint64), ("synd_weight", C.c_uint32), ("datalen_octets", C.c_uint32),
+        ("num_fec_corrections", C.c_int32), ("frame_pwr_dbfs", C.c_float), ("nf_pwr_dbfs", C.c_float),
+        ("ppm_error", C.c_float), ("burst_ord", C.c_int64), ("sync_sample", C.c_int64),
+        ("end_sample", C.c_int64),
+    ]
+
+
+def build(force=False):
+    """Compile the oracle (and oracle/_ref when the reference tree is present)."""
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "vdl2_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.vdl2o_create.restype = C.c_void_p
+        L.vdl2o_create.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.c_int, C.c_uint32, C.c_int, C.c_float]
+        L.vdl2o_destroy.argtypes = [C.c_void_p]
+        L.vdl2o_process.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        L.vdl2o_num_frames.restype = C.c_size_t
+        L.vdl2o_num_frames.argtypes = [C.c_void_p]
+        L.vdl2o_frames.restype = C.POINTER(Frame)
+        L.vdl2o_frames.argtypes = [C.c_void_p]
+        L.vdl2o_octets.restype = C.POINTER(C.c_uint8)
+        L.vdl2o_octets.argtypes = [C.c_void_p]
+        L.vdl2o_clear_frames.argtypes = [C.c_void_p]
+        L.vdl2o_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+        L.vdl2o_get_lpf.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.vdl2o_get_dphi.restype = C.c_uint32
+        L.vdl2o_get_dphi.argtypes = [C.c_void_p, C.c_int]
+        L.vdl2o_get_sincos_lut.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.vdl2o_trace_decimated.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.vdl2o_trace_count.restype = C.c_size_t
+        L.vdl2o_trace_count.argtypes = [C.c_void_p]
+        L.vdl2o_rs_decode.restype = C.c_int
+        L.vdl2o_rs_decode.argtypes = [C.c_void_p, C.c_int]
+        L.vdl2o_rs_encode.argtypes = [C.c_void_p, C.c_void_p]
+        L.vdl2o_header_decode.restype = C.c_uint32
+        L.vdl2o_header_decode.argtypes = [C.POINTER(C.c_uint32)]
+        L.vdl2o_header_parity.restype = C.c_uint32
+        L.vdl2o_header_parity.argtypes = [C.c_uint32]
+        L.vdl2o_crc16.restype = C.c_uint16
+        L.vdl2o_crc16.argtypes = [C.c_void_p, C.c_uint32, C.c_uint16]
+        L.vdl2o_chebyshev.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+class Oracle:
+    """One reference-equivalent receiver: nchan channels fed with raw IQ blocks."""
+
+    def __init__(self, centerfreq, freqs, oversample=20, sample_fmt=FMT_S16LE, max_ppm=0.0):
+        self.L = lib()
+        self.freqs = list(freqs)
+        arr = (C.c_uint32 * len(freqs))(*freqs)
+        self.h = self.L.vdl2o_create(centerfreq, arr, len(freqs), oversample, sample_fmt, max_ppm)
+        self._trace = None
+
+    def close(self):
+        if self.h:
+            self.L.vdl2o_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def process(self, raw, block_bytes=320000, nthreads=1):
+        """Feed raw bytes in block_bytes pieces like process_iq_file() (dumpvdl2.c:353-356)."""
+        raw = np.ascontiguousarray(np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw.view(np.uint8).reshape(-1))
+        n = raw.size
+        base = raw.ctypes.data
+        off = 0
+        while off < n:
+            m = min(block_bytes, n - off)
+            self.L.vdl2o_process(self.h, base + off, m, nthreads)
+            off += m
+
+    def trace(self, chan, cap):
+        self._trace = np.zeros((cap, 2), dtype=np.float32)
+        self.L.vdl2o_trace_decimated(self.h, chan, self._trace.ctypes.data, cap)
+        return self._trace
+
+    def trace_count(self):
+        return self.L.vdl2o_trace_count(self.h)
+
+    def frames(self, clear=True):
+        n = self.L.vdl2o_num_frames(self.h)
+        fr = self.L.vdl2o_frames(self.h)
+        oc = self.L.vdl2o_octets(self.h)
+        out = []
+        for i in range(n):
+            f = fr[i]
+            out.append(dict(
+                chan=f.chan, freq=f.freq, idx=f.idx,
+                octets=bytes(C.string_at(C.addressof(oc.contents) + f.octets_off, f.len)) if f.len else b"",
+                synd_weight=f.synd_weight, datalen_octets=f.datalen_octets,
+                num_fec_corrections=f.num_fec_corrections, frame_pwr_dbfs=f.frame_pwr_dbfs,
+                nf_pwr_dbfs=f.nf_pwr_dbfs, ppm_error=f.ppm_error, burst_ord=f.burst_ord,
+                sync_sample=f.sync_sample, end_sample=f.end_sample))
+        if clear:
+            self.L.vdl2o_clear_frames(self.h)
+        return out
+
+    def counters(self, chan):
+        a = (C.c_uint64 * NUM_COUNTERS)()
+        self.L.vdl2o_counters(self.h, chan, a)
+        return dict(zip(COUNTER_NAMES, list(a)))
+
+    def lpf(self):
+        A = (C.c_float * 3)(); B = (C.c_float * 3)()
+        self.L.vdl2o_get_lpf(self.h, A, B)
+        return np.array(A, dtype=np.float32), np.array(B, dtype=np.float32)
+
+    def dphi(self, chan):
+        return self.L.vdl2o_get_dphi(self.h, chan)
+
+
+def crc16_x25(data, init=0xFFFF):
+    b = bytes(data)
+    return lib().vdl2o_crc16(b, len(b), init)
+
+
+def rs_encode(data249):
+    d = (C.c_uint8 * 249)(*data249)
+    p = (C.c_uint8 * 6)()
+    lib().vdl2o_rs_encode(d, p)
+    return bytes(p)
+
+
+def rs_decode(block255, fec_octets):
+    d = (C.c_uint8 * 255)(*block255)
+    r = lib().vdl2o_rs_decode(d, fec_octets)
+    return r, bytes(d)
