@@ -1,0 +1,832 @@
+// vdl2_core.h - the burst-level logic of the hot path, written once in a
+// "wave-phase" style so that the very same source is (a) the body of the HIP
+// kernels (one 64-lane wavefront per channel / per burst) and (b) compilable
+// with plain g++ for the CPU unit tests (tests/hostsim), where a phase is an
+// ordinary loop over 64 lanes.  There is no CPU product path: hostsim is a
+// test of this file, not something the library can fall back to.
+//
+// Style rules:
+//   * control flow between phases is wave-uniform (decided from shared scalars);
+//   * WAVE_FOR(l) ... WAVE_END runs its body once per lane; lanes talk through
+//     shared arrays (LDS) only;
+//   * LANE0 ... LANE0_END runs a sequential section on one lane and publishes
+//     its results through shared memory.
+//
+// Reference functions restated here (reference v2.6.0):
+//   got_sync()/calc_para_vertex()      src/demod.c:98-198
+//   demod() DM_INIT / DM_SYNC          src/demod.c:222-286
+//   decode_vdl2_burst()/decode_frame() src/decode.c:173-384
+//   decode_header()/get_fec_octetcount()/deinterleave()  src/decode.c:102-163
+//   bitstream_descramble()/bitstream_copy_next_frame()   src/bitstream.c:94-150
+//   rs_verify() + decode_rs_char()     src/rs.c:32-49, src/libfec/decode_rs.h:71-298
+#pragma once
+#include <cstdint>
+#include <cmath>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VDL2_DEVICE_PASS 1
+#else
+#define VDL2_DEVICE_PASS 0
+#endif
+
+#if defined(__HIPCC__)
+#define VDL2_HD __host__ __device__ inline
+#else
+#define VDL2_HD inline
+#endif
+
+#if VDL2_DEVICE_PASS
+#define VDL2_LANE() ((int)(threadIdx.x & 63))
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while(0)
+#define WAVE_FOR(l) { const int l = VDL2_LANE();
+#define WAVE_END } WAVE_SYNC();
+#define LANE0 if(VDL2_LANE() == 0) {
+#define LANE0_END } WAVE_SYNC();
+#else
+#define WAVE_SYNC() do {} while(0)
+#define WAVE_FOR(l) for(int l = 0; l < 64; l++) {
+#define WAVE_END }
+#define LANE0 {
+#define LANE0_END }
+#endif
+
+#if VDL2_DEVICE_PASS
+#define VDL2_CNT_ADD(arr, which, val) atomicAdd(&(arr)[which], (unsigned long long)(val))
+#else
+#define VDL2_CNT_ADD(arr, which, val) ((arr)[which] += (unsigned long long)(val))
+#endif
+
+namespace vdl2 {
+
+// ---- constants (dumpvdl2.h:37-50, demod.c:37-48, decode.c:45-50) ----
+constexpr int kRsK = 249, kRsN = 255, kRsPar = 6;
+constexpr int kHdrBits = 25, kTlBits = 17, kHdrParBits = 5;
+constexpr int kPreamble = 16, kSpsDec = 10, kSyncSkip = 3;
+constexpr float kPherrBig = 1000.f, kSyncThr = 4.f;
+constexpr uint32_t kMaxTl = 0x3FFFu, kMaxTlCorr = 0x1FFFu;
+constexpr uint32_t kLfsrIv = 0x6959u;
+constexpr int kMaxSyms = 5632;            // >= ceil((8*(2048+52)+25)/3) = 5609
+constexpr int kPrbsBits = kMaxSyms * 3;
+constexpr int kMaxOctets = 2112;          // 2048 data + 52 FEC, rounded up
+constexpr int kMaxBlocks = 9;
+constexpr int kFreshAfter = 156;          // evaluations at n >= a+156: n, n-3, n-6 touch only the current interval
+constexpr int kNumIv = 32;                // DM_INIT interval history (160/6 < 32 intervals can matter)
+constexpr int kNumRun = 32;               // evaluation-run history for the noise-floor lookback
+constexpr int kLpTerms = 256;             // 0.9^256 ~ 2e-12: below fp32 resolution of mag_lp
+constexpr int kNumCounters = 20;
+
+enum { CNT_SYNC_GOOD = 0, CNT_CRC_GOOD, CNT_CRC_BAD, CNT_ERR_NO_HEADER, CNT_ERR_TOO_LONG, CNT_ERR_NO_FEC,
+       CNT_ERR_DATA_TRUNCATED, CNT_ERR_FEC_TRUNCATED, CNT_ERR_DEINTERLEAVE_DATA, CNT_ERR_DEINTERLEAVE_FEC,
+       CNT_ERR_FEC_BAD, CNT_ERR_BITSTREAM, CNT_ERR_TRUNCATED_OCTETS, CNT_ERR_UNSTUFF, CNT_BLOCKS_PROCESSED,
+       CNT_BLOCKS_FEC_OK, CNT_MSG_GOOD, CNT_MSG_GOOD_LOUD, CNT_PPM_REJECT, CNT_SLICER_NEG_IDX };
+
+struct cf32 { float re, im; };
+
+// Read-only tables, built on the host once per context (tables.h) and kept in device memory.
+struct Tables {
+	float    pr_phase[kPreamble];      // demod.c:107-124
+	float    lrx[kPreamble];           // demod.c:84-96
+	float    lr_den;
+	float    pad_[3];
+	uint8_t  gray[8];                  // demod.c:223
+	uint32_t hdr_H[kHdrParBits];       // decode.c:55-61
+	uint32_t hdr_fix[32];              // decode.c:63-96
+	uint32_t hdr_weight[32];           // decode.c:98-100
+	uint8_t  gf_exp[512];              // alpha^i, doubled: exp[a+b] valid for a,b <= 254
+	uint8_t  gf_log[256];              // log(0) = 255 marker
+	uint8_t  prbs[kPrbsBits];          // bitstream.c:94-107 from LFSR_IV, one bit per byte
+};
+
+// One channel's decimated-rate streams, ring-addressed by absolute sample index.
+struct ChanView {
+	const cf32     *y;                 // filtered + decimated samples (lp_re, lp_im)
+	const float    *phi;               // atan2 of y (demod.c:232,256)
+	const cf32     *pf;                // {pherr[0], freq_err} of got_sync() evaluated at every n (contiguous ring)
+	const uint64_t *cand;              // bit n: pf[n-3].p < 4 && pf[n].p > pf[n-3].p
+	uint32_t        mask;              // capacity - 1 (capacity is a power of two)
+	VDL2_HD float Phi(int64_t n) const { return n < 0 ? 0.f : phi[(uint32_t)n & mask]; }
+	VDL2_HD cf32  Y(int64_t n) const { return y[(uint32_t)n & mask]; }
+	VDL2_HD cf32  PF(int64_t n) const { return pf[(uint32_t)n & mask]; }
+	VDL2_HD uint64_t Cand(int64_t word) const { return cand[(uint32_t)word & (mask >> 6)]; }
+};
+
+// A burst whose header decoded; consumed by decode_burst().
+struct Burst {
+	int32_t  chan, nsym;
+	int64_t  t_first;                  // sample of the first symbol after the unique word
+	int64_t  sync_sample, end_sample, ord;
+	float    prev_phi0, vdphi, ppm, mag_nf;
+	uint32_t tl_bits, syndrome;
+};
+
+struct OutFrame {
+	int32_t  chan, idx;
+	uint32_t len, pool_off;
+	uint32_t synd_weight, datalen_octets;
+	int32_t  num_fec_corrections;
+	float    frame_pwr_dbfs, nf_pwr_dbfs, ppm_error;
+	int64_t  burst_ord, sync_sample, end_sample;
+};
+
+struct OutCtl {
+	uint32_t nbursts, nframes, pool_used, overflow;
+	uint32_t cap_bursts, cap_frames, cap_pool, pad_;
+};
+
+// Persistent per-channel FSM state of the walker (what vdl2_channel_t carries between samples).
+struct WalkState {
+	int64_t a;                         // first sample of the current DM_INIT interval
+	int64_t e;                         // next got_sync() evaluation
+	int64_t e0;                        // first evaluation of the current grid run
+	int64_t bursts;                    // syncs accepted so far
+	float   pherr1, pherr2, prev_dphi; // v->pherr[1], v->pherr[2], v->prev_dphi
+	float   mag_nf;                    // v->mag_nf
+	int32_t nfcnt;                     // v->nfcnt
+	int32_t mode;                      // 0 search, 1 waiting for header symbols, 2 waiting for burst end
+	int32_t niv, nrun;
+	int64_t iva[kNumIv], ivb[kNumIv];  // earlier DM_INIT intervals, most recent first
+	int64_t runf[kNumRun], runl[kNumRun]; // closed evaluation runs (first, last), most recent first
+	Burst   pb;                        // burst in progress
+};
+
+VDL2_HD void walk_state_init(WalkState &s) {
+	s.a = 0; s.e = 2; s.e0 = 2; s.bursts = 0;
+	s.pherr1 = s.pherr2 = kPherrBig; s.prev_dphi = 0.f;
+	s.mag_nf = 2.0f; s.nfcnt = 0; s.mode = 0; s.niv = 0; s.nrun = 0;
+}
+
+// ======================================================================
+// element-wise pieces
+// ======================================================================
+VDL2_HD float phase_of(cf32 y) { return (float)atan2((double)y.im, (double)y.re); }   // demod.c:232,256
+
+// hypotf() as glibc evaluates it (double intermediate), demod.c:238
+VDL2_HD float mag_of(cf32 y) { return (float)sqrt((double)y.re * (double)y.re + (double)y.im * (double)y.im); }
+
+// got_sync() up to the threshold test: demod.c:129-171.  ph[i] = phase 150-10i samples ago.
+VDL2_HD void sync_metric(const float *ph, const Tables &T, float &pherr, float &slope_out) {
+	float e[kPreamble];
+	float mean = 0.f, unwrap = 0.f;
+	float prev = mean = e[0] = ph[0] - T.pr_phase[0];
+	for(int i = 1; i < kPreamble; i++) {
+		float cur = ph[i] - T.pr_phase[i];
+		float diff = cur - prev;
+		prev = cur;
+		if((double)diff > M_PI) unwrap = (float)((double)unwrap - 2.0f * M_PI);
+		else if((double)diff < -M_PI) unwrap = (float)((double)unwrap + 2.0f * M_PI);
+		e[i] = cur + unwrap;
+		mean += e[i];
+	}
+	mean /= kPreamble;
+	for(int i = 0; i < kPreamble; i++) e[i] -= mean;
+	float slope = 0.f;
+	for(int i = 0; i < kPreamble; i++) slope += T.lrx[i] * e[i];
+	slope /= T.lr_den;
+	float acc = 0.f;
+	for(int i = 0; i < kPreamble; i++) {
+		float r = e[i] - slope * T.lrx[i];
+		acc += r * r;
+	}
+	pherr = acc; slope_out = slope;
+}
+
+// calc_para_vertex(v->sclk = 0, SYNC_SKIP, y1, y2, y3): demod.c:98-103,178
+VDL2_HD float parabola_vertex(float y1, float y2, float y3) {
+	const float x = 0.f; const int d = kSyncSkip;
+	float denom = (float)(d * 2 * d * (-d));
+	float a = (x * (y2 - y1) + (x - d) * (y1 - y3) + (x - 2 * d) * (y3 - y2)) / denom;
+	float b = (x * x * (y1 - y2) + (x - d) * (x - d) * (y3 - y1) + (x - 2 * d) * (x - 2 * d) * (y2 - y3)) / denom;
+	return -b / (2 * a);
+}
+
+// One D8PSK decision: demod.c:256-264.  Returns the phase-step index 0..7.
+VDL2_HD int slice_symbol(float phi, float prev_phi, float vdphi, int &neg) {
+	float dphi = phi - prev_phi - vdphi;
+	if(dphi < 0) dphi = (float)((double)dphi + 2.0f * M_PI);
+	else if((double)dphi > 2.0f * M_PI) dphi = (float)((double)dphi - 2.0f * M_PI);
+	dphi = (float)((double)dphi / M_PI_4);
+	int idx = (int)roundf(dphi) % 8;
+	if(idx < 0) { neg++; idx &= 7; }   // the reference indexes graycode[] out of bounds here
+	return idx;
+}
+
+// got_sync() metric at decimated sample n assuming the phase ring holds the 160 most recent
+// samples contiguously (taps n-150, n-140, ..., n): what the sync kernel tabulates for every n.
+VDL2_HD cf32 metric_contiguous(const float *phi, uint32_t mask, int64_t n, const Tables &T) {
+	float ph[kPreamble];
+	for(int i = 0; i < kPreamble; i++) {
+		int64_t t = n - 150 + 10 * i;
+		ph[i] = t < 0 ? 0.f : phi[(uint32_t)t & mask];
+	}
+	cf32 r;
+	sync_metric(ph, T, r.re, r.im);
+	return r;
+}
+
+// candidate flag: the only places where got_sync() can succeed on a contiguous ring (demod.c:173)
+VDL2_HD bool is_candidate(float p_prev, float p_now) { return p_prev < kSyncThr && p_now > p_prev; }
+
+VDL2_HD int fec_octets_for(uint32_t len) { return len < 3 ? 0 : len < 31 ? 2 : len < 68 ? 4 : 6; }  // decode.c:124-133
+
+VDL2_HD uint32_t parity32(uint32_t v) { v ^= v >> 16; v ^= v >> 8; v ^= v >> 4; v ^= v >> 2; v ^= v >> 1; return v & 1; }
+
+struct Geometry { uint32_t tl_bits, octets, nblocks, last_len, fec_octets, want_bits, syndrome; int status; };
+enum { HDR_OK = 0, HDR_CRC_BAD = 1, HDR_TOO_LONG = 2, HDR_NO_FEC = 3 };
+
+// Header word (25 bits, MSB first) -> burst geometry: decode.c:209-258
+VDL2_HD Geometry header_to_geometry(uint32_t hdr, const Tables &T) {
+	Geometry g{};
+	const uint32_t keep = (1u << (kTlBits + kHdrParBits)) - 1;
+	hdr &= keep;
+	uint32_t s = 0;
+	for(int i = 0; i < kHdrParBits; i++) s |= parity32(hdr & T.hdr_H[i]) << (kHdrParBits - 1 - i);
+	hdr ^= T.hdr_fix[s];
+	g.syndrome = s;
+	if((hdr & keep) != hdr) { g.status = HDR_CRC_BAD; return g; }
+	hdr >>= kHdrParBits;
+	uint32_t tl = 0;
+	for(int i = 0; i < kTlBits; i++) if(hdr & (1u << i)) tl |= 1u << (kTlBits - 1 - i);
+	g.tl_bits = tl;
+	if((s != 0 && tl > kMaxTlCorr) || tl > kMaxTl) { g.status = HDR_TOO_LONG; return g; }
+	g.octets = tl / 8 + (tl % 8 != 0);
+	g.nblocks = g.octets / kRsK;
+	g.fec_octets = g.nblocks * kRsPar;
+	g.last_len = g.octets % kRsK;
+	if(g.last_len != 0) g.nblocks++;
+	g.fec_octets += (uint32_t)fec_octets_for(g.last_len);
+	if(g.last_len == 0) g.last_len = kRsK;
+	if(g.fec_octets == 0) { g.status = HDR_NO_FEC; return g; }
+	g.want_bits = 8 * (g.octets + g.fec_octets);
+	g.status = HDR_OK;
+	return g;
+}
+
+// ======================================================================
+// Walker: the per-channel sequential FSM of demod()/got_sync(), hopping
+// between the sparse places where something can happen.
+// ======================================================================
+struct WalkShared {
+	WalkState st;
+	float p[64], f[64], lp[64];
+	int32_t found[64];
+	int32_t sym[16];
+	int32_t neg[16];
+	// scalars published by LANE0 sections
+	int32_t u_fire, u_count, u_stop;
+	int64_t u_n;
+	float u_y1, u_y2, u_y3, u_prevd;
+};
+
+// absolute index of the DM_INIT sample d steps before n (n inside the current interval); -1 = before the stream
+VDL2_HD int64_t seq_index(const WalkState &st, int64_t n, int d) {
+	if((int64_t)d <= n - st.a) return n - d;
+	int64_t r = d - (n - st.a) - 1;
+	for(int i = 0; i < st.niv; i++) {
+		int64_t len = st.ivb[i] - st.iva[i] + 1;
+		if(r < len) return st.ivb[i] - r;
+		r -= len;
+	}
+	return -1;
+}
+
+VDL2_HD void push_interval(WalkState &st, int64_t a, int64_t b) {
+	int n = st.niv < kNumIv ? st.niv : kNumIv - 1;
+	for(int i = n; i > 0; i--) { st.iva[i] = st.iva[i - 1]; st.ivb[i] = st.ivb[i - 1]; }
+	st.iva[0] = a; st.ivb[0] = b;
+	if(st.niv < kNumIv) st.niv++;
+}
+
+VDL2_HD void push_run(WalkState &st, int64_t first, int64_t last) {
+	if(last < first) return;
+	int n = st.nrun < kNumRun ? st.nrun : kNumRun - 1;
+	for(int i = n; i > 0; i--) { st.runf[i] = st.runf[i - 1]; st.runl[i] = st.runl[i - 1]; }
+	st.runf[0] = first; st.runl[0] = last;
+	if(st.nrun < kNumRun) st.nrun++;
+}
+
+// v->mag_lp right after the evaluation at m (m on the current run): the reference's
+// recurrence mag_lp = mag_lp*0.9 + mag*0.1 (demod.c:239) replayed over the last
+// kLpTerms evaluations, oldest first.
+VDL2_HD float mag_lp_at(const WalkState &st, const ChanView &v, int64_t m) {
+	int64_t ncur = (m - st.e0) / 3 + 1;
+	int run = -1;            // -1 = current run
+	int64_t pos = st.e0;     // start position (oldest evaluation to replay)
+	int64_t have = ncur;
+	if(ncur >= kLpTerms) {
+		pos = m - 3 * (int64_t)(kLpTerms - 1);
+	} else {
+		for(int i = 0; i < st.nrun && have < kLpTerms; i++) {
+			int64_t len = (st.runl[i] - st.runf[i]) / 3 + 1;
+			run = i;
+			if(have + len >= kLpTerms) { pos = st.runl[i] - 3 * (kLpTerms - have - 1); have = kLpTerms; }
+			else { pos = st.runf[i]; have += len; }
+		}
+	}
+	float lp = 0.f;
+	for(;;) {
+		float mag = mag_of(v.Y(pos));
+		lp = lp * 0.9f + mag * (1.0f - 0.9f);
+		if(run < 0) { if(pos >= m) break; pos += 3; }
+		else if(pos >= st.runl[run]) { run--; pos = (run < 0) ? st.e0 : st.runf[run]; }
+		else pos += 3;
+	}
+	return lp;
+}
+
+// `count` evaluations starting at `first` (step 3) are being executed: account nfcnt and
+// the mag_nf updates that fall among them (demod.c:238-243).
+VDL2_HD void account_evals(WalkShared &sh, const ChanView &v, int64_t first, int64_t count) {
+	if(count <= 0) return;
+	const int32_t nf0 = sh.st.nfcnt;
+	const int64_t total = (int64_t)nf0 + count;
+	const int64_t nupd = total / 1000;
+	for(int64_t base = 0; base < nupd; base += 64) {
+		WAVE_FOR(l)
+			int64_t u = base + l;
+			if(u < nupd) {
+				int64_t i = 1000 * (u + 1) - nf0 - 1;
+				sh.lp[l] = mag_lp_at(sh.st, v, first + 3 * i);
+			}
+		WAVE_END
+		LANE0
+			float nf = sh.st.mag_nf;
+			for(int l = 0; l < 64 && base + l < nupd; l++)
+				nf = 0.85f * nf + (1.0f - 0.85f) * fminf(sh.lp[l], nf) + 0.0001f;
+			sh.st.mag_nf = nf;
+		LANE0_END
+	}
+	LANE0
+		sh.st.nfcnt = (int32_t)(total % 1000);
+	LANE0_END
+}
+
+// demod_reset() after a burst or a rejected header: a new DM_INIT interval starts at sample `a`
+VDL2_HD void restart_search(WalkState &st, int64_t a) {
+	st.a = a; st.e = st.e0 = a + 2;
+	st.pherr1 = st.pherr2 = kPherrBig;
+	st.mode = 0;
+}
+
+// Process one channel up to (not including) decimated sample k_end.
+VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end, const Tables &T,
+		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, OutCtl *ctl, WalkShared &sh) {
+	LANE0
+		sh.st = *gstate;
+	LANE0_END
+	for(;;) {
+		if(sh.st.mode == 0) {
+			const int64_t e = sh.st.e;
+			if(e >= k_end) break;
+			int fired = 0;
+			if(e < sh.st.a + kFreshAfter) {
+				// ---- explicit evaluations near an interval start (ring still holds pre-burst samples) ----
+				int64_t lim = sh.st.a + kFreshAfter; if(lim > k_end) lim = k_end;
+				int64_t nb = (lim - e + 2) / 3; if(nb > 64) nb = 64;
+				WAVE_FOR(l)
+					if(l < nb) {
+						int64_t n = e + 3 * l;
+						float ph[kPreamble];
+						for(int i = 0; i < kPreamble; i++) ph[i] = v.Phi(seq_index(sh.st, n, 150 - 10 * i));
+						sync_metric(ph, T, sh.p[l], sh.f[l]);
+					}
+				WAVE_END
+				LANE0
+					float p1 = sh.st.pherr1, p2 = sh.st.pherr2, pd = sh.st.prev_dphi;
+					int j = 0; sh.u_fire = 0;
+					for(; j < nb; j++) {
+						float p0 = sh.p[j];
+						if(p1 < kSyncThr && p0 > p1) { sh.u_fire = 1; sh.u_y1 = p2; sh.u_y2 = p1; sh.u_y3 = p0; sh.u_prevd = pd; break; }
+						p2 = p1; p1 = p0; pd = sh.f[j];
+					}
+					sh.u_count = sh.u_fire ? j + 1 : (int32_t)nb;
+					sh.u_n = e + 3 * (int64_t)j;
+					if(!sh.u_fire) { sh.st.pherr1 = p1; sh.st.pherr2 = p2; sh.st.prev_dphi = pd; sh.st.e = e + 3 * nb; }
+				LANE0_END
+				account_evals(sh, v, e, sh.u_count);
+				fired = sh.u_fire;
+			} else {
+				// ---- hop over the candidate bitmap (got_sync() can only fire where a bit is set) ----
+				// the first evaluation of a run cannot fire (pherr[1] is still PHERR_MAX): start at max(e, e0+3)
+				const int64_t start = e > sh.st.e0 + 3 ? e : sh.st.e0 + 3;
+				int64_t w0 = start >> 6;
+				const int64_t wend = (k_end + 63) >> 6;
+				sh.u_fire = 0;
+				for(; w0 < wend && !sh.u_fire; w0 += 64) {
+					WAVE_FOR(l)
+						int64_t w = w0 + l;
+						int32_t hit = -1;
+						if(w < wend) {
+							uint64_t bits = v.Cand(w);
+							// keep bits with index >= start, < k_end, and congruent to e modulo 3
+							int64_t base = w << 6;
+							int r = (int)(((e - base) % 3 + 3) % 3);   // first bit position on the grid
+							uint64_t grid = 0x9249249249249249ull << r;    // bits r, r+3, ...
+							bits &= grid;
+							if(base < start) bits &= (start - base >= 64) ? 0ull : (~0ull << (start - base));
+							if(base + 64 > k_end) bits &= (k_end - base <= 0) ? 0ull : (~0ull >> (64 - (k_end - base)));
+							if(bits) { int b = 0; while(!((bits >> b) & 1)) b++; hit = b; }
+						}
+						sh.found[l] = hit;
+					WAVE_END
+					LANE0
+						for(int l = 0; l < 64; l++) if(sh.found[l] >= 0) { sh.u_fire = 1; sh.u_n = ((w0 + l) << 6) + sh.found[l]; break; }
+					LANE0_END
+				}
+				if(sh.u_fire) {
+					const int64_t n = sh.u_n;
+					LANE0
+						sh.u_y1 = (n - 6 >= sh.st.e0) ? v.PF(n - 6).re : kPherrBig;
+						sh.u_y2 = v.PF(n - 3).re;
+						sh.u_y3 = v.PF(n).re;
+						sh.u_prevd = v.PF(n - 3).im;
+						sh.u_count = (int32_t)((n - e) / 3 + 1);
+					LANE0_END
+					account_evals(sh, v, e, sh.u_count);
+					fired = 1;
+				} else {
+					// nothing up to k_end: park just past the last evaluation that exists
+					const int64_t cnt_ev = (k_end - 1 - e) / 3 + 1;     // e < k_end here
+					const int64_t nl = e + 3 * (cnt_ev - 1);
+					account_evals(sh, v, e, cnt_ev);
+					LANE0
+						sh.st.pherr1 = v.PF(nl).re;
+						sh.st.pherr2 = (nl - 3 >= sh.st.e0) ? v.PF(nl - 3).re : kPherrBig;
+						sh.st.prev_dphi = v.PF(nl).im;
+						sh.st.e = nl + 3;
+					LANE0_END
+				}
+			}
+			if(fired) {
+				// ---- got_sync() success branch: demod.c:173-193 ----
+				LANE0
+					WalkState &st = sh.st;
+					const int64_t n = sh.u_n;
+					float vx = parabola_vertex(sh.u_y1, sh.u_y2, sh.u_y3);
+					int sclk = (int)(-roundf(vx));
+					float prev_phi0 = v.Phi(seq_index(st, n, sclk));
+					float vdphi = sh.u_prevd;
+					float ppm = (float)((double)(10500 * vdphi) / (2.0f * M_PI * (double)freq) * 1e+6);
+					st.pherr1 = st.pherr2 = kPherrBig;
+					push_run(st, st.e0, n);
+					if(max_ppm != 0.f && fabsf(ppm) > max_ppm) {
+						VDL2_CNT_ADD(cnt, CNT_PPM_REJECT, 1);
+						int64_t step = 3 - sclk; if(step < 1) step = 1;   // v->sclk keeps the vertex value: demod.c:179,233
+						st.e = st.e0 = n + step;
+					} else {
+						VDL2_CNT_ADD(cnt, CNT_SYNC_GOOD, 1);
+						push_interval(st, st.a, n);
+						st.pb.chan = chan; st.pb.nsym = 0;
+						st.pb.t_first = n + (kSpsDec - sclk);
+						st.pb.sync_sample = n; st.pb.end_sample = 0; st.pb.ord = st.bursts++;
+						st.pb.prev_phi0 = prev_phi0; st.pb.vdphi = vdphi; st.pb.ppm = ppm; st.pb.mag_nf = st.mag_nf;
+						st.pb.tl_bits = 0; st.pb.syndrome = 0;
+						st.mode = 1;
+					}
+				LANE0_END
+			}
+		} else if(sh.st.mode == 1) {
+			// ---- header: 9 symbols = 27 bits, of which 25 are the header (decode.c:198-258) ----
+			const int64_t t8 = sh.st.pb.t_first + 8 * kSpsDec;
+			if(t8 >= k_end) break;
+			WAVE_FOR(l)
+				if(l < 9) {
+					int64_t t = sh.st.pb.t_first + (int64_t)l * kSpsDec;
+					float prev = l ? v.Phi(t - kSpsDec) : sh.st.pb.prev_phi0;
+					int neg = 0;
+					sh.sym[l] = T.gray[slice_symbol(v.Phi(t), prev, sh.st.pb.vdphi, neg)];
+					sh.neg[l] = neg;
+				}
+			WAVE_END
+			LANE0
+				WalkState &st = sh.st;
+				uint32_t hdr = 0;
+				for(int b = 0; b < kHdrBits; b++) {
+					uint32_t bit = ((uint32_t)sh.sym[b / 3] >> (2 - b % 3)) & 1u;
+					bit ^= T.prbs[b];
+					hdr |= bit << (kHdrBits - 1 - b);
+				}
+				Geometry g = header_to_geometry(hdr, T);
+				if(g.syndrome == 0) VDL2_CNT_ADD(cnt, CNT_CRC_GOOD, 1);
+				if(g.status != HDR_OK) {
+					int negs = 0; for(int i = 0; i < 9; i++) negs += sh.neg[i];
+					VDL2_CNT_ADD(cnt, CNT_SLICER_NEG_IDX, negs);
+					VDL2_CNT_ADD(cnt, g.status == HDR_CRC_BAD ? CNT_CRC_BAD : g.status == HDR_TOO_LONG ? CNT_ERR_TOO_LONG : CNT_ERR_NO_FEC, 1);
+					restart_search(st, t8 + 1);
+				} else {
+					st.pb.tl_bits = g.tl_bits; st.pb.syndrome = g.syndrome;
+					st.pb.nsym = (int32_t)((g.want_bits + kHdrBits + 2) / 3);
+					st.pb.end_sample = st.pb.t_first + (int64_t)(st.pb.nsym - 1) * kSpsDec;
+					st.mode = 2;
+				}
+			LANE0_END
+		} else {
+			// ---- burst body: wait until its last symbol has arrived, then hand it to the burst decoder ----
+			if(sh.st.pb.end_sample >= k_end) break;
+			LANE0
+				WalkState &st = sh.st;
+#if VDL2_DEVICE_PASS
+				uint32_t slot = atomicAdd(&ctl->nbursts, 1u);
+#else
+				uint32_t slot = ctl->nbursts++;
+#endif
+				if(slot < ctl->cap_bursts) bursts[slot] = st.pb; else ctl->overflow = 1;
+				restart_search(st, st.pb.end_sample + 1);
+			LANE0_END
+		}
+	}
+	LANE0
+		*gstate = sh.st;
+	LANE0_END
+}
+
+// ======================================================================
+// Burst decoder: one wavefront per burst
+// ======================================================================
+struct BurstShared {
+	uint8_t sym[kMaxSyms];             // 3-bit Gray values, one per symbol
+	uint8_t oct[kMaxOctets];           // received data + FEC octets (still interleaved)
+	uint8_t tab[kMaxBlocks * 256];     // de-interleaved RS blocks, row stride 256
+	uint8_t fo[kMaxOctets];            // un-stuffed frame under construction
+	uint8_t synp[kRsPar][64];          // per-lane syndrome partials
+	float   pw[64];
+	int32_t neg[64];
+	int32_t u_ret, u_more, u_flen, u_ok;
+	uint32_t u_pos, u_slot, u_off;
+	float u_pwr;
+};
+
+// decode_rs_char() on one 255-symbol row: libfec/decode_rs.h:71-298.  syn[] = the 6 syndromes in
+// polynomial form.  Sequential (one lane).  Returns corrected-symbol count or -1.
+VDL2_HD int rs_correct(uint8_t *d, const uint8_t syn_poly[kRsPar], int n_era, const int *era_pos, const Tables &T) {
+	const int NN = 255, A0 = 255, FCR = 120;
+	uint8_t lam[kRsPar + 1], syn[kRsPar], b[kRsPar + 1], t[kRsPar + 1], om[kRsPar + 1];
+	uint8_t root[kRsPar], reg[kRsPar + 1], loc[kRsPar];
+	auto EXP = [&](int i) -> uint8_t { return T.gf_exp[i]; };          // i <= 509
+	auto MOD = [](int x) -> int { while(x >= 255) x -= 255; return x; };
+	int any = 0;
+	for(int i = 0; i < kRsPar; i++) { any |= syn_poly[i]; syn[i] = T.gf_log[syn_poly[i]]; }
+	if(!any) return 0;
+	for(int i = 0; i <= kRsPar; i++) lam[i] = 0;
+	lam[0] = 1;
+	if(n_era > 0) {
+		lam[1] = EXP(MOD(NN - 1 - era_pos[0]));
+		for(int i = 1; i < n_era; i++) {
+			int u = MOD(NN - 1 - era_pos[i]);
+			for(int j = i + 1; j > 0; j--) {
+				uint8_t lg = T.gf_log[lam[j - 1]];
+				if(lg != A0) lam[j] ^= EXP(u + lg);
+			}
+		}
+	}
+	for(int i = 0; i <= kRsPar; i++) b[i] = T.gf_log[lam[i]];
+	int r = n_era, el = n_era;
+	while(++r <= kRsPar) {
+		uint8_t disc = 0;
+		for(int i = 0; i < r; i++)
+			if(lam[i] != 0 && syn[r - i - 1] != A0) disc ^= EXP(T.gf_log[lam[i]] + syn[r - i - 1]);
+		disc = T.gf_log[disc];
+		if(disc == A0) {
+			for(int i = kRsPar; i > 0; i--) b[i] = b[i - 1];
+			b[0] = A0;
+		} else {
+			t[0] = lam[0];
+			for(int i = 0; i < kRsPar; i++)
+				t[i + 1] = (b[i] != A0) ? (uint8_t)(lam[i + 1] ^ EXP(disc + b[i])) : lam[i + 1];
+			if(2 * el <= r + n_era - 1) {
+				el = r + n_era - el;
+				for(int i = 0; i <= kRsPar; i++)
+					b[i] = (lam[i] == 0) ? A0 : (uint8_t)MOD(T.gf_log[lam[i]] - disc + NN);
+			} else {
+				for(int i = kRsPar; i > 0; i--) b[i] = b[i - 1];
+				b[0] = A0;
+			}
+			for(int i = 0; i <= kRsPar; i++) lam[i] = t[i];
+		}
+	}
+	int deg_lam = 0;
+	for(int i = 0; i <= kRsPar; i++) { lam[i] = T.gf_log[lam[i]]; if(lam[i] != A0) deg_lam = i; }
+	for(int i = 1; i <= kRsPar; i++) reg[i] = lam[i];
+	int count = 0;
+	for(int i = 1, k = 0; i <= NN; i++, k = MOD(k + 1)) {
+		uint8_t q = 1;
+		for(int j = deg_lam; j > 0; j--)
+			if(reg[j] != A0) { reg[j] = (uint8_t)MOD(reg[j] + j); q ^= EXP(reg[j]); }
+		if(q != 0) continue;
+		root[count] = (uint8_t)i; loc[count] = (uint8_t)k;
+		if(++count == deg_lam) break;
+	}
+	if(deg_lam != count) return -1;
+	int deg_om = deg_lam - 1;
+	for(int i = 0; i <= deg_om; i++) {
+		uint8_t acc = 0;
+		for(int j = i; j >= 0; j--)
+			if(syn[i - j] != A0 && lam[j] != A0) acc ^= EXP(syn[i - j] + lam[j]);
+		om[i] = T.gf_log[acc];
+	}
+	for(int j = count - 1; j >= 0; j--) {
+		uint8_t num1 = 0, den = 0;
+		for(int i = deg_om; i >= 0; i--)
+			if(om[i] != A0) num1 ^= EXP(MOD(om[i] + i * root[j]));
+		uint8_t num2 = EXP(MOD(root[j] * (FCR - 1) + NN));
+		int top = (deg_lam < kRsPar - 1 ? deg_lam : kRsPar - 1) & ~1;
+		for(int i = top; i >= 0; i -= 2)
+			if(lam[i + 1] != A0) den ^= EXP(MOD(lam[i + 1] + i * root[j]));
+		if(num1 != 0)
+			d[loc[j]] ^= EXP(MOD(T.gf_log[num1] + T.gf_log[num2] + NN - T.gf_log[den]));
+	}
+	return count;
+}
+
+// bitstream_copy_next_frame() (bitstream.c:109-150) reading the re-serialised RS rows directly and
+// packing the un-stuffed bits into octets.  Sequential.  Returns 1 more / 0 last / -1 invalid;
+// *flen_bits = length of the extracted frame in bits.
+VDL2_HD int next_hdlc_frame(const uint8_t *tab, uint32_t *pos, uint32_t end, uint8_t *fo, uint32_t *flen_bits) {
+	auto BIT = [&](uint32_t i) -> uint32_t {
+		uint32_t o = i >> 3, r = o / kRsK, c = o - r * kRsK;
+		return (tab[r * 256 + c] >> (i & 7)) & 1u;
+	};
+	for(;;) {
+		int ones = 0, again = 0;
+		uint32_t j = 0, dlen = 0;
+		for(uint32_t i = *pos; i < end; i++, (*pos)++) {
+			uint32_t b = BIT(i);
+			if(b == 0 && ones == 5) { ones = 0; continue; }
+			if(b == 1 && ++ones > 6) return -1;
+			if((j & 7) == 0) fo[j >> 3] = 0;
+			fo[j >> 3] |= (uint8_t)(b << (j & 7));
+			if(b == 0) {
+				if(ones == 6) {
+					if(j == 7) { (*pos)++; again = 1; break; }
+					if(j < 7) return -1;
+					(*pos)++;
+					*flen_bits = j - 7;
+					return *pos < end ? 1 : 0;
+				}
+				ones = 0;
+			}
+			j++; dlen++;
+		}
+		if(again) continue;
+		*flen_bits = dlen;
+		return *pos < end ? 1 : 0;
+	}
+}
+
+// decode_vdl2_burst() DEC_DATA branch + decode_frame(): decode.c:259-380, 173-194
+VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const ChanView &v, unsigned long long *cnt,
+		OutFrame *frames, uint8_t *pool, OutCtl *ctl, BurstShared &sh) {
+	// geometry again from TL (decode.c:233-256)
+	const uint32_t octets = b.tl_bits / 8 + (b.tl_bits % 8 != 0);
+	uint32_t nblk = octets / kRsK, last = octets % kRsK;
+	uint32_t fec = nblk * kRsPar;
+	if(last != 0) nblk++;
+	fec += (uint32_t)fec_octets_for(last);
+	if(last == 0) last = kRsK;
+	const int npar_last = fec_octets_for(last);
+	const int nsym = b.nsym;
+
+	// 1. slice every symbol (demod.c:252-274); decisions are independent because prev_phi is the raw phase
+	WAVE_FOR(l)
+		float pw = 0.f; int neg = 0;
+		for(int m = l; m < nsym; m += 64) {
+			int64_t t = b.t_first + (int64_t)m * kSpsDec;
+			float prev = m ? v.Phi(t - kSpsDec) : b.prev_phi0;
+			sh.sym[m] = T.gray[slice_symbol(v.Phi(t), prev, b.vdphi, neg)];
+			cf32 y = v.Y(t);
+			pw += y.re * y.re + y.im * y.im;
+		}
+		sh.pw[l] = pw; sh.neg[l] = neg;
+	WAVE_END
+	LANE0
+		// frame_pwr: the reference keeps a running mean updated per symbol (demod.c:266-268); the mean
+		// of the same terms is formed here from 64 partial sums (differs only in rounding).
+		double s = 0.0; int negs = 0;
+		for(int l = 0; l < 64; l++) { s += (double)sh.pw[l]; negs += sh.neg[l]; }
+		sh.u_pwr = (float)(s / (double)nsym);
+		if(negs) VDL2_CNT_ADD(cnt, CNT_SLICER_NEG_IDX, negs);
+	LANE0_END
+
+	// 2. descramble + pack data and FEC octets LSB-first (bitstream.c:70-81,94-107)
+	const uint32_t ntot = octets + fec;
+	WAVE_FOR(l)
+		for(uint32_t i = l; i < ntot; i += 64) {
+			uint32_t o = 0, bit0 = kHdrBits + 8 * i;
+			for(int j = 0; j < 8; j++) {
+				uint32_t bb = bit0 + j;
+				uint32_t bit = ((uint32_t)sh.sym[bb / 3] >> (2 - bb % 3)) & 1u;
+				o |= (bit ^ T.prbs[bb]) << j;
+			}
+			sh.oct[i] = (uint8_t)o;
+		}
+		for(uint32_t i = l; i < nblk * 256; i += 64) sh.tab[i] = 0;
+	WAVE_END
+
+	// 3. de-interleave (closed form of decode.c:135-163): column-major, the last row is shorter
+	uint32_t fec_rows = nblk; if(npar_last == 0) fec_rows--;
+	uint32_t flast = fec % kRsPar; if(flast == 0) flast = kRsPar;
+	WAVE_FOR(l)
+		for(uint32_t i = l; i < octets; i += 64) {
+			uint32_t row, col;
+			if(i < last * nblk) { col = i / nblk; row = i - col * nblk; }
+			else { uint32_t r = i - last * nblk; col = last + r / (nblk - 1); row = r % (nblk - 1); }
+			sh.tab[row * 256 + col] = sh.oct[i];
+		}
+		for(uint32_t i = l; i < fec; i += 64) {
+			uint32_t row, col;
+			if(i < flast * fec_rows) { col = i / fec_rows; row = i - col * fec_rows; }
+			else { uint32_t r = i - flast * fec_rows; col = flast + r / (fec_rows - 1); row = r % (fec_rows - 1); }
+			sh.tab[row * 256 + kRsK + col] = sh.oct[octets + i];
+		}
+	WAVE_END
+
+	// 4. Reed-Solomon per block (decode.c:305-334, rs.c:32-49)
+	int fec_fixed = 0; int failed = 0;
+	for(uint32_t r = 0; r < nblk && !failed; r++) {
+		const int npar = (r == nblk - 1) ? npar_last : kRsPar;
+		uint8_t *row = &sh.tab[r * 256];
+		if(npar != 0) {
+			// syndromes S_i = sum_j d[j] * alpha^((120+i)*(254-j)), same values as the Horner loop of decode_rs.h:82-93
+			WAVE_FOR(l)
+				uint8_t acc[kRsPar] = {0, 0, 0, 0, 0, 0};
+				for(int j = l; j < kRsN; j += 64) {
+					uint8_t d = row[j];
+					if(d) {
+						int lg = T.gf_log[d], pw = 254 - j;
+						for(int i = 0; i < kRsPar; i++) acc[i] ^= T.gf_exp[lg + ((120 + i) * pw) % 255];
+					}
+				}
+				for(int i = 0; i < kRsPar; i++) sh.synp[i][l] = acc[i];
+			WAVE_END
+		}
+		LANE0
+			VDL2_CNT_ADD(cnt, CNT_BLOCKS_PROCESSED, 1);
+			int ret = 0;
+			if(npar != 0) {
+				uint8_t syn[kRsPar];
+				for(int i = 0; i < kRsPar; i++) { uint8_t a = 0; for(int l = 0; l < 64; l++) a ^= sh.synp[i][l]; syn[i] = a; }
+				int n_era = kRsPar - npar, era[kRsPar];
+				for(int i = 0; i < n_era; i++) era[i] = kRsK + npar + i;
+				ret = rs_correct(row, syn, n_era, era, T);
+			}
+			if(ret < 0) VDL2_CNT_ADD(cnt, CNT_ERR_FEC_BAD, 1);
+			else VDL2_CNT_ADD(cnt, CNT_BLOCKS_FEC_OK, 1);
+			sh.u_ret = ret;
+		LANE0_END
+		if(sh.u_ret < 0) failed = 1;
+		else if(sh.u_ret > 0) fec_fixed += sh.u_ret - (kRsPar - npar);
+	}
+	if(failed) return;
+
+	// 5. truncate to TL bits, un-stuff, emit frames (decode.c:338-373)
+	uint32_t nbits = 8 * octets; if(b.tl_bits < nbits) nbits = b.tl_bits;
+	LANE0
+		sh.u_pos = 0;
+	LANE0_END
+	int nframes = 0;
+	for(;;) {
+		LANE0
+			uint32_t pos = sh.u_pos, flen = 0;
+			int ret = next_hdlc_frame(sh.tab, &pos, nbits, sh.fo, &flen);
+			sh.u_pos = pos; sh.u_more = ret; sh.u_flen = (int32_t)flen; sh.u_ok = 0;
+			if(ret < 0) VDL2_CNT_ADD(cnt, CNT_ERR_UNSTUFF, 1);
+			else if(flen % 8 != 0) VDL2_CNT_ADD(cnt, CNT_ERR_TRUNCATED_OCTETS, 1);
+			else {
+				VDL2_CNT_ADD(cnt, CNT_MSG_GOOD, 1);
+				uint32_t len = flen / 8;
+#if VDL2_DEVICE_PASS
+				uint32_t slot = atomicAdd(&ctl->nframes, 1u);
+				uint32_t off = atomicAdd(&ctl->pool_used, (len + 3u) & ~3u);
+#else
+				uint32_t slot = ctl->nframes++;
+				uint32_t off = ctl->pool_used; ctl->pool_used += (len + 3u) & ~3u;
+#endif
+				if(slot < ctl->cap_frames && off + len <= ctl->cap_pool) {
+					OutFrame &f = frames[slot];
+					f.chan = b.chan; f.idx = nframes; f.len = len; f.pool_off = off;
+					f.synd_weight = T.hdr_weight[b.syndrome]; f.datalen_octets = octets;
+					f.num_fec_corrections = fec_fixed;
+					f.frame_pwr_dbfs = 10.0f * log10f(sh.u_pwr);
+					f.nf_pwr_dbfs = 20.0f * log10f(b.mag_nf + 0.001f);
+					f.ppm_error = b.ppm;
+					f.burst_ord = b.ord; f.sync_sample = b.sync_sample; f.end_sample = b.end_sample;
+					sh.u_ok = 1; sh.u_slot = slot; sh.u_off = off;
+				} else ctl->overflow = 1;
+			}
+		LANE0_END
+		if(sh.u_more < 0 || sh.u_flen % 8 != 0) return;
+		if(sh.u_ok) {
+			const uint32_t len = (uint32_t)sh.u_flen / 8, off = sh.u_off;
+			WAVE_FOR(l)
+				for(uint32_t i = l; i < len; i += 64) pool[off + i] = sh.fo[i];
+			WAVE_END
+		}
+		nframes++;
+		if(sh.u_more == 0) break;
+	}
+	LANE0
+		if(sh.u_pwr > 1.0f) VDL2_CNT_ADD(cnt, CNT_MSG_GOOD_LOUD, 1);
+	LANE0_END
+	(void)freq;
+}
+
+}  // namespace vdl2

@@ -1,0 +1,150 @@
+/*
+ * vdl2hip.h - C ABI of libvdl2hip.so: the MI355X-native replacement for
+ * dumpvdl2's per-channel DSP + burst decoder hot path.
+ *
+ * Boundary it replaces (reference @ v2.6.0, paths relative to the reference root):
+ *   input  : process_buf_uchar()/process_buf_short()          src/demod.c:339-365, src/dumpvdl2.h:378-380
+ *   setup  : vdl2_channel_init(), input_lpf_init(),
+ *            sincosf_lut_init(), demod_sync_init(), rs_init()   src/demod.c:367-392, src/demod.c:84-96, src/rs.c:27-30
+ *   work   : process_samples() -> demod() -> got_sync()
+ *            -> decode_vdl2_burst() -> decode_frame()            src/demod.c:105-337, src/decode.c:173-384
+ *   output : avlc_decoder_queue_push(metadata, frame, flags)     src/decode.c:165-171, src/decode.h:31
+ *
+ * Plain C: opaque context, plain pointers and sizes, int return codes
+ * (0 = ok, negative = VDL2HIP_E_*).  No HIP or torch types appear here.
+ * The adapter that re-exports the reference's own symbol names on top of
+ * this ABI is include/vdl2hip_dropin.h.
+ */
+#ifndef VDL2HIP_H
+#define VDL2HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDL2HIP_ABI_VERSION 1
+
+/* enum sample_formats, src/dumpvdl2.h:319 */
+#define VDL2HIP_FMT_U8     0
+#define VDL2HIP_FMT_S16LE  1
+
+#define VDL2HIP_OK            0
+#define VDL2HIP_E_INVAL      -1   /* bad argument / configuration */
+#define VDL2HIP_E_NOMEM      -2
+#define VDL2HIP_E_DEVICE     -3   /* HIP runtime error (no GPU, launch failure ...) */
+#define VDL2HIP_E_TOOBIG     -4   /* block larger than max_block_bytes */
+#define VDL2HIP_E_OVERFLOW   -5   /* device-side frame/burst buffer exhausted (frames were dropped) */
+
+/* Per-channel counters = the reference's per-channel statsd counters on this
+ * path (src/statsd.c:34-65; call sites src/demod.c:245, src/decode.c:204-373),
+ * plus two that have no statsd name. */
+enum {
+	VDL2HIP_CNT_SYNC_GOOD = 0,          /* demod.sync.good */
+	VDL2HIP_CNT_CRC_GOOD,               /* decoder.crc.good */
+	VDL2HIP_CNT_CRC_BAD,                /* decoder.crc.bad */
+	VDL2HIP_CNT_ERR_NO_HEADER,          /* decoder.errors.no_header */
+	VDL2HIP_CNT_ERR_TOO_LONG,           /* decoder.errors.too_long */
+	VDL2HIP_CNT_ERR_NO_FEC,             /* decoder.errors.no_fec */
+	VDL2HIP_CNT_ERR_DATA_TRUNCATED,     /* decoder.errors.data_truncated */
+	VDL2HIP_CNT_ERR_FEC_TRUNCATED,      /* decoder.errors.fec_truncated */
+	VDL2HIP_CNT_ERR_DEINTERLEAVE_DATA,  /* decoder.errors.deinterleave_data */
+	VDL2HIP_CNT_ERR_DEINTERLEAVE_FEC,   /* decoder.errors.deinterleave_fec */
+	VDL2HIP_CNT_ERR_FEC_BAD,            /* decoder.errors.fec_bad */
+	VDL2HIP_CNT_ERR_BITSTREAM,          /* decoder.errors.bitstream */
+	VDL2HIP_CNT_ERR_TRUNCATED_OCTETS,   /* decoder.errors.truncated_octets */
+	VDL2HIP_CNT_ERR_UNSTUFF,            /* decoder.errors.unstuff */
+	VDL2HIP_CNT_BLOCKS_PROCESSED,       /* decoder.blocks.processed */
+	VDL2HIP_CNT_BLOCKS_FEC_OK,          /* decoder.blocks.fec_ok */
+	VDL2HIP_CNT_MSG_GOOD,               /* decoder.msg.good */
+	VDL2HIP_CNT_MSG_GOOD_LOUD,          /* decoder.msg.good_loud */
+	VDL2HIP_CNT_PPM_REJECT,             /* preambles dropped by max_ppm (src/demod.c:192) */
+	VDL2HIP_CNT_SLICER_NEG_IDX,         /* slicer index < 0: the reference reads out of bounds there (src/demod.c:264) */
+	VDL2HIP_NUM_COUNTERS
+};
+
+typedef struct vdl2hip_ctx vdl2hip_ctx;
+
+typedef struct {
+	uint32_t struct_size;       /* sizeof(vdl2hip_cfg), for ABI evolution */
+	uint32_t centerfreq;        /* Hz; vdl2_channel_init() arg 1 */
+	uint32_t oversample;        /* sample rate = 105000 * oversample (src/dumpvdl2.c:1073) */
+	uint32_t sample_fmt;        /* VDL2HIP_FMT_* */
+	uint32_t nchan;
+	const uint32_t *freqs;      /* nchan channel frequencies, Hz */
+	float    max_ppm;           /* Config.max_ppm; 0 disables (src/demod.c:192) */
+	int32_t  device;            /* HIP device ordinal */
+	uint32_t max_block_bytes;   /* largest block a feed call may carry; 0 = 320000 (FILE_BUFSIZE) */
+	uint32_t chan_first;        /* multi-GPU sharding: this context decodes channels            */
+	uint32_t chan_count;        /*   [chan_first, chan_first+chan_count) of freqs[]; 0 = all     */
+} vdl2hip_cfg;
+
+/* One AVLC frame plus the vdl2_msg_metadata the reference attaches to it
+ * (src/output-common.h:31-43).  `octets` is only valid during the callback. */
+typedef struct {
+	uint32_t chan;              /* index into cfg.freqs */
+	uint32_t freq;              /* metadata->freq */
+	int32_t  idx;               /* metadata->idx: frame number within the burst */
+	uint32_t len;               /* frame length in octets (may be 0, as in the reference) */
+	const uint8_t *octets;
+	uint32_t synd_weight;
+	uint32_t datalen_octets;
+	int32_t  num_fec_corrections;
+	float    frame_pwr_dbfs;
+	float    nf_pwr_dbfs;
+	float    ppm_error;
+	int64_t  burst_ord;         /* ordinal of the burst on its channel (0,1,...) */
+	int64_t  sync_sample;       /* decimated-sample index (105 kS/s clock) at which the preamble locked */
+	int64_t  end_sample;        /* decimated-sample index at which the burst was complete */
+} vdl2hip_frame;
+
+typedef void (*vdl2hip_frame_cb)(const vdl2hip_frame *frame, void *user);
+
+typedef struct {
+	uint64_t feeds;             /* feed calls so far */
+	uint64_t input_samples;     /* complex input samples consumed */
+	uint64_t chan_samples;      /* channel-samples processed by the channeliser kernel */
+	uint64_t chanfir_launches;  /* launches of the channeliser kernel */
+	double   chanfir_ms;        /* summed HIP-event time of those launches (needs profiling on) */
+	double   phase_ms, sync_ms, walk_ms, burst_ms;   /* other kernels, same convention */
+	uint64_t bursts;            /* bursts handed to the burst decoder */
+	uint64_t frames;            /* frames produced */
+} vdl2hip_stats;
+
+int  vdl2hip_abi_version(void);
+const char *vdl2hip_strerror(int err);
+
+/* = vdl2_channel_init() x nchan + input_lpf_init() + sincosf_lut_init() + demod_sync_init() + rs_init() */
+int  vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out);
+void vdl2hip_destroy(vdl2hip_ctx *ctx);
+
+/* = process_buf_uchar()/process_buf_short(): one block of raw IQ from host memory.
+ * Returns after the block has been queued on the device (the copy out of `buf` is complete). */
+int  vdl2hip_feed(vdl2hip_ctx *ctx, const void *buf, size_t nbytes);
+/* Same, for a block that already lives in this device's memory (e.g. the
+ * destination of an RCCL broadcast).  The block must stay valid until the next
+ * vdl2hip_sync()/vdl2hip_drain(). */
+int  vdl2hip_feed_device(vdl2hip_ctx *ctx, const void *dev_buf, size_t nbytes);
+
+/* Wait for all queued blocks; moves finished frames to the host-side queue. */
+int  vdl2hip_sync(vdl2hip_ctx *ctx);
+/* sync + deliver every queued frame, ordered by (end_sample, chan, idx); returns the number delivered (>= 0). */
+int  vdl2hip_drain(vdl2hip_ctx *ctx, vdl2hip_frame_cb cb, void *user);
+
+int  vdl2hip_counters(vdl2hip_ctx *ctx, uint32_t chan, uint64_t out[VDL2HIP_NUM_COUNTERS]);
+int  vdl2hip_set_profiling(vdl2hip_ctx *ctx, int on);   /* bracket kernels with HIP events on the ctx stream */
+int  vdl2hip_get_stats(vdl2hip_ctx *ctx, vdl2hip_stats *out);
+void *vdl2hip_stream(vdl2hip_ctx *ctx);                 /* the hipStream_t all work is queued on */
+
+/* Introspection used by the parity tests (host copies of what the kernels use) */
+int  vdl2hip_get_lpf(vdl2hip_ctx *ctx, float A[3], float B[3]);      /* = static A/B of src/demod.c:55 */
+int  vdl2hip_get_nco_step(vdl2hip_ctx *ctx, uint32_t chan, uint32_t *dphi); /* = v->downmix_dphi */
+/* Copy up to `cap` decimated (re,im) pairs of one channel starting at decimated index `first`
+ * (must still be inside the device history window); returns the count copied. */
+int  vdl2hip_read_decimated(vdl2hip_ctx *ctx, uint32_t chan, int64_t first, float *dst, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

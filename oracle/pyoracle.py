@@ -69,6 +69,9 @@ def lib():
         L.vdl2o_trace_decimated.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.vdl2o_trace_count.restype = C.c_size_t
         L.vdl2o_trace_count.argtypes = [C.c_void_p]
+        L.vdl2o_trace_all.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.vdl2o_decimated_count.restype = C.c_int64
+        L.vdl2o_decimated_count.argtypes = [C.c_void_p, C.c_int]
         L.vdl2o_rs_decode.restype = C.c_int
         L.vdl2o_rs_decode.argtypes = [C.c_void_p, C.c_int]
         L.vdl2o_rs_encode.argtypes = [C.c_void_p, C.c_void_p]
@@ -116,6 +119,15 @@ class Oracle:
         self._trace = np.zeros((cap, 2), dtype=np.float32)
         self.L.vdl2o_trace_decimated(self.h, chan, self._trace.ctypes.data, cap)
         return self._trace
+
+    def trace_all(self, cap):
+        """Record (lp_re, lp_im) of every channel: returns array [nchan, cap, 2]."""
+        self._trace_all = np.zeros((len(self.freqs), cap, 2), dtype=np.float32)
+        self.L.vdl2o_trace_all(self.h, self._trace_all.ctypes.data, cap)
+        return self._trace_all
+
+    def decimated_count(self, chan=0):
+        return self.L.vdl2o_decimated_count(self.h, chan)
 
     def trace_count(self):
         return self.L.vdl2o_trace_count(self.h)

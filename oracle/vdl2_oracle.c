@@ -105,6 +105,7 @@ struct vdl2o_ctx {
 	vdl2o_frame *fr; size_t nfr, capfr;
 	uint8_t *oct; size_t noct, capoct;
 	int trace_chan; float *trace; size_t trace_cap, trace_n;
+	float *trace_all; size_t trace_all_cap;   /* [nchan][cap] complex, every channel */
 };
 
 /* ======================================================================
@@ -768,6 +769,10 @@ static void chan_scan_block(vdl2o_ctx *c, int k) {
 		if(++v->decim_cnt == (int)v->oversample) {
 			v->decim_cnt = 0;
 			v->dsample++;
+			if(c->trace_all && (size_t)v->dsample < c->trace_all_cap) {
+				float *t = c->trace_all + 2 * ((size_t)k * c->trace_all_cap + (size_t)v->dsample);
+				t[0] = v->yr[0]; t[1] = v->yi[0];
+			}
 			if(tracing && c->trace_n < c->trace_cap) {
 				c->trace[2 * c->trace_n] = v->yr[0]; c->trace[2 * c->trace_n + 1] = v->yi[0]; c->trace_n++;
 			}
@@ -829,3 +834,5 @@ uint32_t vdl2o_get_dphi(const vdl2o_ctx *c, int chan) { return c->ch[chan].nco_d
 void vdl2o_get_sincos_lut(const vdl2o_ctx *c, float s[257], float co[257]) { memcpy(s, c->sin_t, sizeof c->sin_t); memcpy(co, c->cos_t, sizeof c->cos_t); }
 void vdl2o_trace_decimated(vdl2o_ctx *c, int chan, float *dst, size_t cap) { c->trace_chan = chan; c->trace = dst; c->trace_cap = cap; c->trace_n = 0; }
 size_t vdl2o_trace_count(const vdl2o_ctx *c) { return c->trace_n; }
+void vdl2o_trace_all(vdl2o_ctx *c, float *dst, size_t cap_per_chan) { c->trace_all = dst; c->trace_all_cap = cap_per_chan; }
+int64_t vdl2o_decimated_count(const vdl2o_ctx *c, int chan) { return c->ch[chan].dsample + 1; }

@@ -91,6 +91,9 @@ void vdl2o_get_sincos_lut(const vdl2o_ctx *c, float s[257], float co[257]);
  * channel; cap = number of complex samples the buffer can hold. */
 void vdl2o_trace_decimated(vdl2o_ctx *c, int chan, float *dst, size_t cap);
 size_t vdl2o_trace_count(const vdl2o_ctx *c);
+/* trace every channel: dst[chan][cap_per_chan] complex (re,im) */
+void vdl2o_trace_all(vdl2o_ctx *c, float *dst, size_t cap_per_chan);
+int64_t vdl2o_decimated_count(const vdl2o_ctx *c, int chan);
 
 /* Stand-alone pieces, exported for known-answer tests */
 int  vdl2o_rs_decode(uint8_t block[255], int fec_octets);          /* rs.c:32-49 */

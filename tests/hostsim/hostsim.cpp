@@ -1,0 +1,103 @@
+// hostsim.cpp - TEST INFRASTRUCTURE.  Compiles dumpvdl2_amd/csrc/vdl2_core.h (the
+// source of the walker and burst-decoder kernels) with plain g++ and runs it on the
+// CPU, one "wavefront" = a 64-iteration loop, so the burst-level device logic can be
+// unit-tested without a GPU.  Input is the decimated stream of each channel (e.g. the
+// oracle's trace); output is the frame list.  Never linked into libvdl2hip.so.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../dumpvdl2_amd/csrc/vdl2_core.h"
+#include "../../dumpvdl2_amd/csrc/tables.h"
+
+using namespace vdl2;
+
+struct Sim {
+	int nchan; uint32_t cap, mask; float max_ppm;
+	std::vector<uint32_t> freqs;
+	std::vector<cf32> y, pf; std::vector<float> phi; std::vector<uint64_t> cand;
+	std::vector<WalkState> st; std::vector<unsigned long long> cnt;
+	Tables T;
+	int64_t k_total = 0;
+	std::vector<Burst> bursts; std::vector<OutFrame> frames; std::vector<uint8_t> pool;
+	std::vector<OutFrame> all_frames; std::vector<uint8_t> all_pool;
+	OutCtl ctl;
+};
+
+extern "C" {
+
+Sim *hostsim_create(int nchan, const uint32_t *freqs, float max_ppm, int cap_log2) {
+	Sim *s = new Sim();
+	s->nchan = nchan; s->cap = 1u << cap_log2; s->mask = s->cap - 1; s->max_ppm = max_ppm;
+	s->freqs.assign(freqs, freqs + nchan);
+	s->y.assign((size_t)nchan * s->cap, cf32{0, 0}); s->pf.assign((size_t)nchan * s->cap, cf32{0, 0});
+	s->phi.assign((size_t)nchan * s->cap, 0.f); s->cand.assign((size_t)nchan * (s->cap / 64), 0);
+	s->st.resize(nchan); s->cnt.assign((size_t)nchan * kNumCounters, 0);
+	for(auto &w : s->st) { memset(&w, 0, sizeof w); walk_state_init(w); }
+	build_tables(s->T);
+	s->bursts.resize(65536); s->frames.resize(65536); s->pool.resize(1 << 24);
+	return s;
+}
+
+void hostsim_destroy(Sim *s) { delete s; }
+
+// y: [nchan][D] complex (re,im) floats, channel-major
+int hostsim_feed(Sim *s, const float *yin, int64_t D) {
+	const int64_t k0 = s->k_total, k1 = k0 + D;
+	for(int c = 0; c < s->nchan; c++) {
+		cf32 *y = &s->y[(size_t)c * s->cap]; float *phi = &s->phi[(size_t)c * s->cap];
+		cf32 *pf = &s->pf[(size_t)c * s->cap]; uint64_t *cand = &s->cand[(size_t)c * (s->cap / 64)];
+		for(int64_t k = k0; k < k1; k++) {
+			cf32 v{ yin[((size_t)c * D + (k - k0)) * 2], yin[((size_t)c * D + (k - k0)) * 2 + 1] };
+			y[(uint32_t)k & s->mask] = v;
+			phi[(uint32_t)k & s->mask] = phase_of(v);
+		}
+		// sync kernel: whole 64-aligned words covering [k0, k1)
+		for(int64_t n = k0 & ~63ll; n < ((k1 + 63) & ~63ll); n++) {
+			cf32 r = (n < k1) ? metric_contiguous(phi, s->mask, n, s->T) : cf32{kPherrBig, 0.f};
+			pf[(uint32_t)n & s->mask] = r;
+		}
+		for(int64_t w = k0 >> 6; w < ((k1 + 63) >> 6); w++) {
+			uint64_t bits = 0;
+			for(int b = 0; b < 64; b++) {
+				int64_t n = (w << 6) + b;
+				if(n >= k1 || n < 3) continue;
+				if(is_candidate(pf[(uint32_t)(n - 3) & s->mask].re, pf[(uint32_t)n & s->mask].re)) bits |= 1ull << b;
+			}
+			cand[(uint32_t)w & (s->mask >> 6)] = bits;
+		}
+	}
+	s->k_total = k1;
+	memset(&s->ctl, 0, sizeof s->ctl);
+	s->ctl.cap_bursts = (uint32_t)s->bursts.size(); s->ctl.cap_frames = (uint32_t)s->frames.size(); s->ctl.cap_pool = (uint32_t)s->pool.size();
+	static WalkShared wsh;
+	for(int c = 0; c < s->nchan; c++) {
+		ChanView v{ &s->y[(size_t)c * s->cap], &s->phi[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
+		walk_channel(c, s->freqs[c], s->max_ppm, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], s->bursts.data(), &s->ctl, wsh);
+	}
+	static BurstShared bsh;
+	uint32_t nb = s->ctl.nbursts < s->ctl.cap_bursts ? s->ctl.nbursts : s->ctl.cap_bursts;
+	for(uint32_t i = 0; i < nb; i++) {
+		const Burst &b = s->bursts[i];
+		int c = b.chan;
+		ChanView v{ &s->y[(size_t)c * s->cap], &s->phi[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
+		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl, bsh);
+	}
+	uint32_t nf = s->ctl.nframes < s->ctl.cap_frames ? s->ctl.nframes : s->ctl.cap_frames;
+	for(uint32_t i = 0; i < nf; i++) {
+		OutFrame f = s->frames[i];
+		uint32_t off = (uint32_t)s->all_pool.size();
+		s->all_pool.insert(s->all_pool.end(), s->pool.begin() + f.pool_off, s->pool.begin() + f.pool_off + f.len);
+		f.pool_off = off;
+		s->all_frames.push_back(f);
+	}
+	return s->ctl.overflow ? -1 : (int)nf;
+}
+
+int64_t hostsim_num_frames(Sim *s) { return (int64_t)s->all_frames.size(); }
+const OutFrame *hostsim_frames(Sim *s) { return s->all_frames.data(); }
+const uint8_t *hostsim_pool(Sim *s) { return s->all_pool.data(); }
+void hostsim_counters(Sim *s, int chan, unsigned long long *out) { memcpy(out, &s->cnt[(size_t)chan * kNumCounters], sizeof(unsigned long long) * kNumCounters); }
+int hostsim_sizeof_outframe() { return (int)sizeof(OutFrame); }
+
+}

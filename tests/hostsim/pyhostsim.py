@@ -1,0 +1,76 @@
+"""ctypes driver of tests/hostsim/libhostsim.so (CPU build of the walker / burst-decoder kernels' source)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_LIB = os.path.join(_HERE, "libhostsim.so")
+NUM_COUNTERS = 20
+
+
+class OutFrame(C.Structure):
+    _fields_ = [("chan", C.c_int32), ("idx", C.c_int32), ("len", C.c_uint32), ("pool_off", C.c_uint32),
+                ("synd_weight", C.c_uint32), ("datalen_octets", C.c_uint32), ("num_fec_corrections", C.c_int32),
+                ("frame_pwr_dbfs", C.c_float), ("nf_pwr_dbfs", C.c_float), ("ppm_error", C.c_float),
+                ("burst_ord", C.c_int64), ("sync_sample", C.c_int64), ("end_sample", C.c_int64)]
+
+
+def build():
+    srcs = [os.path.join(_HERE, "hostsim.cpp")] + [os.path.join(_ROOT, "dumpvdl2_amd", "csrc", f) for f in ("vdl2_core.h", "tables.h")]
+    if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+                               "-o", _LIB, srcs[0]])
+    return _LIB
+
+
+class HostSim:
+    def __init__(self, freqs, max_ppm=0.0, cap_log2=21):
+        self.L = C.CDLL(build())
+        self.L.hostsim_create.restype = C.c_void_p
+        self.L.hostsim_create.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_float, C.c_int]
+        self.L.hostsim_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        self.L.hostsim_num_frames.restype = C.c_int64
+        self.L.hostsim_num_frames.argtypes = [C.c_void_p]
+        self.L.hostsim_frames.restype = C.POINTER(OutFrame)
+        self.L.hostsim_frames.argtypes = [C.c_void_p]
+        self.L.hostsim_pool.restype = C.POINTER(C.c_uint8)
+        self.L.hostsim_pool.argtypes = [C.c_void_p]
+        self.L.hostsim_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
+        self.L.hostsim_destroy.argtypes = [C.c_void_p]
+        assert self.L.hostsim_sizeof_outframe() == C.sizeof(OutFrame)
+        self.n = len(freqs)
+        self.h = self.L.hostsim_create(self.n, (C.c_uint32 * self.n)(*freqs), max_ppm, cap_log2)
+
+    def feed(self, y):
+        """y: float32 [nchan, D, 2]"""
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        assert y.shape[0] == self.n and y.shape[2] == 2
+        r = self.L.hostsim_feed(self.h, y.ctypes.data, y.shape[1])
+        assert r >= 0, "hostsim output overflow"
+
+    def frames(self):
+        n = self.L.hostsim_num_frames(self.h)
+        fr = self.L.hostsim_frames(self.h)
+        pool = self.L.hostsim_pool(self.h)
+        base = C.addressof(pool.contents) if n else 0
+        out = []
+        for i in range(n):
+            f = fr[i]
+            out.append(dict(chan=f.chan, idx=f.idx, octets=bytes(C.string_at(base + f.pool_off, f.len)) if f.len else b"",
+                            synd_weight=f.synd_weight, datalen_octets=f.datalen_octets,
+                            num_fec_corrections=f.num_fec_corrections, frame_pwr_dbfs=f.frame_pwr_dbfs,
+                            nf_pwr_dbfs=f.nf_pwr_dbfs, ppm_error=f.ppm_error, burst_ord=f.burst_ord,
+                            sync_sample=f.sync_sample, end_sample=f.end_sample))
+        return out
+
+    def counters(self, chan):
+        a = (C.c_ulonglong * NUM_COUNTERS)()
+        self.L.hostsim_counters(self.h, chan, a)
+        return list(a)
+
+    def close(self):
+        if self.h:
+            self.L.hostsim_destroy(self.h)
+            self.h = None
