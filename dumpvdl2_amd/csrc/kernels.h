@@ -1,0 +1,317 @@
+// kernels.h - the HIP kernels of the hot path (gfx950 / CDNA4, wave64).
+//
+//   k_chanfir   K1  NCO mix + 2-pole Chebyshev low-pass + decimate  (src/demod.c:58-79,200-203,302-329)
+//   k_phase     K2  carry fix-up, atan2                              (src/demod.c:232,256)
+//   k_carry         saves the < oversample input samples left over for the next block
+//   k_sync      K3  got_sync() metric for every decimated sample + candidate bitmap (src/demod.c:105-171)
+//   k_walk      K4  per-channel FSM walker (vdl2_core.h)
+//   k_burst     K5  wave-per-burst decoder (vdl2_core.h)
+//
+// K1 is the only kernel that touches every input sample; everything after it runs at
+// 1/oversample of that rate.  See DESIGN.md for the block-form derivation and the roofline.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vdl2_core.h"
+#include "design.h"
+
+namespace vdl2 {
+
+// the slice of BlockForm K1 needs, passed by value so that it lives in the kernarg segment
+// (constant address space -> scalar loads into SGPRs)
+struct K1Consts {
+	float g0[kMaxOversample], g1[kMaxOversample];
+	float P[4], c0, c1, c2, pad_;
+	float Q[6][4];
+	float Pp[kRunMax + 1][4];      // P^i, i <= run
+};
+
+inline K1Consts make_k1_consts(const BlockForm &bf) {
+	K1Consts k{};
+	for(int i = 0; i < kMaxOversample; i++) { k.g0[i] = bf.g0[i]; k.g1[i] = bf.g1[i]; }
+	for(int i = 0; i < 4; i++) k.P[i] = bf.P[i];
+	k.c0 = bf.c0; k.c1 = bf.c1; k.c2 = bf.c2;
+	for(int d = 0; d < 6; d++) for(int i = 0; i < 4; i++) k.Q[d][i] = bf.Q[d][i];
+	for(int r = 0; r <= kRunMax; r++) for(int i = 0; i < 4; i++) k.Pp[r][i] = bf.Ppow[r][i];
+	return k;
+}
+
+struct K1Args {
+	const void *in;            // raw IQ block of this feed (cs16 or cu8), device memory
+	const void *carry;         // raw samples left over from the previous feed
+	uint32_t ncarry;           // number of complex samples in carry
+	uint64_t nlogical;         // ncarry + samples in `in`
+	uint64_t n0;               // absolute index (since stream start) of logical sample 0
+	int64_t  k0;               // absolute index of the first decimated output of this feed
+	int64_t  D;                // decimated outputs produced by this feed
+	int32_t  fmt, nchan, os, nseg, gy;
+	const uint32_t *dphi;      // NCO step per channel (24-bit phase)
+	const Lut4 *lut;
+	K1Consts bf;
+	cf32 *y;                   // [nchan][cap]
+	float4 *seg_end;           // [nchan][nseg_cap] zero-start state at the end of each 64*R-block segment
+	float4 *run_start;         // [nchan][nrun_cap] segment-local state at the start of each lane's R-block run
+	uint32_t cap, mask, nseg_cap, nrun_cap;
+};
+
+__device__ __forceinline__ void load_sample(const K1Args &a, int64_t s, float &re, float &im) {
+	if(a.fmt == 1) {   // S16_LE: (float)v / 32768.0f  (demod.c:362-363)
+		const uint32_t *p = (s < (int64_t)a.ncarry) ? (const uint32_t *)a.carry + s : (const uint32_t *)a.in + (s - a.ncarry);
+		uint32_t w = *p;
+		re = (float)(int16_t)(w & 0xffff) / 32768.0f;
+		im = (float)(int16_t)(w >> 16) / 32768.0f;
+	} else {           // U8: (i - 127.5f) / 127.5f     (demod.c:349-354)
+		const uint16_t *p = (s < (int64_t)a.ncarry) ? (const uint16_t *)a.carry + s : (const uint16_t *)a.in + (s - a.ncarry);
+		uint16_t w = *p;
+		re = ((float)(w & 0xff) - 127.5f) / 127.5f;
+		im = ((float)(w >> 8) - 127.5f) / 127.5f;
+	}
+}
+
+// One workgroup = 4 waves sharing one time tile (64*R blocks of OS samples) staged in LDS;
+// each wave owns CR channels; each lane owns R consecutive decimated outputs.
+// OS == 0 selects the generic (run-time oversample) build of the same code.
+template<int OS, int R, int CR>
+__global__ __launch_bounds__(256, 3) void k_chanfir(K1Args a) {
+	extern __shared__ __align__(16) unsigned char smem[];
+	const int os = OS ? OS : a.os;
+	const int run = R * os;                       // input samples per lane
+	float4 *lut = (float4 *)smem;                 // 256 entries
+	float2 *tile = (float2 *)(smem + 4096);       // [run][65]
+	const int tid = threadIdx.x;
+
+	// XCD-aware decode of the 1-D block id: workgroups that share a time tile land on one XCD (same L2)
+	const int bid = blockIdx.x;
+	const int xcd = bid & 7, q = bid >> 3;
+	const int gy = q % a.gy;
+	const int seg = (q / a.gy) * 8 + xcd;
+	if(seg >= a.nseg) return;
+
+	lut[tid] = ((const float4 *)a.lut)[tid];
+	const int tile_n = 64 * run;
+	const int64_t sbase = (int64_t)seg * tile_n;
+	for(int t = tid; t < tile_n; t += 256) {
+		int64_t s = sbase + t;
+		float re = 0.f, im = 0.f;
+		if(s < (int64_t)a.nlogical) load_sample(a, s, re, im);
+		int l = t / run, m = t - l * run;
+		tile[m * 65 + l] = make_float2(re, im);
+	}
+	__syncthreads();
+
+	const int wave = tid >> 6, lane = tid & 63;
+	const int cbase = (gy * 4 + wave) * CR;
+	if(cbase >= a.nchan) return;
+	const K1Consts &bf = a.bf;
+
+	uint32_t ph[CR], dph[CR];
+	const uint32_t nabs = (uint32_t)((a.n0 + (uint64_t)sbase + (uint64_t)lane * run) & 0xffffffu);
+	#pragma unroll
+	for(int c = 0; c < CR; c++) {
+		int ch = cbase + c < a.nchan ? cbase + c : a.nchan - 1;
+		dph[c] = a.dphi[ch];
+		ph[c] = nabs * dph[c];
+	}
+	// last valid block of this segment (segment-local index) and who owns it
+	const int64_t rem = a.D - (int64_t)seg * (64 * R);
+	const int blast = rem >= 64 * R ? 64 * R - 1 : (int)rem - 1;
+	const int lb = blast / R, ib = blast - lb * R;
+
+	float t0r[CR], t0i[CR], t1r[CR], t1i[CR];     // running (zero-start) state of this lane's run
+	float sv[CR][4];                              // state after block `ib` (only lane lb's copy is used)
+	#pragma unroll
+	for(int c = 0; c < CR; c++) { t0r[c] = t0i[c] = t1r[c] = t1i[c] = 0.f; sv[c][0] = sv[c][1] = sv[c][2] = sv[c][3] = 0.f; }
+
+	const float P0 = bf.P[0], P1 = bf.P[1], P2 = bf.P[2], P3 = bf.P[3];
+	const float c0 = bf.c0, c1 = bf.c1, c2 = bf.c2;
+	const int64_t kloc = (int64_t)seg * (64 * R) + (int64_t)lane * R;   // feed-local index of this lane's first output
+
+	// The block loop stays rolled: one iteration = OS samples x CR channels of straight-line code,
+	// which is all the instruction-level parallelism the register file can hold.
+	#pragma unroll 1
+	for(int i = 0; i < R; i++) {
+		float a0r[CR], a0i[CR], a1r[CR], a1i[CR], lr[CR], li[CR];
+		#pragma unroll
+		for(int c = 0; c < CR; c++) { a0r[c] = a0i[c] = a1r[c] = a1i[c] = 0.f; lr[c] = li[c] = 0.f; }
+		const float2 *trow = tile + (size_t)(i * os) * 65 + lane;
+		// Partially unrolled on purpose: a fully unrolled run makes the scheduler hoist every LUT
+		// gather (4 VGPRs each) to the top and spill.  Taps come from scalar loads (uniform index).
+		#pragma unroll 4
+		for(int j = 0; j < os; j++) {
+			const float2 x = trow[j * 65];
+			const float g0 = bf.g0[j], g1 = bf.g1[j];
+			#pragma unroll
+			for(int c = 0; c < CR; c++) {
+				const uint32_t p = ph[c];
+				const float F = (float)(p & 0xffffu);                 // sincosf_lut(): fract * 65536
+				const float4 e = lut[(p >> 16) & 0xffu];
+				const float sn = __builtin_fmaf(e.y, F, e.x);
+				const float cs = __builtin_fmaf(e.w, F, e.z);
+				const float mr = __builtin_fmaf(x.x, cs, -(x.y * sn)); // multiply(): re*cos - im*sin
+				const float mi = __builtin_fmaf(x.y, cs, x.x * sn);    //             im*cos + re*sin
+				a0r[c] = __builtin_fmaf(g0, mr, a0r[c]); a0i[c] = __builtin_fmaf(g0, mi, a0i[c]);
+				a1r[c] = __builtin_fmaf(g1, mr, a1r[c]); a1i[c] = __builtin_fmaf(g1, mi, a1i[c]);
+				lr[c] = mr; li[c] = mi;
+				ph[c] = p + dph[c];
+			}
+		}
+		#pragma unroll
+		for(int c = 0; c < CR; c++) {
+			// state update t <- P t + acc, then y = c0*v[n] + c1*v[n-1] + c2*xm[n] (zero-start part; K2 adds the rest)
+			const float n0r = __builtin_fmaf(P0, t0r[c], __builtin_fmaf(P1, t1r[c], a0r[c]));
+			const float n0i = __builtin_fmaf(P0, t0i[c], __builtin_fmaf(P1, t1i[c], a0i[c]));
+			const float n1r = __builtin_fmaf(P2, t0r[c], __builtin_fmaf(P3, t1r[c], a1r[c]));
+			const float n1i = __builtin_fmaf(P2, t0i[c], __builtin_fmaf(P3, t1i[c], a1i[c]));
+			t0r[c] = n0r; t0i[c] = n0i; t1r[c] = n1r; t1i[c] = n1i;
+			const float yr = __builtin_fmaf(c0, n0r, __builtin_fmaf(c1, n1r, c2 * lr[c]));
+			const float yi = __builtin_fmaf(c0, n0i, __builtin_fmaf(c1, n1i, c2 * li[c]));
+			if(i == ib) { sv[c][0] = n0r; sv[c][1] = n0i; sv[c][2] = n1r; sv[c][3] = n1i; }
+			if(cbase + c < a.nchan && kloc + i < a.D)
+				a.y[(size_t)(cbase + c) * a.cap + ((uint32_t)(a.k0 + kloc + i) & a.mask)] = cf32{yr, yi};
+		}
+	}
+
+	// wave-level scan of the lane end states: X_l = Q X_{l-1} + E_l, Q = P^R (Kogge-Stone, 6 steps)
+	#pragma unroll
+	for(int d = 0; d < 6; d++) {
+		const float q0 = bf.Q[d][0], q1 = bf.Q[d][1], q2 = bf.Q[d][2], q3 = bf.Q[d][3];
+		#pragma unroll
+		for(int c = 0; c < CR; c++) {
+			const float o0r = __shfl_up(t0r[c], 1u << d), o0i = __shfl_up(t0i[c], 1u << d);
+			const float o1r = __shfl_up(t1r[c], 1u << d), o1i = __shfl_up(t1i[c], 1u << d);
+			if(lane >= (1 << d)) {
+				t0r[c] += q0 * o0r + q1 * o1r; t0i[c] += q0 * o0i + q1 * o1i;
+				t1r[c] += q2 * o0r + q3 * o1r; t1i[c] += q2 * o0i + q3 * o1i;
+			}
+		}
+	}
+	#pragma unroll
+	for(int c = 0; c < CR; c++) {
+		// state at the START of this lane's run (segment-local): what K2 adds back, decayed, to the lane's R outputs
+		float T0r = __shfl_up(t0r[c], 1), T0i = __shfl_up(t0i[c], 1), T1r = __shfl_up(t1r[c], 1), T1i = __shfl_up(t1i[c], 1);
+		if(lane == 0) { T0r = T0i = T1r = T1i = 0.f; }
+		if(cbase + c < a.nchan) {
+			if(kloc < a.D) a.run_start[(size_t)(cbase + c) * a.nrun_cap + (size_t)seg * 64 + lane] = make_float4(T0r, T0i, T1r, T1i);
+			if(lane == lb) {
+				const float *Pp = bf.Pp[ib + 1];
+				float4 e;
+				e.x = sv[c][0] + (Pp[0] * T0r + Pp[1] * T1r); e.y = sv[c][1] + (Pp[0] * T0i + Pp[1] * T1i);
+				e.z = sv[c][2] + (Pp[2] * T0r + Pp[3] * T1r); e.w = sv[c][3] + (Pp[2] * T0i + Pp[3] * T1i);
+				a.seg_end[(size_t)(cbase + c) * a.nseg_cap + seg] = e;
+			}
+		}
+	}
+}
+
+struct K2Args {
+	cf32 *y; float *phi; const float4 *seg_end; const float4 *run_start; const float4 *carry_in; float4 *carry_out;
+	const BlockForm *bf;
+	int64_t k0, D; uint32_t cap, mask, nseg_cap, nrun_cap; int32_t seglen, run;
+};
+
+// K2: complete K1's zero-start outputs with the decayed start states (lane run, then segment), then phase.
+__global__ __launch_bounds__(256) void k_phase(K2Args a) {
+	const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	const int c = blockIdx.y;
+	if(k >= a.D) return;
+	const BlockForm &bf = *a.bf;
+	const uint32_t slot = (uint32_t)(a.k0 + k) & a.mask;
+	cf32 v = a.y[(size_t)c * a.cap + slot];
+	const int seg = (int)(k / a.seglen), i = (int)(k - (int64_t)seg * a.seglen);
+	{
+		const int64_t rho = k / a.run; const int ir = (int)(k - rho * a.run);
+		const float4 tr = a.run_start[(size_t)c * a.nrun_cap + rho];
+		v.re += bf.cP[ir][0] * tr.x + bf.cP[ir][1] * tr.z;
+		v.im += bf.cP[ir][0] * tr.y + bf.cP[ir][1] * tr.w;
+	}
+	if(i < kFixW) {
+		const float4 ts = seg ? a.seg_end[(size_t)c * a.nseg_cap + seg - 1] : a.carry_in[c];
+		v.re += bf.cP[i][0] * ts.x + bf.cP[i][1] * ts.z;
+		v.im += bf.cP[i][0] * ts.y + bf.cP[i][1] * ts.w;
+	}
+	a.y[(size_t)c * a.cap + slot] = v;
+	a.phi[(size_t)c * a.cap + slot] = phase_of(v);
+	if(k == a.D - 1) {   // filter state handed to the next feed
+		const int len = i + 1;
+		float4 e = a.seg_end[(size_t)c * a.nseg_cap + seg];
+		if(len <= kFixW) {
+			const float4 ts = seg ? a.seg_end[(size_t)c * a.nseg_cap + seg - 1] : a.carry_in[c];
+			const float *Pp = bf.Ppow[len];
+			e.x += Pp[0] * ts.x + Pp[1] * ts.z; e.y += Pp[0] * ts.y + Pp[1] * ts.w;
+			e.z += Pp[2] * ts.x + Pp[3] * ts.z; e.w += Pp[2] * ts.y + Pp[3] * ts.w;
+		}
+		a.carry_out[c] = e;
+	}
+}
+
+// keep the input samples that did not fill a whole decimation block (process_samples()' cnt, demod.c:322)
+__global__ void k_carry(K1Args a, void *carry_out, uint32_t nrem) {
+	const uint32_t i = threadIdx.x;
+	if(i >= nrem) return;
+	const int64_t s = (int64_t)(a.nlogical - nrem) + i;
+	if(a.fmt == 1) {
+		const uint32_t *p = (s < (int64_t)a.ncarry) ? (const uint32_t *)a.carry + s : (const uint32_t *)a.in + (s - a.ncarry);
+		((uint32_t *)carry_out)[i] = *p;
+	} else {
+		const uint16_t *p = (s < (int64_t)a.ncarry) ? (const uint16_t *)a.carry + s : (const uint16_t *)a.in + (s - a.ncarry);
+		((uint16_t *)carry_out)[i] = *p;
+	}
+}
+
+struct K3Args {
+	const float *phi; cf32 *pf; uint64_t *cand; const Tables *tab;
+	int64_t nbase, k1;        // first sample to (re)compute (multiple of 64); one past the last valid sample
+	uint32_t cap, mask;
+};
+
+// K3: got_sync() metric of every decimated sample (contiguous ring) + the candidate bitmap
+__global__ __launch_bounds__(256) void k_sync(K3Args a) {
+	__shared__ float psh[256 + 3];
+	const int c = blockIdx.y;
+	const int64_t nblk = a.nbase + (int64_t)blockIdx.x * 256;
+	const int64_t n = nblk + threadIdx.x;
+	const float *phi = a.phi + (size_t)c * a.cap;
+	cf32 r = (n < a.k1) ? metric_contiguous(phi, a.mask, n, *a.tab) : cf32{kPherrBig, 0.f};
+	a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = r;
+	psh[threadIdx.x + 3] = r.re;
+	if(threadIdx.x < 3) {
+		const int64_t m = nblk - 3 + threadIdx.x;
+		psh[threadIdx.x] = (m >= 0) ? metric_contiguous(phi, a.mask, m, *a.tab).re : kPherrBig;
+	}
+	__syncthreads();
+	const bool cnd = n >= 3 && n < a.k1 && is_candidate(psh[threadIdx.x], psh[threadIdx.x + 3]);
+	const unsigned long long bits = __ballot(cnd);
+	if((threadIdx.x & 63) == 0) a.cand[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
+}
+
+struct K4Args {
+	const cf32 *y; const float *phi; const cf32 *pf; const uint64_t *cand; const Tables *tab;
+	WalkState *ws; unsigned long long *cnt; Burst *bursts; OutCtl *ctl; const uint32_t *freq;
+	int64_t k_end; float max_ppm; uint32_t cap, mask; int32_t chan_first;
+};
+
+__global__ __launch_bounds__(64) void k_walk(K4Args a) {
+	__shared__ WalkShared sh;
+	const int c = blockIdx.x;
+	ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
+	walk_channel(c, a.freq[c], a.max_ppm, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters, a.bursts, a.ctl, sh);
+}
+
+struct K5Args {
+	const cf32 *y; const float *phi; const Tables *tab; unsigned long long *cnt;
+	const Burst *bursts; OutFrame *frames; uint8_t *pool; OutCtl *ctl; const uint32_t *freq;
+	uint32_t cap, mask;
+};
+
+__global__ __launch_bounds__(64) void k_burst(K5Args a) {
+	__shared__ BurstShared sh;
+	uint32_t nb = a.ctl->nbursts; if(nb > a.ctl->cap_bursts) nb = a.ctl->cap_bursts;
+	for(uint32_t i = blockIdx.x; i < nb; i += gridDim.x) {
+		const Burst b = a.bursts[i];
+		const int c = b.chan;
+		ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, nullptr, nullptr, a.mask };
+		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
+		__syncthreads();
+	}
+}
+
+}  // namespace vdl2

@@ -1,0 +1,401 @@
+// vdl2hip.hip - libvdl2hip.so: context management and the C ABI of include/vdl2hip.h.
+// Host code only orchestrates: every sample-rate or burst-rate computation runs in the
+// kernels of kernels.h.  There is deliberately no CPU fallback: without a HIP device
+// vdl2hip_create() fails with VDL2HIP_E_DEVICE.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "../../include/vdl2hip.h"
+#include "kernels.h"
+#include "tables.h"
+
+using namespace vdl2;
+
+static_assert(VDL2HIP_NUM_COUNTERS == kNumCounters, "counter enum out of sync");
+
+namespace {
+
+struct HostFrame {
+	OutFrame f;
+	std::vector<uint8_t> octets;
+};
+
+constexpr int kRun = 4;                  // decimated outputs per lane in K1 (specialised builds)
+constexpr int kRunGeneric = 2;
+constexpr int kHistory = 65536;          // decimated samples kept behind the newest block (> longest burst, 56 090)
+constexpr int kNumEv = 12;
+
+}  // namespace
+
+struct vdl2hip_ctx {
+	vdl2hip_cfg cfg{};
+	int C = 0, chan_first = 0, os = 0, fmt = 0, run = kRun, cr = 1;
+	bool specialised = false;
+	std::vector<uint32_t> freqs, dphi;
+	LpfCoeffs lpf{};
+	BlockForm bf{};
+	hipStream_t stream = nullptr;
+	// device memory
+	BlockForm *d_bf = nullptr; Lut4 *d_lut = nullptr; Tables *d_tab = nullptr;
+	uint32_t *d_dphi = nullptr, *d_freq = nullptr;
+	uint8_t *d_in = nullptr; size_t in_cap = 0;
+	uint8_t *d_carry[2] = {nullptr, nullptr}; int carry_sel = 0; uint32_t ncarry = 0;
+	cf32 *d_y = nullptr, *d_pf = nullptr; float *d_phi = nullptr; uint64_t *d_cand = nullptr;
+	uint32_t cap = 0;
+	float4 *d_segend = nullptr; uint32_t nseg_cap = 0;
+	float4 *d_runstart = nullptr; uint32_t nrun_cap = 0;
+	float4 *d_tcarry[2] = {nullptr, nullptr}; int tcarry_sel = 0;
+	WalkState *d_ws = nullptr; unsigned long long *d_cnt = nullptr;
+	Burst *d_bursts = nullptr; OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
+	OutCtl ctl_template{};
+	OutCtl *h_ctl = nullptr;               // pinned
+	bool pending = false, overflowed = false;
+	std::vector<HostFrame> queue;
+	int64_t k_total = 0; uint64_t n_total = 0;
+	// profiling
+	bool profiling = false; hipEvent_t ev[kNumEv] = {}; bool ev_valid = false;
+	vdl2hip_stats stats{};
+};
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) { \
+	fprintf(stderr, "vdl2hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); return VDL2HIP_E_DEVICE; } } while(0)
+
+static size_t sample_bytes(int fmt) { return fmt == VDL2HIP_FMT_S16LE ? 4 : 2; }
+
+template<int OS, int R>
+static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds) {
+	const int groups = (c->C + cr - 1) / cr;
+	K1Args b = a;
+	b.gy = (groups + 3) / 4;
+	const int nseg8 = (a.nseg + 7) / 8 * 8;
+	dim3 grid((unsigned)(nseg8 * b.gy)), block(256);
+	switch(cr) {
+		case 4: hipLaunchKernelGGL((k_chanfir<OS, R, 4>), grid, block, lds, c->stream, b); break;
+		case 2: hipLaunchKernelGGL((k_chanfir<OS, R, 2>), grid, block, lds, c->stream, b); break;
+		default: hipLaunchKernelGGL((k_chanfir<OS, R, 1>), grid, block, lds, c->stream, b); break;
+	}
+}
+
+static int collect_pending(vdl2hip_ctx *c) {
+	if(!c->pending) return VDL2HIP_OK;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->pending = false;
+	if(c->profiling && c->ev_valid) {
+		float ms = 0.f;
+		if(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.chanfir_ms += ms;
+		if(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.phase_ms += ms;
+		if(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.sync_ms += ms;
+		if(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->stats.walk_ms += ms;
+		if(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) c->stats.burst_ms += ms;
+		c->ev_valid = false;
+	}
+	const OutCtl ctl = *c->h_ctl;
+	if(ctl.overflow) c->overflowed = true;
+	c->stats.bursts += std::min(ctl.nbursts, ctl.cap_bursts);
+	const uint32_t nf = std::min(ctl.nframes, ctl.cap_frames);
+	if(nf) {
+		std::vector<OutFrame> fr(nf);
+		const uint32_t pool_n = std::min(ctl.pool_used, ctl.cap_pool);
+		std::vector<uint8_t> pool(pool_n ? pool_n : 1);
+		HIPCHK(hipMemcpy(fr.data(), c->d_frames, sizeof(OutFrame) * nf, hipMemcpyDeviceToHost));
+		if(pool_n) HIPCHK(hipMemcpy(pool.data(), c->d_pool, pool_n, hipMemcpyDeviceToHost));
+		for(uint32_t i = 0; i < nf; i++) {
+			HostFrame h;
+			h.f = fr[i];
+			if(h.f.pool_off + h.f.len <= pool_n) h.octets.assign(pool.begin() + h.f.pool_off, pool.begin() + h.f.pool_off + h.f.len);
+			c->queue.push_back(std::move(h));
+		}
+		c->stats.frames += nf;
+	}
+	return c->overflowed ? VDL2HIP_E_OVERFLOW : VDL2HIP_OK;
+}
+
+static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
+	const size_t sb = sample_bytes(c->fmt);
+	const uint64_t nnew = nbytes / sb;
+	const uint64_t nlogical = c->ncarry + nnew;
+	const int64_t D = (int64_t)(nlogical / (uint64_t)c->os);
+	const uint32_t nrem = (uint32_t)(nlogical - (uint64_t)D * c->os);
+	const int seglen = 64 * c->run;
+
+	K1Args a{};
+	a.in = dev_in; a.carry = c->d_carry[c->carry_sel]; a.ncarry = c->ncarry; a.nlogical = nlogical;
+	a.n0 = c->n_total - c->ncarry; a.k0 = c->k_total; a.D = D;
+	a.fmt = c->fmt; a.nchan = c->C; a.os = c->os; a.nseg = (int)((D + seglen - 1) / seglen); a.gy = 1;
+	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.seg_end = c->d_segend;
+	a.run_start = c->d_runstart; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap; a.nrun_cap = c->nrun_cap;
+
+	HIPCHK(hipMemcpyAsync(c->d_ctl, &c->ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, c->stream));
+	const bool prof = c->profiling;
+	if(D > 0) {
+		if(prof) HIPCHK(hipEventRecord(c->ev[0], c->stream));
+		const size_t lds = 4096 + (size_t)c->run * c->os * 65 * sizeof(float2);
+		if(c->specialised) {
+			switch(c->os) {
+				case 20: launch_chanfir<20, kRun>(c, a, c->cr, lds); break;
+				case 13: launch_chanfir<13, kRun>(c, a, c->cr, lds); break;
+				default: launch_chanfir<10, kRun>(c, a, c->cr, lds); break;
+			}
+		} else {
+			launch_chanfir<0, kRunGeneric>(c, a, c->cr, lds);
+		}
+		if(prof) HIPCHK(hipEventRecord(c->ev[1], c->stream));
+		K2Args k2{ c->d_y, c->d_phi, c->d_segend, c->d_runstart, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
+		           c->k_total, D, c->cap, c->cap - 1, c->nseg_cap, c->nrun_cap, seglen, c->run };
+		hipLaunchKernelGGL(k_phase, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), 0, c->stream, k2);
+		c->tcarry_sel ^= 1;
+	}
+	if(nrem) hipLaunchKernelGGL(k_carry, dim3(1), dim3(64), 0, c->stream, a, (void *)c->d_carry[c->carry_sel ^ 1], nrem);
+	c->carry_sel ^= 1; c->ncarry = nrem;
+	if(D > 0) {
+		if(prof) HIPCHK(hipEventRecord(c->ev[2], c->stream));
+		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
+		K3Args k3{ c->d_phi, c->d_pf, c->d_cand, c->d_tab, nbase, k1, c->cap, c->cap - 1 };
+		hipLaunchKernelGGL(k_sync, dim3((unsigned)((k1 - nbase + 255) / 256), (unsigned)c->C), dim3(256), 0, c->stream, k3);
+		if(prof) HIPCHK(hipEventRecord(c->ev[3], c->stream));
+		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, c->d_bursts, c->d_ctl, c->d_freq,
+		           k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
+		hipLaunchKernelGGL(k_walk, dim3((unsigned)c->C), dim3(64), 0, c->stream, k4);
+		if(prof) HIPCHK(hipEventRecord(c->ev[4], c->stream));
+		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, c->d_bursts, c->d_frames, c->d_pool, c->d_ctl, c->d_freq, c->cap, c->cap - 1 };
+		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, c->stream, k5);
+		if(prof) { HIPCHK(hipEventRecord(c->ev[5], c->stream)); c->ev_valid = true; }
+	}
+	HIPCHK(hipMemcpyAsync(c->h_ctl, c->d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipGetLastError());
+	c->pending = true;
+	c->k_total += D; c->n_total += nnew;
+	c->stats.feeds++; c->stats.input_samples += nnew;
+	if(D > 0) { c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C; }
+	return VDL2HIP_OK;
+}
+
+extern "C" {
+
+int vdl2hip_abi_version(void) { return VDL2HIP_ABI_VERSION; }
+
+const char *vdl2hip_strerror(int err) {
+	switch(err) {
+		case VDL2HIP_OK: return "ok";
+		case VDL2HIP_E_INVAL: return "invalid argument";
+		case VDL2HIP_E_NOMEM: return "out of memory";
+		case VDL2HIP_E_DEVICE: return "HIP device error";
+		case VDL2HIP_E_TOOBIG: return "block larger than max_block_bytes";
+		case VDL2HIP_E_OVERFLOW: return "device output buffer overflow";
+		default: return "unknown error";
+	}
+}
+
+void vdl2hip_destroy(vdl2hip_ctx *c) {
+	if(!c) return;
+	if(c->stream) (void)hipStreamSynchronize(c->stream);
+	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
+	                 c->d_phi, c->d_cand, c->d_segend, c->d_runstart, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_bursts,
+	                 c->d_frames, c->d_pool, c->d_ctl };
+	for(void *p : ptrs) if(p) (void)hipFree(p);
+	if(c->h_ctl) (void)hipHostFree(c->h_ctl);
+	for(int i = 0; i < kNumEv; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	if(c->stream) (void)hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
+	if(!cfg || !out || cfg->struct_size < sizeof(vdl2hip_cfg) || !cfg->freqs || cfg->nchan == 0) return VDL2HIP_E_INVAL;
+	if(cfg->oversample == 0 || cfg->oversample > (uint32_t)kMaxOversample) return VDL2HIP_E_INVAL;
+	if(cfg->sample_fmt != VDL2HIP_FMT_U8 && cfg->sample_fmt != VDL2HIP_FMT_S16LE) return VDL2HIP_E_INVAL;
+	uint32_t first = cfg->chan_first, count = cfg->chan_count ? cfg->chan_count : cfg->nchan - first;
+	if(first >= cfg->nchan || first + count > cfg->nchan) return VDL2HIP_E_INVAL;
+	*out = nullptr;
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		fprintf(stderr, "vdl2hip: no HIP device available - this library has no CPU path\n");
+		return VDL2HIP_E_DEVICE;
+	}
+	HIPCHK(hipSetDevice(cfg->device));
+	vdl2hip_ctx *c = new(std::nothrow) vdl2hip_ctx();
+	if(!c) return VDL2HIP_E_NOMEM;
+	c->cfg = *cfg; c->cfg.freqs = nullptr;
+	c->C = (int)count; c->chan_first = (int)first; c->os = (int)cfg->oversample; c->fmt = (int)cfg->sample_fmt;
+	c->freqs.assign(cfg->freqs + first, cfg->freqs + first + count);
+	const uint32_t fs = (uint32_t)kSymbolRate * kSps * cfg->oversample;
+	c->lpf = design_lpf(8000.f / (float)fs, 0.5f);                // input_lpf_init(), demod.c:45-46,367-370
+	c->specialised = (c->os == 10 || c->os == 13 || c->os == 20);
+	c->run = c->specialised ? kRun : kRunGeneric;
+	c->cr = c->C >= 16 ? 4 : c->C >= 8 ? 2 : 1;                   // channels per wave: keep >= 4 channel groups where possible
+	c->bf = derive_block_form(c->lpf, c->os, c->run);
+	c->dphi.resize(count);
+	for(uint32_t i = 0; i < count; i++) c->dphi[i] = nco_step(cfg->centerfreq, c->freqs[i], fs) & 0xffffffu;
+
+	const uint32_t max_bytes = cfg->max_block_bytes ? cfg->max_block_bytes : 320000u;
+	const size_t sb = sample_bytes(c->fmt);
+	const uint64_t max_samples = max_bytes / sb + c->os;
+	const uint64_t dmax = max_samples / c->os + 1;
+	uint32_t cap = 1; while(cap < dmax + kHistory + 1024) cap <<= 1;
+	c->cap = cap;
+	c->in_cap = max_bytes;
+	c->nseg_cap = (uint32_t)(dmax / (64 * c->run) + 2);
+	c->nrun_cap = c->nseg_cap * 64;
+
+	#define DEV_ALLOC(ptr, bytes) do { if(hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_NOMEM; } } while(0)
+	#define DEV_CHK(expr) do { if((expr) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_DEVICE; } } while(0)
+	DEV_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&c->ev[i]));
+	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
+	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count);
+	DEV_ALLOC(c->d_in, c->in_cap + 16);
+	DEV_ALLOC(c->d_carry[0], 4 * kMaxOversample); DEV_ALLOC(c->d_carry[1], 4 * kMaxOversample);
+	const size_t nring = (size_t)count * cap;
+	DEV_ALLOC(c->d_y, nring * sizeof(cf32)); DEV_ALLOC(c->d_pf, nring * sizeof(cf32));
+	DEV_ALLOC(c->d_phi, nring * sizeof(float)); DEV_ALLOC(c->d_cand, nring / 8);
+	DEV_ALLOC(c->d_segend, (size_t)count * c->nseg_cap * sizeof(float4));
+	DEV_ALLOC(c->d_runstart, (size_t)count * c->nrun_cap * sizeof(float4));
+	DEV_ALLOC(c->d_tcarry[0], count * sizeof(float4)); DEV_ALLOC(c->d_tcarry[1], count * sizeof(float4));
+	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, (size_t)count * kNumCounters * 8);
+	// a decodable burst occupies >= 22 symbols = 220 decimated samples (header + 3 data + 2 FEC octets)
+	uint64_t cap_b = (uint64_t)count * (dmax / 220 + 2); if(cap_b < 1024) cap_b = 1024;
+	uint64_t cap_f = cap_b * 2; if(cap_f < 4096) cap_f = 4096;
+	uint64_t cap_p = cap_b * 512; if(cap_p < (1u << 22)) cap_p = 1u << 22; if(cap_p > (1u << 30)) cap_p = 1u << 30;
+	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, 0 };
+	DEV_ALLOC(c->d_bursts, cap_b * sizeof(Burst)); DEV_ALLOC(c->d_frames, cap_f * sizeof(OutFrame)); DEV_ALLOC(c->d_pool, cap_p);
+	DEV_ALLOC(c->d_ctl, sizeof(OutCtl));
+	DEV_CHK(hipHostMalloc((void **)&c->h_ctl, sizeof(OutCtl), hipHostMallocDefault));
+	memset(c->h_ctl, 0, sizeof(OutCtl));
+
+	Lut4 lut[256]; build_nco_lut(lut);                            // sincosf_lut_init()
+	Tables *tab = new Tables; build_tables(*tab);                 // demod_sync_init(), rs_init(), header tables
+	std::vector<WalkState> ws(count);
+	for(auto &w : ws) { memset(&w, 0, sizeof w); walk_state_init(w); }
+	DEV_CHK(hipMemcpy(c->d_bf, &c->bf, sizeof(BlockForm), hipMemcpyHostToDevice));
+	DEV_CHK(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+	DEV_CHK(hipMemcpy(c->d_tab, tab, sizeof(Tables), hipMemcpyHostToDevice));
+	delete tab;
+	DEV_CHK(hipMemcpy(c->d_dphi, c->dphi.data(), 4 * count, hipMemcpyHostToDevice));
+	DEV_CHK(hipMemcpy(c->d_freq, c->freqs.data(), 4 * count, hipMemcpyHostToDevice));
+	DEV_CHK(hipMemcpy(c->d_ws, ws.data(), count * sizeof(WalkState), hipMemcpyHostToDevice));
+	DEV_CHK(hipMemset(c->d_y, 0, nring * sizeof(cf32))); DEV_CHK(hipMemset(c->d_pf, 0, nring * sizeof(cf32)));
+	DEV_CHK(hipMemset(c->d_phi, 0, nring * sizeof(float))); DEV_CHK(hipMemset(c->d_cand, 0, nring / 8));
+	DEV_CHK(hipMemset(c->d_tcarry[0], 0, count * sizeof(float4))); DEV_CHK(hipMemset(c->d_tcarry[1], 0, count * sizeof(float4)));
+	DEV_CHK(hipMemset(c->d_cnt, 0, (size_t)count * kNumCounters * 8));
+	DEV_CHK(hipMemset(c->d_segend, 0, (size_t)count * c->nseg_cap * sizeof(float4)));
+	// the generic-oversample build may need more than the default dynamic LDS limit
+	const size_t lds = 4096 + (size_t)c->run * c->os * 65 * sizeof(float2);
+	if(lds > 65536) { vdl2hip_destroy(c); return VDL2HIP_E_INVAL; }
+	DEV_CHK(hipDeviceSynchronize());
+	#undef DEV_ALLOC
+	#undef DEV_CHK
+	*out = c;
+	return VDL2HIP_OK;
+}
+
+int vdl2hip_feed(vdl2hip_ctx *c, const void *buf, size_t nbytes) {
+	if(!c || (!buf && nbytes)) return VDL2HIP_E_INVAL;
+	if(nbytes == 0) return VDL2HIP_OK;                             // process_buf_*: len == 0 is a no-op (demod.c:341,358)
+	if(nbytes > c->in_cap) return VDL2HIP_E_TOOBIG;
+	nbytes -= nbytes % sample_bytes(c->fmt);
+	int r = collect_pending(c);                                    // the previous block's outputs live in the buffers we are about to reuse
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	HIPCHK(hipMemcpyAsync(c->d_in, buf, nbytes, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));                       // `buf` is only ours during the call
+	return feed_common(c, c->d_in, nbytes);
+}
+
+int vdl2hip_feed_device(vdl2hip_ctx *c, const void *dev_buf, size_t nbytes) {
+	if(!c || (!dev_buf && nbytes)) return VDL2HIP_E_INVAL;
+	if(nbytes == 0) return VDL2HIP_OK;
+	if(nbytes > c->in_cap) return VDL2HIP_E_TOOBIG;
+	if(((uintptr_t)dev_buf) % sample_bytes(c->fmt)) return VDL2HIP_E_INVAL;
+	nbytes -= nbytes % sample_bytes(c->fmt);
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	return feed_common(c, dev_buf, nbytes);
+}
+
+int vdl2hip_sync(vdl2hip_ctx *c) {
+	if(!c) return VDL2HIP_E_INVAL;
+	return collect_pending(c);
+}
+
+int vdl2hip_drain(vdl2hip_ctx *c, vdl2hip_frame_cb cb, void *user) {
+	if(!c) return VDL2HIP_E_INVAL;
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	std::stable_sort(c->queue.begin(), c->queue.end(), [](const HostFrame &a, const HostFrame &b) {
+		if(a.f.end_sample != b.f.end_sample) return a.f.end_sample < b.f.end_sample;
+		if(a.f.chan != b.f.chan) return a.f.chan < b.f.chan;
+		return a.f.idx < b.f.idx;
+	});
+	int n = 0;
+	for(const HostFrame &h : c->queue) {
+		if(cb) {
+			vdl2hip_frame f{};
+			f.chan = (uint32_t)(h.f.chan + c->chan_first); f.freq = c->freqs[h.f.chan]; f.idx = h.f.idx;
+			f.len = h.f.len; f.octets = h.octets.data();
+			f.synd_weight = h.f.synd_weight; f.datalen_octets = h.f.datalen_octets; f.num_fec_corrections = h.f.num_fec_corrections;
+			f.frame_pwr_dbfs = h.f.frame_pwr_dbfs; f.nf_pwr_dbfs = h.f.nf_pwr_dbfs; f.ppm_error = h.f.ppm_error;
+			f.burst_ord = h.f.burst_ord; f.sync_sample = h.f.sync_sample; f.end_sample = h.f.end_sample;
+			cb(&f, user);
+		}
+		n++;
+	}
+	c->queue.clear();
+	return n;
+}
+
+int vdl2hip_counters(vdl2hip_ctx *c, uint32_t chan, uint64_t out[VDL2HIP_NUM_COUNTERS]) {
+	if(!c || !out || chan < (uint32_t)c->chan_first || chan >= (uint32_t)(c->chan_first + c->C)) return VDL2HIP_E_INVAL;
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	HIPCHK(hipMemcpy(out, c->d_cnt + (size_t)(chan - c->chan_first) * kNumCounters, 8 * kNumCounters, hipMemcpyDeviceToHost));
+	return VDL2HIP_OK;
+}
+
+int vdl2hip_set_profiling(vdl2hip_ctx *c, int on) {
+	if(!c) return VDL2HIP_E_INVAL;
+	int r = collect_pending(c);
+	c->profiling = on != 0;
+	return r == VDL2HIP_E_OVERFLOW ? VDL2HIP_OK : r;
+}
+
+int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) {
+	if(!c || !out) return VDL2HIP_E_INVAL;
+	int r = collect_pending(c);
+	*out = c->stats;
+	return r == VDL2HIP_E_OVERFLOW ? VDL2HIP_OK : r;
+}
+
+void *vdl2hip_stream(vdl2hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int vdl2hip_get_lpf(vdl2hip_ctx *c, float A[3], float B[3]) {
+	if(!c) return VDL2HIP_E_INVAL;
+	memcpy(A, c->lpf.A, sizeof c->lpf.A); memcpy(B, c->lpf.B, sizeof c->lpf.B);
+	return VDL2HIP_OK;
+}
+
+int vdl2hip_get_nco_step(vdl2hip_ctx *c, uint32_t chan, uint32_t *dphi) {
+	if(!c || !dphi || chan < (uint32_t)c->chan_first || chan >= (uint32_t)(c->chan_first + c->C)) return VDL2HIP_E_INVAL;
+	*dphi = nco_step(c->cfg.centerfreq, c->freqs[chan - c->chan_first], (uint32_t)kSymbolRate * kSps * c->os);
+	return VDL2HIP_OK;
+}
+
+int vdl2hip_read_decimated(vdl2hip_ctx *c, uint32_t chan, int64_t first, float *dst, size_t cap) {
+	if(!c || !dst || chan < (uint32_t)c->chan_first || chan >= (uint32_t)(c->chan_first + c->C)) return VDL2HIP_E_INVAL;
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	if(first < 0 || first > c->k_total || c->k_total - first > (int64_t)c->cap) return VDL2HIP_E_INVAL;
+	size_t n = std::min<size_t>(cap, (size_t)(c->k_total - first));
+	const cf32 *base = c->d_y + (size_t)(chan - c->chan_first) * c->cap;
+	size_t done = 0;
+	while(done < n) {
+		uint32_t slot = (uint32_t)(first + (int64_t)done) & (c->cap - 1);
+		size_t m = std::min<size_t>(n - done, c->cap - slot);
+		HIPCHK(hipMemcpy(dst + 2 * done, base + slot, m * sizeof(cf32), hipMemcpyDeviceToHost));
+		done += m;
+	}
+	return (int)n;
+}
+
+}  // extern "C"

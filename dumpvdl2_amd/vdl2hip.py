@@ -1,0 +1,184 @@
+"""ctypes binding of libvdl2hip.so - the host-side mirror of the reference's
+process_buf_*() -> avlc_decoder_queue_push() boundary (include/vdl2hip.h).
+
+The library is the product; this module only passes pointers and sizes.
+It raises if the shared library is missing or no HIP device exists: there is
+no CPU implementation to fall back to.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvdl2hip.so")
+
+FMT_U8, FMT_S16LE = 0, 1
+COUNTER_NAMES = [
+    "demod.sync.good", "decoder.crc.good", "decoder.crc.bad", "decoder.errors.no_header",
+    "decoder.errors.too_long", "decoder.errors.no_fec", "decoder.errors.data_truncated",
+    "decoder.errors.fec_truncated", "decoder.errors.deinterleave_data",
+    "decoder.errors.deinterleave_fec", "decoder.errors.fec_bad", "decoder.errors.bitstream",
+    "decoder.errors.truncated_octets", "decoder.errors.unstuff", "decoder.blocks.processed",
+    "decoder.blocks.fec_ok", "decoder.msg.good", "decoder.msg.good_loud",
+    "demod.ppm_reject", "demod.slicer_neg_idx",
+]
+NUM_COUNTERS = len(COUNTER_NAMES)
+EXPORTS = [
+    "vdl2hip_abi_version", "vdl2hip_strerror", "vdl2hip_create", "vdl2hip_destroy", "vdl2hip_feed",
+    "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
+    "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
+]
+
+
+class Cfg(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("centerfreq", C.c_uint32), ("oversample", C.c_uint32),
+                ("sample_fmt", C.c_uint32), ("nchan", C.c_uint32), ("freqs", C.POINTER(C.c_uint32)),
+                ("max_ppm", C.c_float), ("device", C.c_int32), ("max_block_bytes", C.c_uint32),
+                ("chan_first", C.c_uint32), ("chan_count", C.c_uint32)]
+
+
+class CFrame(C.Structure):
+    _fields_ = [("chan", C.c_uint32), ("freq", C.c_uint32), ("idx", C.c_int32), ("len", C.c_uint32),
+                ("octets", C.POINTER(C.c_uint8)), ("synd_weight", C.c_uint32), ("datalen_octets", C.c_uint32),
+                ("num_fec_corrections", C.c_int32), ("frame_pwr_dbfs", C.c_float), ("nf_pwr_dbfs", C.c_float),
+                ("ppm_error", C.c_float), ("burst_ord", C.c_int64), ("sync_sample", C.c_int64),
+                ("end_sample", C.c_int64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("feeds", C.c_uint64), ("input_samples", C.c_uint64), ("chan_samples", C.c_uint64),
+                ("chanfir_launches", C.c_uint64), ("chanfir_ms", C.c_double), ("phase_ms", C.c_double),
+                ("sync_ms", C.c_double), ("walk_ms", C.c_double), ("burst_ms", C.c_double),
+                ("bursts", C.c_uint64), ("frames", C.c_uint64)]
+
+
+FRAME_CB = C.CFUNCTYPE(None, C.POINTER(CFrame), C.c_void_p)
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing - build it with dumpvdl2_amd.build.build(); there is no CPU fallback")
+    L = C.CDLL(path)
+    L.vdl2hip_abi_version.restype = C.c_int
+    L.vdl2hip_strerror.restype = C.c_char_p
+    L.vdl2hip_strerror.argtypes = [C.c_int]
+    L.vdl2hip_create.argtypes = [C.POINTER(Cfg), C.POINTER(C.c_void_p)]
+    L.vdl2hip_destroy.argtypes = [C.c_void_p]
+    L.vdl2hip_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.vdl2hip_feed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.vdl2hip_sync.argtypes = [C.c_void_p]
+    L.vdl2hip_drain.argtypes = [C.c_void_p, FRAME_CB, C.c_void_p]
+    L.vdl2hip_counters.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.vdl2hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.vdl2hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.vdl2hip_stream.restype = C.c_void_p
+    L.vdl2hip_stream.argtypes = [C.c_void_p]
+    L.vdl2hip_get_lpf.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.vdl2hip_get_nco_step.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.vdl2hip_read_decimated.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_void_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+class Vdl2HipError(RuntimeError):
+    pass
+
+
+class Receiver:
+    """One multi-channel VDL2 receiver on one GPU (= the reference's set of demod threads)."""
+
+    def __init__(self, centerfreq: int, freqs: Sequence[int], oversample: int = 20, sample_fmt: int = FMT_S16LE,
+                 max_ppm: float = 0.0, device: int = 0, max_block_bytes: int = 320000,
+                 chan_first: int = 0, chan_count: int = 0):
+        self.L = load_library()
+        self.freqs = list(freqs)
+        self._freq_arr = (C.c_uint32 * len(self.freqs))(*self.freqs)
+        cfg = Cfg(C.sizeof(Cfg), centerfreq, oversample, sample_fmt, len(self.freqs), self._freq_arr,
+                  max_ppm, device, max_block_bytes, chan_first, chan_count)
+        h = C.c_void_p()
+        self._chk(self.L.vdl2hip_create(C.byref(cfg), C.byref(h)), "vdl2hip_create")
+        self.h = h
+        self.chan_first = chan_first
+        self.chan_count = chan_count or (len(self.freqs) - chan_first)
+
+    def _chk(self, r, what):
+        if r < 0:
+            raise Vdl2HipError(f"{what}: {self.L.vdl2hip_strerror(r).decode()} ({r})")
+        return r
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vdl2hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feed(self, raw) -> None:
+        """process_buf_uchar()/process_buf_short(): one block of raw IQ bytes from host memory."""
+        a = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        self._chk(self.L.vdl2hip_feed(self.h, a.ctypes.data, a.size), "vdl2hip_feed")
+
+    def feed_device(self, dev_ptr: int, nbytes: int) -> None:
+        self._chk(self.L.vdl2hip_feed_device(self.h, C.c_void_p(dev_ptr), nbytes), "vdl2hip_feed_device")
+
+    def sync(self) -> None:
+        self._chk(self.L.vdl2hip_sync(self.h), "vdl2hip_sync")
+
+    def drain(self) -> List[dict]:
+        out: List[dict] = []
+
+        def cb(fp, _user):
+            f = fp.contents
+            out.append(dict(chan=f.chan, freq=f.freq, idx=f.idx,
+                            octets=bytes(C.string_at(f.octets, f.len)) if f.len else b"",
+                            synd_weight=f.synd_weight, datalen_octets=f.datalen_octets,
+                            num_fec_corrections=f.num_fec_corrections, frame_pwr_dbfs=f.frame_pwr_dbfs,
+                            nf_pwr_dbfs=f.nf_pwr_dbfs, ppm_error=f.ppm_error, burst_ord=f.burst_ord,
+                            sync_sample=f.sync_sample, end_sample=f.end_sample))
+
+        self._cb = FRAME_CB(cb)
+        self._chk(self.L.vdl2hip_drain(self.h, self._cb, None), "vdl2hip_drain")
+        return out
+
+    def counters(self, chan: int) -> dict:
+        a = (C.c_uint64 * NUM_COUNTERS)()
+        self._chk(self.L.vdl2hip_counters(self.h, chan, a), "vdl2hip_counters")
+        return dict(zip(COUNTER_NAMES, list(a)))
+
+    def set_profiling(self, on: bool) -> None:
+        self._chk(self.L.vdl2hip_set_profiling(self.h, int(on)), "vdl2hip_set_profiling")
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._chk(self.L.vdl2hip_get_stats(self.h, C.byref(s)), "vdl2hip_get_stats")
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def stream(self) -> int:
+        return self.L.vdl2hip_stream(self.h) or 0
+
+    def lpf(self):
+        A = (C.c_float * 3)(); B = (C.c_float * 3)()
+        self._chk(self.L.vdl2hip_get_lpf(self.h, A, B), "vdl2hip_get_lpf")
+        return np.array(A, dtype=np.float32), np.array(B, dtype=np.float32)
+
+    def nco_step(self, chan: int) -> int:
+        d = C.c_uint32()
+        self._chk(self.L.vdl2hip_get_nco_step(self.h, chan, C.byref(d)), "vdl2hip_get_nco_step")
+        return d.value
+
+    def read_decimated(self, chan: int, first: int, count: int) -> np.ndarray:
+        buf = np.zeros((count, 2), dtype=np.float32)
+        n = self._chk(self.L.vdl2hip_read_decimated(self.h, chan, first, buf.ctypes.data, count), "vdl2hip_read_decimated")
+        return buf[:n]
