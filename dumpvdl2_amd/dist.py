@@ -1,0 +1,47 @@
+"""Multi-GPU layout of the hot path: channels are independent, so they shard statically across
+ranks (one process per GPU); the only exchange is a broadcast of each raw IQ block from the
+ingest rank to the others (RCCL over xGMI on GPUs, gloo in the CPU tests).  Frames never cross
+GPUs: every rank drains its own and rank 0 may gather them (tiny) for a deterministic merge.
+
+The reference's equivalent is "one pthread per channel over a shared sbuf" (src/dumpvdl2.c:117-135,
+src/demod.c:300-301,342-346).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+
+def shard_channels(nchan: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous static partition: rank r owns channels [first, first+count)."""
+    base, extra = divmod(nchan, world)
+    first = rank * base + min(rank, extra)
+    count = base + (1 if rank < extra else 0)
+    return first, count
+
+
+def broadcast_block(tensor, src: int = 0, group=None):
+    """In-place broadcast of one raw IQ block (uint8/int16 tensor, same shape on every rank)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        # raw bytes: ncclUint8 / gloo uint8 exist on every backend (int16 does not on gloo)
+        dist.broadcast(tensor.view(torch.uint8) if tensor.dtype != torch.uint8 else tensor, src=src, group=group)
+    return tensor
+
+
+def merge_frames(per_rank: Sequence[Sequence[dict]]) -> List[dict]:
+    """Deterministic global order of frames from all shards: (end_sample, chan, idx)."""
+    out = [f for fr in per_rank for f in fr]
+    out.sort(key=lambda f: (f["end_sample"], f["chan"], f["idx"]))
+    return out
+
+
+def gather_frames(frames: Sequence[dict], dst: int = 0, group=None):
+    """Collect every rank's frame list on `dst` (python objects; a few KB per second of signal)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return merge_frames([frames])
+    world = dist.get_world_size(group)
+    bucket = [None] * world if dist.get_rank(group) == dst else None
+    dist.gather_object(list(frames), bucket, dst=dst, group=group)
+    return merge_frames(bucket) if bucket is not None else None

@@ -1,0 +1,46 @@
+"""Seeded inputs shared by the CPU and GPU parity tests (same factories as tests/golden/make_golden.py)."""
+import functools
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from make_golden import CASES  # noqa: E402
+from dumpvdl2_amd import synth  # noqa: E402
+
+
+@functools.lru_cache(maxsize=None)
+def load(name):
+    """-> (cfg, iq int16 array, tx bursts, golden dict)"""
+    cfg = CASES[name]()
+    iq, bursts = synth.synthesize(cfg)
+    with open(os.path.join(ROOT, "tests", "golden", name + ".json")) as f:
+        gold = json.load(f)
+    assert hashlib.sha1(iq.tobytes()).hexdigest() == gold["iq_sha1"], \
+        f"{name}: regenerated IQ differs from the one the golden answers were made for"
+    return cfg, iq, bursts, gold
+
+
+def golden_frames_as_dicts(gold):
+    return gold["frames"]
+
+
+def check_against_golden(frames, counters, gold, tol_db=0.05, tol_ppm=0.01, label=""):
+    """frames: decoder output dicts (with octets); gold: committed oracle answers."""
+    got = sorted(frames, key=lambda f: (f["chan"], f["burst_ord"], f["idx"]))
+    want = gold["frames"]
+    assert len(got) == len(want), f"{label}: {len(got)} frames, golden has {len(want)}"
+    for g, w in zip(got, want):
+        assert (g["chan"], g["burst_ord"], g["idx"]) == (w["chan"], w["burst_ord"], w["idx"])
+        assert len(g["octets"]) == w["len"] and hashlib.sha1(g["octets"]).hexdigest() == w["sha1"], f"{label}: octets differ in {w}"
+        for k in ("synd_weight", "datalen_octets", "num_fec_corrections", "sync_sample", "end_sample"):
+            assert g[k] == w[k], f"{label}: {k} {g[k]} != {w[k]}"
+        assert abs(g["frame_pwr_dbfs"] - w["frame_pwr_dbfs"]) <= tol_db
+        assert abs(g["nf_pwr_dbfs"] - w["nf_pwr_dbfs"]) <= tol_db
+        assert abs(g["ppm_error"] - w["ppm_error"]) <= tol_ppm
+    if counters is not None:
+        assert [list(c) for c in counters] == gold["counters"], f"{label}: per-channel counters differ"

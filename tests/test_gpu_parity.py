@@ -1,0 +1,165 @@
+"""Parity of the HIP path (through the C ABI of libvdl2hip.so) with the CPU oracle and with the
+committed golden answers.  Frame octets, integer metadata, burst timing and per-channel counters
+must be identical; float metadata within SURVEY.md 8.5's tolerances (0.05 dB, 0.01 ppm) because a
+time-parallel IIR cannot reproduce the reference's rounding sequence."""
+import numpy as np
+import pytest
+
+import cases
+from util import assert_frames_equal, truth_is_subset
+
+pytestmark = pytest.mark.gpu
+CF = 136975000
+
+
+@pytest.fixture(scope="module")
+def vh():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from dumpvdl2_amd import vdl2hip
+    vdl2hip.load_library()          # raises if the HIP library is missing: no fallback
+    return vdl2hip
+
+
+def gpu_decode(vh, cfg, raw, fmt=1, chunks=None, max_block=None, seed=3, **kw):
+    raw = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+    rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, fmt, cfg.rx_max_ppm,
+                     max_block_bytes=max_block or raw.size, **kw)
+    sb = 4 if fmt == 1 else 2
+    if chunks is None:
+        rx.feed(raw)
+    else:
+        rng = np.random.default_rng(seed); k = 0
+        while k < raw.size:
+            m = min(raw.size - k, int(rng.integers(*chunks)) * sb)
+            rx.feed(raw[k:k + m]); k += m
+    fr = rx.drain()
+    first = kw.get("chan_first", 0)
+    cnt = [list(rx.counters(c).values()) for c in range(first, first + rx.chan_count)]
+    return rx, fr, cnt
+
+
+def test_reference_wav_is_a_drop_in(vh, oracle_mod, golden_wav):
+    """BASELINE configs[0]: the reference's own test vector, file blocks of FILE_BUFSIZE bytes."""
+    import types
+    cfg = types.SimpleNamespace(centerfreq=CF, freqs=[CF], oversample=10, rx_max_ppm=0.0)
+    rx = vh.Receiver(CF, [CF], 10, vh.FMT_S16LE)
+    for k in range(0, golden_wav.size, 320000):        # process_iq_file(), dumpvdl2.c:353-356
+        rx.feed(golden_wav[k:k + 320000])
+    fr = rx.drain()
+    assert [len(f["octets"]) for f in fr] == [314, 186]
+    assert b" -RA BR OVC005\n" in fr[0]["octets"] and b" SLP135\n" in fr[1]["octets"]
+    o = oracle_mod.Oracle(CF, [CF], oversample=10)
+    o.process(golden_wav)
+    assert_frames_equal(o.frames(), fr, label="wav")
+    assert list(o.counters(0).values()) == list(rx.counters(0).values())
+    A, B = rx.lpf(); Ao, Bo = o.lpf()
+    assert A.tobytes() == Ao.tobytes() and B.tobytes() == Bo.tobytes()
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_golden_cases_single_feed(vh, name):
+    cfg, iq, bursts, gold = cases.load(name)
+    rx, fr, cnt = gpu_decode(vh, cfg, iq)
+    cases.check_against_golden(fr, cnt, gold, label=name)
+    rx.close()
+
+
+@pytest.mark.parametrize("name,chunks", [("config2_1s", (1, 3000)), ("config2_1s", (100000, 900000)),
+                                         ("config4_0p4s", (20000, 200000)), ("os10_noisy_1s", (7, 20000))])
+def test_chunking_does_not_change_the_answer(vh, name, chunks):
+    cfg, iq, bursts, gold = cases.load(name)
+    rx, fr, cnt = gpu_decode(vh, cfg, iq, chunks=chunks, max_block=4 * chunks[1])
+    cases.check_against_golden(fr, cnt, gold, label=f"{name} chunks {chunks}")
+    rx.close()
+
+
+def test_decimated_stream_close_to_reference(vh, oracle_mod):
+    """K1+K2 against the reference's sequential IIR: not bit-equal by construction, but within the
+    reference filter's own rounding noise (~1e-5 of full scale of the channel)."""
+    cfg, iq, _, _ = cases.load("config2_1s")
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample)
+    D = iq.size // 2 // cfg.oversample
+    tr = o.trace_all(D)
+    o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=4)
+    rx, _, _ = gpu_decode(vh, cfg, iq)
+    for c in range(len(cfg.freqs)):
+        y = rx.read_decimated(c, 0, D)
+        ref = tr[c, :len(y)]
+        assert np.abs(y - ref).max() <= 3e-4 * np.abs(ref).max()
+        assert o.dphi(c) & 0xFFFFFF == rx.nco_step(c) & 0xFFFFFF
+    rx.close()
+
+
+def test_shards_reproduce_the_whole(vh):
+    """chan_first/chan_count (the multi-GPU split) decode exactly the frames of the full receiver."""
+    cfg, iq, _, gold = cases.load("config3_0p6s")
+    parts = []
+    for first, count in ((0, 20), (20, 20), (40, 24)):
+        rx, fr, _ = gpu_decode(vh, cfg, iq, chan_first=first, chan_count=count)
+        parts += fr
+        rx.close()
+    cases.check_against_golden(parts, None, gold, label="3 shards")
+
+
+def test_feed_device_matches_feed_host(vh):
+    import torch
+    cfg, iq, _, gold = cases.load("config2_1s")
+    t = torch.from_numpy(iq.copy()).cuda()
+    rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=iq.nbytes)
+    half = (iq.size // 4) * 2
+    rx.feed_device(t.data_ptr(), half * 2)
+    rx.feed_device(t.data_ptr() + half * 2, (iq.size - half) * 2)
+    fr = rx.drain()
+    cases.check_against_golden(fr, [list(rx.counters(c).values()) for c in range(len(cfg.freqs))], gold, label="device feed")
+    rx.close()
+
+
+def test_uint8_input(vh, oracle_mod):
+    from dumpvdl2_amd import synth
+    cfg = synth.SynthConfig(centerfreq=CF, freqs=[CF, CF + 40000], oversample=10, duration_s=0.6, seed=12, amplitude=0.3, noise_sigma=0.01)
+    iq8, _ = synth.synthesize(cfg, dtype=np.uint8)
+    o = oracle_mod.Oracle(CF, list(cfg.freqs), oversample=10, sample_fmt=oracle_mod.FMT_U8)
+    o.process(iq8)
+    rx, fr, cnt = gpu_decode(vh, cfg, iq8, fmt=0, chunks=(11, 50000), max_block=200000)
+    assert_frames_equal(o.frames(), fr, label="u8")
+    assert cnt == [list(o.counters(c).values()) for c in range(2)]
+
+
+@pytest.mark.parametrize("os_", [13, 16, 7])
+def test_other_oversampling_factors(vh, oracle_mod, os_):
+    """13 = Mirics rate (specialised build), 16 and 7 go through the generic-oversample build."""
+    from dumpvdl2_amd import synth
+    cfg = synth.SynthConfig(centerfreq=CF, freqs=[CF + 30000, CF - 60000], oversample=os_, duration_s=0.7, seed=40 + os_)
+    iq, bursts = synth.synthesize(cfg)
+    o = oracle_mod.Oracle(CF, list(cfg.freqs), oversample=os_)
+    o.process(iq.view(np.uint8))
+    rx, fr, cnt = gpu_decode(vh, cfg, iq, chunks=(1000, 100000), max_block=400000)
+    assert len(fr) > 0
+    assert_frames_equal(o.frames(), fr, label=f"os{os_}")
+    assert cnt == [list(o.counters(c).values()) for c in range(2)]
+
+
+def test_full_size_config2_properties(vh, oracle_mod):
+    """BASELINE configs[1] at full size (16 s, 8 channels): properties that need no oracle run -
+    every transmitted frame comes back on its channel, decoding is deterministic, and feeding the
+    stream in 7 pieces gives the same frames as feeding it at once - plus an oracle check on the
+    first 2 s of the very same bytes."""
+    from dumpvdl2_amd import workloads, synth
+    cfg = workloads.config2(16.0)
+    iq, bursts = synth.synthesize(cfg)
+    rx, fr, cnt = gpu_decode(vh, cfg, iq)
+    assert truth_is_subset(bursts, fr) == 0
+    assert len(fr) == sum(len(b.frames) for b in bursts if b.decodable)
+    rx2, fr2, cnt2 = gpu_decode(vh, cfg, iq, chunks=(3_000_000, 6_000_000), max_block=24_000_000)
+    key = lambda f: (f["chan"], f["burst_ord"], f["idx"])
+    assert [(key(f), f["octets"], f["sync_sample"], f["num_fec_corrections"]) for f in sorted(fr, key=key)] == \
+           [(key(f), f["octets"], f["sync_sample"], f["num_fec_corrections"]) for f in sorted(fr2, key=key)]
+    assert cnt == cnt2
+    n2 = 2 * cfg.sample_rate * 2                      # int16 values in the first 2 s
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=20)
+    o.process(iq[:n2].view(np.uint8), block_bytes=1 << 24, nthreads=8)
+    fo = o.frames()
+    head = [f for f in fr if f["end_sample"] < 2 * 105000 - 200]
+    fo = [f for f in fo if f["end_sample"] < 2 * 105000 - 200]
+    assert_frames_equal(fo, head, label="first 2 s vs oracle")

@@ -1,0 +1,58 @@
+"""The source of the walker (K4) and burst-decoder (K5) kernels, compiled for the CPU by
+tests/hostsim, against the oracle: fed with the oracle's own decimated samples it must
+reproduce frames, timing, metadata and counters exactly, for any chunking of the stream."""
+import numpy as np
+import pytest
+
+import cases
+import pyhostsim
+from util import assert_frames_equal
+
+
+def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None):
+    C = len(cfg.freqs)
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+    D = iq.size // 2 // cfg.oversample
+    tr = o.trace_all(D + 4)
+    o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=4)
+    D = o.decimated_count(0)
+    hs = pyhostsim.HostSim(list(cfg.freqs), cfg.rx_max_ppm, cap_log2=cap_log2 or int(np.ceil(np.log2(D + 70000))))
+    if chunks is None:
+        hs.feed(tr[:, :D, :])
+    else:
+        rng = np.random.default_rng(1); k = 0
+        while k < D:
+            m = min(D - k, int(rng.integers(*chunks))); hs.feed(tr[:, k:k + m, :]); k += m
+    fo, fh = o.frames(), hs.frames()
+    cnt_o = [list(o.counters(c).values()) for c in range(C)]
+    cnt_h = [hs.counters(c) for c in range(C)]
+    hs.close()
+    return fo, fh, cnt_o, cnt_h
+
+
+@pytest.mark.parametrize("name,chunks", [("config2_1s", None), ("config2_1s", (100, 30000)), ("config3_0p6s", None),
+                                         ("config4_0p4s", (3000, 50000)), ("config5_0p4s", None),
+                                         ("dirty25k_1s", (500, 20000)), ("os10_noisy_1s", (64, 5000))])
+def test_device_logic_matches_oracle(oracle_mod, name, chunks):
+    cfg, iq, _, _ = cases.load(name)
+    fo, fh, co, ch = run_both(oracle_mod, cfg, iq, chunks, cap_log2=17 if chunks else None)
+    assert_frames_equal(fo, fh, label=name)
+    for a, b in zip(fo, sorted(fh, key=lambda f: (f["chan"], f["burst_ord"], f["idx"]))):
+        pass
+    assert co == ch
+    # nf and ppm follow the reference's arithmetic exactly on identical input
+    fo = sorted(fo, key=lambda f: (f["chan"], f["burst_ord"], f["idx"])); fh = sorted(fh, key=lambda f: (f["chan"], f["burst_ord"], f["idx"]))
+    assert [f["nf_pwr_dbfs"] for f in fo] == [f["nf_pwr_dbfs"] for f in fh]
+    assert [f["ppm_error"] for f in fo] == [f["ppm_error"] for f in fh]
+
+
+def test_reference_wav(oracle_mod, golden_wav):
+    cf = 136975000
+    o = oracle_mod.Oracle(cf, [cf], oversample=10)
+    tr = o.trace_all(len(golden_wav) // 40 + 4)
+    o.process(golden_wav)
+    D = o.decimated_count(0)
+    hs = pyhostsim.HostSim([cf], 0.0, cap_log2=17)
+    for k in range(0, D, 7001):
+        hs.feed(tr[:, k:min(D, k + 7001), :])
+    assert_frames_equal(o.frames(), hs.frames(), label="wav")

@@ -1,0 +1,66 @@
+"""Pins the CPU oracle to the reference's own test vector and recorded known answers."""
+import numpy as np
+import pytest
+
+
+def test_reference_wav_two_frames(oracle_mod, golden_wav):
+    # the reference's CI runs exactly this input and greps two strings (.github/workflows/build.yml:16-18,57-62);
+    # intermediates below were recorded from the compiled reference in SURVEY.md section 4
+    cf = 136975000
+    o = oracle_mod.Oracle(cf, [cf], oversample=10)
+    o.process(golden_wav)      # whole file incl. the 44-byte RIFF header, as the reference reads it
+    fr = o.frames()
+    assert [len(f["octets"]) for f in fr] == [314, 186]
+    assert fr[0]["octets"][:12].hex() == "b2107684948a341f22544146" and fr[0]["octets"][-3:].hex() == "0a44bf"
+    assert fr[1]["octets"][:12].hex() == "b2107684948a341f344d4554" and fr[1]["octets"][-3:].hex() == "0a3ef9"
+    assert b" -RA BR OVC005\n" in fr[0]["octets"] and b" SLP135\n" in fr[1]["octets"]
+    for f in fr:
+        assert oracle_mod.crc16_x25(f["octets"]) == 0xF0B8          # avlc.c:40,177 good-FCS residual
+        assert (f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"]) == (0, 504, 0)
+        assert abs(f["frame_pwr_dbfs"] - (-9.841)) < 1e-3 and abs(f["nf_pwr_dbfs"] - 1.799) < 1e-3
+        assert f["sync_sample"] == 11972 + 3                        # "Preamble found at" prints samplenum - SYNC_SKIP
+    c = o.counters(0)
+    assert c["demod.sync.good"] == 1 and c["decoder.blocks.processed"] == 3 and c["decoder.blocks.fec_ok"] == 3
+    assert c["decoder.msg.good"] == 2
+
+
+def test_filter_coefficients_kat(oracle_mod):
+    # strict-IEEE values recorded from the reference build
+    import ctypes as C
+    L = oracle_mod.lib()
+    for os_, a0, b1, b2 in [(20, "0x1.0e48p-13", "0x1.f8215p+0", "-0x1.f08632p-1"),
+                            (10, "0x1.0a28p-11", "0x1.f03d0ap+0", "-0x1.e1843cp-1")]:
+        A = (C.c_float * 3)(); B = (C.c_float * 3)()
+        L.vdl2o_chebyshev(C.c_float(8000.0 / (105000.0 * os_)), C.c_float(0.5), A, B)
+        assert float(A[0]) == float.fromhex(a0) and float(A[2]) == float.fromhex(a0)
+        assert float(A[1]) == 2 * float.fromhex(a0)
+        assert float(B[1]) == float.fromhex(b1) and float(B[2]) == float.fromhex(b2)
+
+
+def test_nco_step_fp32_rounding(oracle_mod):
+    # demod.c:385 converts both frequencies to fp32 first: 250 000 Hz becomes 250 016 Hz
+    cf = 136975000
+    o = oracle_mod.Oracle(cf, [136725000, 137000000], oversample=20)
+    fs = 2100000
+    assert o.dphi(0) == int(np.float32(np.float32(cf) - np.float32(136725000)) / np.float32(fs) * np.float32(256.0) * np.float32(65536.0))
+    assert abs(o.dphi(0) / 2 ** 24 * fs - 250016) < 1
+    assert o.dphi(1) == (int(-25000 / fs * 2 ** 24) & 0xFFFFFFFF) or abs(((o.dphi(1) ^ 0xFFFFFFFF) + 1) / 2 ** 24 * fs - 25000) < 20
+
+
+def test_header_code_table(oracle_mod):
+    import ctypes as C
+    L = oracle_mod.lib()
+    # synd_weight row of decode.c:98-100 (data): weight of the pattern each syndrome corrects
+    weight = [0, 1, 1, 2, 1, 2, 1, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1, 1, 2, 1, 2, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1]
+    seen = set()
+    for tl in (0, 1, 4029, 0x1FFFF):
+        word = (tl << 5) | L.vdl2o_header_parity(tl)
+        w = C.c_uint32(word)
+        assert L.vdl2o_header_decode(C.byref(w)) == 0 and w.value == word
+        for bit in range(25):                      # every single-bit error is corrected
+            w = C.c_uint32(word ^ (1 << bit))
+            s = L.vdl2o_header_decode(C.byref(w))
+            assert w.value == word and weight[s] == 1
+            seen.add(s)
+    assert len(seen) == 25
+    assert sorted(set(range(1, 32)) - seen) == [3, 5, 13, 18, 20, 23]   # the six double-error syndromes

@@ -1,0 +1,63 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+EXACT_KEYS = ("chan", "idx", "octets", "synd_weight", "datalen_octets", "num_fec_corrections", "burst_ord")
+# tolerances from SURVEY.md 8.5 (floats are compared, not bit-matched: the time-parallel
+# filter cannot reproduce the reference's rounding sequence)
+TOL_DB = 0.05
+TOL_PPM = 0.01
+
+
+def frame_key(f):
+    return (f["chan"], f["burst_ord"], f["idx"])
+
+
+def assert_frames_equal(ref, got, exact_samples=True, label=""):
+    """ref/got: lists of frame dicts.  Octets and integer metadata must match exactly."""
+    ref = sorted(ref, key=frame_key)
+    got = sorted(got, key=frame_key)
+    assert len(ref) == len(got), f"{label}: frame count {len(got)} != reference {len(ref)}"
+    for a, b in zip(ref, got):
+        for k in EXACT_KEYS:
+            assert a[k] == b[k], f"{label}: frame {frame_key(a)} field {k}: {b[k]!r} != {a[k]!r}"
+        if exact_samples:
+            assert a["sync_sample"] == b["sync_sample"] and a["end_sample"] == b["end_sample"], \
+                f"{label}: frame {frame_key(a)} timing {b['sync_sample']},{b['end_sample']} != {a['sync_sample']},{a['end_sample']}"
+        assert abs(a["frame_pwr_dbfs"] - b["frame_pwr_dbfs"]) <= TOL_DB, f"{label}: frame_pwr {a['frame_pwr_dbfs']} vs {b['frame_pwr_dbfs']}"
+        assert abs(a["nf_pwr_dbfs"] - b["nf_pwr_dbfs"]) <= TOL_DB, f"{label}: nf_pwr {a['nf_pwr_dbfs']} vs {b['nf_pwr_dbfs']}"
+        assert abs(a["ppm_error"] - b["ppm_error"]) <= TOL_PPM, f"{label}: ppm {a['ppm_error']} vs {b['ppm_error']}"
+
+
+def frames_multiset(frames):
+    return sorted((f["chan"], f["idx"], f["octets"]) for f in frames)
+
+
+def truth_is_subset(bursts, frames):
+    """Every frame of every decodable transmitted burst must appear on its channel, in order."""
+    from collections import defaultdict
+    got = defaultdict(list)
+    for f in sorted(frames, key=lambda f: (f["chan"], f["end_sample"], f["idx"])):
+        got[f["chan"]].append(f["octets"])
+    missing = 0
+    for ch in set(b.chan for b in bursts):
+        want = [fr for b in sorted((b for b in bursts if b.chan == ch), key=lambda b: b.start_sample) if b.decodable for fr in b.frames]
+        have = got.get(ch, [])
+        pos = 0
+        for w in want:
+            try:
+                pos = have.index(w, pos) + 1
+            except ValueError:
+                missing += 1
+    return missing
+
+
+def run_oracle(po, cfg, raw, nthreads=4, trace=False):
+    import numpy as np
+    o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+    tr = None
+    if trace:
+        D = raw.size // 4 // cfg.oversample
+        tr = o.trace_all(D + 4)
+    o.process(np.ascontiguousarray(raw).view(np.uint8), block_bytes=1 << 24, nthreads=nthreads)
+    fr = o.frames()
+    return o, fr, tr
