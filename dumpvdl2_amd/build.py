@@ -37,5 +37,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_dropin(force=False):
+    """Compile the reference-named C adapter (csrc/dropin.c) to an object a dumpvdl2 tree (or the test harness) links."""
+    src = os.path.join(CSRC, "dropin.c")
+    obj = os.path.join(HERE, "vdl2hip_dropin.o")
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(inc, "vdl2hip_dropin.h"))):
+        subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Wall", "-Wextra", "-fPIC", "-I", inc, "-c", src, "-o", obj])
+    return obj
+
+
+def build_harness(out_path):
+    """Link tests/dropin_harness.c (stand-in for the unmodified dumpvdl2 main) against the adapter and libvdl2hip.so."""
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "dropin_harness.c"), build_dropin(), "-L", HERE, "-lvdl2hip",
+                           "-Wl,-rpath," + HERE, "-lpthread", "-o", out_path])
+    return out_path
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -163,3 +163,25 @@ def test_full_size_config2_properties(vh, oracle_mod):
     head = [f for f in fr if f["end_sample"] < 2 * 105000 - 200]
     fo = [f for f in fo if f["end_sample"] < 2 * 105000 - 200]
     assert_frames_equal(fo, head, label="first 2 s vs oracle")
+
+
+def test_dropin_adapter_with_reference_main_sequence(vh, oracle_mod, golden_wav, tmp_path):
+    """The reference-named entry points (include/vdl2hip_dropin.h) driven by a stand-in for the
+    unmodified dumpvdl2 main(): same call sequence, barriers and thread-per-channel as src/dumpvdl2.c;
+    the frames arriving at avlc_decoder_queue_push() must be the oracle's."""
+    import os, subprocess
+    from dumpvdl2_amd import build
+    exe = build.build_harness(str(tmp_path / "dropin_harness"))
+    wav = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "vdl2_model_16b_1050kHz.wav")
+    out = subprocess.run([exe, wav, "10", str(CF), str(CF)], check=True, capture_output=True, text=True, timeout=120).stdout
+    lines = [l for l in out.splitlines() if l.startswith("FRAME")]
+    o = oracle_mod.Oracle(CF, [CF], oversample=10)
+    o.process(golden_wav)
+    ref = o.frames()
+    assert len(lines) == len(ref) == 2
+    for l, f in zip(lines, ref):
+        kv = dict(t.split("=", 1) for t in l.split()[1:])
+        assert bytes.fromhex(kv["octets"]) == f["octets"]
+        assert (int(kv["idx"]), int(kv["S"]), int(kv["L"]), int(kv["F"]), int(kv["freq"])) == (f["idx"], f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"], CF)
+        assert abs(float(kv["pwr"]) - f["frame_pwr_dbfs"]) < 0.05 and abs(float(kv["nf"]) - f["nf_pwr_dbfs"]) < 0.05
+        assert kv["station"] == "HARNESS" and kv["flags"] == "0"
