@@ -78,13 +78,14 @@ def main():
             vdist.broadcast_block(dev_iq, src=0)
             torch.cuda.current_stream().synchronize()      # the library runs on its own stream
         rx.feed_device(dev_iq.data_ptr(), nbytes)
-        return rx.drain()
+        return rx.drain_packed()            # every frame of the step copied to host memory (records + octets)
 
     # ---- warm-up, with the parity gate on the first pass ----
     verified = None
     for w in range(max(args.warmup, 1)):
-        fr = step()
+        n, recs, octs = step()
         if w == 0 and rank == 0 and not args.no_verify:
+            fr = vdl2hip.Receiver.unpack(n, recs, octs)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from util import truth_is_subset, assert_frames_equal
             missing = truth_is_subset(bursts, fr)
@@ -108,7 +109,7 @@ def main():
     t0 = time.perf_counter()
     nframes = 0
     for _ in range(args.steps):
-        nframes += len(step())
+        nframes += step()[0]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

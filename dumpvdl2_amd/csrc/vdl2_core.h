@@ -56,6 +56,28 @@
 #define VDL2_CNT_ADD(arr, which, val) ((arr)[which] += (unsigned long long)(val))
 #endif
 
+// optional per-phase cycle probe of the burst decoder (development aid; compiled out by default)
+#if defined(__HIPCC__) && defined(VDL2_K5_PROF)
+__device__ unsigned long long vdl2_k5_prof[16];
+__device__ unsigned long long vdl2_k4_prof[16];
+#endif
+#if VDL2_DEVICE_PASS && defined(VDL2_K5_PROF)
+#define K4_BEGIN() unsigned long long k4_t0_ = __builtin_readcyclecounter()
+#define K4_MARK(k) do { if(VDL2_LANE() == 0) { unsigned long long t_ = __builtin_readcyclecounter(); \
+	atomicAdd(&vdl2_k4_prof[k], t_ - k4_t0_); atomicAdd(&vdl2_k4_prof[8 + k], 1ull); k4_t0_ = t_; } } while(0)
+#else
+#define K4_BEGIN() do {} while(0)
+#define K4_MARK(k) do {} while(0)
+#endif
+#if VDL2_DEVICE_PASS && defined(VDL2_K5_PROF)
+#define K5_MARK(k) do { if(VDL2_LANE() == 0) { unsigned long long t_ = __builtin_readcyclecounter(); \
+	atomicMax(&vdl2_k5_prof[k], t_ - k5_t0_); atomicAdd(&vdl2_k5_prof[8 + k], t_ - k5_t0_); k5_t0_ = t_; } } while(0)
+#define K5_BEGIN() unsigned long long k5_t0_ = __builtin_readcyclecounter()
+#else
+#define K5_MARK(k) do {} while(0)
+#define K5_BEGIN() do {} while(0)
+#endif
+
 namespace vdl2 {
 
 // ---- constants (dumpvdl2.h:37-50, demod.c:37-48, decode.c:45-50) ----
@@ -69,6 +91,8 @@ constexpr int kMaxSyms = 5632;            // >= ceil((8*(2048+52)+25)/3) = 5609
 constexpr int kPrbsBits = kMaxSyms * 3;
 constexpr int kMaxOctets = 2112;          // 2048 data + 52 FEC, rounded up
 constexpr int kMaxBlocks = 9;
+constexpr int kMaxWords = 512;            // 16 384 bits of corrected data
+constexpr int kMaxTerm = 2048;            // a flag needs 8 bits
 constexpr int kFreshAfter = 156;          // evaluations at n >= a+156: n, n-3, n-6 touch only the current interval
 constexpr int kNumIv = 32;                // DM_INIT interval history (160/6 < 32 intervals can matter)
 constexpr int kNumRun = 32;               // evaluation-run history for the noise-floor lookback
@@ -265,17 +289,31 @@ VDL2_HD Geometry header_to_geometry(uint32_t hdr, const Tables &T) {
 // Walker: the per-channel sequential FSM of demod()/got_sync(), hopping
 // between the sparse places where something can happen.
 // ======================================================================
+constexpr int kLpGroup = 16;               // noise-floor updates replayed per pass
 struct WalkShared {
 	WalkState st;
 	float p[64], f[64], lp[64];
 	int32_t found[64];
+	int32_t flag[64];
 	int32_t sym[16];
 	int32_t neg[16];
+	float mags[kLpGroup][kLpTerms + 1];    // +1: row padding keeps the per-lane replay off one LDS bank
 	// scalars published by LANE0 sections
-	int32_t u_fire, u_count, u_stop;
-	int64_t u_n;
 	float u_y1, u_y2, u_y3, u_prevd;
 };
+
+// lowest lane whose flag is set, or -1.  Call from wave-uniform code after a WAVE_END.
+#if VDL2_DEVICE_PASS
+VDL2_HD int wave_first_flag(const int32_t *flags) {
+	const unsigned long long b = __ballot(flags[VDL2_LANE()] != 0);
+	return b ? (int)__ffsll((long long)b) - 1 : -1;
+}
+#else
+VDL2_HD int wave_first_flag(const int32_t *flags) {
+	for(int l = 0; l < 64; l++) if(flags[l]) return l;
+	return -1;
+}
+#endif
 
 // absolute index of the DM_INIT sample d steps before n (n inside the current interval); -1 = before the stream
 VDL2_HD int64_t seq_index(const WalkState &st, int64_t n, int d) {
@@ -304,53 +342,68 @@ VDL2_HD void push_run(WalkState &st, int64_t first, int64_t last) {
 	if(st.nrun < kNumRun) st.nrun++;
 }
 
-// v->mag_lp right after the evaluation at m (m on the current run): the reference's
-// recurrence mag_lp = mag_lp*0.9 + mag*0.1 (demod.c:239) replayed over the last
-// kLpTerms evaluations, oldest first.
-VDL2_HD float mag_lp_at(const WalkState &st, const ChanView &v, int64_t m) {
-	int64_t ncur = (m - st.e0) / 3 + 1;
-	int run = -1;            // -1 = current run
-	int64_t pos = st.e0;     // start position (oldest evaluation to replay)
-	int64_t have = ncur;
-	if(ncur >= kLpTerms) {
-		pos = m - 3 * (int64_t)(kLpTerms - 1);
-	} else {
-		for(int i = 0; i < st.nrun && have < kLpTerms; i++) {
-			int64_t len = (st.runl[i] - st.runf[i]) / 3 + 1;
-			run = i;
-			if(have + len >= kLpTerms) { pos = st.runl[i] - 3 * (kLpTerms - have - 1); have = kLpTerms; }
-			else { pos = st.runf[i]; have += len; }
-		}
+// position of the j-th evaluation before m (j = 0: m itself) in the sequence of executed
+// got_sync() evaluations (current run, then the closed runs), or -1 when history is exhausted
+VDL2_HD int64_t eval_index(const WalkState &st, int64_t m, int64_t j) {
+	const int64_t ncur = (m - st.e0) / 3 + 1;
+	if(j < ncur) return m - 3 * j;
+	j -= ncur;
+	for(int i = 0; i < st.nrun; i++) {
+		const int64_t len = (st.runl[i] - st.runf[i]) / 3 + 1;
+		if(j < len) return st.runl[i] - 3 * j;
+		j -= len;
 	}
-	float lp = 0.f;
-	for(;;) {
-		float mag = mag_of(v.Y(pos));
-		lp = lp * 0.9f + mag * (1.0f - 0.9f);
-		if(run < 0) { if(pos >= m) break; pos += 3; }
-		else if(pos >= st.runl[run]) { run--; pos = (run < 0) ? st.e0 : st.runf[run]; }
-		else pos += 3;
-	}
-	return lp;
+	return -1;
 }
 
-// `count` evaluations starting at `first` (step 3) are being executed: account nfcnt and
-// the mag_nf updates that fall among them (demod.c:238-243).
+// `count` evaluations starting at `first` (step 3, all on the current run) are being executed:
+// account nfcnt and the mag_nf updates that fall among them (demod.c:238-243).  v->mag_lp at an
+// update is the reference's recurrence mag_lp = mag_lp*0.9 + mag*0.1 (demod.c:239) replayed over
+// the last kLpTerms evaluations: the wave gathers the magnitudes of kLpGroup updates at once
+// (independent loads), then one lane per update replays them oldest first.
 VDL2_HD void account_evals(WalkShared &sh, const ChanView &v, int64_t first, int64_t count) {
 	if(count <= 0) return;
 	const int32_t nf0 = sh.st.nfcnt;
 	const int64_t total = (int64_t)nf0 + count;
 	const int64_t nupd = total / 1000;
-	for(int64_t base = 0; base < nupd; base += 64) {
+	for(int64_t base = 0; base < nupd; base += kLpGroup) {
+		const int ng = (int)(nupd - base < kLpGroup ? nupd - base : kLpGroup);
 		WAVE_FOR(l)
-			int64_t u = base + l;
-			if(u < nupd) {
-				int64_t i = 1000 * (u + 1) - nf0 - 1;
-				sh.lp[l] = mag_lp_at(sh.st, v, first + 3 * i);
+			// 8 independent loads in flight per lane before anything waits on them
+			for(int idx0 = l; idx0 < ng * kLpTerms; idx0 += 64 * 8) {
+				cf32 yv[8]; bool have[8];
+				for(int q = 0; q < 8; q++) {
+					const int idx = idx0 + 64 * q;
+					have[q] = false; yv[q] = cf32{0.f, 0.f};
+					if(idx < ng * kLpTerms) {
+						const int u = idx / kLpTerms, j = idx - u * kLpTerms;
+						const int64_t m = first + 3 * (1000 * (base + u + 1) - nf0 - 1);
+						const int64_t pos = eval_index(sh.st, m, j);
+						if(pos >= 0) { have[q] = true; yv[q] = v.Y(pos); }
+					}
+				}
+				for(int q = 0; q < 8; q++) {
+					const int idx = idx0 + 64 * q;
+					if(idx < ng * kLpTerms) {
+						const int u = idx / kLpTerms, j = idx - u * kLpTerms;
+						sh.mags[u][j] = have[q] ? mag_of(yv[q]) : -1.f;
+					}
+				}
+			}
+		WAVE_END
+		WAVE_FOR(l)
+			if(l < ng) {
+				float lp = 0.f;
+				for(int j = kLpTerms - 1; j >= 0; j--) {
+					const float mg = sh.mags[l][j];
+					if(mg >= 0.f) lp = lp * 0.9f + mg * (1.0f - 0.9f);
+				}
+				sh.lp[l] = lp;
 			}
 		WAVE_END
 		LANE0
 			float nf = sh.st.mag_nf;
-			for(int l = 0; l < 64 && base + l < nupd; l++)
+			for(int l = 0; l < ng; l++)
 				nf = 0.85f * nf + (1.0f - 0.85f) * fminf(sh.lp[l], nf) + 0.0001f;
 			sh.st.mag_nf = nf;
 		LANE0_END
@@ -370,14 +423,17 @@ VDL2_HD void restart_search(WalkState &st, int64_t a) {
 // Process one channel up to (not including) decimated sample k_end.
 VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end, const Tables &T,
 		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, OutCtl *ctl, WalkShared &sh) {
+	K4_BEGIN();
 	LANE0
 		sh.st = *gstate;
 	LANE0_END
+	K4_MARK(0);
 	for(;;) {
 		if(sh.st.mode == 0) {
 			const int64_t e = sh.st.e;
 			if(e >= k_end) break;
 			int fired = 0;
+			int64_t fire_n = 0;
 			if(e < sh.st.a + kFreshAfter) {
 				// ---- explicit evaluations near an interval start (ring still holds pre-burst samples) ----
 				int64_t lim = sh.st.a + kFreshAfter; if(lim > k_end) lim = k_end;
@@ -390,28 +446,39 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 						sync_metric(ph, T, sh.p[l], sh.f[l]);
 					}
 				WAVE_END
+				WAVE_FOR(l)
+					const float pm1 = l ? sh.p[l - 1] : sh.st.pherr1;
+					sh.flag[l] = (l < nb && pm1 < kSyncThr && sh.p[l] > pm1) ? 1 : 0;
+				WAVE_END
+				const int jf = wave_first_flag(sh.flag);
+				const int64_t nexec = jf >= 0 ? jf + 1 : nb;
 				LANE0
-					float p1 = sh.st.pherr1, p2 = sh.st.pherr2, pd = sh.st.prev_dphi;
-					int j = 0; sh.u_fire = 0;
-					for(; j < nb; j++) {
-						float p0 = sh.p[j];
-						if(p1 < kSyncThr && p0 > p1) { sh.u_fire = 1; sh.u_y1 = p2; sh.u_y2 = p1; sh.u_y3 = p0; sh.u_prevd = pd; break; }
-						p2 = p1; p1 = p0; pd = sh.f[j];
+					WalkState &st = sh.st;
+					if(jf >= 0) {
+						sh.u_y3 = sh.p[jf];
+						sh.u_y2 = jf >= 1 ? sh.p[jf - 1] : st.pherr1;
+						sh.u_y1 = jf >= 2 ? sh.p[jf - 2] : (jf == 1 ? st.pherr1 : st.pherr2);
+						sh.u_prevd = jf >= 1 ? sh.f[jf - 1] : st.prev_dphi;
+					} else {
+						const float o1 = st.pherr1;
+						st.pherr1 = sh.p[nb - 1];
+						st.pherr2 = nb >= 2 ? sh.p[nb - 2] : o1;
+						st.prev_dphi = sh.f[nb - 1];
+						st.e = e + 3 * nb;
 					}
-					sh.u_count = sh.u_fire ? j + 1 : (int32_t)nb;
-					sh.u_n = e + 3 * (int64_t)j;
-					if(!sh.u_fire) { sh.st.pherr1 = p1; sh.st.pherr2 = p2; sh.st.prev_dphi = pd; sh.st.e = e + 3 * nb; }
 				LANE0_END
-				account_evals(sh, v, e, sh.u_count);
-				fired = sh.u_fire;
+				K4_MARK(1);
+				account_evals(sh, v, e, nexec);
+				K4_MARK(2);
+				fired = jf >= 0;
+				fire_n = e + 3 * (int64_t)(jf >= 0 ? jf : 0);
 			} else {
 				// ---- hop over the candidate bitmap (got_sync() can only fire where a bit is set) ----
 				// the first evaluation of a run cannot fire (pherr[1] is still PHERR_MAX): start at max(e, e0+3)
 				const int64_t start = e > sh.st.e0 + 3 ? e : sh.st.e0 + 3;
 				int64_t w0 = start >> 6;
 				const int64_t wend = (k_end + 63) >> 6;
-				sh.u_fire = 0;
-				for(; w0 < wend && !sh.u_fire; w0 += 64) {
+				for(; w0 < wend && !fired; w0 += 64) {
 					WAVE_FOR(l)
 						int64_t w = w0 + l;
 						int32_t hit = -1;
@@ -427,27 +494,28 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 							if(bits) { int b = 0; while(!((bits >> b) & 1)) b++; hit = b; }
 						}
 						sh.found[l] = hit;
+						sh.flag[l] = hit >= 0;
 					WAVE_END
-					LANE0
-						for(int l = 0; l < 64; l++) if(sh.found[l] >= 0) { sh.u_fire = 1; sh.u_n = ((w0 + l) << 6) + sh.found[l]; break; }
-					LANE0_END
+					const int lf = wave_first_flag(sh.flag);
+					if(lf >= 0) { fired = 1; fire_n = ((w0 + lf) << 6) + sh.found[lf]; }
 				}
-				if(sh.u_fire) {
-					const int64_t n = sh.u_n;
+				K4_MARK(3);
+				if(fired) {
+					const int64_t n = fire_n;
 					LANE0
 						sh.u_y1 = (n - 6 >= sh.st.e0) ? v.PF(n - 6).re : kPherrBig;
 						sh.u_y2 = v.PF(n - 3).re;
 						sh.u_y3 = v.PF(n).re;
 						sh.u_prevd = v.PF(n - 3).im;
-						sh.u_count = (int32_t)((n - e) / 3 + 1);
 					LANE0_END
-					account_evals(sh, v, e, sh.u_count);
-					fired = 1;
+					account_evals(sh, v, e, (n - e) / 3 + 1);
+					K4_MARK(2);
 				} else {
 					// nothing up to k_end: park just past the last evaluation that exists
 					const int64_t cnt_ev = (k_end - 1 - e) / 3 + 1;     // e < k_end here
 					const int64_t nl = e + 3 * (cnt_ev - 1);
 					account_evals(sh, v, e, cnt_ev);
+					K4_MARK(2);
 					LANE0
 						sh.st.pherr1 = v.PF(nl).re;
 						sh.st.pherr2 = (nl - 3 >= sh.st.e0) ? v.PF(nl - 3).re : kPherrBig;
@@ -457,10 +525,11 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 				}
 			}
 			if(fired) {
+				K4_MARK(4);
 				// ---- got_sync() success branch: demod.c:173-193 ----
 				LANE0
 					WalkState &st = sh.st;
-					const int64_t n = sh.u_n;
+					const int64_t n = fire_n;
 					float vx = parabola_vertex(sh.u_y1, sh.u_y2, sh.u_y3);
 					int sclk = (int)(-roundf(vx));
 					float prev_phi0 = v.Phi(seq_index(st, n, sclk));
@@ -484,6 +553,7 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 					}
 				LANE0_END
 			}
+			K4_MARK(5);
 		} else if(sh.st.mode == 1) {
 			// ---- header: 9 symbols = 27 bits, of which 25 are the header (decode.c:198-258) ----
 			const int64_t t8 = sh.st.pb.t_first + 8 * kSpsDec;
@@ -519,6 +589,7 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 					st.mode = 2;
 				}
 			LANE0_END
+			K4_MARK(6);
 		} else {
 			// ---- burst body: wait until its last symbol has arrived, then hand it to the burst decoder ----
 			if(sh.st.pb.end_sample >= k_end) break;
@@ -534,9 +605,11 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 			LANE0_END
 		}
 	}
+	K4_MARK(7);
 	LANE0
 		*gstate = sh.st;
 	LANE0_END
+	K4_MARK(0);
 }
 
 // ======================================================================
@@ -546,12 +619,22 @@ struct BurstShared {
 	uint8_t sym[kMaxSyms];             // 3-bit Gray values, one per symbol
 	uint8_t oct[kMaxOctets];           // received data + FEC octets (still interleaved)
 	uint8_t tab[kMaxBlocks * 256];     // de-interleaved RS blocks, row stride 256
-	uint8_t fo[kMaxOctets];            // un-stuffed frame under construction
+	uint32_t xw[kMaxWords + 1];        // corrected data as 32-bit words, stream bit 32w+k = bit k of xw[w]
+	uint32_t keptw[kMaxWords + 1];     // bits that survive zero-deletion (valid and not a stuffed zero)
+	uint32_t termw[kMaxWords];         // flag terminators (a 0 after exactly six 1s)
+	uint16_t cumk[kMaxWords + 1];      // kept bits before word w
+	uint16_t cumt[kMaxWords + 1];      // terminators before word w
+	uint16_t tpos[kMaxTerm];           // terminator positions, ascending
+	uint16_t tG[kMaxTerm];             // kept bits before each terminator
+	uint32_t lanek[64], lanet[64];
+	int32_t  laneerr[64];
+	int32_t  flag_err[64];
 	uint8_t synp[kRsPar][64];          // per-lane syndrome partials
+	uint8_t syn[8];
 	float   pw[64];
 	int32_t neg[64];
-	int32_t u_ret, u_more, u_flen, u_ok;
-	uint32_t u_pos, u_slot, u_off;
+	int32_t u_ret, u_kind, u_ok;
+	uint32_t u_k, u_sprev, u_lastend, u_S, u_L, u_off;
 	float u_pwr;
 };
 
@@ -637,40 +720,8 @@ VDL2_HD int rs_correct(uint8_t *d, const uint8_t syn_poly[kRsPar], int n_era, co
 	return count;
 }
 
-// bitstream_copy_next_frame() (bitstream.c:109-150) reading the re-serialised RS rows directly and
-// packing the un-stuffed bits into octets.  Sequential.  Returns 1 more / 0 last / -1 invalid;
-// *flen_bits = length of the extracted frame in bits.
-VDL2_HD int next_hdlc_frame(const uint8_t *tab, uint32_t *pos, uint32_t end, uint8_t *fo, uint32_t *flen_bits) {
-	auto BIT = [&](uint32_t i) -> uint32_t {
-		uint32_t o = i >> 3, r = o / kRsK, c = o - r * kRsK;
-		return (tab[r * 256 + c] >> (i & 7)) & 1u;
-	};
-	for(;;) {
-		int ones = 0, again = 0;
-		uint32_t j = 0, dlen = 0;
-		for(uint32_t i = *pos; i < end; i++, (*pos)++) {
-			uint32_t b = BIT(i);
-			if(b == 0 && ones == 5) { ones = 0; continue; }
-			if(b == 1 && ++ones > 6) return -1;
-			if((j & 7) == 0) fo[j >> 3] = 0;
-			fo[j >> 3] |= (uint8_t)(b << (j & 7));
-			if(b == 0) {
-				if(ones == 6) {
-					if(j == 7) { (*pos)++; again = 1; break; }
-					if(j < 7) return -1;
-					(*pos)++;
-					*flen_bits = j - 7;
-					return *pos < end ? 1 : 0;
-				}
-				ones = 0;
-			}
-			j++; dlen++;
-		}
-		if(again) continue;
-		*flen_bits = dlen;
-		return *pos < end ? 1 : 0;
-	}
-}
+VDL2_HD int popc32(uint32_t v) { return __builtin_popcount(v); }
+VDL2_HD int ctz32(uint32_t v) { return __builtin_ctz(v); }
 
 // decode_vdl2_burst() DEC_DATA branch + decode_frame(): decode.c:259-380, 173-194
 VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const ChanView &v, unsigned long long *cnt,
@@ -684,6 +735,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 	if(last == 0) last = kRsK;
 	const int npar_last = fec_octets_for(last);
 	const int nsym = b.nsym;
+	K5_BEGIN();
 
 	// 1. slice every symbol (demod.c:252-274); decisions are independent because prev_phi is the raw phase
 	WAVE_FOR(l)
@@ -706,6 +758,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		if(negs) VDL2_CNT_ADD(cnt, CNT_SLICER_NEG_IDX, negs);
 	LANE0_END
 
+	K5_MARK(0);
 	// 2. descramble + pack data and FEC octets LSB-first (bitstream.c:70-81,94-107)
 	const uint32_t ntot = octets + fec;
 	WAVE_FOR(l)
@@ -721,6 +774,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		for(uint32_t i = l; i < nblk * 256; i += 64) sh.tab[i] = 0;
 	WAVE_END
 
+	K5_MARK(1);
 	// 3. de-interleave (closed form of decode.c:135-163): column-major, the last row is shorter
 	uint32_t fec_rows = nblk; if(npar_last == 0) fec_rows--;
 	uint32_t flast = fec % kRsPar; if(flast == 0) flast = kRsPar;
@@ -739,6 +793,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		}
 	WAVE_END
 
+	K5_MARK(2);
 	// 4. Reed-Solomon per block (decode.c:305-334, rs.c:32-49)
 	int fec_fixed = 0; int failed = 0;
 	for(uint32_t r = 0; r < nblk && !failed; r++) {
@@ -757,13 +812,16 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 				}
 				for(int i = 0; i < kRsPar; i++) sh.synp[i][l] = acc[i];
 			WAVE_END
+			WAVE_FOR(l)
+				if(l < kRsPar) { uint8_t a = 0; for(int q = 0; q < 64; q++) a ^= sh.synp[l][q]; sh.syn[l] = a; }
+			WAVE_END
 		}
 		LANE0
 			VDL2_CNT_ADD(cnt, CNT_BLOCKS_PROCESSED, 1);
 			int ret = 0;
 			if(npar != 0) {
 				uint8_t syn[kRsPar];
-				for(int i = 0; i < kRsPar; i++) { uint8_t a = 0; for(int l = 0; l < 64; l++) a ^= sh.synp[i][l]; syn[i] = a; }
+				for(int i = 0; i < kRsPar; i++) syn[i] = sh.syn[i];
 				int n_era = kRsPar - npar, era[kRsPar];
 				for(int i = 0; i < n_era; i++) era[i] = kRsK + npar + i;
 				ret = rs_correct(row, syn, n_era, era, T);
@@ -776,23 +834,109 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		else if(sh.u_ret > 0) fec_fixed += sh.u_ret - (kRsPar - npar);
 	}
 	if(failed) return;
+	K5_MARK(3);
 
-	// 5. truncate to TL bits, un-stuff, emit frames (decode.c:338-373)
+	// 5. re-serialise the corrected rows LSB-first (decode.c:325-328), truncate to TL bits (decode.c:338-342),
+	//    then bitstream_copy_next_frame() (bitstream.c:109-150) for the whole burst at once:
+	//    with R(i) = length of the run of 1s ending just before bit i (the reference's `ones`),
+	//      stuffed zero  : x[i]=0, R=5          flag terminator : x[i]=0, R=6          error : x[i]=1, R>=6
+	//    a segment between terminators with j kept bits before its terminator is a leading flag (j=7,
+	//    skipped), an error (j<7) or a frame of j-7 bits; what follows the last terminator is the tail frame.
 	uint32_t nbits = 8 * octets; if(b.tl_bits < nbits) nbits = b.tl_bits;
+	const int nw = (int)((nbits + 31) / 32);
+	WAVE_FOR(l)
+		for(int w = l; w <= nw; w += 64) {
+			uint32_t x = 0;
+			for(int k = 0; k < 4; k++) {
+				const uint32_t i = 4u * (uint32_t)w + (uint32_t)k;
+				if(i < octets) { const uint32_t r = i / kRsK; x |= (uint32_t)sh.tab[r * 256 + (i - r * kRsK)] << (8 * k); }
+			}
+			sh.xw[w] = x;
+		}
+	WAVE_END
+	WAVE_FOR(l)
+		// lane l owns words 8l .. 8l+7
+		uint32_t ck = 0, ct = 0; int32_t err = -1;
+		for(int q = 0; q < 8; q++) {
+			const int w = 8 * l + q;
+			if(w >= nw) break;
+			const uint64_t z = ((uint64_t)sh.xw[w] << 32) | (w ? sh.xw[w - 1] : 0u);
+			const uint64_t s1 = z << 1, s2 = s1 & (z << 2), s3 = s2 & (z << 3), s4 = s3 & (z << 4);
+			const uint64_t s5 = s4 & (z << 5), s6 = s5 & (z << 6), s7 = s6 & (z << 7);
+			const uint32_t rem = nbits - 32u * (uint32_t)w;
+			const uint32_t valid = rem >= 32 ? 0xffffffffu : ((1u << rem) - 1u);
+			const uint32_t stuffed = (uint32_t)((~z & s5 & ~s6) >> 32) & valid;
+			const uint32_t term = (uint32_t)((~z & s6 & ~s7) >> 32) & valid;
+			const uint32_t bad = (uint32_t)((z & s6) >> 32) & valid;
+			sh.keptw[w] = valid & ~stuffed;
+			sh.termw[w] = term;
+			ck += (uint32_t)popc32(valid & ~stuffed); ct += (uint32_t)popc32(term);
+			if(bad && err < 0) err = 32 * w + ctz32(bad);
+		}
+		sh.lanek[l] = ck; sh.lanet[l] = ct; sh.laneerr[l] = err;
+	WAVE_END
+	WAVE_FOR(l)
+		uint32_t bk = 0, bt = 0;
+		for(int q = 0; q < l; q++) { bk += sh.lanek[q]; bt += sh.lanet[q]; }
+		for(int q = 0; q < 8; q++) {
+			const int w = 8 * l + q;
+			if(w > nw) break;
+			sh.cumk[w] = (uint16_t)bk; sh.cumt[w] = (uint16_t)bt;
+			if(w < nw) {
+				uint32_t t = sh.termw[w];
+				const uint32_t kw = sh.keptw[w];
+				uint32_t r = bt;
+				while(t) {
+					const int bit = ctz32(t); t &= t - 1;
+					if(r < (uint32_t)kMaxTerm) { sh.tpos[r] = (uint16_t)(32 * w + bit); sh.tG[r] = (uint16_t)(bk + (uint32_t)popc32(kw & ((1u << bit) - 1u))); }
+					r++;
+				}
+				bk += (uint32_t)popc32(kw); bt += (uint32_t)popc32(sh.termw[w]);
+			}
+		}
+		sh.flag_err[l] = sh.laneerr[l] >= 0;
+	WAVE_END
+	const int le = wave_first_flag(sh.flag_err);
+	const uint32_t E = le >= 0 ? (uint32_t)sh.laneerr[le] : 0xffffffffu;      // first "seven ones" position
+	const uint32_t nterm = sh.cumt[nw];
+	const uint32_t gtotal = sh.cumk[nw];
 	LANE0
-		sh.u_pos = 0;
+		sh.u_k = 0; sh.u_sprev = 0; sh.u_lastend = 0xffffffffu;
 	LANE0_END
+	K5_MARK(4);
 	int nframes = 0;
 	for(;;) {
+		// one lane walks the (few) terminators to the next frame, error or the tail
 		LANE0
-			uint32_t pos = sh.u_pos, flen = 0;
-			int ret = next_hdlc_frame(sh.tab, &pos, nbits, sh.fo, &flen);
-			sh.u_pos = pos; sh.u_more = ret; sh.u_flen = (int32_t)flen; sh.u_ok = 0;
-			if(ret < 0) VDL2_CNT_ADD(cnt, CNT_ERR_UNSTUFF, 1);
-			else if(flen % 8 != 0) VDL2_CNT_ADD(cnt, CNT_ERR_TRUNCATED_OCTETS, 1);
-			else {
+			uint32_t k = sh.u_k, sprev = sh.u_sprev;
+			int kind = 0;                    // 1 frame, 2 unstuff error, 3 truncated octets, 4 done
+			uint32_t S = 0, L = 0;
+			for(; k < nterm && k < (uint32_t)kMaxTerm; k++) {
+				const uint32_t tp = sh.tpos[k], g = sh.tG[k];
+				if(tp > E) { kind = 2; break; }
+				const uint32_t j = g - sprev;
+				const uint32_t snext = g + 1;
+				if(j == 7) { sprev = snext; continue; }
+				if(j < 7) { kind = 2; break; }
+				S = sprev; L = j - 7; sprev = snext;
+				sh.u_lastend = tp;
+				kind = (L % 8) ? 3 : 1;
+				k++;
+				break;
+			}
+			if(kind == 0) {
+				// past the last terminator: the tail is processed iff a call is still made (bitstream.c:149, decode.c:345)
+				const bool call = sh.u_lastend == 0xffffffffu || sh.u_lastend + 1 < nbits;
+				if(!call || sh.u_k == 0xffffffffu) kind = 4;
+				else if(E != 0xffffffffu) kind = 2;
+				else { S = sprev; L = gtotal - sprev; kind = (L % 8) ? 3 : 1; k = 0xffffffffu; }
+			}
+			sh.u_k = k; sh.u_sprev = sprev; sh.u_kind = kind; sh.u_S = S; sh.u_L = L; sh.u_ok = 0;
+			if(kind == 2) VDL2_CNT_ADD(cnt, CNT_ERR_UNSTUFF, 1);
+			else if(kind == 3) VDL2_CNT_ADD(cnt, CNT_ERR_TRUNCATED_OCTETS, 1);
+			else if(kind == 1) {
 				VDL2_CNT_ADD(cnt, CNT_MSG_GOOD, 1);
-				uint32_t len = flen / 8;
+				const uint32_t len = L / 8;
 #if VDL2_DEVICE_PASS
 				uint32_t slot = atomicAdd(&ctl->nframes, 1u);
 				uint32_t off = atomicAdd(&ctl->pool_used, (len + 3u) & ~3u);
@@ -809,20 +953,36 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 					f.nf_pwr_dbfs = 20.0f * log10f(b.mag_nf + 0.001f);
 					f.ppm_error = b.ppm;
 					f.burst_ord = b.ord; f.sync_sample = b.sync_sample; f.end_sample = b.end_sample;
-					sh.u_ok = 1; sh.u_slot = slot; sh.u_off = off;
+					sh.u_ok = 1; sh.u_off = off;
 				} else ctl->overflow = 1;
 			}
 		LANE0_END
-		if(sh.u_more < 0 || sh.u_flen % 8 != 0) return;
+		if(sh.u_kind != 1) { if(sh.u_kind == 4) break; return; }
 		if(sh.u_ok) {
-			const uint32_t len = (uint32_t)sh.u_flen / 8, off = sh.u_off;
+			// gather kept bits S+8i .. S+8i+7 into output octet i (LSB first, bitstream.c:70-81)
+			const uint32_t len = sh.u_L / 8, off = sh.u_off, S = sh.u_S;
 			WAVE_FOR(l)
-				for(uint32_t i = l; i < len; i += 64) pool[off + i] = sh.fo[i];
+				for(uint32_t i = l; i < len; i += 64) {
+					const uint32_t q0 = S + 8 * i;
+					int lo = 0, hi = nw;              // last word with cumk[w] <= q0
+					while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sh.cumk[mid] <= q0) lo = mid; else hi = mid; }
+					int w = lo;
+					uint32_t m = sh.keptw[w];
+					for(uint32_t r = q0 - sh.cumk[w]; r > 0; r--) m &= m - 1;
+					uint32_t o = 0;
+					for(int t = 0; t < 8; t++) {
+						while(m == 0) { w++; m = sh.keptw[w]; }
+						const int bit = ctz32(m); m &= m - 1;
+						o |= ((sh.xw[w] >> bit) & 1u) << t;
+					}
+					pool[off + i] = (uint8_t)o;
+				}
 			WAVE_END
 		}
 		nframes++;
-		if(sh.u_more == 0) break;
+		if(sh.u_k == 0xffffffffu) break;
 	}
+	K5_MARK(5);
 	LANE0
 		if(sh.u_pwr > 1.0f) VDL2_CNT_ADD(cnt, CNT_MSG_GOOD_LOUD, 1);
 	LANE0_END

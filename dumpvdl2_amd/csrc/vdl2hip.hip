@@ -174,6 +174,22 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	return VDL2HIP_OK;
 }
 
+static void sort_queue(vdl2hip_ctx *c) {
+	std::stable_sort(c->queue.begin(), c->queue.end(), [](const HostFrame &a, const HostFrame &b) {
+		if(a.f.end_sample != b.f.end_sample) return a.f.end_sample < b.f.end_sample;
+		if(a.f.chan != b.f.chan) return a.f.chan < b.f.chan;
+		return a.f.idx < b.f.idx;
+	});
+}
+
+static void fill_frame(const vdl2hip_ctx *c, const HostFrame &h, vdl2hip_frame &f) {
+	f.chan = (uint32_t)(h.f.chan + c->chan_first); f.freq = c->freqs[h.f.chan]; f.idx = h.f.idx;
+	f.len = h.f.len; f.octets = h.octets.data();
+	f.synd_weight = h.f.synd_weight; f.datalen_octets = h.f.datalen_octets; f.num_fec_corrections = h.f.num_fec_corrections;
+	f.frame_pwr_dbfs = h.f.frame_pwr_dbfs; f.nf_pwr_dbfs = h.f.nf_pwr_dbfs; f.ppm_error = h.f.ppm_error;
+	f.burst_ord = h.f.burst_ord; f.sync_sample = h.f.sync_sample; f.end_sample = h.f.end_sample;
+}
+
 extern "C" {
 
 int vdl2hip_abi_version(void) { return VDL2HIP_ABI_VERSION; }
@@ -323,26 +339,39 @@ int vdl2hip_drain(vdl2hip_ctx *c, vdl2hip_frame_cb cb, void *user) {
 	if(!c) return VDL2HIP_E_INVAL;
 	int r = collect_pending(c);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
-	std::stable_sort(c->queue.begin(), c->queue.end(), [](const HostFrame &a, const HostFrame &b) {
-		if(a.f.end_sample != b.f.end_sample) return a.f.end_sample < b.f.end_sample;
-		if(a.f.chan != b.f.chan) return a.f.chan < b.f.chan;
-		return a.f.idx < b.f.idx;
-	});
+	sort_queue(c);
 	int n = 0;
 	for(const HostFrame &h : c->queue) {
 		if(cb) {
 			vdl2hip_frame f{};
-			f.chan = (uint32_t)(h.f.chan + c->chan_first); f.freq = c->freqs[h.f.chan]; f.idx = h.f.idx;
-			f.len = h.f.len; f.octets = h.octets.data();
-			f.synd_weight = h.f.synd_weight; f.datalen_octets = h.f.datalen_octets; f.num_fec_corrections = h.f.num_fec_corrections;
-			f.frame_pwr_dbfs = h.f.frame_pwr_dbfs; f.nf_pwr_dbfs = h.f.nf_pwr_dbfs; f.ppm_error = h.f.ppm_error;
-			f.burst_ord = h.f.burst_ord; f.sync_sample = h.f.sync_sample; f.end_sample = h.f.end_sample;
+			fill_frame(c, h, f);
 			cb(&f, user);
 		}
 		n++;
 	}
 	c->queue.clear();
 	return n;
+}
+
+int vdl2hip_drain_packed(vdl2hip_ctx *c, vdl2hip_packed_frame *frames, size_t cap_frames,
+		uint8_t *octets, size_t cap_octets, size_t *octets_used) {
+	if(!c || (!frames && cap_frames) || (!octets && cap_octets)) return VDL2HIP_E_INVAL;
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	sort_queue(c);
+	size_t n = 0, used = 0;
+	for(const HostFrame &h : c->queue) {
+		if(n >= cap_frames || used + h.f.len > cap_octets) break;
+		fill_frame(c, h, frames[n].frame);
+		frames[n].frame.octets = nullptr;
+		frames[n].octets_off = used;
+		if(h.f.len) memcpy(octets + used, h.octets.data(), h.f.len);
+		used += h.f.len;
+		n++;
+	}
+	c->queue.erase(c->queue.begin(), c->queue.begin() + (long)n);
+	if(octets_used) *octets_used = used;
+	return (int)n;
 }
 
 int vdl2hip_counters(vdl2hip_ctx *c, uint32_t chan, uint64_t out[VDL2HIP_NUM_COUNTERS]) {
@@ -368,6 +397,15 @@ int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) {
 }
 
 void *vdl2hip_stream(vdl2hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+#ifdef VDL2_K5_PROF
+int vdl2hip_debug_k5_prof(unsigned long long out[16]) {
+	return hipMemcpyFromSymbol(out, HIP_SYMBOL(vdl2_k5_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+int vdl2hip_debug_k4_prof(unsigned long long out[16]) {
+	return hipMemcpyFromSymbol(out, HIP_SYMBOL(vdl2_k4_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int vdl2hip_get_lpf(vdl2hip_ctx *c, float A[3], float B[3]) {
 	if(!c) return VDL2HIP_E_INVAL;

@@ -147,9 +147,10 @@ class BurstBits:
 
 def build_burst(frames: Sequence[bytes], rng: Optional[np.random.Generator] = None,
                 byte_errors_per_block: Optional[Sequence[int]] = None, header_flips: int = 0,
-                separate_flags: bool = False) -> BurstBits:
-    """AVLC frames -> header + interleaved data + FEC, scrambled, as D8PSK phase steps."""
-    hb = hdlc_bits(frames, separate_flags)
+                separate_flags: bool = False, raw_bits: Optional[np.ndarray] = None) -> BurstBits:
+    """AVLC frames -> header + interleaved data + FEC, scrambled, as D8PSK phase steps.
+    raw_bits (tests only) replaces the HDLC-framed bit string, e.g. to send malformed framing."""
+    hb = hdlc_bits(frames, separate_flags) if raw_bits is None else np.asarray(raw_bits, dtype=np.uint8)
     tl = int(hb.size)
     assert tl <= 0x3FFF, "transmission length field limited by decode.c:45"
     noct = (tl + 7) // 8

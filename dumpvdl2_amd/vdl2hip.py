@@ -30,7 +30,7 @@ NUM_COUNTERS = len(COUNTER_NAMES)
 EXPORTS = [
     "vdl2hip_abi_version", "vdl2hip_strerror", "vdl2hip_create", "vdl2hip_destroy", "vdl2hip_feed",
     "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
-    "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
+    "vdl2hip_drain_packed", "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
 ]
 
 
@@ -56,6 +56,10 @@ class Stats(C.Structure):
                 ("bursts", C.c_uint64), ("frames", C.c_uint64)]
 
 
+class PackedFrame(C.Structure):
+    _fields_ = [("frame", CFrame), ("octets_off", C.c_uint64)]
+
+
 FRAME_CB = C.CFUNCTYPE(None, C.POINTER(CFrame), C.c_void_p)
 _lib = None
 
@@ -76,6 +80,7 @@ def load_library(path: str = LIB_PATH):
     L.vdl2hip_feed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.vdl2hip_sync.argtypes = [C.c_void_p]
     L.vdl2hip_drain.argtypes = [C.c_void_p, FRAME_CB, C.c_void_p]
+    L.vdl2hip_drain_packed.argtypes = [C.c_void_p, C.POINTER(PackedFrame), C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.vdl2hip_counters.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
     L.vdl2hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.vdl2hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -150,6 +155,28 @@ class Receiver:
 
         self._cb = FRAME_CB(cb)
         self._chk(self.L.vdl2hip_drain(self.h, self._cb, None), "vdl2hip_drain")
+        return out
+
+    def drain_packed(self, cap_frames: int = 1 << 16, cap_octets: int = 1 << 24):
+        """One call for all queued frames: returns (records ctypes array view, octets bytes).  Used where a Python
+        callback per frame would dominate (bench.py)."""
+        if getattr(self, "_pk", None) is None or len(self._pk) < cap_frames or len(self._po) < cap_octets:
+            self._pk = (PackedFrame * cap_frames)()
+            self._po = (C.c_uint8 * cap_octets)()
+        used = C.c_size_t(0)
+        n = self._chk(self.L.vdl2hip_drain_packed(self.h, self._pk, cap_frames, self._po, cap_octets, C.byref(used)), "vdl2hip_drain_packed")
+        return n, self._pk, memoryview(self._po)[:used.value]
+
+    @staticmethod
+    def unpack(n, recs, octets) -> List[dict]:
+        out = []
+        for i in range(n):
+            f = recs[i].frame; off = recs[i].octets_off
+            out.append(dict(chan=f.chan, freq=f.freq, idx=f.idx, octets=bytes(octets[off:off + f.len]),
+                            synd_weight=f.synd_weight, datalen_octets=f.datalen_octets,
+                            num_fec_corrections=f.num_fec_corrections, frame_pwr_dbfs=f.frame_pwr_dbfs,
+                            nf_pwr_dbfs=f.nf_pwr_dbfs, ppm_error=f.ppm_error, burst_ord=f.burst_ord,
+                            sync_sample=f.sync_sample, end_sample=f.end_sample))
         return out
 
     def counters(self, chan: int) -> dict:

@@ -132,6 +132,16 @@ int  vdl2hip_sync(vdl2hip_ctx *ctx);
 /* sync + deliver every queued frame, ordered by (end_sample, chan, idx); returns the number delivered (>= 0). */
 int  vdl2hip_drain(vdl2hip_ctx *ctx, vdl2hip_frame_cb cb, void *user);
 
+/* Bulk form of vdl2hip_drain for callers that want no per-frame callback: copies up to `cap_frames`
+ * frame records (same order; `octets` is NULL, `octets_off` below locates the payload) and their octets,
+ * concatenated, into caller memory.  Returns the number of frames copied; frames that did not fit stay queued. */
+typedef struct {
+	vdl2hip_frame frame;
+	uint64_t octets_off;
+} vdl2hip_packed_frame;
+int  vdl2hip_drain_packed(vdl2hip_ctx *ctx, vdl2hip_packed_frame *frames, size_t cap_frames,
+		uint8_t *octets, size_t cap_octets, size_t *octets_used);
+
 int  vdl2hip_counters(vdl2hip_ctx *ctx, uint32_t chan, uint64_t out[VDL2HIP_NUM_COUNTERS]);
 int  vdl2hip_set_profiling(vdl2hip_ctx *ctx, int on);   /* bracket kernels with HIP events on the ctx stream */
 int  vdl2hip_get_stats(vdl2hip_ctx *ctx, vdl2hip_stats *out);

@@ -115,6 +115,16 @@ def test_feed_device_matches_feed_host(vh):
     rx.close()
 
 
+def test_drain_packed_equals_drain(vh):
+    cfg, iq, _, gold = cases.load("config2_1s")
+    rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=iq.nbytes)
+    rx.feed(iq)
+    n, recs, octs = rx.drain_packed()
+    cases.check_against_golden(vh.Receiver.unpack(n, recs, octs), None, gold, label="packed")
+    assert rx.drain() == []
+    rx.close()
+
+
 def test_uint8_input(vh, oracle_mod):
     from dumpvdl2_amd import synth
     cfg = synth.SynthConfig(centerfreq=CF, freqs=[CF, CF + 40000], oversample=10, duration_s=0.6, seed=12, amplitude=0.3, noise_sigma=0.01)
