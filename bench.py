@@ -123,7 +123,7 @@ def main():
     k1_ms = (s1["chanfir_ms"] - s0["chanfir_ms"]) / max(1, s1["chanfir_launches"] - s0["chanfir_launches"])
     k1_chan_samples = (s1["chan_samples"] - s0["chan_samples"]) / max(1, s1["chanfir_launches"] - s0["chanfir_launches"])
     achieved = k1_chan_samples * ALGO_BYTES_PER_CHAN_SAMPLE / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-    stage_ms = {k: (s1[k] - s0[k]) / args.steps for k in ("chanfir_ms", "phase_ms", "sync_ms", "walk_ms", "burst_ms")}
+    stage_ms = {k: (s1[k] - s0[k]) / args.steps for k in ("chanfir_ms", "phase_ms", "sync_ms", "walk_ms", "nf_ms", "burst_ms")}
 
     if rank == 0:
         value = world * nsamples * args.steps / dt / 1e6

@@ -5,6 +5,7 @@
 //   k_carry         saves the < oversample input samples left over for the next block
 //   k_sync      K3  got_sync() metric for every decimated sample + candidate bitmap (src/demod.c:105-171)
 //   k_walk      K4  per-channel FSM walker (vdl2_core.h)
+//   k_nf        K4b noise-floor replay from the walker's evaluation log (src/demod.c:238-243)
 //   k_burst     K5  wave-per-burst decoder (vdl2_core.h)
 //
 // K1 is the only kernel that touches every input sample; everything after it runs at
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(256) void k_sync(K3Args a) {
 struct K4Args {
 	const cf32 *y; const float *phi; const cf32 *pf; const uint64_t *cand; const Tables *tab;
 	WalkState *ws; unsigned long long *cnt; Burst *bursts; OutCtl *ctl; const uint32_t *freq;
+	EvalChunk *log; uint32_t *nlog; uint32_t cap_log;
 	int64_t k_end; float max_ppm; uint32_t cap, mask; int32_t chan_first;
 };
 
@@ -293,12 +295,46 @@ __global__ __launch_bounds__(64) void k_walk(K4Args a) {
 	__shared__ WalkShared sh;
 	const int c = blockIdx.x;
 	ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
-	walk_channel(c, a.freq[c], a.max_ppm, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters, a.bursts, a.ctl, sh);
+	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
+	walk_channel(c, a.freq[c], a.max_ppm, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters, a.bursts, a.ctl, lg, sh);
+}
+
+struct K4bArgs {
+	const cf32 *y; NfState *nf; WalkState *ws; EvalChunk *log; uint32_t *nlog; int64_t *sc_first; int64_t *sc_cum;
+	NfFeed *feed; float *lpbuf; float *hist; int64_t *hist_base; uint32_t cap, mask, cap_log, cap_comb, cap_hist;
+};
+
+// K4b: noise-floor replay from the walker's evaluation log, in three small passes
+__global__ __launch_bounds__(64) void k_nf_prepare(K4bArgs a) {
+	const int c = blockIdx.x;
+	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
+	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
+	nf_prepare(&a.nf[c], lg, sc, a.cap_comb, &a.feed[c]);
+}
+
+__global__ __launch_bounds__(64) void k_nf_replay(K4bArgs a) {
+	__shared__ NfShared sh;
+	const int c = blockIdx.y;
+	ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, nullptr, a.mask };
+	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
+	const NfFeed fd = a.feed[c];
+	for(int64_t g = blockIdx.x; fd.u0 + 1 + kNfGroup * g <= fd.u1; g += gridDim.x) {
+		nf_replay_group(v, sc, fd, g, a.lpbuf + (size_t)c * a.cap_hist, a.cap_hist, sh);
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(64) void k_nf_finish(K4bArgs a) {
+	const int c = blockIdx.x;
+	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
+	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
+	nf_finish(&a.nf[c], lg, sc, a.feed[c], a.lpbuf + (size_t)c * a.cap_hist, a.hist + (size_t)c * a.cap_hist, a.cap_hist, a.hist_base + c, &a.ws[c]);
 }
 
 struct K5Args {
 	const cf32 *y; const float *phi; const Tables *tab; unsigned long long *cnt;
 	const Burst *bursts; OutFrame *frames; uint8_t *pool; OutCtl *ctl; const uint32_t *freq;
+	const float *nf_hist; const int64_t *nf_base; uint32_t cap_hist;
 	uint32_t cap, mask;
 };
 
@@ -309,7 +345,8 @@ __global__ __launch_bounds__(64) void k_burst(K5Args a) {
 		const Burst b = a.bursts[i];
 		const int c = b.chan;
 		ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, nullptr, nullptr, a.mask };
-		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
+		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl,
+		             a.nf_hist + (size_t)c * a.cap_hist, a.cap_hist, a.nf_base[c], sh);
 		__syncthreads();
 	}
 }

@@ -95,7 +95,7 @@ constexpr int kMaxWords = 512;            // 16 384 bits of corrected data
 constexpr int kMaxTerm = 2048;            // a flag needs 8 bits
 constexpr int kFreshAfter = 156;          // evaluations at n >= a+156: n, n-3, n-6 touch only the current interval
 constexpr int kNumIv = 32;                // DM_INIT interval history (160/6 < 32 intervals can matter)
-constexpr int kNumRun = 32;               // evaluation-run history for the noise-floor lookback
+constexpr int kNfTail = 64;               // evaluation chunks remembered across feeds for the noise-floor lookback
 constexpr int kLpTerms = 256;             // 0.9^256 ~ 2e-12: below fp32 resolution of mag_lp
 constexpr int kNumCounters = 20;
 
@@ -139,8 +139,9 @@ struct Burst {
 	int32_t  chan, nsym;
 	int64_t  t_first;                  // sample of the first symbol after the unique word
 	int64_t  sync_sample, end_sample, ord;
-	float    prev_phi0, vdphi, ppm, mag_nf;
+	float    prev_phi0, vdphi, ppm, mag_nf;   // mag_nf: stamped by the noise-floor kernel of the feed the sync happened in
 	uint32_t tl_bits, syndrome;
+	int64_t  nf_upd;                   // number of mag_nf updates that preceded the sync (v->mag_nf at decode_frame())
 };
 
 struct OutFrame {
@@ -154,8 +155,25 @@ struct OutFrame {
 
 struct OutCtl {
 	uint32_t nbursts, nframes, pool_used, overflow;
-	uint32_t cap_bursts, cap_frames, cap_pool, pad_;
+	uint32_t cap_bursts, cap_frames, cap_pool, cap_log;
 };
+
+// A stretch of executed got_sync() evaluations: samples first, first+3, ..., first+3*(count-1).
+struct EvalChunk { int64_t first; int64_t count; };
+
+// Per-channel evaluation log of one feed (written by the walker, consumed by the noise-floor kernel)
+struct EvalLog { EvalChunk *chunks; uint32_t *n; };
+
+// Persistent per-channel noise-floor state (v->mag_nf, v->nfcnt and enough history to replay v->mag_lp)
+struct NfState {
+	float   mag_nf;                    // after `updates` updates
+	int32_t ntail;
+	int64_t evals;                     // evaluations accounted so far
+	int64_t tail_ord;                  // ordinal (0-based) of the first evaluation of tail[0]
+	EvalChunk tail[kNfTail];           // most recent chunks, oldest first, covering >= kLpTerms evaluations when available
+};
+
+VDL2_HD void nf_state_init(NfState &s) { s.mag_nf = 2.0f; s.ntail = 0; s.evals = 0; s.tail_ord = 0; }
 
 // Persistent per-channel FSM state of the walker (what vdl2_channel_t carries between samples).
 struct WalkState {
@@ -164,19 +182,17 @@ struct WalkState {
 	int64_t e0;                        // first evaluation of the current grid run
 	int64_t bursts;                    // syncs accepted so far
 	float   pherr1, pherr2, prev_dphi; // v->pherr[1], v->pherr[2], v->prev_dphi
-	float   mag_nf;                    // v->mag_nf
-	int32_t nfcnt;                     // v->nfcnt
+	int64_t evals;                     // got_sync() evaluations executed so far (v->nfcnt = evals % 1000)
 	int32_t mode;                      // 0 search, 1 waiting for header symbols, 2 waiting for burst end
-	int32_t niv, nrun;
+	int32_t niv, pad_;
 	int64_t iva[kNumIv], ivb[kNumIv];  // earlier DM_INIT intervals, most recent first
-	int64_t runf[kNumRun], runl[kNumRun]; // closed evaluation runs (first, last), most recent first
 	Burst   pb;                        // burst in progress
 };
 
 VDL2_HD void walk_state_init(WalkState &s) {
 	s.a = 0; s.e = 2; s.e0 = 2; s.bursts = 0;
 	s.pherr1 = s.pherr2 = kPherrBig; s.prev_dphi = 0.f;
-	s.mag_nf = 2.0f; s.nfcnt = 0; s.mode = 0; s.niv = 0; s.nrun = 0;
+	s.evals = 0; s.mode = 0; s.niv = 0; s.pad_ = 0;
 }
 
 // ======================================================================
@@ -289,15 +305,13 @@ VDL2_HD Geometry header_to_geometry(uint32_t hdr, const Tables &T) {
 // Walker: the per-channel sequential FSM of demod()/got_sync(), hopping
 // between the sparse places where something can happen.
 // ======================================================================
-constexpr int kLpGroup = 16;               // noise-floor updates replayed per pass
 struct WalkShared {
 	WalkState st;
-	float p[64], f[64], lp[64];
+	float p[64], f[64];
 	int32_t found[64];
 	int32_t flag[64];
 	int32_t sym[16];
 	int32_t neg[16];
-	float mags[kLpGroup][kLpTerms + 1];    // +1: row padding keeps the per-lane replay off one LDS bank
 	// scalars published by LANE0 sections
 	float u_y1, u_y2, u_y3, u_prevd;
 };
@@ -334,82 +348,16 @@ VDL2_HD void push_interval(WalkState &st, int64_t a, int64_t b) {
 	if(st.niv < kNumIv) st.niv++;
 }
 
-VDL2_HD void push_run(WalkState &st, int64_t first, int64_t last) {
-	if(last < first) return;
-	int n = st.nrun < kNumRun ? st.nrun : kNumRun - 1;
-	for(int i = n; i > 0; i--) { st.runf[i] = st.runf[i - 1]; st.runl[i] = st.runl[i - 1]; }
-	st.runf[0] = first; st.runl[0] = last;
-	if(st.nrun < kNumRun) st.nrun++;
-}
-
-// position of the j-th evaluation before m (j = 0: m itself) in the sequence of executed
-// got_sync() evaluations (current run, then the closed runs), or -1 when history is exhausted
-VDL2_HD int64_t eval_index(const WalkState &st, int64_t m, int64_t j) {
-	const int64_t ncur = (m - st.e0) / 3 + 1;
-	if(j < ncur) return m - 3 * j;
-	j -= ncur;
-	for(int i = 0; i < st.nrun; i++) {
-		const int64_t len = (st.runl[i] - st.runf[i]) / 3 + 1;
-		if(j < len) return st.runl[i] - 3 * j;
-		j -= len;
-	}
-	return -1;
-}
-
-// `count` evaluations starting at `first` (step 3, all on the current run) are being executed:
-// account nfcnt and the mag_nf updates that fall among them (demod.c:238-243).  v->mag_lp at an
-// update is the reference's recurrence mag_lp = mag_lp*0.9 + mag*0.1 (demod.c:239) replayed over
-// the last kLpTerms evaluations: the wave gathers the magnitudes of kLpGroup updates at once
-// (independent loads), then one lane per update replays them oldest first.
-VDL2_HD void account_evals(WalkShared &sh, const ChanView &v, int64_t first, int64_t count) {
+// `count` evaluations starting at `first` (step 3) are being executed: note them for the noise-floor
+// kernel (demod.c:238-243 is replayed there, off the walker's critical path).
+VDL2_HD void log_evals(WalkShared &sh, const EvalLog &lg, OutCtl *ctl, int64_t first, int64_t count) {
 	if(count <= 0) return;
-	const int32_t nf0 = sh.st.nfcnt;
-	const int64_t total = (int64_t)nf0 + count;
-	const int64_t nupd = total / 1000;
-	for(int64_t base = 0; base < nupd; base += kLpGroup) {
-		const int ng = (int)(nupd - base < kLpGroup ? nupd - base : kLpGroup);
-		WAVE_FOR(l)
-			// 8 independent loads in flight per lane before anything waits on them
-			for(int idx0 = l; idx0 < ng * kLpTerms; idx0 += 64 * 8) {
-				cf32 yv[8]; bool have[8];
-				for(int q = 0; q < 8; q++) {
-					const int idx = idx0 + 64 * q;
-					have[q] = false; yv[q] = cf32{0.f, 0.f};
-					if(idx < ng * kLpTerms) {
-						const int u = idx / kLpTerms, j = idx - u * kLpTerms;
-						const int64_t m = first + 3 * (1000 * (base + u + 1) - nf0 - 1);
-						const int64_t pos = eval_index(sh.st, m, j);
-						if(pos >= 0) { have[q] = true; yv[q] = v.Y(pos); }
-					}
-				}
-				for(int q = 0; q < 8; q++) {
-					const int idx = idx0 + 64 * q;
-					if(idx < ng * kLpTerms) {
-						const int u = idx / kLpTerms, j = idx - u * kLpTerms;
-						sh.mags[u][j] = have[q] ? mag_of(yv[q]) : -1.f;
-					}
-				}
-			}
-		WAVE_END
-		WAVE_FOR(l)
-			if(l < ng) {
-				float lp = 0.f;
-				for(int j = kLpTerms - 1; j >= 0; j--) {
-					const float mg = sh.mags[l][j];
-					if(mg >= 0.f) lp = lp * 0.9f + mg * (1.0f - 0.9f);
-				}
-				sh.lp[l] = lp;
-			}
-		WAVE_END
-		LANE0
-			float nf = sh.st.mag_nf;
-			for(int l = 0; l < ng; l++)
-				nf = 0.85f * nf + (1.0f - 0.85f) * fminf(sh.lp[l], nf) + 0.0001f;
-			sh.st.mag_nf = nf;
-		LANE0_END
-	}
 	LANE0
-		sh.st.nfcnt = (int32_t)(total % 1000);
+		uint32_t n = *lg.n;
+		if(n > 0 && lg.chunks[n - 1].first + 3 * lg.chunks[n - 1].count == first) lg.chunks[n - 1].count += count;
+		else if(n < ctl->cap_log) { lg.chunks[n].first = first; lg.chunks[n].count = count; *lg.n = n + 1; }
+		else ctl->overflow = 1;          // pathological storm of grid shifts: noise floor becomes approximate
+		sh.st.evals += count;
 	LANE0_END
 }
 
@@ -422,7 +370,7 @@ VDL2_HD void restart_search(WalkState &st, int64_t a) {
 
 // Process one channel up to (not including) decimated sample k_end.
 VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end, const Tables &T,
-		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, OutCtl *ctl, WalkShared &sh) {
+		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
 	K4_BEGIN();
 	LANE0
 		sh.st = *gstate;
@@ -468,7 +416,7 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 					}
 				LANE0_END
 				K4_MARK(1);
-				account_evals(sh, v, e, nexec);
+				log_evals(sh, lg, ctl, e, nexec);
 				K4_MARK(2);
 				fired = jf >= 0;
 				fire_n = e + 3 * (int64_t)(jf >= 0 ? jf : 0);
@@ -508,13 +456,13 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 						sh.u_y3 = v.PF(n).re;
 						sh.u_prevd = v.PF(n - 3).im;
 					LANE0_END
-					account_evals(sh, v, e, (n - e) / 3 + 1);
+					log_evals(sh, lg, ctl, e, (n - e) / 3 + 1);
 					K4_MARK(2);
 				} else {
 					// nothing up to k_end: park just past the last evaluation that exists
 					const int64_t cnt_ev = (k_end - 1 - e) / 3 + 1;     // e < k_end here
 					const int64_t nl = e + 3 * (cnt_ev - 1);
-					account_evals(sh, v, e, cnt_ev);
+					log_evals(sh, lg, ctl, e, cnt_ev);
 					K4_MARK(2);
 					LANE0
 						sh.st.pherr1 = v.PF(nl).re;
@@ -536,7 +484,6 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 					float vdphi = sh.u_prevd;
 					float ppm = (float)((double)(10500 * vdphi) / (2.0f * M_PI * (double)freq) * 1e+6);
 					st.pherr1 = st.pherr2 = kPherrBig;
-					push_run(st, st.e0, n);
 					if(max_ppm != 0.f && fabsf(ppm) > max_ppm) {
 						VDL2_CNT_ADD(cnt, CNT_PPM_REJECT, 1);
 						int64_t step = 3 - sclk; if(step < 1) step = 1;   // v->sclk keeps the vertex value: demod.c:179,233
@@ -547,7 +494,7 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 						st.pb.chan = chan; st.pb.nsym = 0;
 						st.pb.t_first = n + (kSpsDec - sclk);
 						st.pb.sync_sample = n; st.pb.end_sample = 0; st.pb.ord = st.bursts++;
-						st.pb.prev_phi0 = prev_phi0; st.pb.vdphi = vdphi; st.pb.ppm = ppm; st.pb.mag_nf = st.mag_nf;
+						st.pb.prev_phi0 = prev_phi0; st.pb.vdphi = vdphi; st.pb.ppm = ppm; st.pb.mag_nf = 0.f; st.pb.nf_upd = st.evals / 1000;
 						st.pb.tl_bits = 0; st.pb.syndrome = 0;
 						st.mode = 1;
 					}
@@ -610,6 +557,117 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 		*gstate = sh.st;
 	LANE0_END
 	K4_MARK(0);
+}
+
+// ======================================================================
+// Noise floor: v->mag_lp / v->mag_nf of demod.c:238-243, replayed per feed from the walker's
+// evaluation log.  Update U happens at the (1000*U)-th evaluation; v->mag_lp there is the
+// recurrence mag_lp = mag_lp*0.9 + mag*0.1 over the preceding evaluations, replayed over the last
+// kLpTerms of them (0.9^256 ~ 2e-12, below fp32 resolution).  One lane per update.
+// ======================================================================
+constexpr int kNfGroup = 16;               // updates replayed per wavefront pass (4 lanes gather for each)
+struct NfShared {
+	float mags[kNfGroup][kLpTerms + 1];    // +1: row padding keeps the per-lane replay off one LDS bank
+};
+
+struct NfScratch { int64_t *first; int64_t *cum; };   // combined (tail + feed) chunk list: first sample, ordinal of first evaluation
+
+// what the three noise-floor passes of one feed share (per channel)
+struct NfFeed { int64_t ev0, ev1, u0, u1, begin_ord; uint32_t ncomb, pad_; };
+
+// pass 1 (one lane): combined chunk list = remembered tail + this feed's log, with evaluation ordinals
+VDL2_HD void nf_prepare(const NfState *g, const EvalLog &lg, const NfScratch &sc, uint32_t cap_comb, NfFeed *fd) {
+	LANE0
+		const uint32_t nlog = *lg.n;
+		int64_t ord = g->tail_ord;
+		uint32_t k = 0;
+		for(int i = 0; i < g->ntail && k < cap_comb; i++, k++) { sc.first[k] = g->tail[i].first; sc.cum[k] = ord; ord += g->tail[i].count; }
+		for(uint32_t i = 0; i < nlog && k < cap_comb; i++, k++) { sc.first[k] = lg.chunks[i].first; sc.cum[k] = ord; ord += lg.chunks[i].count; }
+		sc.cum[k] = ord;
+		fd->ncomb = k; fd->ev0 = g->evals; fd->ev1 = ord; fd->u0 = g->evals / 1000; fd->u1 = ord / 1000;
+		fd->begin_ord = k ? sc.cum[0] : ord;
+	LANE0_END
+}
+
+// pass 2 (one wavefront per group of kNfGroup updates): v->mag_lp at each update of the group
+VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFeed &fd, int64_t group, float *lpbuf, uint32_t cap_hist, NfShared &sh) {
+	const int64_t ubase = fd.u0 + 1 + (int64_t)kNfGroup * group;      // first (1-based, global) update of this group
+	if(ubase > fd.u1) return;
+	const int ncomb = (int)fd.ncomb;
+	WAVE_FOR(l)
+		const int u = l >> 2, part = l & 3;
+		const int64_t U = ubase + u;
+		if(U <= fd.u1) {
+			const int64_t o_last = 1000 * U - 1;                     // ordinal of the evaluation that triggers the update
+			// this lane gathers evaluations o_last - j, j = 64*part .. 64*part+63 (newest first)
+			int64_t o = o_last - 64 * part;
+			int ci = 0; int64_t pos = 0, off = 0;
+			if(o >= fd.begin_ord) {
+				int lo = 0, hi = ncomb;
+				while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sc.cum[mid] <= o) lo = mid; else hi = mid; }
+				ci = lo; off = o - sc.cum[ci]; pos = sc.first[ci] + 3 * off;
+			}
+			for(int j0 = 0; j0 < 64; j0 += 8) {
+				int64_t ps[8]; cf32 yv[8];
+				for(int q = 0; q < 8; q++) {
+					ps[q] = -1;
+					if(o >= fd.begin_ord) {
+						ps[q] = pos;
+						o--;
+						if(off > 0) { off--; pos -= 3; }
+						else if(ci > 0 && o >= fd.begin_ord) { ci--; off = sc.cum[ci + 1] - sc.cum[ci] - 1; pos = sc.first[ci] + 3 * off; }
+					} else o--;
+				}
+				for(int q = 0; q < 8; q++) yv[q] = ps[q] >= 0 ? v.Y(ps[q]) : cf32{0.f, 0.f};
+				for(int q = 0; q < 8; q++) sh.mags[u][64 * part + j0 + q] = ps[q] >= 0 ? mag_of(yv[q]) : -1.f;
+			}
+		}
+	WAVE_END
+	WAVE_FOR(l)
+		const int64_t U = ubase + l;
+		if(l < kNfGroup && U <= fd.u1) {
+			float lp = 0.f;
+			for(int j = kLpTerms - 1; j >= 0; j--) {
+				const float mg = sh.mags[l][j];
+				if(mg >= 0.f) lp = lp * 0.9f + mg * (1.0f - 0.9f);
+			}
+			const int64_t i = U - fd.u0;
+			if(i < (int64_t)cap_hist) lpbuf[i] = lp;
+		}
+	WAVE_END
+}
+
+// pass 3 (one lane): the mag_nf chain over this feed's updates, history for the burst decoder, state for the next feed.
+// hist[i] = mag_nf after (u0 + i) updates
+VDL2_HD void nf_finish(NfState *g, const EvalLog &lg, const NfScratch &sc, const NfFeed &fd, const float *lpbuf, float *hist,
+		uint32_t cap_hist, int64_t *hist_base, WalkState *ws) {
+	LANE0
+		float nf = g->mag_nf;
+		hist[0] = nf;
+		*hist_base = fd.u0;
+		for(int64_t U = fd.u0 + 1; U <= fd.u1; U++) {
+			const int64_t i = U - fd.u0;
+			if(i >= (int64_t)cap_hist) break;
+			nf = 0.85f * nf + (1.0f - 0.85f) * fminf(lpbuf[i], nf) + 0.0001f;
+			hist[i] = nf;
+		}
+		g->mag_nf = nf;
+		g->evals = fd.ev1;
+		// keep the newest chunks that cover the last kLpTerms evaluations
+		const int ncomb = (int)fd.ncomb;
+		int first_keep = ncomb;
+		while(first_keep > 0 && (fd.ev1 - sc.cum[first_keep] < kLpTerms) && (ncomb - first_keep < kNfTail)) first_keep--;
+		int nt = 0;
+		for(int i = first_keep; i < ncomb; i++, nt++) { g->tail[nt].first = sc.first[i]; g->tail[nt].count = sc.cum[i + 1] - sc.cum[i]; }
+		g->ntail = nt;
+		g->tail_ord = ncomb ? sc.cum[first_keep] : fd.ev1;
+		*lg.n = 0;
+		// a burst that locked in this feed and is still in flight gets its noise floor now
+		if(ws->mode != 0 && ws->pb.nf_upd >= fd.u0) {
+			const int64_t i = ws->pb.nf_upd - fd.u0;
+			ws->pb.mag_nf = hist[i < (int64_t)cap_hist ? i : (int64_t)cap_hist - 1];
+		}
+	LANE0_END
 }
 
 // ======================================================================
@@ -725,7 +783,10 @@ VDL2_HD int ctz32(uint32_t v) { return __builtin_ctz(v); }
 
 // decode_vdl2_burst() DEC_DATA branch + decode_frame(): decode.c:259-380, 173-194
 VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const ChanView &v, unsigned long long *cnt,
-		OutFrame *frames, uint8_t *pool, OutCtl *ctl, BurstShared &sh) {
+		OutFrame *frames, uint8_t *pool, OutCtl *ctl, const float *nf_hist, uint32_t cap_hist, int64_t nf_base, BurstShared &sh) {
+	// v->mag_nf at decode time: from this feed's update history if the sync happened in this feed, else as stamped earlier
+	float mag_nf = b.mag_nf;
+	if(b.nf_upd >= nf_base) { const int64_t i = b.nf_upd - nf_base; mag_nf = nf_hist[i < (int64_t)cap_hist ? i : (int64_t)cap_hist - 1]; }
 	// geometry again from TL (decode.c:233-256)
 	const uint32_t octets = b.tl_bits / 8 + (b.tl_bits % 8 != 0);
 	uint32_t nblk = octets / kRsK, last = octets % kRsK;
@@ -950,7 +1011,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 					f.synd_weight = T.hdr_weight[b.syndrome]; f.datalen_octets = octets;
 					f.num_fec_corrections = fec_fixed;
 					f.frame_pwr_dbfs = 10.0f * log10f(sh.u_pwr);
-					f.nf_pwr_dbfs = 20.0f * log10f(b.mag_nf + 0.001f);
+					f.nf_pwr_dbfs = 20.0f * log10f(mag_nf + 0.001f);
 					f.ppm_error = b.ppm;
 					f.burst_ord = b.ord; f.sync_sample = b.sync_sample; f.end_sample = b.end_sample;
 					sh.u_ok = 1; sh.u_off = off;

@@ -50,6 +50,8 @@ struct vdl2hip_ctx {
 	float4 *d_runstart = nullptr; uint32_t nrun_cap = 0;
 	float4 *d_tcarry[2] = {nullptr, nullptr}; int tcarry_sel = 0;
 	WalkState *d_ws = nullptr; unsigned long long *d_cnt = nullptr;
+	NfState *d_nf = nullptr; EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
+	float *d_nfhist = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; int64_t *d_nfbase = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0;
 	Burst *d_bursts = nullptr; OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
 	OutCtl ctl_template{};
 	OutCtl *h_ctl = nullptr;               // pinned
@@ -89,7 +91,8 @@ static int collect_pending(vdl2hip_ctx *c) {
 		if(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.chanfir_ms += ms;
 		if(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.phase_ms += ms;
 		if(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.sync_ms += ms;
-		if(hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->stats.walk_ms += ms;
+		if(hipEventElapsedTime(&ms, c->ev[3], c->ev[6]) == hipSuccess) c->stats.walk_ms += ms;
+		if(hipEventElapsedTime(&ms, c->ev[6], c->ev[4]) == hipSuccess) c->stats.nf_ms += ms;
 		if(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) c->stats.burst_ms += ms;
 		c->ev_valid = false;
 	}
@@ -158,10 +161,18 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		hipLaunchKernelGGL(k_sync, dim3((unsigned)((k1 - nbase + 255) / 256), (unsigned)c->C), dim3(256), 0, c->stream, k3);
 		if(prof) HIPCHK(hipEventRecord(c->ev[3], c->stream));
 		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, c->d_bursts, c->d_ctl, c->d_freq,
-		           k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
+		           c->d_log, c->d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
 		hipLaunchKernelGGL(k_walk, dim3((unsigned)c->C), dim3(64), 0, c->stream, k4);
+		if(prof) HIPCHK(hipEventRecord(c->ev[6], c->stream));
+		K4bArgs k4b{ c->d_y, c->d_nf, c->d_ws, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfhist, c->d_nfbase,
+		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist };
+		hipLaunchKernelGGL(k_nf_prepare, dim3((unsigned)c->C), dim3(64), 0, c->stream, k4b);
+		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup - 1) / kNfGroup);
+		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, c->stream, k4b);
+		hipLaunchKernelGGL(k_nf_finish, dim3((unsigned)c->C), dim3(64), 0, c->stream, k4b);
 		if(prof) HIPCHK(hipEventRecord(c->ev[4], c->stream));
-		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, c->d_bursts, c->d_frames, c->d_pool, c->d_ctl, c->d_freq, c->cap, c->cap - 1 };
+		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, c->d_bursts, c->d_frames, c->d_pool, c->d_ctl, c->d_freq,
+		           c->d_nfhist, c->d_nfbase, c->cap_hist, c->cap, c->cap - 1 };
 		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, c->stream, k5);
 		if(prof) { HIPCHK(hipEventRecord(c->ev[5], c->stream)); c->ev_valid = true; }
 	}
@@ -210,7 +221,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_phi, c->d_cand, c->d_segend, c->d_runstart, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_bursts,
+	                 c->d_phi, c->d_cand, c->d_segend, c->d_runstart, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nfhist, c->d_lpbuf, c->d_nffeed, c->d_nfbase, c->d_bursts,
 	                 c->d_frames, c->d_pool, c->d_ctl };
 	for(void *p : ptrs) if(p) (void)hipFree(p);
 	if(c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -275,7 +286,12 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	uint64_t cap_b = (uint64_t)count * (dmax / 220 + 2); if(cap_b < 1024) cap_b = 1024;
 	uint64_t cap_f = cap_b * 2; if(cap_f < 4096) cap_f = 4096;
 	uint64_t cap_p = cap_b * 512; if(cap_p < (1u << 22)) cap_p = 1u << 22; if(cap_p > (1u << 30)) cap_p = 1u << 30;
-	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, 0 };
+	c->cap_log = 8192; c->cap_comb = c->cap_log + kNfTail; c->cap_hist = (uint32_t)(dmax / 3000 + 8);
+	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, c->cap_log };
+	DEV_ALLOC(c->d_nf, count * sizeof(NfState)); DEV_ALLOC(c->d_log, (size_t)count * c->cap_log * sizeof(EvalChunk));
+	DEV_ALLOC(c->d_nlog, count * 4); DEV_ALLOC(c->d_scfirst, (size_t)count * (c->cap_comb + 1) * 8); DEV_ALLOC(c->d_sccum, (size_t)count * (c->cap_comb + 1) * 8);
+	DEV_ALLOC(c->d_nfhist, (size_t)count * c->cap_hist * 4); DEV_ALLOC(c->d_nfbase, count * 8);
+	DEV_ALLOC(c->d_lpbuf, (size_t)count * c->cap_hist * 4); DEV_ALLOC(c->d_nffeed, count * sizeof(NfFeed));
 	DEV_ALLOC(c->d_bursts, cap_b * sizeof(Burst)); DEV_ALLOC(c->d_frames, cap_f * sizeof(OutFrame)); DEV_ALLOC(c->d_pool, cap_p);
 	DEV_ALLOC(c->d_ctl, sizeof(OutCtl));
 	DEV_CHK(hipHostMalloc((void **)&c->h_ctl, sizeof(OutCtl), hipHostMallocDefault));
@@ -292,6 +308,14 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_CHK(hipMemcpy(c->d_dphi, c->dphi.data(), 4 * count, hipMemcpyHostToDevice));
 	DEV_CHK(hipMemcpy(c->d_freq, c->freqs.data(), 4 * count, hipMemcpyHostToDevice));
 	DEV_CHK(hipMemcpy(c->d_ws, ws.data(), count * sizeof(WalkState), hipMemcpyHostToDevice));
+	{
+		std::vector<NfState> nfs(count);
+		for(auto &n : nfs) { memset(&n, 0, sizeof n); nf_state_init(n); }
+		DEV_CHK(hipMemcpy(c->d_nf, nfs.data(), count * sizeof(NfState), hipMemcpyHostToDevice));
+		DEV_CHK(hipMemset(c->d_nlog, 0, count * 4)); DEV_CHK(hipMemset(c->d_nfbase, 0, count * 8));
+		DEV_CHK(hipMemset(c->d_nfhist, 0, (size_t)count * c->cap_hist * 4)); DEV_CHK(hipMemset(c->d_lpbuf, 0, (size_t)count * c->cap_hist * 4));
+		DEV_CHK(hipMemset(c->d_nffeed, 0, count * sizeof(NfFeed)));
+	}
 	DEV_CHK(hipMemset(c->d_y, 0, nring * sizeof(cf32))); DEV_CHK(hipMemset(c->d_pf, 0, nring * sizeof(cf32)));
 	DEV_CHK(hipMemset(c->d_phi, 0, nring * sizeof(float))); DEV_CHK(hipMemset(c->d_cand, 0, nring / 8));
 	DEV_CHK(hipMemset(c->d_tcarry[0], 0, count * sizeof(float4))); DEV_CHK(hipMemset(c->d_tcarry[1], 0, count * sizeof(float4)));

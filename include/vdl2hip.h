@@ -108,6 +108,7 @@ typedef struct {
 	uint64_t chanfir_launches;  /* launches of the channeliser kernel */
 	double   chanfir_ms;        /* summed HIP-event time of those launches (needs profiling on) */
 	double   phase_ms, sync_ms, walk_ms, burst_ms;   /* other kernels, same convention */
+	double   nf_ms;             /* noise-floor passes */
 	uint64_t bursts;            /* bursts handed to the burst decoder */
 	uint64_t frames;            /* frames produced */
 } vdl2hip_stats;

@@ -17,6 +17,8 @@ struct Sim {
 	std::vector<uint32_t> freqs;
 	std::vector<cf32> y, pf; std::vector<float> phi; std::vector<uint64_t> cand;
 	std::vector<WalkState> st; std::vector<unsigned long long> cnt;
+	std::vector<NfState> nf; std::vector<EvalChunk> log; std::vector<uint32_t> nlog; std::vector<int64_t> scf, scc, nfbase; std::vector<float> hist, lpbuf;
+	uint32_t cap_log = 8192, cap_comb = 8192 + kNfTail, cap_hist = 4096;
 	Tables T;
 	int64_t k_total = 0;
 	std::vector<Burst> bursts; std::vector<OutFrame> frames; std::vector<uint8_t> pool;
@@ -34,6 +36,9 @@ Sim *hostsim_create(int nchan, const uint32_t *freqs, float max_ppm, int cap_log
 	s->phi.assign((size_t)nchan * s->cap, 0.f); s->cand.assign((size_t)nchan * (s->cap / 64), 0);
 	s->st.resize(nchan); s->cnt.assign((size_t)nchan * kNumCounters, 0);
 	for(auto &w : s->st) { memset(&w, 0, sizeof w); walk_state_init(w); }
+	s->nf.resize(nchan); for(auto &n : s->nf) { memset(&n, 0, sizeof n); nf_state_init(n); }
+	s->log.resize((size_t)nchan * s->cap_log); s->nlog.assign(nchan, 0); s->scf.resize((size_t)nchan * (s->cap_comb + 1)); s->scc.resize((size_t)nchan * (s->cap_comb + 1));
+	s->nfbase.assign(nchan, 0); s->hist.assign((size_t)nchan * s->cap_hist, 0.f); s->lpbuf.assign((size_t)nchan * s->cap_hist, 0.f);
 	build_tables(s->T);
 	s->bursts.resize(65536); s->frames.resize(65536); s->pool.resize(1 << 24);
 	return s;
@@ -69,11 +74,18 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 	}
 	s->k_total = k1;
 	memset(&s->ctl, 0, sizeof s->ctl);
-	s->ctl.cap_bursts = (uint32_t)s->bursts.size(); s->ctl.cap_frames = (uint32_t)s->frames.size(); s->ctl.cap_pool = (uint32_t)s->pool.size();
+	s->ctl.cap_bursts = (uint32_t)s->bursts.size(); s->ctl.cap_frames = (uint32_t)s->frames.size(); s->ctl.cap_pool = (uint32_t)s->pool.size(); s->ctl.cap_log = s->cap_log;
 	static WalkShared wsh;
 	for(int c = 0; c < s->nchan; c++) {
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->phi[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
-		walk_channel(c, s->freqs[c], s->max_ppm, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], s->bursts.data(), &s->ctl, wsh);
+		EvalLog lg{ &s->log[(size_t)c * s->cap_log], &s->nlog[c] };
+		walk_channel(c, s->freqs[c], s->max_ppm, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], s->bursts.data(), &s->ctl, lg, wsh);
+		static NfShared nsh;
+		NfScratch sc{ &s->scf[(size_t)c * (s->cap_comb + 1)], &s->scc[(size_t)c * (s->cap_comb + 1)] };
+		NfFeed fd;
+		nf_prepare(&s->nf[c], lg, sc, s->cap_comb, &fd);
+		for(int64_t g = 0; fd.u0 + 1 + kNfGroup * g <= fd.u1; g++) nf_replay_group(v, sc, fd, g, &s->lpbuf[(size_t)c * s->cap_hist], s->cap_hist, nsh);
+		nf_finish(&s->nf[c], lg, sc, fd, &s->lpbuf[(size_t)c * s->cap_hist], &s->hist[(size_t)c * s->cap_hist], s->cap_hist, &s->nfbase[c], &s->st[c]);
 	}
 	static BurstShared bsh;
 	uint32_t nb = s->ctl.nbursts < s->ctl.cap_bursts ? s->ctl.nbursts : s->ctl.cap_bursts;
@@ -81,7 +93,8 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		const Burst &b = s->bursts[i];
 		int c = b.chan;
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->phi[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
-		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl, bsh);
+		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl,
+		             &s->hist[(size_t)c * s->cap_hist], s->cap_hist, s->nfbase[c], bsh);
 	}
 	uint32_t nf = s->ctl.nframes < s->ctl.cap_frames ? s->ctl.nframes : s->ctl.cap_frames;
 	for(uint32_t i = 0; i < nf; i++) {
