@@ -15,6 +15,14 @@
 #include "vdl2_core.h"
 #include "design.h"
 
+// tuning knobs of K1 (overridable at build time for experiments: tests/gpu_k1_variants.sh)
+#ifndef VDL2_K1_UNROLL
+#define VDL2_K1_UNROLL 4
+#endif
+#ifndef VDL2_K1_WAVES_PER_EU
+#define VDL2_K1_WAVES_PER_EU 3
+#endif
+
 namespace vdl2 {
 
 // the slice of BlockForm K1 needs, passed by value so that it lives in the kernarg segment
@@ -72,7 +80,7 @@ __device__ __forceinline__ void load_sample(const K1Args &a, int64_t s, float &r
 // each wave owns CR channels; each lane owns R consecutive decimated outputs.
 // OS == 0 selects the generic (run-time oversample) build of the same code.
 template<int OS, int R, int CR>
-__global__ __launch_bounds__(256, 3) void k_chanfir(K1Args a) {
+__global__ __launch_bounds__(256, VDL2_K1_WAVES_PER_EU) void k_chanfir(K1Args a) {
 	extern __shared__ __align__(16) unsigned char smem[];
 	const int os = OS ? OS : a.os;
 	const int run = R * os;                       // input samples per lane
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256, 3) void k_chanfir(K1Args a) {
 		const float2 *trow = tile + (size_t)(i * os) * 65 + lane;
 		// Partially unrolled on purpose: a fully unrolled run makes the scheduler hoist every LUT
 		// gather (4 VGPRs each) to the top and spill.  Taps come from scalar loads (uniform index).
-		#pragma unroll 4
+		#pragma unroll VDL2_K1_UNROLL
 		for(int j = 0; j < os; j++) {
 			const float2 x = trow[j * 65];
 			const float g0 = bf.g0[j], g1 = bf.g1[j];

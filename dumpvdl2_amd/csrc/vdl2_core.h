@@ -85,6 +85,7 @@ constexpr int kRsK = 249, kRsN = 255, kRsPar = 6;
 constexpr int kHdrBits = 25, kTlBits = 17, kHdrParBits = 5;
 constexpr int kPreamble = 16, kSpsDec = 10, kSyncSkip = 3;
 constexpr float kPherrBig = 1000.f, kSyncThr = 4.f;
+constexpr float kPiBelow = 0x1.921fb4p+1f; // largest float < M_PI: (double)x > M_PI  <=>  x > kPiBelow for float x
 constexpr uint32_t kMaxTl = 0x3FFFu, kMaxTlCorr = 0x1FFFu;
 constexpr uint32_t kLfsrIv = 0x6959u;
 constexpr int kMaxSyms = 5632;            // >= ceil((8*(2048+52)+25)/3) = 5609
@@ -212,8 +213,10 @@ VDL2_HD void sync_metric(const float *ph, const Tables &T, float &pherr, float &
 		float cur = ph[i] - T.pr_phase[i];
 		float diff = cur - prev;
 		prev = cur;
-		if((double)diff > M_PI) unwrap = (float)((double)unwrap - 2.0f * M_PI);
-		else if((double)diff < -M_PI) unwrap = (float)((double)unwrap + 2.0f * M_PI);
+		// demod.c:137-141 compares the float against the double M_PI.  For a float operand that is
+		// exactly "diff > 0x1.921fb4p+1f" (the largest float below pi): same decisions, no f64 compare.
+		if(diff > kPiBelow) unwrap = (float)((double)unwrap - 2.0f * M_PI);
+		else if(diff < -kPiBelow) unwrap = (float)((double)unwrap + 2.0f * M_PI);
 		e[i] = cur + unwrap;
 		mean += e[i];
 	}

@@ -24,7 +24,10 @@ struct HostFrame {
 	std::vector<uint8_t> octets;
 };
 
-constexpr int kRun = 4;                  // decimated outputs per lane in K1 (specialised builds)
+#ifndef VDL2_K1_RUN
+#define VDL2_K1_RUN 2
+#endif
+constexpr int kRun = VDL2_K1_RUN;        // decimated outputs per lane in K1 (specialised builds); 2 measured best: tests/gpu_k1_variants.sh
 constexpr int kRunGeneric = 2;
 constexpr int kHistory = 65536;          // decimated samples kept behind the newest block (> longest burst, 56 090)
 constexpr int kNumEv = 12;
@@ -253,6 +256,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	c->specialised = (c->os == 10 || c->os == 13 || c->os == 20);
 	c->run = c->specialised ? kRun : kRunGeneric;
 	c->cr = c->C >= 16 ? 4 : c->C >= 8 ? 2 : 1;                   // channels per wave: keep >= 4 channel groups where possible
+	if(const char *e = getenv("VDL2HIP_CR")) { int v = atoi(e); if(v == 1 || v == 2 || v == 4) c->cr = v; }   // experiments only
 	c->bf = derive_block_form(c->lpf, c->os, c->run);
 	c->dphi.resize(count);
 	for(uint32_t i = 0; i < count; i++) c->dphi[i] = nco_step(cfg->centerfreq, c->freqs[i], fs) & 0xffffffu;
