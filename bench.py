@@ -125,6 +125,18 @@ def main():
     achieved = k1_chan_samples * ALGO_BYTES_PER_CHAN_SAMPLE / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
     stage_ms = {k: (s1[k] - s0[k]) / args.steps for k in ("chanfir_ms", "phase_ms", "sync_ms", "walk_ms", "nf_ms", "burst_ms")}
 
+    # HBM traffic of K1 per launch: PMC counters cannot be read from inside this process; the number measured with
+    # rocprofv3 on this same command is kept under profiles/ and quoted when the workload is the one it was taken on
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)["k_chanfir"]
+        w = pt["workload"]
+        if (w["channels_per_gpu"], w["duration_s"], w["oversample"]) == (len(cfg.freqs), float(cfg.duration_s), cfg.oversample):
+            traffic = pt["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
+
     if rank == 0:
         value = world * nsamples * args.steps / dt / 1e6
         out = {
@@ -142,7 +154,7 @@ def main():
                        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}, "verified": verified,
                        "synth_s": round(t_synth, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_chanfir", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": k1_chan_samples * ALGO_BYTES_PER_CHAN_SAMPLE,
                          "avg_launch_ms": round(k1_ms, 5)},
         }

@@ -195,3 +195,27 @@ def test_dropin_adapter_with_reference_main_sequence(vh, oracle_mod, golden_wav,
         assert (int(kv["idx"]), int(kv["S"]), int(kv["L"]), int(kv["F"]), int(kv["freq"])) == (f["idx"], f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"], CF)
         assert abs(float(kv["pwr"]) - f["frame_pwr_dbfs"]) < 0.05 and abs(float(kv["nf"]) - f["nf_pwr_dbfs"]) < 0.05
         assert kv["station"] == "HARNESS" and kv["flags"] == "0"
+
+
+@pytest.mark.parametrize("which,secs", [("config3", 4.0), ("config4", 3.0), ("config5", 3.0)])
+def test_many_channel_configs_vs_oracle(vh, oracle_mod, which, secs):
+    """BASELINE configs[2..4] (64 / 256 channels, cross-talk + --max-ppm gate, injected RS errors) at a few
+    seconds each: the oracle runs on the same bytes on the box's host cores; frames, timing, integer metadata and
+    the reference's counters must be identical, and every decodable transmitted frame must be present."""
+    import os
+    from dumpvdl2_amd import workloads, synth
+    cfg = getattr(workloads, which)(secs)
+    iq, bursts = synth.synthesize(cfg)
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=20, max_ppm=cfg.rx_max_ppm)
+    o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=min(len(cfg.freqs), os.cpu_count() or 8))
+    fo = o.frames()
+    rx, fg, cnt = gpu_decode(vh, cfg, iq, chunks=(2_000_000, 4_000_000), max_block=16_000_000)
+    assert len(fo) > 100
+    assert_frames_equal(fo, fg, label=which)
+    cases.assert_counters_equal(cnt, [list(o.counters(c).values()) for c in range(len(cfg.freqs))], which, exact_diagnostics=False)
+    assert truth_is_subset(bursts, fg) == 0
+    if which == "config5":
+        assert sum(f["num_fec_corrections"] for f in fg) > 100          # the FEC-heavy path really ran
+        tot = [sum(c[i] for c in cnt) for i in range(20)]
+        assert tot[10] > 5                                               # decoder.errors.fec_bad: over-capacity blocks dropped by both
+    rx.close()
