@@ -311,6 +311,7 @@ VDL2_HD Geometry header_to_geometry(uint32_t hdr, const Tables &T) {
 struct WalkShared {
 	WalkState st;
 	float p[64], f[64];
+	float vring[320];
 	int32_t found[64];
 	int32_t flag[64];
 	int32_t sym[16];
@@ -389,11 +390,22 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 				// ---- explicit evaluations near an interval start (ring still holds pre-burst samples) ----
 				int64_t lim = sh.st.a + kFreshAfter; if(lim > k_end) lim = k_end;
 				int64_t nb = (lim - e + 2) / 3; if(nb > 64) nb = 64;
+				// stage the reference's phase ring as it stands around this interval start: vring[160+t] = sample a+t,
+				// vring[159-r] = the (r+1)-th DM_INIT sample before a (through the interval history)
+				const int64_t a0 = sh.st.a;
+				WAVE_FOR(l)
+					for(int j = l; j < 320; j += 64) {
+						float val = 0.f;
+						if(j >= 160) { const int64_t n = a0 + (j - 160); if(n < k_end) val = v.Phi(n); }
+						else val = v.Phi(seq_index(sh.st, a0, 160 - j));
+						sh.vring[j] = val;
+					}
+				WAVE_END
 				WAVE_FOR(l)
 					if(l < nb) {
-						int64_t n = e + 3 * l;
+						const int t = (int)(e + 3 * l - a0);
 						float ph[kPreamble];
-						for(int i = 0; i < kPreamble; i++) ph[i] = v.Phi(seq_index(sh.st, n, 150 - 10 * i));
+						for(int i = 0; i < kPreamble; i++) ph[i] = sh.vring[160 + t - 150 + 10 * i];
 						sync_metric(ph, T, sh.p[l], sh.f[l]);
 					}
 				WAVE_END
@@ -429,28 +441,30 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 				const int64_t start = e > sh.st.e0 + 3 ? e : sh.st.e0 + 3;
 				int64_t w0 = start >> 6;
 				const int64_t wend = (k_end + 63) >> 6;
-				for(; w0 < wend && !fired; w0 += 64) {
+				for(; w0 < wend && !fired; w0 += 256) {
 					WAVE_FOR(l)
-						int64_t w = w0 + l;
 						int32_t hit = -1;
-						if(w < wend) {
-							uint64_t bits = v.Cand(w);
-							// keep bits with index >= start, < k_end, and congruent to e modulo 3
-							int64_t base = w << 6;
-							int r = (int)(((e - base) % 3 + 3) % 3);   // first bit position on the grid
-							uint64_t grid = 0x9249249249249249ull << r;    // bits r, r+3, ...
-							bits &= grid;
-							if(base < start) bits &= (start - base >= 64) ? 0ull : (~0ull << (start - base));
-							if(base + 64 > k_end) bits &= (k_end - base <= 0) ? 0ull : (~0ull >> (64 - (k_end - base)));
-							if(bits) { int b = 0; while(!((bits >> b) & 1)) b++; hit = b; }
+						uint64_t wd[4];
+						for(int q = 0; q < 4; q++) { const int64_t w = w0 + 4 * l + q; wd[q] = w < wend ? v.Cand(w) : 0ull; }
+						for(int q = 0; q < 4 && hit < 0; q++) {
+							const int64_t w = w0 + 4 * l + q;
+							uint64_t bits = wd[q];
+							if(bits) {
+								// keep bits with index >= start, < k_end, and congruent to e modulo 3
+								const int64_t base = w << 6;
+								const int r = (int)(((e - base) % 3 + 3) % 3);   // first bit position on the grid
+								bits &= 0x9249249249249249ull << r;                // bits r, r+3, ...
+								if(base < start) bits &= (start - base >= 64) ? 0ull : (~0ull << (start - base));
+								if(base + 64 > k_end) bits &= (k_end - base <= 0) ? 0ull : (~0ull >> (64 - (k_end - base)));
+								if(bits) { int b = 0; while(!((bits >> b) & 1)) b++; hit = 64 * q + b; }
+							}
 						}
 						sh.found[l] = hit;
 						sh.flag[l] = hit >= 0;
 					WAVE_END
 					const int lf = wave_first_flag(sh.flag);
-					if(lf >= 0) { fired = 1; fire_n = ((w0 + lf) << 6) + sh.found[lf]; }
+					if(lf >= 0) { fired = 1; fire_n = ((w0 + 4 * lf) << 6) + sh.found[lf]; }
 				}
-				K4_MARK(3);
 				if(fired) {
 					const int64_t n = fire_n;
 					LANE0
@@ -692,6 +706,10 @@ struct BurstShared {
 	int32_t  flag_err[64];
 	uint8_t synp[kRsPar][64];          // per-lane syndrome partials
 	uint8_t syn[8];
+	uint8_t rs_lam[8];
+	int32_t rs_deg;
+	uint32_t rs_hits[64];
+	uint8_t gf_exp[512], gf_log[256];  // LDS copies of the field tables
 	float   pw[64];
 	int32_t neg[64];
 	int32_t u_ret, u_kind, u_ok;
@@ -699,86 +717,140 @@ struct BurstShared {
 	float u_pwr;
 };
 
-// decode_rs_char() on one 255-symbol row: libfec/decode_rs.h:71-298.  syn[] = the 6 syndromes in
-// polynomial form.  Sequential (one lane).  Returns corrected-symbol count or -1.
-VDL2_HD int rs_correct(uint8_t *d, const uint8_t syn_poly[kRsPar], int n_era, const int *era_pos, const Tables &T) {
-	const int NN = 255, A0 = 255, FCR = 120;
-	uint8_t lam[kRsPar + 1], syn[kRsPar], b[kRsPar + 1], t[kRsPar + 1], om[kRsPar + 1];
-	uint8_t root[kRsPar], reg[kRsPar + 1], loc[kRsPar];
-	auto EXP = [&](int i) -> uint8_t { return T.gf_exp[i]; };          // i <= 509
-	auto MOD = [](int x) -> int { while(x >= 255) x -= 255; return x; };
-	int any = 0;
-	for(int i = 0; i < kRsPar; i++) { any |= syn_poly[i]; syn[i] = T.gf_log[syn_poly[i]]; }
-	if(!any) return 0;
-	for(int i = 0; i <= kRsPar; i++) lam[i] = 0;
-	lam[0] = 1;
-	if(n_era > 0) {
-		lam[1] = EXP(MOD(NN - 1 - era_pos[0]));
-		for(int i = 1; i < n_era; i++) {
-			int u = MOD(NN - 1 - era_pos[i]);
-			for(int j = i + 1; j > 0; j--) {
-				uint8_t lg = T.gf_log[lam[j - 1]];
-				if(lg != A0) lam[j] ^= EXP(u + lg);
+// decode_rs_char() on one 255-symbol row (libfec/decode_rs.h:71-298) behind rs_verify() (rs.c:32-49), split in
+// wave phases: syndromes (all lanes), erasure locator + Berlekamp-Massey (one lane), Chien search (all lanes),
+// Forney (one lane).  The single-lane parts are written with fully unrolled, statically indexed loops so the
+// small polynomials live in registers.  Result (corrected-symbol count or -1) in sh.u_ret.
+VDL2_HD int gf_mod255(int x) { while(x >= 255) x -= 255; return x; }
+
+VDL2_HD void rs_decode_row(uint8_t *row, int npar, BurstShared &sh) {
+	const uint8_t *EXP = sh.gf_exp, *LOG = sh.gf_log;
+	const int n_era = kRsPar - npar;
+	if(npar == 0) { LANE0 sh.u_ret = 0; LANE0_END return; }
+	// syndromes S_i = sum_j d[j] * alpha^((120+i)*(254-j)): the value the Horner loop of decode_rs.h:82-93 produces
+	WAVE_FOR(l)
+		uint8_t acc[kRsPar] = {0, 0, 0, 0, 0, 0};
+		for(int j = l; j < kRsN; j += 64) {
+			const uint8_t d = row[j];
+			if(d) {
+				const int lg = LOG[d], pw = 254 - j;
+				for(int i = 0; i < kRsPar; i++) acc[i] ^= EXP[lg + ((120 + i) * pw) % 255];
 			}
 		}
-	}
-	for(int i = 0; i <= kRsPar; i++) b[i] = T.gf_log[lam[i]];
-	int r = n_era, el = n_era;
-	while(++r <= kRsPar) {
-		uint8_t disc = 0;
-		for(int i = 0; i < r; i++)
-			if(lam[i] != 0 && syn[r - i - 1] != A0) disc ^= EXP(T.gf_log[lam[i]] + syn[r - i - 1]);
-		disc = T.gf_log[disc];
-		if(disc == A0) {
-			for(int i = kRsPar; i > 0; i--) b[i] = b[i - 1];
-			b[0] = A0;
-		} else {
-			t[0] = lam[0];
-			for(int i = 0; i < kRsPar; i++)
-				t[i + 1] = (b[i] != A0) ? (uint8_t)(lam[i + 1] ^ EXP(disc + b[i])) : lam[i + 1];
-			if(2 * el <= r + n_era - 1) {
-				el = r + n_era - el;
-				for(int i = 0; i <= kRsPar; i++)
-					b[i] = (lam[i] == 0) ? A0 : (uint8_t)MOD(T.gf_log[lam[i]] - disc + NN);
-			} else {
-				for(int i = kRsPar; i > 0; i--) b[i] = b[i - 1];
-				b[0] = A0;
+		for(int i = 0; i < kRsPar; i++) sh.synp[i][l] = acc[i];
+	WAVE_END
+	WAVE_FOR(l)
+		if(l < kRsPar) { uint8_t a = 0; for(int q = 0; q < 64; q++) a ^= sh.synp[l][q]; sh.syn[l] = a; }
+	WAVE_END
+	const int any = sh.syn[0] | sh.syn[1] | sh.syn[2] | sh.syn[3] | sh.syn[4] | sh.syn[5];
+	if(!any) { LANE0 sh.u_ret = 0; LANE0_END return; }           // decode_rs.h:102-108: a codeword, data untouched
+
+	LANE0
+		const int A0 = 255;
+		int syn[kRsPar], lam[kRsPar + 1], b[kRsPar + 1], t[kRsPar + 1];
+		for(int i = 0; i < kRsPar; i++) syn[i] = LOG[sh.syn[i]];                // index form (:96-100)
+		for(int i = 0; i <= kRsPar; i++) lam[i] = 0;
+		lam[0] = 1;
+		if(n_era > 0) {                                                           // erasure locator (:113-123)
+			lam[1] = EXP[gf_mod255(254 - (kRsK + npar))];
+			for(int i = 1; i < kRsPar; i++) {
+				if(i < n_era) {
+					const int u = gf_mod255(254 - (kRsK + npar + i));
+					for(int j = kRsPar; j > 0; j--) {
+						if(j <= i + 1) { const int lg = LOG[lam[j - 1]]; if(lg != A0) lam[j] ^= EXP[u + lg]; }
+					}
+				}
 			}
-			for(int i = 0; i <= kRsPar; i++) lam[i] = t[i];
 		}
-	}
-	int deg_lam = 0;
-	for(int i = 0; i <= kRsPar; i++) { lam[i] = T.gf_log[lam[i]]; if(lam[i] != A0) deg_lam = i; }
-	for(int i = 1; i <= kRsPar; i++) reg[i] = lam[i];
-	int count = 0;
-	for(int i = 1, k = 0; i <= NN; i++, k = MOD(k + 1)) {
-		uint8_t q = 1;
-		for(int j = deg_lam; j > 0; j--)
-			if(reg[j] != A0) { reg[j] = (uint8_t)MOD(reg[j] + j); q ^= EXP(reg[j]); }
-		if(q != 0) continue;
-		root[count] = (uint8_t)i; loc[count] = (uint8_t)k;
-		if(++count == deg_lam) break;
-	}
-	if(deg_lam != count) return -1;
-	int deg_om = deg_lam - 1;
-	for(int i = 0; i <= deg_om; i++) {
-		uint8_t acc = 0;
-		for(int j = i; j >= 0; j--)
-			if(syn[i - j] != A0 && lam[j] != A0) acc ^= EXP(syn[i - j] + lam[j]);
-		om[i] = T.gf_log[acc];
-	}
-	for(int j = count - 1; j >= 0; j--) {
-		uint8_t num1 = 0, den = 0;
-		for(int i = deg_om; i >= 0; i--)
-			if(om[i] != A0) num1 ^= EXP(MOD(om[i] + i * root[j]));
-		uint8_t num2 = EXP(MOD(root[j] * (FCR - 1) + NN));
-		int top = (deg_lam < kRsPar - 1 ? deg_lam : kRsPar - 1) & ~1;
-		for(int i = top; i >= 0; i -= 2)
-			if(lam[i + 1] != A0) den ^= EXP(MOD(lam[i + 1] + i * root[j]));
-		if(num1 != 0)
-			d[loc[j]] ^= EXP(MOD(T.gf_log[num1] + T.gf_log[num2] + NN - T.gf_log[den]));
-	}
-	return count;
+		for(int i = 0; i <= kRsPar; i++) b[i] = LOG[lam[i]];
+		int el = n_era;
+		for(int r = 1; r <= kRsPar; r++) {                                      // Berlekamp-Massey (:166-207)
+			if(r > n_era) {
+				int disc = 0;
+				for(int i = 0; i < kRsPar; i++) {
+					if(i < r) { const int sy = syn[r - i - 1 < 0 ? 0 : r - i - 1]; if(lam[i] != 0 && sy != A0) disc ^= EXP[LOG[lam[i]] + sy]; }
+				}
+				disc = LOG[disc];
+				if(disc == A0) {
+					for(int i = kRsPar; i > 0; i--) b[i] = b[i - 1];
+					b[0] = A0;
+				} else {
+					t[0] = lam[0];
+					for(int i = 0; i < kRsPar; i++) t[i + 1] = (b[i] != A0) ? (lam[i + 1] ^ EXP[disc + b[i]]) : lam[i + 1];
+					if(2 * el <= r + n_era - 1) {
+						el = r + n_era - el;
+						for(int i = 0; i <= kRsPar; i++) b[i] = (lam[i] == 0) ? A0 : gf_mod255(LOG[lam[i]] - disc + 255);
+					} else {
+						for(int i = kRsPar; i > 0; i--) b[i] = b[i - 1];
+						b[0] = A0;
+					}
+					for(int i = 0; i <= kRsPar; i++) lam[i] = t[i];
+				}
+			}
+		}
+		int deg = 0;
+		for(int i = 0; i <= kRsPar; i++) { lam[i] = LOG[lam[i]]; if(lam[i] != A0) deg = i; sh.rs_lam[i] = (uint8_t)lam[i]; }   // (:210-215)
+		sh.rs_deg = deg;
+	LANE0_END
+
+	// Chien search (:217-240): position i (1..255) is a root iff 1 + sum_j alpha^(lambda_j + j*i) == 0
+	WAVE_FOR(l)
+		uint32_t hits = 0;
+		for(int q = 0; q < 4; q++) {
+			const int i = 1 + l + 64 * q;
+			if(i <= 255) {
+				int qv = 1;
+				for(int j = 1; j <= kRsPar; j++) {
+					const int lj = sh.rs_lam[j];
+					if(j <= sh.rs_deg && lj != 255) qv ^= EXP[gf_mod255(lj + (j * i) % 255)];
+				}
+				if(qv == 0) hits |= 1u << q;
+			}
+		}
+		sh.rs_hits[l] = hits;
+	WAVE_END
+
+	LANE0
+		const int A0 = 255, FCR = 120;
+		const int deg = sh.rs_deg;
+		int root[kRsPar], count = 0;
+		for(int i = 0; i < kRsPar; i++) root[i] = 0;
+		for(int q = 0; q < 4; q++)
+			for(int l = 0; l < 64; l++)
+				if((sh.rs_hits[l] >> q) & 1u) {
+					const int i = 1 + l + 64 * q;
+					for(int c = 0; c < kRsPar; c++) if(c == count) root[c] = i;
+					count++;
+				}
+		int ret;
+		if(deg != count) ret = -1;                                                // (:241-248)
+		else {
+			int lam[kRsPar + 1], syn[kRsPar], om[kRsPar];
+			for(int i = 0; i <= kRsPar; i++) lam[i] = sh.rs_lam[i];
+			for(int i = 0; i < kRsPar; i++) syn[i] = LOG[sh.syn[i]];
+			const int deg_om = deg - 1;
+			for(int i = 0; i < kRsPar; i++) {                                     // omega = syn*lambda mod x^6 (:253-261)
+				int acc = 0;
+				for(int j = 0; j < kRsPar; j++)
+					if(i <= deg_om && j <= i) { const int sy = syn[i - j < 0 ? 0 : i - j]; if(sy != A0 && lam[j] != A0) acc ^= EXP[sy + lam[j]]; }
+				om[i] = LOG[acc];
+			}
+			for(int c = 0; c < kRsPar; c++) {                                     // Forney (:267-291)
+				if(c < count) {
+					const int rt = root[c];
+					int num1 = 0, den = 0;
+					for(int i = 0; i < kRsPar; i++) if(i <= deg_om && om[i] != A0) num1 ^= EXP[gf_mod255(om[i] + (i * rt) % 255)];
+					const int num2 = EXP[gf_mod255((rt * (FCR - 1)) % 255 + 255)];
+					const int top = (deg < kRsPar - 1 ? deg : kRsPar - 1) & ~1;
+					for(int i = 0; i <= 4; i += 2) if(i <= top && lam[i + 1] != A0) den ^= EXP[gf_mod255(lam[i + 1] + (i * rt) % 255)];
+					// loc = k of decode_rs.h:224 with iprim = 1: k = i - 1
+					if(num1 != 0) row[rt - 1] ^= EXP[gf_mod255(LOG[num1] + LOG[num2] + 255 - LOG[den])];
+				}
+			}
+			ret = count;
+		}
+		sh.u_ret = ret;
+	LANE0_END
 }
 
 VDL2_HD int popc32(uint32_t v) { return __builtin_popcount(v); }
@@ -800,6 +872,10 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 	const int npar_last = fec_octets_for(last);
 	const int nsym = b.nsym;
 	K5_BEGIN();
+	WAVE_FOR(l)
+		for(int i = l; i < 512; i += 64) sh.gf_exp[i] = T.gf_exp[i];
+		for(int i = l; i < 256; i += 64) sh.gf_log[i] = T.gf_log[i];
+	WAVE_END
 
 	// 1. slice every symbol (demod.c:252-274); decisions are independent because prev_phi is the raw phase
 	WAVE_FOR(l)
@@ -863,36 +939,11 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 	for(uint32_t r = 0; r < nblk && !failed; r++) {
 		const int npar = (r == nblk - 1) ? npar_last : kRsPar;
 		uint8_t *row = &sh.tab[r * 256];
-		if(npar != 0) {
-			// syndromes S_i = sum_j d[j] * alpha^((120+i)*(254-j)), same values as the Horner loop of decode_rs.h:82-93
-			WAVE_FOR(l)
-				uint8_t acc[kRsPar] = {0, 0, 0, 0, 0, 0};
-				for(int j = l; j < kRsN; j += 64) {
-					uint8_t d = row[j];
-					if(d) {
-						int lg = T.gf_log[d], pw = 254 - j;
-						for(int i = 0; i < kRsPar; i++) acc[i] ^= T.gf_exp[lg + ((120 + i) * pw) % 255];
-					}
-				}
-				for(int i = 0; i < kRsPar; i++) sh.synp[i][l] = acc[i];
-			WAVE_END
-			WAVE_FOR(l)
-				if(l < kRsPar) { uint8_t a = 0; for(int q = 0; q < 64; q++) a ^= sh.synp[l][q]; sh.syn[l] = a; }
-			WAVE_END
-		}
+		rs_decode_row(row, npar, sh);
 		LANE0
 			VDL2_CNT_ADD(cnt, CNT_BLOCKS_PROCESSED, 1);
-			int ret = 0;
-			if(npar != 0) {
-				uint8_t syn[kRsPar];
-				for(int i = 0; i < kRsPar; i++) syn[i] = sh.syn[i];
-				int n_era = kRsPar - npar, era[kRsPar];
-				for(int i = 0; i < n_era; i++) era[i] = kRsK + npar + i;
-				ret = rs_correct(row, syn, n_era, era, T);
-			}
-			if(ret < 0) VDL2_CNT_ADD(cnt, CNT_ERR_FEC_BAD, 1);
+			if(sh.u_ret < 0) VDL2_CNT_ADD(cnt, CNT_ERR_FEC_BAD, 1);
 			else VDL2_CNT_ADD(cnt, CNT_BLOCKS_FEC_OK, 1);
-			sh.u_ret = ret;
 		LANE0_END
 		if(sh.u_ret < 0) failed = 1;
 		else if(sh.u_ret > 0) fec_fixed += sh.u_ret - (kRsPar - npar);

@@ -113,4 +113,14 @@ const uint8_t *hostsim_pool(Sim *s) { return s->all_pool.data(); }
 void hostsim_counters(Sim *s, int chan, unsigned long long *out) { memcpy(out, &s->cnt[(size_t)chan * kNumCounters], sizeof(unsigned long long) * kNumCounters); }
 int hostsim_sizeof_outframe() { return (int)sizeof(OutFrame); }
 
+// the burst decoder's RS stage on one 255-octet row (for direct comparison with libfec / the oracle)
+int hostsim_rs_decode(uint8_t *row, int npar) {
+	static BurstShared sh; static Tables T; static bool init = false;
+	if(!init) { build_tables(T); memcpy(sh.gf_exp, T.gf_exp, 512); memcpy(sh.gf_log, T.gf_log, 256); init = true; }
+	memcpy(sh.tab, row, 255);
+	rs_decode_row(sh.tab, npar, sh);
+	memcpy(row, sh.tab, 255);
+	return sh.u_ret;
+}
+
 }

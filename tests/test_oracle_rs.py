@@ -82,3 +82,30 @@ def test_random_garbage_blocks(oracle_mod, libfec):
         r_ref, out_ref = ref_verify(L, rs, block, fec)
         r_or, out_or = oracle_mod.rs_decode(block, fec)
         assert (r_or, out_or) == (r_ref, out_ref)
+
+
+def test_device_rs_stage_matches_libfec(oracle_mod, libfec):
+    """The RS stage of the burst-decoder kernel (vdl2_core.h:rs_decode_row, built for the CPU by tests/hostsim)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
+    import pyhostsim
+    H = C.CDLL(pyhostsim.build())
+    H.hostsim_rs_decode.restype = C.c_int
+    H.hostsim_rs_decode.argtypes = [C.c_void_p, C.c_int]
+    L, rs = libfec
+    rng = np.random.default_rng(77)
+    for trial in range(4000):
+        fec = int(rng.choice([6, 6, 4, 2, 0]))
+        if trial % 3 == 0:
+            block = rng.integers(0, 256, 255, dtype=np.uint8).tolist()       # garbage
+        else:
+            data = rng.integers(0, 256, 249, dtype=np.uint8)
+            block = list(data) + list(oracle_mod.rs_encode(data.tolist()))
+            for p in rng.choice(249 + max(fec, 1), size=int(rng.integers(0, 6)), replace=False):
+                block[p] ^= int(rng.integers(1, 256))
+        for i in range(249 + fec, 255):
+            block[i] = 0
+        r_ref, out_ref = ref_verify(L, rs, block, fec)
+        d = (C.c_uint8 * 255)(*block)
+        r_dev = H.hostsim_rs_decode(d, fec)
+        assert (r_dev, bytes(d)) == (r_ref, out_ref), f"trial {trial} fec {fec}"
