@@ -5,8 +5,9 @@ Metric (BASELINE.json): IQ MS/s demodulated end-to-end.  One "step" = one pass o
 path (K1 channeliser ... K5 burst decoder, frames delivered to the host) over one 16 s batch of
 synthetic 2.1 MS/s cs16 IQ that is already resident in HBM.  N=1 runs BASELINE configs[1]
 (8 VDL2 channels on one GPU).  With N>1 (one process per GPU, launched by torch.distributed.run)
-every rank decodes 8 channels of the same IQ stream (weak scaling: 8 channels per GPU); the raw IQ
-block is broadcast from rank 0 with RCCL inside the timed step - the path's only exchange.
+every rank decodes 8 channels of the same IQ stream (weak scaling: 8 channels per GPU); each raw IQ
+block is broadcast from rank 0 with RCCL inside the timed steps (double-buffered: the broadcast of
+block i+1 overlaps the demodulation of block i) - the path's only exchange.
 
 Prints ONE JSON line on rank 0.
 """
@@ -62,23 +63,40 @@ def main():
         iq, bursts = synth.synthesize(cfg)
         assert iq.size == nvals
         t_synth = time.time() - t0
-        dev_iq = torch.from_numpy(iq).cuda()
+        bufs = [torch.from_numpy(iq).cuda()]
     else:
         iq = None
         t_synth = 0.0
-        dev_iq = torch.zeros(nvals, dtype=torch.int16, device="cuda")
+        bufs = [torch.zeros(nvals, dtype=torch.int16, device="cuda")]
+    if world > 1:       # double buffer: block i+1 is broadcast over xGMI while block i is being demodulated
+        bufs.append(bufs[0].clone())
     nbytes = nvals * 2
     nsamples = nvals // 2
 
     rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm,
                           device=local, max_block_bytes=nbytes)
 
+    state = {"i": 0, "work": None}
+    if world > 1:       # block 0 arrives before the first step
+        vdist.broadcast_block(bufs[0], src=0)
+        torch.cuda.synchronize()
+
     def step():
+        """One pass of the hot path over one 16 s block; with N>1 the RCCL broadcast of the NEXT block runs
+        concurrently (its own stream) and is waited for before the step ends, so every step pays
+        max(compute, broadcast) - the exchange is inside the timed region."""
+        i = state["i"]
+        cur = bufs[i % len(bufs)]
         if world > 1:
-            vdist.broadcast_block(dev_iq, src=0)
-            torch.cuda.current_stream().synchronize()      # the library runs on its own stream
-        rx.feed_device(dev_iq.data_ptr(), nbytes)
-        return rx.drain_packed()            # every frame of the step copied to host memory (records + octets)
+            nxt = bufs[(i + 1) % len(bufs)]
+            state["work"] = dist.broadcast(nxt.view(torch.uint8), src=0, async_op=True)
+        rx.feed_device(cur.data_ptr(), nbytes)
+        out = rx.drain_packed()            # every frame of the step copied to host memory (records + octets)
+        if world > 1:
+            state["work"].wait()
+            torch.cuda.current_stream().synchronize()
+        state["i"] = i + 1
+        return out
 
     # ---- warm-up, with the parity gate on the first pass ----
     verified = None
@@ -161,14 +179,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle as po
             nth = min(len(cfg.freqs), os.cpu_count() or 1)
-            o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
-            t0 = time.perf_counter()
-            o.process(iq.view(np.uint8), block_bytes=320000, nthreads=nth)
-            tc = time.perf_counter() - t0
+            best, nfr = None, 0
+            for _ in range(3):                                  # best of 3: shared host, noisy neighbours
+                o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+                t0 = time.perf_counter()
+                o.process(iq.view(np.uint8), block_bytes=320000, nthreads=nth)
+                tc1 = time.perf_counter() - t0
+                nfr = len(o.frames())
+                o.close()
+                best = tc1 if best is None else min(best, tc1)
+            tc = best
             out["cpu_baseline"] = {"value": round(nsamples / tc / 1e6, 3), "unit": "MS/s", "cores": nth, "kind": "port",
-                                   "sample": f"the same {cfg.duration_s:g} s x {len(cfg.freqs)}-channel batch, once; CPU restatement of the reference "
+                                   "sample": f"the same {cfg.duration_s:g} s x {len(cfg.freqs)}-channel batch, best of 3 passes; CPU restatement of the reference "
                                              f"(oracle/), one thread per channel + serial sample conversion, 320000-byte blocks as process_iq_file()",
-                                   "frames": len(o.frames())}
+                                   "frames": nfr}
         print(json.dumps(out), flush=True)
     rx.close()
     if world > 1:

@@ -56,5 +56,16 @@ def build_harness(out_path):
     return out_path
 
 
+def build_cli(out_path=None):
+    """tools/vdl2hip_iqfile: the `dumpvdl2 --iq-file` work-alike (C) on top of libvdl2hip.so."""
+    root = os.path.dirname(HERE)
+    out_path = out_path or os.path.join(root, "tools", "vdl2hip_iqfile")
+    src = os.path.join(root, "tools", "vdl2hip_iqfile.c")
+    if not os.path.exists(out_path) or os.path.getmtime(out_path) < max(os.path.getmtime(src), os.path.getmtime(LIB) if os.path.exists(LIB) else 0):
+        subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Wall", "-Wextra", "-I", os.path.join(root, "include"), src,
+                               "-L", HERE, "-lvdl2hip", "-Wl,-rpath," + HERE, "-o", out_path])
+    return out_path
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

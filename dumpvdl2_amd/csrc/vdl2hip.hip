@@ -402,6 +402,46 @@ int vdl2hip_drain_packed(vdl2hip_ctx *c, vdl2hip_packed_frame *frames, size_t ca
 	return (int)n;
 }
 
+// ---- proto3 wire format, hand-rolled (no protobuf runtime in the product) ----
+namespace {
+struct PbOut {
+	uint8_t *p; size_t cap, n; bool ok;
+	void byte(uint8_t b) { if(n < cap) p[n] = b; else ok = false; n++; }
+	void varint(uint64_t v) { while(v >= 0x80) { byte((uint8_t)(v | 0x80)); v >>= 7; } byte((uint8_t)v); }
+	void tag(uint32_t field, uint32_t wt) { varint((uint64_t)field << 3 | wt); }
+	void u32(uint32_t field, uint32_t v) { if(v) { tag(field, 0); varint(v); } }                       // proto3: defaults are omitted
+	void i32(uint32_t field, int32_t v) { if(v) { tag(field, 0); varint((uint64_t)(int64_t)v); } }      // negative int32 -> 10-byte varint
+	void i64(uint32_t field, int64_t v) { if(v) { tag(field, 0); varint((uint64_t)v); } }
+	void f32(uint32_t field, float v) { uint32_t u; memcpy(&u, &v, 4); if(u) { tag(field, 5); for(int i = 0; i < 4; i++) byte((uint8_t)(u >> (8 * i))); } }
+	void bytes(uint32_t field, const uint8_t *d, size_t len) { tag(field, 2); varint(len); for(size_t i = 0; i < len; i++) byte(d[i]); }
+};
+size_t pack_metadata(PbOut &o, const vdl2hip_frame *f, const char *station_id, int64_t tv_sec, int64_t tv_usec) {
+	const size_t start = o.n;
+	if(station_id && station_id[0]) o.bytes(1, (const uint8_t *)station_id, strlen(station_id));
+	o.u32(2, f->freq); o.u32(3, f->synd_weight); o.u32(4, f->datalen_octets);
+	o.f32(5, f->frame_pwr_dbfs); o.f32(6, f->nf_pwr_dbfs); o.f32(7, f->ppm_error);
+	o.i32(8, 1 /* metadata->version, src/decode.c:177 */); o.i32(9, f->num_fec_corrections); o.i32(10, f->idx);
+	uint8_t tsbuf[24]; PbOut ts{ tsbuf, sizeof tsbuf, 0, true };
+	ts.i64(1, tv_sec); ts.i64(2, tv_usec);
+	o.bytes(11, tsbuf, ts.n);                                    // the timestamp sub-message is always present (src/fmtr-binary.c:38)
+	return o.n - start;
+}
+}  // namespace
+
+int vdl2hip_pack_raw_frame(const vdl2hip_frame *f, const char *station_id, int64_t tv_sec, int64_t tv_usec, uint8_t *out, size_t cap) {
+	if(!f || !out || (f->len && !f->octets)) return VDL2HIP_E_INVAL;
+	uint8_t meta[512]; PbOut m{ meta, sizeof meta, 0, true };
+	pack_metadata(m, f, station_id, tv_sec, tv_usec);
+	if(!m.ok) return VDL2HIP_E_TOOBIG;
+	PbOut o{ out, cap, 0, true };
+	o.byte(0); o.byte(0);                                         // record length, patched below
+	o.bytes(1, meta, m.n);
+	if(f->len) o.bytes(2, f->octets, f->len);                    // proto3 omits empty bytes
+	if(!o.ok || o.n > 65535) return VDL2HIP_E_TOOBIG;
+	out[0] = (uint8_t)(o.n >> 8); out[1] = (uint8_t)o.n;         // htons(payload + 2), src/output-file.c:181-188
+	return (int)o.n;
+}
+
 int vdl2hip_counters(vdl2hip_ctx *c, uint32_t chan, uint64_t out[VDL2HIP_NUM_COUNTERS]) {
 	if(!c || !out || chan < (uint32_t)c->chan_first || chan >= (uint32_t)(c->chan_first + c->C)) return VDL2HIP_E_INVAL;
 	int r = collect_pending(c);

@@ -30,7 +30,7 @@ NUM_COUNTERS = len(COUNTER_NAMES)
 EXPORTS = [
     "vdl2hip_abi_version", "vdl2hip_strerror", "vdl2hip_create", "vdl2hip_destroy", "vdl2hip_feed",
     "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
-    "vdl2hip_drain_packed", "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
+    "vdl2hip_drain_packed", "vdl2hip_pack_raw_frame", "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
 ]
 
 
@@ -81,6 +81,7 @@ def load_library(path: str = LIB_PATH):
     L.vdl2hip_sync.argtypes = [C.c_void_p]
     L.vdl2hip_drain.argtypes = [C.c_void_p, FRAME_CB, C.c_void_p]
     L.vdl2hip_drain_packed.argtypes = [C.c_void_p, C.POINTER(PackedFrame), C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.vdl2hip_pack_raw_frame.argtypes = [C.POINTER(CFrame), C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t]
     L.vdl2hip_counters.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
     L.vdl2hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.vdl2hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -95,6 +96,22 @@ def load_library(path: str = LIB_PATH):
 
 class Vdl2HipError(RuntimeError):
     pass
+
+
+def pack_raw_frame(frame: dict, station_id: Optional[str] = None, tv_sec: int = 0, tv_usec: int = 0) -> bytes:
+    """One record of the reference's raw-frame archive (`--output raw:binary:file` / `--raw-frames-file`)."""
+    L = load_library()
+    octs = frame["octets"]
+    buf = (C.c_uint8 * max(1, len(octs)))(*octs)
+    f = CFrame(frame["chan"], frame["freq"], frame["idx"], len(octs), C.cast(buf, C.POINTER(C.c_uint8)),
+               frame["synd_weight"], frame["datalen_octets"], frame["num_fec_corrections"], frame["frame_pwr_dbfs"],
+               frame["nf_pwr_dbfs"], frame["ppm_error"], frame.get("burst_ord", 0), frame.get("sync_sample", 0),
+               frame.get("end_sample", 0))
+    out = (C.c_uint8 * (len(octs) + 600))()
+    n = L.vdl2hip_pack_raw_frame(C.byref(f), station_id.encode() if station_id else None, tv_sec, tv_usec, out, len(out))
+    if n < 0:
+        raise Vdl2HipError(L.vdl2hip_strerror(n).decode())
+    return bytes(out[:n])
 
 
 class Receiver:

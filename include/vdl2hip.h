@@ -143,6 +143,15 @@ typedef struct {
 int  vdl2hip_drain_packed(vdl2hip_ctx *ctx, vdl2hip_packed_frame *frames, size_t cap_frames,
 		uint8_t *octets, size_t cap_octets, size_t *octets_used);
 
+/* Serialise one frame in the reference's raw-frame archive format, i.e. what `--output raw:binary:file:...`
+ * writes and `--raw-frames-file` reads back: 2-byte big-endian record length (payload + 2) followed by the
+ * proto3 message dumpvdl2.raw_avlc_frame { vdl2_msg_metadata metadata = 1; bytes data = 2; }
+ * (proto/dumpvdl2.proto:24-47, src/fmtr-binary.c:28-60, src/output-file.c:176-192, reader
+ * src/input-raw_frames_file.c:33-107).  `frame->octets` must be valid.  Needs no GPU.
+ * Returns the number of bytes written, or VDL2HIP_E_TOOBIG if `cap` is too small / the record exceeds 65535. */
+int  vdl2hip_pack_raw_frame(const vdl2hip_frame *frame, const char *station_id, int64_t tv_sec, int64_t tv_usec,
+		uint8_t *out, size_t cap);
+
 int  vdl2hip_counters(vdl2hip_ctx *ctx, uint32_t chan, uint64_t out[VDL2HIP_NUM_COUNTERS]);
 int  vdl2hip_set_profiling(vdl2hip_ctx *ctx, int on);   /* bracket kernels with HIP events on the ctx stream */
 int  vdl2hip_get_stats(vdl2hip_ctx *ctx, vdl2hip_stats *out);

@@ -219,3 +219,32 @@ def test_many_channel_configs_vs_oracle(vh, oracle_mod, which, secs):
         tot = [sum(c[i] for c in cnt) for i in range(20)]
         assert tot[10] > 5                                               # decoder.errors.fec_bad: over-capacity blocks dropped by both
     rx.close()
+
+
+def test_cli_runner_and_raw_frame_archive(vh, oracle_mod, golden_wav, tmp_path):
+    """tools/vdl2hip_iqfile with the reference CI's own arguments (.github/workflows/build.yml:16-18):
+    --iq-file test/vdl2_model_16b_1050kHz.wav --sample-format S16_LE.  The two messages must appear, and the
+    raw-frame archive it writes must parse back (2-byte BE length + proto3 raw_avlc_frame) to the same octets."""
+    import os, struct, subprocess
+    from dumpvdl2_amd import build
+    exe = build.build_cli(str(tmp_path / "vdl2hip_iqfile"))
+    wav = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "vdl2_model_16b_1050kHz.wav")
+    raw = str(tmp_path / "frames.bin")
+    p = subprocess.run([exe, "--iq-file", wav, "--sample-format", "S16_LE", "--station-id", "TEST", "--raw-frames-out", raw],
+                       check=True, capture_output=True, text=True, timeout=120)
+    lines = [l for l in p.stdout.splitlines() if "[S:" in l]
+    assert len(lines) == 2 and all("[S:0] [L:504] [F:0]" in l for l in lines)
+    hexes = [bytes.fromhex(l.rsplit(" ", 1)[1]) for l in lines]
+    assert b" -RA BR OVC005\n" in hexes[0] and b" SLP135\n" in hexes[1]
+    o = oracle_mod.Oracle(CF, [CF], oversample=10)
+    o.process(golden_wav)
+    assert [f["octets"] for f in o.frames()] == hexes
+    import test_rawframe_format as trf
+    RawFrame = trf.build_schema()
+    blob = open(raw, "rb").read()
+    off, got = 0, []
+    while off < len(blob):
+        (ln,) = struct.unpack(">H", blob[off:off + 2])
+        m = RawFrame(); m.ParseFromString(blob[off + 2:off + ln]); got.append(m); off += ln
+    assert [m.data for m in got] == hexes
+    assert all(m.metadata.station_id == "TEST" and m.metadata.frequency == CF and m.metadata.datalen_octets == 504 for m in got)
