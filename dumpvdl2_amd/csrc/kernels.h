@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void k_sync(K3Args a) {
 
 struct K4Args {
 	const cf32 *y; const float *phi; const cf32 *pf; const uint64_t *cand; const Tables *tab;
-	WalkState *ws; unsigned long long *cnt; Burst *bursts; OutCtl *ctl; const uint32_t *freq;
+	WalkState *ws; unsigned long long *cnt; Burst *bursts; uint32_t *nb_chan; uint32_t cap_bursts_chan; OutCtl *ctl; const uint32_t *freq;
 	EvalChunk *log; uint32_t *nlog; uint32_t cap_log;
 	int64_t k_end; float max_ppm; uint32_t cap, mask; int32_t chan_first;
 };
@@ -304,7 +304,8 @@ __global__ __launch_bounds__(64) void k_walk(K4Args a) {
 	const int c = blockIdx.x;
 	ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
-	walk_channel(c, a.freq[c], a.max_ppm, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters, a.bursts, a.ctl, lg, sh);
+	walk_channel(c, a.freq[c], a.max_ppm, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
+	             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh);
 }
 
 struct K4bArgs {
@@ -339,19 +340,32 @@ __global__ __launch_bounds__(64) void k_nf_finish(K4bArgs a) {
 	nf_finish(&a.nf[c], lg, sc, a.feed[c], a.lpbuf + (size_t)c * a.cap_hist, a.hist + (size_t)c * a.cap_hist, a.cap_hist, a.hist_base + c, &a.ws[c]);
 }
 
+// Each channel's walker fills its own burst list (no atomics on its critical path); this one-wave kernel turns the
+// per-channel counts into offsets so that K5 can spread all bursts of the feed over its workgroups.
+__global__ __launch_bounds__(64) void k_burst_index(const uint32_t *nb_chan, uint32_t *bbase, int nchan, OutCtl *ctl) {
+	if(threadIdx.x != 0) return;
+	uint32_t acc = 0;
+	for(int c = 0; c < nchan; c++) { bbase[c] = acc; acc += nb_chan[c]; }
+	bbase[nchan] = acc;
+	ctl->nbursts = acc;
+}
+
 struct K5Args {
 	const cf32 *y; const float *phi; const Tables *tab; unsigned long long *cnt;
-	const Burst *bursts; OutFrame *frames; uint8_t *pool; OutCtl *ctl; const uint32_t *freq;
+	const Burst *bursts; const uint32_t *bbase; uint32_t cap_bursts_chan; int32_t nchan;
+	OutFrame *frames; uint8_t *pool; OutCtl *ctl; const uint32_t *freq;
 	const float *nf_hist; const int64_t *nf_base; uint32_t cap_hist;
 	uint32_t cap, mask;
 };
 
 __global__ __launch_bounds__(64) void k_burst(K5Args a) {
 	__shared__ BurstShared sh;
-	uint32_t nb = a.ctl->nbursts; if(nb > a.ctl->cap_bursts) nb = a.ctl->cap_bursts;
-	for(uint32_t i = blockIdx.x; i < nb; i += gridDim.x) {
-		const Burst b = a.bursts[i];
-		const int c = b.chan;
+	const uint32_t total = a.bbase[a.nchan];
+	for(uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
+		int lo = 0, hi = a.nchan;                       // channel c with bbase[c] <= g < bbase[c+1]
+		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(a.bbase[mid] <= g) lo = mid; else hi = mid; }
+		const int c = lo;
+		const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - a.bbase[c])];
 		ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, nullptr, nullptr, a.mask };
 		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl,
 		             a.nf_hist + (size_t)c * a.cap_hist, a.cap_hist, a.nf_base[c], sh);

@@ -199,7 +199,33 @@ VDL2_HD void walk_state_init(WalkState &s) {
 // ======================================================================
 // element-wise pieces
 // ======================================================================
-VDL2_HD float phase_of(cf32 y) { return (float)atan2((double)y.im, (double)y.re); }   // demod.c:232,256
+// atan2() in double for demod.c:232,256 ("atan2(im, re)" narrowed to float).  Same value as libm's after the
+// narrowing: |error| <= ~3e-16 (about 2 double ulps), so the float result differs from a correctly rounded
+// double atan2 only when that lands within 2 ulp_double of a float rounding boundary (~1e-8 of samples; libm and
+// OCML differ from each other just as often).  Argument reduction: with t = min/max in [0,1] and c = k/8 the
+// nearest eighth, atan(t) = atan(c) + atan((min - c*max)/(max + c*min)), |u| <= 1/16 -> 8-term odd series.
+// One f64 division instead of the ~100-instruction library routine: K2 is bound by it.
+VDL2_HD double atan2_f64(double y, double x) {
+	const double ax = fabs(x), ay = fabs(y);
+	const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+	if(!(mx > 0.0) || !(mx < 1.0e300)) return atan2(y, x);         // zeros, infinities, NaN: leave to the library
+	const float r = (float)mn / (float)mx;
+	if(!(r >= 0.f && r <= 1.f)) return atan2(y, x);                // operands outside the float range (never for float inputs)
+	const int k = (int)(r * 8.0f + 0.5f);
+	static const double A[9] = { 0.0, 0.12435499454676144, 0.24497866312686414, 0.35877067027057225, 0.4636476090008061,
+	                             0.5585993153435624, 0.6435011087932844, 0.7188299996216245, 0.7853981633974483 };
+	const double c = 0.125 * (double)k;
+	const double u = fma(-c, mx, mn) / fma(c, mn, mx);
+	const double z = u * u;
+	double p = -1.0 / 15.0;
+	p = fma(p, z, 1.0 / 13.0); p = fma(p, z, -1.0 / 11.0); p = fma(p, z, 1.0 / 9.0); p = fma(p, z, -1.0 / 7.0);
+	p = fma(p, z, 1.0 / 5.0); p = fma(p, z, -1.0 / 3.0);
+	double a = A[k] + fma(p * z, u, u);
+	if(ay > ax) a = 1.5707963267948966 - a;
+	if(x < 0.0) a = 3.141592653589793 - a;
+	return copysign(a, y);
+}
+VDL2_HD float phase_of(cf32 y) { return (float)atan2_f64((double)y.im, (double)y.re); }
 
 // hypotf() as glibc evaluates it (double intermediate), demod.c:238
 VDL2_HD float mag_of(cf32 y) { return (float)sqrt((double)y.re * (double)y.re + (double)y.im * (double)y.im); }
@@ -277,13 +303,13 @@ struct Geometry { uint32_t tl_bits, octets, nblocks, last_len, fec_octets, want_
 enum { HDR_OK = 0, HDR_CRC_BAD = 1, HDR_TOO_LONG = 2, HDR_NO_FEC = 3 };
 
 // Header word (25 bits, MSB first) -> burst geometry: decode.c:209-258
-VDL2_HD Geometry header_to_geometry(uint32_t hdr, const Tables &T) {
+VDL2_HD Geometry header_to_geometry(uint32_t hdr, const uint32_t *tH, const uint32_t *tfix) {
 	Geometry g{};
 	const uint32_t keep = (1u << (kTlBits + kHdrParBits)) - 1;
 	hdr &= keep;
 	uint32_t s = 0;
-	for(int i = 0; i < kHdrParBits; i++) s |= parity32(hdr & T.hdr_H[i]) << (kHdrParBits - 1 - i);
-	hdr ^= T.hdr_fix[s];
+	for(int i = 0; i < kHdrParBits; i++) s |= parity32(hdr & tH[i]) << (kHdrParBits - 1 - i);
+	hdr ^= tfix[s];
 	g.syndrome = s;
 	if((hdr & keep) != hdr) { g.status = HDR_CRC_BAD; return g; }
 	hdr >>= kHdrParBits;
@@ -318,6 +344,13 @@ struct WalkShared {
 	int32_t neg[16];
 	// scalars published by LANE0 sections
 	float u_y1, u_y2, u_y3, u_prevd;
+	// open chunk of the evaluation log
+	int64_t lg_first, lg_count; uint32_t lg_n;
+	// speculative loads made together with a candidate's metric values (one memory round trip instead of three)
+	float spec[48]; int64_t spec_n; int64_t vring_a;
+	// small read-only tables staged once per launch
+	uint32_t t_H[kHdrParBits], t_fix[32]; uint8_t t_gray[8], t_prbs[32];
+	uint32_t nb;                       // bursts emitted by this channel in this feed
 };
 
 // lowest lane whose flag is set, or -1.  Call from wave-uniform code after a WAVE_END.
@@ -357,10 +390,16 @@ VDL2_HD void push_interval(WalkState &st, int64_t a, int64_t b) {
 VDL2_HD void log_evals(WalkShared &sh, const EvalLog &lg, OutCtl *ctl, int64_t first, int64_t count) {
 	if(count <= 0) return;
 	LANE0
-		uint32_t n = *lg.n;
-		if(n > 0 && lg.chunks[n - 1].first + 3 * lg.chunks[n - 1].count == first) lg.chunks[n - 1].count += count;
-		else if(n < ctl->cap_log) { lg.chunks[n].first = first; lg.chunks[n].count = count; *lg.n = n + 1; }
-		else ctl->overflow = 1;          // pathological storm of grid shifts: noise floor becomes approximate
+		// the open chunk lives in LDS; a chunk is written out (a plain store, nothing waits for it) only when
+		// the next one cannot be merged into it
+		if(sh.lg_count > 0 && sh.lg_first + 3 * sh.lg_count == first) sh.lg_count += count;
+		else {
+			if(sh.lg_count > 0) {
+				if(sh.lg_n < ctl->cap_log) { lg.chunks[sh.lg_n].first = sh.lg_first; lg.chunks[sh.lg_n].count = sh.lg_count; sh.lg_n++; }
+				else ctl->overflow = 1;  // pathological storm of grid shifts: noise floor becomes approximate
+			}
+			sh.lg_first = first; sh.lg_count = count;
+		}
 		sh.st.evals += count;
 	LANE0_END
 }
@@ -374,11 +413,19 @@ VDL2_HD void restart_search(WalkState &st, int64_t a) {
 
 // Process one channel up to (not including) decimated sample k_end.
 VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end, const Tables &T,
-		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
+		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
+		OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
 	K4_BEGIN();
 	LANE0
 		sh.st = *gstate;
+		sh.lg_n = *lg.n; sh.lg_first = 0; sh.lg_count = 0;
+		sh.spec_n = -1; sh.vring_a = -1; sh.nb = 0;
 	LANE0_END
+	WAVE_FOR(l)
+		if(l < kHdrParBits) sh.t_H[l] = T.hdr_H[l];
+		if(l < 32) { sh.t_fix[l] = T.hdr_fix[l]; sh.t_prbs[l] = T.prbs[l]; }
+		if(l < 8) sh.t_gray[l] = T.gray[l];
+	WAVE_END
 	K4_MARK(0);
 	for(;;) {
 		if(sh.st.mode == 0) {
@@ -400,6 +447,7 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 						else val = v.Phi(seq_index(sh.st, a0, 160 - j));
 						sh.vring[j] = val;
 					}
+					if(l == 0) sh.vring_a = a0;
 				WAVE_END
 				WAVE_FOR(l)
 					if(l < nb) {
@@ -452,11 +500,11 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 							if(bits) {
 								// keep bits with index >= start, < k_end, and congruent to e modulo 3
 								const int64_t base = w << 6;
-								const int r = (int)(((e - base) % 3 + 3) % 3);   // first bit position on the grid
+								const int r = (((int)(e - base)) % 3 + 3) % 3;   // first bit position on the grid (|e - base| << 2^31)
 								bits &= 0x9249249249249249ull << r;                // bits r, r+3, ...
 								if(base < start) bits &= (start - base >= 64) ? 0ull : (~0ull << (start - base));
 								if(base + 64 > k_end) bits &= (k_end - base <= 0) ? 0ull : (~0ull >> (64 - (k_end - base)));
-								if(bits) { int b = 0; while(!((bits >> b) & 1)) b++; hit = 64 * q + b; }
+								if(bits) hit = 64 * q + __builtin_ctzll(bits);
 							}
 						}
 						sh.found[l] = hit;
@@ -467,11 +515,21 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 				}
 				if(fired) {
 					const int64_t n = fire_n;
+					// one round trip: the three metric values, the four possible sync-point phases (sclk = 2..5)
+					// and the nine header-symbol phases for each of them
+					WAVE_FOR(l)
+						float val = 0.f;
+						if(l < 4) val = v.Phi(n - 2 - l);
+						else if(l < 40) { const int sc = 2 + (l - 4) / 9, m = (l - 4) % 9; const int64_t t = n + kSpsDec - sc + (int64_t)kSpsDec * m; if(t < k_end) val = v.Phi(t); }
+						else if(l == 40) val = (n - 6 >= sh.st.e0) ? v.PF(n - 6).re : kPherrBig;
+						else if(l == 41) val = v.PF(n - 3).re;
+						else if(l == 42) val = v.PF(n).re;
+						else if(l == 43) val = v.PF(n - 3).im;
+						if(l < 44) sh.spec[l] = val;
+					WAVE_END
 					LANE0
-						sh.u_y1 = (n - 6 >= sh.st.e0) ? v.PF(n - 6).re : kPherrBig;
-						sh.u_y2 = v.PF(n - 3).re;
-						sh.u_y3 = v.PF(n).re;
-						sh.u_prevd = v.PF(n - 3).im;
+						sh.u_y1 = sh.spec[40]; sh.u_y2 = sh.spec[41]; sh.u_y3 = sh.spec[42]; sh.u_prevd = sh.spec[43];
+						sh.spec_n = n;
 					LANE0_END
 					log_evals(sh, lg, ctl, e, (n - e) / 3 + 1);
 					K4_MARK(2);
@@ -497,7 +555,10 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 					const int64_t n = fire_n;
 					float vx = parabola_vertex(sh.u_y1, sh.u_y2, sh.u_y3);
 					int sclk = (int)(-roundf(vx));
-					float prev_phi0 = v.Phi(seq_index(st, n, sclk));
+					float prev_phi0;
+					if(sh.spec_n == n && sclk >= 2 && sclk <= 5) prev_phi0 = sh.spec[sclk - 2];
+					else if(sh.vring_a == st.a && sclk >= 0 && 160 + (n - st.a) - sclk >= 0 && 160 + (n - st.a) - sclk < 320) prev_phi0 = sh.vring[160 + (n - st.a) - sclk];
+					else prev_phi0 = v.Phi(seq_index(st, n, sclk));
 					float vdphi = sh.u_prevd;
 					float ppm = (float)((double)(10500 * vdphi) / (2.0f * M_PI * (double)freq) * 1e+6);
 					st.pherr1 = st.pherr2 = kPherrBig;
@@ -522,12 +583,16 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 			// ---- header: 9 symbols = 27 bits, of which 25 are the header (decode.c:198-258) ----
 			const int64_t t8 = sh.st.pb.t_first + 8 * kSpsDec;
 			if(t8 >= k_end) break;
+			const int sclk_pb = (int)(sh.st.pb.sync_sample + kSpsDec - sh.st.pb.t_first);
+			const bool have_spec = sh.spec_n == sh.st.pb.sync_sample && sclk_pb >= 2 && sclk_pb <= 5;
 			WAVE_FOR(l)
 				if(l < 9) {
 					int64_t t = sh.st.pb.t_first + (int64_t)l * kSpsDec;
-					float prev = l ? v.Phi(t - kSpsDec) : sh.st.pb.prev_phi0;
+					float cur, prev;
+					if(have_spec) { cur = sh.spec[4 + 9 * (sclk_pb - 2) + l]; prev = l ? sh.spec[4 + 9 * (sclk_pb - 2) + l - 1] : sh.st.pb.prev_phi0; }
+					else { cur = v.Phi(t); prev = l ? v.Phi(t - kSpsDec) : sh.st.pb.prev_phi0; }
 					int neg = 0;
-					sh.sym[l] = T.gray[slice_symbol(v.Phi(t), prev, sh.st.pb.vdphi, neg)];
+					sh.sym[l] = sh.t_gray[slice_symbol(cur, prev, sh.st.pb.vdphi, neg)];
 					sh.neg[l] = neg;
 				}
 			WAVE_END
@@ -536,10 +601,10 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 				uint32_t hdr = 0;
 				for(int b = 0; b < kHdrBits; b++) {
 					uint32_t bit = ((uint32_t)sh.sym[b / 3] >> (2 - b % 3)) & 1u;
-					bit ^= T.prbs[b];
+					bit ^= sh.t_prbs[b];
 					hdr |= bit << (kHdrBits - 1 - b);
 				}
-				Geometry g = header_to_geometry(hdr, T);
+				Geometry g = header_to_geometry(hdr, sh.t_H, sh.t_fix);
 				if(g.syndrome == 0) VDL2_CNT_ADD(cnt, CNT_CRC_GOOD, 1);
 				if(g.status != HDR_OK) {
 					int negs = 0; for(int i = 0; i < 9; i++) negs += sh.neg[i];
@@ -559,12 +624,7 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 			if(sh.st.pb.end_sample >= k_end) break;
 			LANE0
 				WalkState &st = sh.st;
-#if VDL2_DEVICE_PASS
-				uint32_t slot = atomicAdd(&ctl->nbursts, 1u);
-#else
-				uint32_t slot = ctl->nbursts++;
-#endif
-				if(slot < ctl->cap_bursts) bursts[slot] = st.pb; else ctl->overflow = 1;
+				if(sh.nb < cap_bursts) bursts[sh.nb++] = st.pb; else ctl->overflow = 1;
 				restart_search(st, st.pb.end_sample + 1);
 			LANE0_END
 		}
@@ -572,6 +632,12 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 	K4_MARK(7);
 	LANE0
 		*gstate = sh.st;
+		if(sh.lg_count > 0) {
+			if(sh.lg_n < ctl->cap_log) { lg.chunks[sh.lg_n].first = sh.lg_first; lg.chunks[sh.lg_n].count = sh.lg_count; sh.lg_n++; }
+			else ctl->overflow = 1;
+		}
+		*lg.n = sh.lg_n;
+		*nbursts_out = sh.nb;
 	LANE0_END
 	K4_MARK(0);
 }

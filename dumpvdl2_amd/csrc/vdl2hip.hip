@@ -30,7 +30,7 @@ struct HostFrame {
 constexpr int kRun = VDL2_K1_RUN;        // decimated outputs per lane in K1 (specialised builds); 2 measured best: tests/gpu_k1_variants.sh
 constexpr int kRunGeneric = 2;
 constexpr int kHistory = 65536;          // decimated samples kept behind the newest block (> longest burst, 56 090)
-constexpr int kNumEv = 12;
+constexpr int kNumEv = 8;
 
 }  // namespace
 
@@ -55,7 +55,7 @@ struct vdl2hip_ctx {
 	WalkState *d_ws = nullptr; unsigned long long *d_cnt = nullptr;
 	NfState *d_nf = nullptr; EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
 	float *d_nfhist = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; int64_t *d_nfbase = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0;
-	Burst *d_bursts = nullptr; OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
+	Burst *d_bursts = nullptr; uint32_t *d_nbchan = nullptr, *d_bbase = nullptr; uint32_t cap_bursts_chan = 0; OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
 	OutCtl ctl_template{};
 	OutCtl *h_ctl = nullptr;               // pinned
 	bool pending = false, overflowed = false;
@@ -90,15 +90,16 @@ static int collect_pending(vdl2hip_ctx *c) {
 	HIPCHK(hipStreamSynchronize(c->stream));
 	c->pending = false;
 	if(c->profiling && c->ev_valid) {
+		hipEvent_t *ev = c->ev;
 		float ms = 0.f;
-		if(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.chanfir_ms += ms;
-		if(hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.phase_ms += ms;
-		if(hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.sync_ms += ms;
-		if(hipEventElapsedTime(&ms, c->ev[3], c->ev[6]) == hipSuccess) c->stats.walk_ms += ms;
-		if(hipEventElapsedTime(&ms, c->ev[6], c->ev[4]) == hipSuccess) c->stats.nf_ms += ms;
-		if(hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) c->stats.burst_ms += ms;
-		c->ev_valid = false;
+		if(hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->stats.chanfir_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->stats.phase_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.sync_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[3], ev[6]) == hipSuccess) c->stats.walk_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[6], ev[4]) == hipSuccess) c->stats.nf_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->stats.burst_ms += ms;
 	}
+	c->ev_valid = false;
 	const OutCtl ctl = *c->h_ctl;
 	if(ctl.overflow) c->overflowed = true;
 	c->stats.bursts += std::min(ctl.nbursts, ctl.cap_bursts);
@@ -127,6 +128,9 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	const int64_t D = (int64_t)(nlogical / (uint64_t)c->os);
 	const uint32_t nrem = (uint32_t)(nlogical - (uint64_t)D * c->os);
 	const int seglen = 64 * c->run;
+	hipStream_t st = c->stream;
+	hipEvent_t *ev = c->ev;
+	const bool prof = c->profiling;
 
 	K1Args a{};
 	a.in = dev_in; a.carry = c->d_carry[c->carry_sel]; a.ncarry = c->ncarry; a.nlogical = nlogical;
@@ -135,10 +139,10 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.seg_end = c->d_segend;
 	a.run_start = c->d_runstart; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap; a.nrun_cap = c->nrun_cap;
 
-	HIPCHK(hipMemcpyAsync(c->d_ctl, &c->ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, c->stream));
-	const bool prof = c->profiling;
+	HIPCHK(hipMemcpyAsync(c->d_ctl, &c->ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, st));
+	c->ev_valid = false;
 	if(D > 0) {
-		if(prof) HIPCHK(hipEventRecord(c->ev[0], c->stream));
+		if(prof) HIPCHK(hipEventRecord(ev[0], st));
 		const size_t lds = 4096 + (size_t)c->run * c->os * 65 * sizeof(float2);
 		if(c->specialised) {
 			switch(c->os) {
@@ -149,42 +153,43 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		} else {
 			launch_chanfir<0, kRunGeneric>(c, a, c->cr, lds);
 		}
-		if(prof) HIPCHK(hipEventRecord(c->ev[1], c->stream));
+		if(prof) HIPCHK(hipEventRecord(ev[1], st));
 		K2Args k2{ c->d_y, c->d_phi, c->d_segend, c->d_runstart, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
 		           c->k_total, D, c->cap, c->cap - 1, c->nseg_cap, c->nrun_cap, seglen, c->run };
-		hipLaunchKernelGGL(k_phase, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), 0, c->stream, k2);
+		hipLaunchKernelGGL(k_phase, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), 0, st, k2);
 		c->tcarry_sel ^= 1;
 	}
-	if(nrem) hipLaunchKernelGGL(k_carry, dim3(1), dim3(64), 0, c->stream, a, (void *)c->d_carry[c->carry_sel ^ 1], nrem);
+	if(nrem) hipLaunchKernelGGL(k_carry, dim3(1), dim3(64), 0, st, a, (void *)c->d_carry[c->carry_sel ^ 1], nrem);
 	c->carry_sel ^= 1; c->ncarry = nrem;
 	if(D > 0) {
-		if(prof) HIPCHK(hipEventRecord(c->ev[2], c->stream));
+		if(prof) HIPCHK(hipEventRecord(ev[2], st));
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
 		K3Args k3{ c->d_phi, c->d_pf, c->d_cand, c->d_tab, nbase, k1, c->cap, c->cap - 1 };
-		hipLaunchKernelGGL(k_sync, dim3((unsigned)((k1 - nbase + 255) / 256), (unsigned)c->C), dim3(256), 0, c->stream, k3);
-		if(prof) HIPCHK(hipEventRecord(c->ev[3], c->stream));
-		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, c->d_bursts, c->d_ctl, c->d_freq,
+		hipLaunchKernelGGL(k_sync, dim3((unsigned)((k1 - nbase + 255) / 256), (unsigned)c->C), dim3(256), 0, st, k3);
+		if(prof) HIPCHK(hipEventRecord(ev[3], st));
+		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, c->d_bursts, c->d_nbchan, c->cap_bursts_chan, c->d_ctl, c->d_freq,
 		           c->d_log, c->d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
-		hipLaunchKernelGGL(k_walk, dim3((unsigned)c->C), dim3(64), 0, c->stream, k4);
-		if(prof) HIPCHK(hipEventRecord(c->ev[6], c->stream));
+		hipLaunchKernelGGL(k_walk, dim3((unsigned)c->C), dim3(64), 0, st, k4);
+		if(prof) HIPCHK(hipEventRecord(ev[6], st));
 		K4bArgs k4b{ c->d_y, c->d_nf, c->d_ws, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfhist, c->d_nfbase,
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist };
-		hipLaunchKernelGGL(k_nf_prepare, dim3((unsigned)c->C), dim3(64), 0, c->stream, k4b);
+		hipLaunchKernelGGL(k_nf_prepare, dim3((unsigned)c->C), dim3(64), 0, st, k4b);
 		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup - 1) / kNfGroup);
-		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, c->stream, k4b);
-		hipLaunchKernelGGL(k_nf_finish, dim3((unsigned)c->C), dim3(64), 0, c->stream, k4b);
-		if(prof) HIPCHK(hipEventRecord(c->ev[4], c->stream));
-		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, c->d_bursts, c->d_frames, c->d_pool, c->d_ctl, c->d_freq,
-		           c->d_nfhist, c->d_nfbase, c->cap_hist, c->cap, c->cap - 1 };
-		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, c->stream, k5);
-		if(prof) { HIPCHK(hipEventRecord(c->ev[5], c->stream)); c->ev_valid = true; }
+		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, st, k4b);
+		hipLaunchKernelGGL(k_nf_finish, dim3((unsigned)c->C), dim3(64), 0, st, k4b);
+		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, st, (const uint32_t *)c->d_nbchan, c->d_bbase, c->C, c->d_ctl);
+		if(prof) HIPCHK(hipEventRecord(ev[4], st));
+		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, c->d_bursts, c->d_bbase, c->cap_bursts_chan, c->C,
+		           c->d_frames, c->d_pool, c->d_ctl, c->d_freq, c->d_nfhist, c->d_nfbase, c->cap_hist, c->cap, c->cap - 1 };
+		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, st, k5);
+		if(prof) { HIPCHK(hipEventRecord(ev[5], st)); c->ev_valid = true; }
+		c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C;
 	}
-	HIPCHK(hipMemcpyAsync(c->h_ctl, c->d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(c->h_ctl, c->d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, st));
 	HIPCHK(hipGetLastError());
 	c->pending = true;
 	c->k_total += D; c->n_total += nnew;
 	c->stats.feeds++; c->stats.input_samples += nnew;
-	if(D > 0) { c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C; }
 	return VDL2HIP_OK;
 }
 
@@ -224,7 +229,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_phi, c->d_cand, c->d_segend, c->d_runstart, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nfhist, c->d_lpbuf, c->d_nffeed, c->d_nfbase, c->d_bursts,
+	                 c->d_phi, c->d_cand, c->d_segend, c->d_runstart, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nfhist, c->d_lpbuf, c->d_nffeed, c->d_nfbase, c->d_nbchan, c->d_bbase, c->d_bursts,
 	                 c->d_frames, c->d_pool, c->d_ctl };
 	for(void *p : ptrs) if(p) (void)hipFree(p);
 	if(c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -287,7 +292,8 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_tcarry[0], count * sizeof(float4)); DEV_ALLOC(c->d_tcarry[1], count * sizeof(float4));
 	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, (size_t)count * kNumCounters * 8);
 	// a decodable burst occupies >= 22 symbols = 220 decimated samples (header + 3 data + 2 FEC octets)
-	uint64_t cap_b = (uint64_t)count * (dmax / 220 + 2); if(cap_b < 1024) cap_b = 1024;
+	c->cap_bursts_chan = (uint32_t)(dmax / 220 + 4);
+	uint64_t cap_b = (uint64_t)count * c->cap_bursts_chan;
 	uint64_t cap_f = cap_b * 2; if(cap_f < 4096) cap_f = 4096;
 	uint64_t cap_p = cap_b * 512; if(cap_p < (1u << 22)) cap_p = 1u << 22; if(cap_p > (1u << 30)) cap_p = 1u << 30;
 	c->cap_log = 8192; c->cap_comb = c->cap_log + kNfTail; c->cap_hist = (uint32_t)(dmax / 3000 + 8);
@@ -296,7 +302,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_nlog, count * 4); DEV_ALLOC(c->d_scfirst, (size_t)count * (c->cap_comb + 1) * 8); DEV_ALLOC(c->d_sccum, (size_t)count * (c->cap_comb + 1) * 8);
 	DEV_ALLOC(c->d_nfhist, (size_t)count * c->cap_hist * 4); DEV_ALLOC(c->d_nfbase, count * 8);
 	DEV_ALLOC(c->d_lpbuf, (size_t)count * c->cap_hist * 4); DEV_ALLOC(c->d_nffeed, count * sizeof(NfFeed));
-	DEV_ALLOC(c->d_bursts, cap_b * sizeof(Burst)); DEV_ALLOC(c->d_frames, cap_f * sizeof(OutFrame)); DEV_ALLOC(c->d_pool, cap_p);
+	DEV_ALLOC(c->d_bursts, cap_b * sizeof(Burst)); DEV_ALLOC(c->d_nbchan, count * 4); DEV_ALLOC(c->d_bbase, (count + 1) * 4); DEV_ALLOC(c->d_frames, cap_f * sizeof(OutFrame)); DEV_ALLOC(c->d_pool, cap_p);
 	DEV_ALLOC(c->d_ctl, sizeof(OutCtl));
 	DEV_CHK(hipHostMalloc((void **)&c->h_ctl, sizeof(OutCtl), hipHostMallocDefault));
 	memset(c->h_ctl, 0, sizeof(OutCtl));

@@ -79,7 +79,10 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 	for(int c = 0; c < s->nchan; c++) {
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->phi[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
 		EvalLog lg{ &s->log[(size_t)c * s->cap_log], &s->nlog[c] };
-		walk_channel(c, s->freqs[c], s->max_ppm, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], s->bursts.data(), &s->ctl, lg, wsh);
+		uint32_t nbc = 0;
+		walk_channel(c, s->freqs[c], s->max_ppm, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], s->bursts.data() + s->ctl.nbursts,
+		             (uint32_t)s->bursts.size() - s->ctl.nbursts, &nbc, &s->ctl, lg, wsh);
+		s->ctl.nbursts += nbc;
 		static NfShared nsh;
 		NfScratch sc{ &s->scf[(size_t)c * (s->cap_comb + 1)], &s->scc[(size_t)c * (s->cap_comb + 1)] };
 		NfFeed fd;
@@ -88,7 +91,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		nf_finish(&s->nf[c], lg, sc, fd, &s->lpbuf[(size_t)c * s->cap_hist], &s->hist[(size_t)c * s->cap_hist], s->cap_hist, &s->nfbase[c], &s->st[c]);
 	}
 	static BurstShared bsh;
-	uint32_t nb = s->ctl.nbursts < s->ctl.cap_bursts ? s->ctl.nbursts : s->ctl.cap_bursts;
+	uint32_t nb = s->ctl.nbursts;
 	for(uint32_t i = 0; i < nb; i++) {
 		const Burst &b = s->bursts[i];
 		int c = b.chan;
@@ -111,6 +114,10 @@ int64_t hostsim_num_frames(Sim *s) { return (int64_t)s->all_frames.size(); }
 const OutFrame *hostsim_frames(Sim *s) { return s->all_frames.data(); }
 const uint8_t *hostsim_pool(Sim *s) { return s->all_pool.data(); }
 void hostsim_counters(Sim *s, int chan, unsigned long long *out) { memcpy(out, &s->cnt[(size_t)chan * kNumCounters], sizeof(unsigned long long) * kNumCounters); }
+// phase_of() of the device code on n (re, im) pairs, for comparison with libm
+void hostsim_phase(const float *reim, float *out, int64_t n) { for(int64_t i = 0; i < n; i++) out[i] = phase_of(cf32{reim[2 * i], reim[2 * i + 1]}); }
+double hostsim_atan2(double y, double x) { return atan2_f64(y, x); }
+
 int hostsim_sizeof_outframe() { return (int)sizeof(OutFrame); }
 
 // the burst decoder's RS stage on one 255-octet row (for direct comparison with libfec / the oracle)

@@ -1,0 +1,36 @@
+"""The device atan2 (vdl2_core.h:atan2_f64, also what tests/hostsim runs) against libm."""
+import ctypes as C
+import math
+
+import numpy as np
+
+import pyhostsim
+
+
+def test_atan2_matches_libm_after_narrowing():
+    H = C.CDLL(pyhostsim.build())
+    H.hostsim_phase.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    H.hostsim_atan2.restype = C.c_double
+    H.hostsim_atan2.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(9)
+    n = 4_000_000
+    mag = np.exp(rng.uniform(-20, 2, n))
+    ang = rng.uniform(-np.pi, np.pi, n)
+    xy = np.empty((n, 2), dtype=np.float32)
+    xy[:, 0] = mag * np.cos(ang); xy[:, 1] = mag * np.sin(ang)
+    # the places where the reduction switches (ratio k/16, axes, diagonals) deserve their own samples
+    edge = np.array([[1, 0], [0, 1], [-1, 0], [0, -1], [1, 1], [-1, 1], [1, -1], [-1, -1], [1e-30, 1], [1, 1e-30], [-1e-30, -1],
+                     [3, 0.1875], [0.1875, 3], [1, 0.0625], [1, 0.062500004], [-2, 1e-38], [1e-38, -2], [-1, -0.0],
+                     [5e-39, 1e-45], [1e-45, -5e-39]], dtype=np.float32)
+    xy = np.concatenate([xy, edge, -edge])
+    out = np.empty(len(xy), dtype=np.float32)
+    H.hostsim_phase(xy.ctypes.data, out.ctypes.data, len(xy))
+    ref = np.arctan2(xy[:, 1].astype(np.float64), xy[:, 0].astype(np.float64)).astype(np.float32)
+    nz = ~((xy[:, 0] == 0) & (xy[:, 1] == 0))
+    diff = out[nz] != ref[nz]
+    assert diff.sum() <= 2, f"{diff.sum()} of {nz.sum()} phases differ from libm after narrowing"
+    if diff.any():
+        assert np.all(np.abs(out[nz][diff].astype(np.float64) - ref[nz][diff]) <= np.spacing(np.abs(ref[nz][diff])))
+    for y, x in [(0.3, -2.0), (-7.5, 0.01), (1e-200, 1e-190), (5.0, 5.0), (-0.0, -1.0), (0.0, -1.0)]:
+        a, b = H.hostsim_atan2(y, x), math.atan2(y, x)
+        assert abs(a - b) <= 4 * np.spacing(abs(b)) and math.copysign(1, a) == math.copysign(1, b)
