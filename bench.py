@@ -119,7 +119,11 @@ def main():
             verified = {"tx_frames": want, "decoded": len(fr), "oracle_window_s": n2 / 2 / cfg.sample_rate}
 
     # ---- timed region: exactly K steps ----
+    # Streaming mode: a step queues its block and collects the frames of the previous one, so the sample-rate
+    # front of block i+1 overlaps the burst-rate back of block i; the frames of the last block are collected before
+    # the clock stops (vdl2hip_sync + drain), so all K blocks are fully delivered inside the timed region.
     rx.set_profiling(True)
+    rx.set_drain_lag(1)
     s0 = rx.stats()
     if world > 1:
         dist.barrier()
@@ -128,6 +132,8 @@ def main():
     nframes = 0
     for _ in range(args.steps):
         nframes += step()[0]
+    rx.set_drain_lag(0)
+    nframes += rx.drain_packed()[0]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -34,6 +34,15 @@ constexpr int kNumEv = 8;
 
 }  // namespace
 
+struct OutSlot {
+	Burst *d_bursts = nullptr; uint32_t *d_nbchan = nullptr, *d_bbase = nullptr;
+	OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
+	OutCtl *h_ctl = nullptr;               // pinned
+	hipEvent_t done = nullptr, ev[kNumEv] = {};
+	bool pending = false, ev_valid = false;
+	uint64_t seq = 0;
+};
+
 struct vdl2hip_ctx {
 	vdl2hip_cfg cfg{};
 	int C = 0, chan_first = 0, os = 0, fmt = 0, run = kRun, cr = 1;
@@ -55,14 +64,16 @@ struct vdl2hip_ctx {
 	WalkState *d_ws = nullptr; unsigned long long *d_cnt = nullptr;
 	NfState *d_nf = nullptr; EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
 	float *d_nfhist = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; int64_t *d_nfbase = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0;
-	Burst *d_bursts = nullptr; uint32_t *d_nbchan = nullptr, *d_bbase = nullptr; uint32_t cap_bursts_chan = 0; OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
-	OutCtl ctl_template{};
-	OutCtl *h_ctl = nullptr;               // pinned
-	bool pending = false, overflowed = false;
+	uint32_t cap_bursts_chan = 0;
+	OutSlot slot[2];                       // per-feed output buffers: feed i+1's front runs while feed i's back still fills slot i&1
+	uint64_t feed_no = 0; int drain_lag = 0;
+	hipStream_t stream_back = nullptr; hipEvent_t ev_front = nullptr;
+	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
+	bool overflowed = false;
 	std::vector<HostFrame> queue;
 	int64_t k_total = 0; uint64_t n_total = 0;
 	// profiling
-	bool profiling = false; hipEvent_t ev[kNumEv] = {}; bool ev_valid = false;
+	bool profiling = false;
 	vdl2hip_stats stats{};
 };
 
@@ -85,22 +96,22 @@ static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds) 
 	}
 }
 
-static int collect_pending(vdl2hip_ctx *c) {
-	if(!c->pending) return VDL2HIP_OK;
-	HIPCHK(hipStreamSynchronize(c->stream));
-	c->pending = false;
-	if(c->profiling && c->ev_valid) {
-		hipEvent_t *ev = c->ev;
+static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
+	if(!sl.pending) return VDL2HIP_OK;
+	HIPCHK(hipEventSynchronize(sl.done));
+	sl.pending = false;
+	if(c->profiling && sl.ev_valid) {
+		hipEvent_t *ev = sl.ev;
 		float ms = 0.f;
 		if(hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->stats.chanfir_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->stats.phase_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.sync_ms += ms;
-		if(hipEventElapsedTime(&ms, ev[3], ev[6]) == hipSuccess) c->stats.walk_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[7], ev[6]) == hipSuccess) c->stats.walk_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[6], ev[4]) == hipSuccess) c->stats.nf_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->stats.burst_ms += ms;
 	}
-	c->ev_valid = false;
-	const OutCtl ctl = *c->h_ctl;
+	sl.ev_valid = false;
+	const OutCtl ctl = *sl.h_ctl;
 	if(ctl.overflow) c->overflowed = true;
 	c->stats.bursts += std::min(ctl.nbursts, ctl.cap_bursts);
 	const uint32_t nf = std::min(ctl.nframes, ctl.cap_frames);
@@ -108,17 +119,33 @@ static int collect_pending(vdl2hip_ctx *c) {
 		std::vector<OutFrame> fr(nf);
 		const uint32_t pool_n = std::min(ctl.pool_used, ctl.cap_pool);
 		std::vector<uint8_t> pool(pool_n ? pool_n : 1);
-		HIPCHK(hipMemcpy(fr.data(), c->d_frames, sizeof(OutFrame) * nf, hipMemcpyDeviceToHost));
-		if(pool_n) HIPCHK(hipMemcpy(pool.data(), c->d_pool, pool_n, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(fr.data(), sl.d_frames, sizeof(OutFrame) * nf, hipMemcpyDeviceToHost));
+		if(pool_n) HIPCHK(hipMemcpy(pool.data(), sl.d_pool, pool_n, hipMemcpyDeviceToHost));
+		// frames of one feed are sorted here, so that feeds can be appended to the queue in order
+		std::vector<HostFrame> batch(nf);
 		for(uint32_t i = 0; i < nf; i++) {
-			HostFrame h;
-			h.f = fr[i];
-			if(h.f.pool_off + h.f.len <= pool_n) h.octets.assign(pool.begin() + h.f.pool_off, pool.begin() + h.f.pool_off + h.f.len);
-			c->queue.push_back(std::move(h));
+			batch[i].f = fr[i];
+			if(fr[i].pool_off + fr[i].len <= pool_n) batch[i].octets.assign(pool.begin() + fr[i].pool_off, pool.begin() + fr[i].pool_off + fr[i].len);
 		}
+		for(auto &h : batch) c->queue.push_back(std::move(h));
 		c->stats.frames += nf;
 	}
 	return c->overflowed ? VDL2HIP_E_OVERFLOW : VDL2HIP_OK;
+}
+
+// collect every feed except the `keep` most recent ones, oldest first
+static int collect_pending(vdl2hip_ctx *c, int keep = 0) {
+	int rc = VDL2HIP_OK;
+	for(int pass = 0; pass < 2; pass++) {
+		OutSlot *oldest = nullptr;
+		int npend = 0;
+		for(auto &sl : c->slot) if(sl.pending) { npend++; if(!oldest || sl.seq < oldest->seq) oldest = &sl; }
+		if(!oldest || npend <= keep) break;
+		int r = collect_slot(c, *oldest);
+		if(r != VDL2HIP_OK) rc = r;
+		if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	}
+	return rc;
 }
 
 static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
@@ -128,8 +155,10 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	const int64_t D = (int64_t)(nlogical / (uint64_t)c->os);
 	const uint32_t nrem = (uint32_t)(nlogical - (uint64_t)D * c->os);
 	const int seglen = 64 * c->run;
-	hipStream_t st = c->stream;
-	hipEvent_t *ev = c->ev;
+	OutSlot &sl = c->slot[c->feed_no & 1];
+	{ int r = collect_slot(c, sl); if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r; }   // its buffers are about to be reused
+	hipStream_t st = c->stream, sb_ = c->stream_back;
+	hipEvent_t *ev = sl.ev;
 	const bool prof = c->profiling;
 
 	K1Args a{};
@@ -139,8 +168,8 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.seg_end = c->d_segend;
 	a.run_start = c->d_runstart; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap; a.nrun_cap = c->nrun_cap;
 
-	HIPCHK(hipMemcpyAsync(c->d_ctl, &c->ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, st));
-	c->ev_valid = false;
+	HIPCHK(hipMemcpyAsync(sl.d_ctl, c->h_ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, sb_));
+	sl.ev_valid = false;
 	if(D > 0) {
 		if(prof) HIPCHK(hipEventRecord(ev[0], st));
 		const size_t lds = 4096 + (size_t)c->run * c->os * 65 * sizeof(float2);
@@ -167,27 +196,35 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		K3Args k3{ c->d_phi, c->d_pf, c->d_cand, c->d_tab, nbase, k1, c->cap, c->cap - 1 };
 		hipLaunchKernelGGL(k_sync, dim3((unsigned)((k1 - nbase + 255) / 256), (unsigned)c->C), dim3(256), 0, st, k3);
 		if(prof) HIPCHK(hipEventRecord(ev[3], st));
-		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, c->d_bursts, c->d_nbchan, c->cap_bursts_chan, c->d_ctl, c->d_freq,
+	}
+	// the burst-rate back end of this feed runs on its own stream, so the next feed's front can start under it
+	HIPCHK(hipEventRecord(c->ev_front, st));
+	HIPCHK(hipStreamWaitEvent(sb_, c->ev_front, 0));
+	if(D > 0) {
+		const int64_t k1 = c->k_total + D;
+		if(prof) HIPCHK(hipEventRecord(ev[7], sb_));
+		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           c->d_log, c->d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
-		hipLaunchKernelGGL(k_walk, dim3((unsigned)c->C), dim3(64), 0, st, k4);
-		if(prof) HIPCHK(hipEventRecord(ev[6], st));
+		hipLaunchKernelGGL(k_walk, dim3((unsigned)c->C), dim3(64), 0, sb_, k4);
+		if(prof) HIPCHK(hipEventRecord(ev[6], sb_));
 		K4bArgs k4b{ c->d_y, c->d_nf, c->d_ws, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfhist, c->d_nfbase,
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist };
-		hipLaunchKernelGGL(k_nf_prepare, dim3((unsigned)c->C), dim3(64), 0, st, k4b);
+		hipLaunchKernelGGL(k_nf_prepare, dim3((unsigned)c->C), dim3(64), 0, sb_, k4b);
 		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup - 1) / kNfGroup);
-		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, st, k4b);
-		hipLaunchKernelGGL(k_nf_finish, dim3((unsigned)c->C), dim3(64), 0, st, k4b);
-		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, st, (const uint32_t *)c->d_nbchan, c->d_bbase, c->C, c->d_ctl);
-		if(prof) HIPCHK(hipEventRecord(ev[4], st));
-		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, c->d_bursts, c->d_bbase, c->cap_bursts_chan, c->C,
-		           c->d_frames, c->d_pool, c->d_ctl, c->d_freq, c->d_nfhist, c->d_nfbase, c->cap_hist, c->cap, c->cap - 1 };
-		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, st, k5);
-		if(prof) { HIPCHK(hipEventRecord(ev[5], st)); c->ev_valid = true; }
+		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, sb_, k4b);
+		hipLaunchKernelGGL(k_nf_finish, dim3((unsigned)c->C), dim3(64), 0, sb_, k4b);
+		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, sb_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl);
+		if(prof) HIPCHK(hipEventRecord(ev[4], sb_));
+		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
+		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->d_nfhist, c->d_nfbase, c->cap_hist, c->cap, c->cap - 1 };
+		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, sb_, k5);
+		if(prof) { HIPCHK(hipEventRecord(ev[5], sb_)); sl.ev_valid = true; }
 		c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C;
 	}
-	HIPCHK(hipMemcpyAsync(c->h_ctl, c->d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(sl.h_ctl, sl.d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, sb_));
+	HIPCHK(hipEventRecord(sl.done, sb_));
 	HIPCHK(hipGetLastError());
-	c->pending = true;
+	sl.pending = true; sl.seq = c->feed_no++;
 	c->k_total += D; c->n_total += nnew;
 	c->stats.feeds++; c->stats.input_samples += nnew;
 	return VDL2HIP_OK;
@@ -229,11 +266,18 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_phi, c->d_cand, c->d_segend, c->d_runstart, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nfhist, c->d_lpbuf, c->d_nffeed, c->d_nfbase, c->d_nbchan, c->d_bbase, c->d_bursts,
-	                 c->d_frames, c->d_pool, c->d_ctl };
+	                 c->d_phi, c->d_cand, c->d_segend, c->d_runstart, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nfhist, c->d_lpbuf, c->d_nffeed, c->d_nfbase };
+	for(auto &sl : c->slot) {
+		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl };
+		for(void *p : q) if(p) (void)hipFree(p);
+		if(sl.h_ctl) (void)hipHostFree(sl.h_ctl);
+		if(sl.done) (void)hipEventDestroy(sl.done);
+		for(int i = 0; i < kNumEv; i++) if(sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
+	}
+	if(c->h_ctl_template) (void)hipHostFree(c->h_ctl_template);
+	if(c->ev_front) (void)hipEventDestroy(c->ev_front);
+	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
 	for(void *p : ptrs) if(p) (void)hipFree(p);
-	if(c->h_ctl) (void)hipHostFree(c->h_ctl);
-	for(int i = 0; i < kNumEv; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -270,7 +314,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	const size_t sb = sample_bytes(c->fmt);
 	const uint64_t max_samples = max_bytes / sb + c->os;
 	const uint64_t dmax = max_samples / c->os + 1;
-	uint32_t cap = 1; while(cap < dmax + kHistory + 1024) cap <<= 1;
+	uint32_t cap = 1; while(cap < 2 * dmax + kHistory + 1024) cap <<= 1;   // two feeds may be in flight (front of i+1 over back of i)
 	c->cap = cap;
 	c->in_cap = max_bytes;
 	c->nseg_cap = (uint32_t)(dmax / (64 * c->run) + 2);
@@ -279,7 +323,9 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	#define DEV_ALLOC(ptr, bytes) do { if(hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_NOMEM; } } while(0)
 	#define DEV_CHK(expr) do { if((expr) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_DEVICE; } } while(0)
 	DEV_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-	for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&c->ev[i]));
+	DEV_CHK(hipStreamCreateWithFlags(&c->stream_back, hipStreamNonBlocking));
+	DEV_CHK(hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));
+	for(auto &sl : c->slot) { DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i])); }
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
 	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count);
 	DEV_ALLOC(c->d_in, c->in_cap + 16);
@@ -302,10 +348,15 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_nlog, count * 4); DEV_ALLOC(c->d_scfirst, (size_t)count * (c->cap_comb + 1) * 8); DEV_ALLOC(c->d_sccum, (size_t)count * (c->cap_comb + 1) * 8);
 	DEV_ALLOC(c->d_nfhist, (size_t)count * c->cap_hist * 4); DEV_ALLOC(c->d_nfbase, count * 8);
 	DEV_ALLOC(c->d_lpbuf, (size_t)count * c->cap_hist * 4); DEV_ALLOC(c->d_nffeed, count * sizeof(NfFeed));
-	DEV_ALLOC(c->d_bursts, cap_b * sizeof(Burst)); DEV_ALLOC(c->d_nbchan, count * 4); DEV_ALLOC(c->d_bbase, (count + 1) * 4); DEV_ALLOC(c->d_frames, cap_f * sizeof(OutFrame)); DEV_ALLOC(c->d_pool, cap_p);
-	DEV_ALLOC(c->d_ctl, sizeof(OutCtl));
-	DEV_CHK(hipHostMalloc((void **)&c->h_ctl, sizeof(OutCtl), hipHostMallocDefault));
-	memset(c->h_ctl, 0, sizeof(OutCtl));
+	DEV_CHK(hipHostMalloc((void **)&c->h_ctl_template, sizeof(OutCtl), hipHostMallocDefault));
+	*c->h_ctl_template = c->ctl_template;
+	for(auto &sl : c->slot) {
+		DEV_ALLOC(sl.d_bursts, cap_b * sizeof(Burst)); DEV_ALLOC(sl.d_nbchan, count * 4); DEV_ALLOC(sl.d_bbase, (count + 1) * 4);
+		DEV_ALLOC(sl.d_frames, cap_f * sizeof(OutFrame)); DEV_ALLOC(sl.d_pool, cap_p); DEV_ALLOC(sl.d_ctl, sizeof(OutCtl));
+		DEV_CHK(hipHostMalloc((void **)&sl.h_ctl, sizeof(OutCtl), hipHostMallocDefault));
+		memset(sl.h_ctl, 0, sizeof(OutCtl));
+		DEV_CHK(hipMemset(sl.d_nbchan, 0, count * 4));
+	}
 
 	Lut4 lut[256]; build_nco_lut(lut);                            // sincosf_lut_init()
 	Tables *tab = new Tables; build_tables(*tab);                 // demod_sync_init(), rs_init(), header tables
@@ -346,9 +397,7 @@ int vdl2hip_feed(vdl2hip_ctx *c, const void *buf, size_t nbytes) {
 	if(nbytes == 0) return VDL2HIP_OK;                             // process_buf_*: len == 0 is a no-op (demod.c:341,358)
 	if(nbytes > c->in_cap) return VDL2HIP_E_TOOBIG;
 	nbytes -= nbytes % sample_bytes(c->fmt);
-	int r = collect_pending(c);                                    // the previous block's outputs live in the buffers we are about to reuse
-	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
-	HIPCHK(hipMemcpyAsync(c->d_in, buf, nbytes, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(c->d_in, buf, nbytes, hipMemcpyHostToDevice, c->stream));   // ordered behind the previous block's K1 on the front stream
 	HIPCHK(hipStreamSynchronize(c->stream));                       // `buf` is only ours during the call
 	return feed_common(c, c->d_in, nbytes);
 }
@@ -359,8 +408,6 @@ int vdl2hip_feed_device(vdl2hip_ctx *c, const void *dev_buf, size_t nbytes) {
 	if(nbytes > c->in_cap) return VDL2HIP_E_TOOBIG;
 	if(((uintptr_t)dev_buf) % sample_bytes(c->fmt)) return VDL2HIP_E_INVAL;
 	nbytes -= nbytes % sample_bytes(c->fmt);
-	int r = collect_pending(c);
-	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	return feed_common(c, dev_buf, nbytes);
 }
 
@@ -371,7 +418,7 @@ int vdl2hip_sync(vdl2hip_ctx *c) {
 
 int vdl2hip_drain(vdl2hip_ctx *c, vdl2hip_frame_cb cb, void *user) {
 	if(!c) return VDL2HIP_E_INVAL;
-	int r = collect_pending(c);
+	int r = collect_pending(c, c->drain_lag);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	sort_queue(c);
 	int n = 0;
@@ -390,7 +437,7 @@ int vdl2hip_drain(vdl2hip_ctx *c, vdl2hip_frame_cb cb, void *user) {
 int vdl2hip_drain_packed(vdl2hip_ctx *c, vdl2hip_packed_frame *frames, size_t cap_frames,
 		uint8_t *octets, size_t cap_octets, size_t *octets_used) {
 	if(!c || (!frames && cap_frames) || (!octets && cap_octets)) return VDL2HIP_E_INVAL;
-	int r = collect_pending(c);
+	int r = collect_pending(c, c->drain_lag);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	sort_queue(c);
 	size_t n = 0, used = 0;
@@ -471,6 +518,12 @@ int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) {
 }
 
 void *vdl2hip_stream(vdl2hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int vdl2hip_set_drain_lag(vdl2hip_ctx *c, int lag) {
+	if(!c || lag < 0 || lag > 1) return VDL2HIP_E_INVAL;
+	c->drain_lag = lag;
+	return VDL2HIP_OK;
+}
 
 #ifdef VDL2_K5_PROF
 int vdl2hip_debug_k5_prof(unsigned long long out[16]) {

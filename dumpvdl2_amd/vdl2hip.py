@@ -30,7 +30,7 @@ NUM_COUNTERS = len(COUNTER_NAMES)
 EXPORTS = [
     "vdl2hip_abi_version", "vdl2hip_strerror", "vdl2hip_create", "vdl2hip_destroy", "vdl2hip_feed",
     "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
-    "vdl2hip_drain_packed", "vdl2hip_pack_raw_frame", "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
+    "vdl2hip_drain_packed", "vdl2hip_pack_raw_frame", "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_set_drain_lag", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
 ]
 
 
@@ -85,6 +85,7 @@ def load_library(path: str = LIB_PATH):
     L.vdl2hip_counters.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
     L.vdl2hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.vdl2hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.vdl2hip_set_drain_lag.argtypes = [C.c_void_p, C.c_int]
     L.vdl2hip_stream.restype = C.c_void_p
     L.vdl2hip_stream.argtypes = [C.c_void_p]
     L.vdl2hip_get_lpf.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -154,6 +155,9 @@ class Receiver:
 
     def feed_device(self, dev_ptr: int, nbytes: int) -> None:
         self._chk(self.L.vdl2hip_feed_device(self.h, C.c_void_p(dev_ptr), nbytes), "vdl2hip_feed_device")
+
+    def set_drain_lag(self, lag: int) -> None:
+        self._chk(self.L.vdl2hip_set_drain_lag(self.h, lag), "vdl2hip_set_drain_lag")
 
     def sync(self) -> None:
         self._chk(self.L.vdl2hip_sync(self.h), "vdl2hip_sync")

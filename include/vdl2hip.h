@@ -124,9 +124,15 @@ void vdl2hip_destroy(vdl2hip_ctx *ctx);
  * Returns after the block has been queued on the device (the copy out of `buf` is complete). */
 int  vdl2hip_feed(vdl2hip_ctx *ctx, const void *buf, size_t nbytes);
 /* Same, for a block that already lives in this device's memory (e.g. the
- * destination of an RCCL broadcast).  The block must stay valid until the next
- * vdl2hip_sync()/vdl2hip_drain(). */
+ * destination of an RCCL broadcast).  The block must stay valid until it has been drained
+ * (vdl2hip_sync(), or a drain that covers it - see vdl2hip_set_drain_lag). */
 int  vdl2hip_feed_device(vdl2hip_ctx *ctx, const void *dev_buf, size_t nbytes);
+
+/* Pipelining.  A feed call only queues work: the sample-rate front (K1-K3) of block i+1 may run while the burst-rate
+ * back (K4-K5) of block i is still in flight.  By default the drain functions wait for everything (lag 0 = the
+ * reference's blocking behaviour).  With lag 1 they deliver every block except the most recent one, so a
+ * feed/drain loop keeps two blocks in flight; vdl2hip_sync() always completes everything. */
+int  vdl2hip_set_drain_lag(vdl2hip_ctx *ctx, int lag);
 
 /* Wait for all queued blocks; moves finished frames to the host-side queue. */
 int  vdl2hip_sync(vdl2hip_ctx *ctx);

@@ -125,6 +125,25 @@ def test_drain_packed_equals_drain(vh):
     rx.close()
 
 
+def test_pipelined_feeds_with_drain_lag(vh):
+    """Streaming mode (drain lag 1): two blocks in flight, frames arrive one block late, nothing is lost or reordered."""
+    cfg, iq, _, gold = cases.load("config2_1s")
+    raw = iq.view(np.uint8)
+    rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=1 << 20)
+    rx.set_drain_lag(1)
+    got = []
+    for k in range(0, raw.size, 1 << 20):
+        rx.feed(raw[k:k + (1 << 20)])
+        got += rx.drain()
+    rx.set_drain_lag(0)
+    got += rx.drain()
+    cases.check_against_golden(got, [list(rx.counters(c).values()) for c in range(len(cfg.freqs))], gold, label="lag-1 streaming",
+                               exact_diagnostics=False)
+    ends = [f["end_sample"] for f in got]
+    assert ends == sorted(ends)
+    rx.close()
+
+
 def test_uint8_input(vh, oracle_mod):
     from dumpvdl2_amd import synth
     cfg = synth.SynthConfig(centerfreq=CF, freqs=[CF, CF + 40000], oversample=10, duration_s=0.6, seed=12, amplitude=0.3, noise_sigma=0.01)
