@@ -32,7 +32,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--duration", type=float, default=16.0, help="seconds of 2.1 MS/s signal per step")
-    ap.add_argument("--channels", type=int, default=8, help="channels per GPU")
+    ap.add_argument("--channels", type=int, default=8, help="channels per GPU (config2 only)")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
+                    help="BASELINE configs[1..4]; the headline line is config2 (8 channels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -53,8 +55,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     # ---- workload: BASELINE configs[1] ----
-    cfg = workloads.config2(args.duration)
-    if args.channels != 8:
+    cfg = getattr(workloads, args.workload)(args.duration)
+    if args.workload == "config2" and args.channels != 8:
         cfg.freqs = synth.channel_plan(args.channels, cfg.centerfreq, max(8000, min(100000, 2000000 // args.channels)))
     nvals = 2 * (int(round(cfg.duration_s * cfg.sample_rate)) // 2 * 2)
     bursts = None
@@ -77,6 +79,7 @@ def main():
                           device=local, max_block_bytes=nbytes)
 
     state = {"i": 0, "work": None}
+    front = torch.cuda.ExternalStream(rx.stream()) if world > 1 else None
     if world > 1:       # block 0 arrives before the first step
         vdist.broadcast_block(bufs[0], src=0)
         torch.cuda.synchronize()
@@ -89,6 +92,9 @@ def main():
         cur = bufs[i % len(bufs)]
         if world > 1:
             nxt = bufs[(i + 1) % len(bufs)]
+            # `nxt` was the input of block i-1: its channeliser (front stream of the library) must have finished
+            # reading it before RCCL overwrites it
+            torch.cuda.current_stream().wait_event(front.record_event())
             state["work"] = dist.broadcast(nxt.view(torch.uint8), src=0, async_op=True)
         rx.feed_device(cur.data_ptr(), nbytes)
         out = rx.drain_packed()            # every frame of the step copied to host memory (records + octets)
@@ -108,12 +114,15 @@ def main():
             from util import truth_is_subset, assert_frames_equal
             missing = truth_is_subset(bursts, fr)
             want = sum(len(b.frames) for b in bursts if b.decodable)
-            assert missing == 0 and len(fr) == want, f"parity gate: {missing} transmitted frames missing, {len(fr)} decoded vs {want} sent"
+            # with injected errors some bursts pushed past the nominal RS capacity still decode (both here and in the oracle)
+            exact = not cfg.error_injection
+            assert missing == 0 and (len(fr) == want if exact else len(fr) >= want), \
+                f"parity gate: {missing} transmitted frames missing, {len(fr)} decoded vs {want} sent"
             # bounded oracle check on the first 2 s of the very same bytes
             from oracle import pyoracle as po
             n2 = min(nvals, 2 * cfg.sample_rate * 2)
             o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
-            o.process(iq[:n2].view(np.uint8), block_bytes=1 << 24, nthreads=8)
+            o.process(iq[:n2].view(np.uint8), block_bytes=1 << 24, nthreads=min(len(cfg.freqs), os.cpu_count() or 8))
             lim = n2 // 2 // cfg.oversample - 200
             assert_frames_equal([f for f in o.frames() if f["end_sample"] < lim], [f for f in fr if f["end_sample"] < lim], label="bench oracle gate")
             verified = {"tx_frames": want, "decoded": len(fr), "oracle_window_s": n2 / 2 / cfg.sample_rate}
@@ -156,7 +165,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pt = json.load(f)["k_chanfir"]
         w = pt["workload"]
-        if (w["channels_per_gpu"], w["duration_s"], w["oversample"]) == (len(cfg.freqs), float(cfg.duration_s), cfg.oversample):
+        if args.workload == "config2" and (w["channels_per_gpu"], w["duration_s"], w["oversample"]) == (len(cfg.freqs), float(cfg.duration_s), cfg.oversample):
             traffic = pt["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         traffic = None
@@ -168,8 +177,8 @@ def main():
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: synthetic 2.1 MS/s cs16 IQ, {cfg.duration_s:g} s, {len(cfg.freqs)} VDL2 channels per GPU "
-                                   f"(100 kHz raster, Poisson bursts), input resident in HBM",
+            "config": {"workload": f"configs[{int(args.workload[-1]) - 1}] ({args.workload}): synthetic 2.1 MS/s cs16 IQ, {cfg.duration_s:g} s, "
+                                   f"{len(cfg.freqs)} VDL2 channels per GPU, input resident in HBM, two blocks in flight",
                        "channels_per_gpu": len(cfg.freqs), "samples_per_step": nsamples,
                        "channel_MS_per_s": round(value * len(cfg.freqs), 1),
                        "realtime_channels_at_2.1MSps": round(value * len(cfg.freqs) / 2.1, 1),

@@ -144,6 +144,17 @@ def test_pipelined_feeds_with_drain_lag(vh):
     rx.close()
 
 
+def test_front_stream_handle_is_usable_from_torch(vh):
+    """bench.py orders the RCCL broadcast behind the channeliser through this handle."""
+    import torch
+    rx = vh.Receiver(CF, [CF], 10, vh.FMT_S16LE)
+    ext = torch.cuda.ExternalStream(rx.stream())
+    ev = ext.record_event()
+    torch.cuda.current_stream().wait_event(ev)
+    torch.cuda.synchronize()
+    rx.close()
+
+
 def test_uint8_input(vh, oracle_mod):
     from dumpvdl2_amd import synth
     cfg = synth.SynthConfig(centerfreq=CF, freqs=[CF, CF + 40000], oversample=10, duration_s=0.6, seed=12, amplitude=0.3, noise_sigma=0.01)
