@@ -25,6 +25,8 @@
 
 namespace vdl2 {
 
+constexpr int kK1Unroll = VDL2_K1_UNROLL;
+
 // the slice of BlockForm K1 needs, passed by value so that it lives in the kernarg segment
 // (constant address space -> scalar loads into SGPRs)
 struct K1Consts {
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256, VDL2_K1_WAVES_PER_EU) void k_chanfir(K1Args a)
 		const float2 *trow = tile + (size_t)(i * os) * 65 + lane;
 		// Partially unrolled on purpose: a fully unrolled run makes the scheduler hoist every LUT
 		// gather (4 VGPRs each) to the top and spill.  Taps come from scalar loads (uniform index).
-		#pragma unroll VDL2_K1_UNROLL
+		#pragma unroll(kK1Unroll)
 		for(int j = 0; j < os; j++) {
 			const float2 x = trow[j * 65];
 			const float g0 = bf.g0[j], g1 = bf.g1[j];
@@ -272,24 +274,43 @@ struct K3Args {
 	uint32_t cap, mask;
 };
 
-// K3: got_sync() metric of every decimated sample (contiguous ring) + the candidate bitmap
+// K3: got_sync() metric of every decimated sample (contiguous ring) + the candidate bitmap.
+// A block of 256 consecutive samples stages the 409 phases it needs (150 back + 3 for the n-3 neighbours) in LDS,
+// so the 16 taps are plain ds_reads at constant offsets.
 __global__ __launch_bounds__(256) void k_sync(K3Args a) {
 	__shared__ float psh[256 + 3];
-	const int c = blockIdx.y;
+	__shared__ float tile[256 + 153 + 3];
+	const int c = blockIdx.y, tid = threadIdx.x;
 	const int64_t nblk = a.nbase + (int64_t)blockIdx.x * 256;
-	const int64_t n = nblk + threadIdx.x;
+	const int64_t n = nblk + tid;
 	const float *phi = a.phi + (size_t)c * a.cap;
-	cf32 r = (n < a.k1) ? metric_contiguous(phi, a.mask, n, *a.tab) : cf32{kPherrBig, 0.f};
-	a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = r;
-	psh[threadIdx.x + 3] = r.re;
-	if(threadIdx.x < 3) {
-		const int64_t m = nblk - 3 + threadIdx.x;
-		psh[threadIdx.x] = (m >= 0) ? metric_contiguous(phi, a.mask, m, *a.tab).re : kPherrBig;
+	const Tables &T = *a.tab;
+	for(int j = tid; j < 256 + 153; j += 256) {
+		const int64_t t = nblk - 153 + j;
+		tile[j] = (t < 0 || t >= a.k1) ? 0.f : phi[(uint32_t)t & a.mask];
 	}
 	__syncthreads();
-	const bool cnd = n >= 3 && n < a.k1 && is_candidate(psh[threadIdx.x], psh[threadIdx.x + 3]);
+	float ph[kPreamble];
+	#pragma unroll
+	for(int i = 0; i < kPreamble; i++) ph[i] = tile[tid + 3 + 10 * i];
+	cf32 r{kPherrBig, 0.f};
+	if(n < a.k1) sync_metric(ph, T, r.re, r.im);
+	a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = r;
+	psh[tid + 3] = r.re;
+	if(tid < 3) {
+		const int64_t m = nblk - 3 + tid;
+		float pm = kPherrBig, fm;
+		if(m >= 0) {
+			#pragma unroll
+			for(int i = 0; i < kPreamble; i++) ph[i] = tile[tid + 10 * i];
+			sync_metric(ph, T, pm, fm);
+		}
+		psh[tid] = pm;
+	}
+	__syncthreads();
+	const bool cnd = n >= 3 && n < a.k1 && is_candidate(psh[tid], psh[tid + 3]);
 	const unsigned long long bits = __ballot(cnd);
-	if((threadIdx.x & 63) == 0) a.cand[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
+	if((tid & 63) == 0) a.cand[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
 }
 
 struct K4Args {

@@ -107,6 +107,7 @@ enum { CNT_SYNC_GOOD = 0, CNT_CRC_GOOD, CNT_CRC_BAD, CNT_ERR_NO_HEADER, CNT_ERR_
 
 struct cf32 { float re, im; };
 
+
 // Read-only tables, built on the host once per context (tables.h) and kept in device memory.
 struct Tables {
 	float    pr_phase[kPreamble];      // demod.c:107-124
@@ -239,10 +240,11 @@ VDL2_HD void sync_metric(const float *ph, const Tables &T, float &pherr, float &
 		float cur = ph[i] - T.pr_phase[i];
 		float diff = cur - prev;
 		prev = cur;
-		// demod.c:137-141 compares the float against the double M_PI.  For a float operand that is
-		// exactly "diff > 0x1.921fb4p+1f" (the largest float below pi): same decisions, no f64 compare.
-		if(diff > kPiBelow) unwrap = (float)((double)unwrap - 2.0f * M_PI);
-		else if(diff < -kPiBelow) unwrap = (float)((double)unwrap + 2.0f * M_PI);
+		// demod.c:137-141: "if(errdiff > M_PI) unwrap -= 2.0f * M_PI; else if(errdiff < -M_PI) unwrap += ..." with the
+		// float operands promoted to double.  (double)x > M_PI  <=>  x > kPiBelow for a float x, and adding 0.0 in
+		// double and narrowing back leaves unwrap unchanged, so the update is written without branches.
+		const double step = diff > kPiBelow ? -(2.0f * M_PI) : (diff < -kPiBelow ? (2.0f * M_PI) : 0.0);
+		unwrap = (float)((double)unwrap + step);
 		e[i] = cur + unwrap;
 		mean += e[i];
 	}
