@@ -98,6 +98,7 @@ struct BlockForm {
 	float cP[kFixW][2];             // (c0,c1) * P^(i+1): fix-up row for the i-th output after a start state
 	float Ppow[kFixW + 1][4];       // P^i, i = 0..kFixW
 	float Q[6][4];                  // P^(run * 2^d): wave-scan step matrices, d = 0..5
+	float Qpow[64][4];              // P^(run * (l+1)), l = 0..63: a carried state's contribution to lane l's end state
 };
 
 inline BlockForm derive_block_form(const LpfCoeffs &lp, int os, int run) {
@@ -120,6 +121,14 @@ inline BlockForm derive_block_form(const LpfCoeffs &lp, int os, int run) {
 		bf.Ppow[i][0] = (float)Pi.a; bf.Ppow[i][1] = (float)Pi.b; bf.Ppow[i][2] = (float)Pi.c; bf.Ppow[i][3] = (float)Pi.d;
 		Pi = mul(Pi, P);
 		if(i < kFixW) { bf.cP[i][0] = (float)(c0 * Pi.a + c1 * Pi.c); bf.cP[i][1] = (float)(c0 * Pi.b + c1 * Pi.d); }
+	}
+	{
+		const Mat2 Q1 = mpow(P, run);
+		Mat2 Ql = Q1;
+		for(int l = 0; l < 64; l++) {
+			bf.Qpow[l][0] = (float)Ql.a; bf.Qpow[l][1] = (float)Ql.b; bf.Qpow[l][2] = (float)Ql.c; bf.Qpow[l][3] = (float)Ql.d;
+			Ql = mul(Ql, Q1);
+		}
 	}
 	Mat2 Q = mpow(P, run);
 	for(int d = 0; d < 6; d++) {

@@ -34,6 +34,7 @@ struct K1Consts {
 	float P[4], c0, c1, c2, pad_;
 	float Q[6][4];
 	float Pp[kRunMax + 1][4];      // P^i, i <= run
+	float cP[kRunMax][2];          // (c0,c1) P^(i+1), i < run
 };
 
 inline K1Consts make_k1_consts(const BlockForm &bf) {
@@ -43,6 +44,7 @@ inline K1Consts make_k1_consts(const BlockForm &bf) {
 	k.c0 = bf.c0; k.c1 = bf.c1; k.c2 = bf.c2;
 	for(int d = 0; d < 6; d++) for(int i = 0; i < 4; i++) k.Q[d][i] = bf.Q[d][i];
 	for(int r = 0; r <= kRunMax; r++) for(int i = 0; i < 4; i++) k.Pp[r][i] = bf.Ppow[r][i];
+	for(int r = 0; r < kRunMax; r++) { k.cP[r][0] = bf.cP[r][0]; k.cP[r][1] = bf.cP[r][1]; }
 	return k;
 }
 
@@ -59,9 +61,10 @@ struct K1Args {
 	const Lut4 *lut;
 	K1Consts bf;
 	cf32 *y;                   // [nchan][cap]
-	float4 *seg_end;           // [nchan][nseg_cap] zero-start state at the end of each 64*R-block segment
-	float4 *run_start;         // [nchan][nrun_cap] segment-local state at the start of each lane's R-block run
-	uint32_t cap, mask, nseg_cap, nrun_cap;
+	float4 *seg_end;           // [nchan][nseg_cap] zero-start state at the end of each workgroup segment
+	const float4 *qpow;        // [64] Q^(l+1) row-major 2x2, Q = P^R
+	int32_t  tiles;            // tiles per workgroup segment
+	uint32_t cap, mask, nseg_cap;
 };
 
 __device__ __forceinline__ void load_sample(const K1Args &a, int64_t s, float &re, float &im) {
@@ -78,148 +81,182 @@ __device__ __forceinline__ void load_sample(const K1Args &a, int64_t s, float &r
 	}
 }
 
-// One workgroup = 4 waves sharing one time tile (64*R blocks of OS samples) staged in LDS;
-// each wave owns CR channels; each lane owns R consecutive decimated outputs.
+// One workgroup = 4 waves that walk `a.tiles` consecutive time tiles (64*R blocks of OS samples each, staged in LDS
+// and shared by the waves); each wave owns CR channels; each lane owns R consecutive decimated outputs per tile.
+// Within a workgroup's segment the filter state is carried from tile to tile in registers, so the outputs it
+// stores are final except for the (decayed) state at the segment start, which K2 adds to the first kFixW of them.
 // OS == 0 selects the generic (run-time oversample) build of the same code.
 template<int OS, int R, int CR>
-__global__ __launch_bounds__(256, VDL2_K1_WAVES_PER_EU) void k_chanfir(K1Args a) {
+__global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
+	static_assert(R >= 1 && R <= 2, "the run's outputs are held in two register pairs");
 	extern __shared__ __align__(16) unsigned char smem[];
 	const int os = OS ? OS : a.os;
-	const int run = R * os;                       // input samples per lane
+	const int run = R * os;                       // input samples per lane and tile
 	float4 *lut = (float4 *)smem;                 // 256 entries
-	float2 *tile = (float2 *)(smem + 4096);       // [run][65]
+	float4 *qpow = (float4 *)(smem + 4096);       // Q^(l+1), l = 0..63: what a carry contributes to lane l's end state
+	float *park = (float *)(smem + 4096 + 1024);  // per wave: carried state and the end-of-feed state, [wave][2][CR][4]
+	float2 *tile = (float2 *)(smem + 4096 + 2048);   // [run][65]
 	const int tid = threadIdx.x;
 
 	// XCD-aware decode of the 1-D block id: workgroups that share a time tile land on one XCD (same L2)
 	const int bid = blockIdx.x;
 	const int xcd = bid & 7, q = bid >> 3;
 	const int gy = q % a.gy;
-	const int seg = (q / a.gy) * 8 + xcd;
+	const int seg = (q / a.gy) * 8 + xcd;         // workgroup segment = a.tiles tiles
 	if(seg >= a.nseg) return;
 
 	lut[tid] = ((const float4 *)a.lut)[tid];
-	const int tile_n = 64 * run;
-	const int64_t sbase = (int64_t)seg * tile_n;
-	for(int t = tid; t < tile_n; t += 256) {
-		int64_t s = sbase + t;
-		float re = 0.f, im = 0.f;
-		if(s < (int64_t)a.nlogical) load_sample(a, s, re, im);
-		int l = t / run, m = t - l * run;
-		tile[m * 65 + l] = make_float2(re, im);
-	}
-	__syncthreads();
-
+	if(tid < 64) qpow[tid] = a.qpow[tid];
 	const int wave = tid >> 6, lane = tid & 63;
 	const int cbase = (gy * 4 + wave) * CR;
-	if(cbase >= a.nchan) return;
+	const bool wave_active = cbase < a.nchan;
 	const K1Consts &bf = a.bf;
+	const int tile_n = 64 * run;                  // input samples per tile
+	const int L = 64 * R;                         // decimated outputs per tile
 
-	uint32_t ph[CR], dph[CR];
-	const uint32_t nabs = (uint32_t)((a.n0 + (uint64_t)sbase + (uint64_t)lane * run) & 0xffffffu);
+	uint32_t dph[CR];
+	float4 *carry = (float4 *)(park + wave * (2 * CR * 4));    // state carried into the current tile (zero at the segment start)
+	float4 *svp = carry + CR;                                   // zero-start state after the feed's last valid block
 	#pragma unroll
 	for(int c = 0; c < CR; c++) {
-		int ch = cbase + c < a.nchan ? cbase + c : a.nchan - 1;
+		const int ch = cbase + c < a.nchan ? cbase + c : a.nchan - 1;
 		dph[c] = a.dphi[ch];
-		ph[c] = nabs * dph[c];
+		if(lane == 0) carry[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 	}
-	// last valid block of this segment (segment-local index) and who owns it
-	const int64_t rem = a.D - (int64_t)seg * (64 * R);
-	const int blast = rem >= 64 * R ? 64 * R - 1 : (int)rem - 1;
-	const int lb = blast / R, ib = blast - lb * R;
-
-	float t0r[CR], t0i[CR], t1r[CR], t1i[CR];     // running (zero-start) state of this lane's run
-	float sv[CR][4];                              // state after block `ib` (only lane lb's copy is used)
-	#pragma unroll
-	for(int c = 0; c < CR; c++) { t0r[c] = t0i[c] = t1r[c] = t1i[c] = 0.f; sv[c][0] = sv[c][1] = sv[c][2] = sv[c][3] = 0.f; }
-
 	const float P0 = bf.P[0], P1 = bf.P[1], P2 = bf.P[2], P3 = bf.P[3];
 	const float c0 = bf.c0, c1 = bf.c1, c2 = bf.c2;
-	const int64_t kloc = (int64_t)seg * (64 * R) + (int64_t)lane * R;   // feed-local index of this lane's first output
 
-	// The block loop stays rolled: one iteration = OS samples x CR channels of straight-line code,
-	// which is all the instruction-level parallelism the register file can hold.
-	#pragma unroll 1
-	for(int i = 0; i < R; i++) {
-		float a0r[CR], a0i[CR], a1r[CR], a1i[CR], lr[CR], li[CR];
+	for(int ts = 0; ts < a.tiles; ts++) {
+		const int64_t tix = (int64_t)seg * a.tiles + ts;       // tile index within the feed
+		const int64_t kbase = tix * L;                           // feed-local index of the tile's first output
+		if(kbase >= a.D) break;
+		const int64_t sbase = tix * tile_n;
+		if(ts) __syncthreads();                                  // everyone is done with the previous tile
+		for(int t = tid; t < tile_n; t += 256) {
+			const int64_t sidx = sbase + t;
+			float re = 0.f, im = 0.f;
+			if(sidx < (int64_t)a.nlogical) load_sample(a, sidx, re, im);
+			const int l = t / run, m = t - l * run;
+			tile[m * 65 + l] = make_float2(re, im);
+		}
+		__syncthreads();
+		if(!wave_active) continue;
+
+		uint32_t ph[CR];
+		const uint32_t nabs = (uint32_t)((a.n0 + (uint64_t)sbase + (uint64_t)lane * run) & 0xffffffu);
 		#pragma unroll
-		for(int c = 0; c < CR; c++) { a0r[c] = a0i[c] = a1r[c] = a1i[c] = 0.f; lr[c] = li[c] = 0.f; }
-		const float2 *trow = tile + (size_t)(i * os) * 65 + lane;
-		// Partially unrolled on purpose: a fully unrolled run makes the scheduler hoist every LUT
-		// gather (4 VGPRs each) to the top and spill.  Taps come from scalar loads (uniform index).
-		#pragma unroll(kK1Unroll)
-		for(int j = 0; j < os; j++) {
-			const float2 x = trow[j * 65];
-			const float g0 = bf.g0[j], g1 = bf.g1[j];
+		for(int c = 0; c < CR; c++) ph[c] = nabs * dph[c];
+		// last valid block of this tile (tile-local index) and who owns it
+		const int64_t rem = a.D - kbase;
+		const int blast = rem >= L ? L - 1 : (int)rem - 1;
+		const int lb = blast / R, ib = blast - lb * R;
+
+		float t0r[CR], t0i[CR], t1r[CR], t1i[CR];     // running (zero-start) state of this lane's run
+		float ya[CR][2], yb[CR][2];                   // zero-start outputs of the run (R <= 2 kept in registers)
+		#pragma unroll
+		for(int c = 0; c < CR; c++) {
+			t0r[c] = t0i[c] = t1r[c] = t1i[c] = 0.f;
+			ya[c][0] = ya[c][1] = yb[c][0] = yb[c][1] = 0.f;
+		}
+
+		// The block loop stays rolled: one iteration = OS samples x CR channels of straight-line code.
+		#pragma unroll 1
+		for(int i = 0; i < R; i++) {
+			float a0r[CR], a0i[CR], a1r[CR], a1i[CR], lr[CR], li[CR];
+			#pragma unroll
+			for(int c = 0; c < CR; c++) { a0r[c] = a0i[c] = a1r[c] = a1i[c] = 0.f; lr[c] = li[c] = 0.f; }
+			const float2 *trow = tile + (size_t)(i * os) * 65 + lane;
+			// Partially unrolled on purpose: a fully unrolled run makes the scheduler hoist every LUT
+			// gather (4 VGPRs each) to the top and spill.  Taps come from scalar loads (uniform index).
+			#pragma unroll kK1Unroll
+			for(int j = 0; j < os; j++) {
+				const float2 x = trow[j * 65];
+				const float g0 = bf.g0[j], g1 = bf.g1[j];
+				#pragma unroll
+				for(int c = 0; c < CR; c++) {
+					const uint32_t p = ph[c];
+					const float F = (float)(p & 0xffffu);                 // sincosf_lut(): fract * 65536
+					const float4 e = lut[(p >> 16) & 0xffu];
+					const float sn = __builtin_fmaf(e.y, F, e.x);
+					const float cs = __builtin_fmaf(e.w, F, e.z);
+					const float mr = __builtin_fmaf(x.x, cs, -(x.y * sn)); // multiply(): re*cos - im*sin
+					const float mi = __builtin_fmaf(x.y, cs, x.x * sn);    //             im*cos + re*sin
+					a0r[c] = __builtin_fmaf(g0, mr, a0r[c]); a0i[c] = __builtin_fmaf(g0, mi, a0i[c]);
+					a1r[c] = __builtin_fmaf(g1, mr, a1r[c]); a1i[c] = __builtin_fmaf(g1, mi, a1i[c]);
+					lr[c] = mr; li[c] = mi;
+					ph[c] = p + dph[c];
+				}
+			}
 			#pragma unroll
 			for(int c = 0; c < CR; c++) {
-				const uint32_t p = ph[c];
-				const float F = (float)(p & 0xffffu);                 // sincosf_lut(): fract * 65536
-				const float4 e = lut[(p >> 16) & 0xffu];
-				const float sn = __builtin_fmaf(e.y, F, e.x);
-				const float cs = __builtin_fmaf(e.w, F, e.z);
-				const float mr = __builtin_fmaf(x.x, cs, -(x.y * sn)); // multiply(): re*cos - im*sin
-				const float mi = __builtin_fmaf(x.y, cs, x.x * sn);    //             im*cos + re*sin
-				a0r[c] = __builtin_fmaf(g0, mr, a0r[c]); a0i[c] = __builtin_fmaf(g0, mi, a0i[c]);
-				a1r[c] = __builtin_fmaf(g1, mr, a1r[c]); a1i[c] = __builtin_fmaf(g1, mi, a1i[c]);
-				lr[c] = mr; li[c] = mi;
-				ph[c] = p + dph[c];
+				// state update t <- P t + acc, then y = c0*v[n] + c1*v[n-1] + c2*xm[n] (zero-start part)
+				const float n0r = __builtin_fmaf(P0, t0r[c], __builtin_fmaf(P1, t1r[c], a0r[c]));
+				const float n0i = __builtin_fmaf(P0, t0i[c], __builtin_fmaf(P1, t1i[c], a0i[c]));
+				const float n1r = __builtin_fmaf(P2, t0r[c], __builtin_fmaf(P3, t1r[c], a1r[c]));
+				const float n1i = __builtin_fmaf(P2, t0i[c], __builtin_fmaf(P3, t1i[c], a1i[c]));
+				t0r[c] = n0r; t0i[c] = n0i; t1r[c] = n1r; t1i[c] = n1i;
+				const float yr = __builtin_fmaf(c0, n0r, __builtin_fmaf(c1, n1r, c2 * lr[c]));
+				const float yi = __builtin_fmaf(c0, n0i, __builtin_fmaf(c1, n1i, c2 * li[c]));
+				if(i == ib && lane == lb) svp[c] = make_float4(n0r, n0i, n1r, n1i);
+				if(i == 0) { ya[c][0] = yr; ya[c][1] = yi; } else { yb[c][0] = yr; yb[c][1] = yi; }
 			}
 		}
-		#pragma unroll
-		for(int c = 0; c < CR; c++) {
-			// state update t <- P t + acc, then y = c0*v[n] + c1*v[n-1] + c2*xm[n] (zero-start part; K2 adds the rest)
-			const float n0r = __builtin_fmaf(P0, t0r[c], __builtin_fmaf(P1, t1r[c], a0r[c]));
-			const float n0i = __builtin_fmaf(P0, t0i[c], __builtin_fmaf(P1, t1i[c], a0i[c]));
-			const float n1r = __builtin_fmaf(P2, t0r[c], __builtin_fmaf(P3, t1r[c], a1r[c]));
-			const float n1i = __builtin_fmaf(P2, t0i[c], __builtin_fmaf(P3, t1i[c], a1i[c]));
-			t0r[c] = n0r; t0i[c] = n0i; t1r[c] = n1r; t1i[c] = n1i;
-			const float yr = __builtin_fmaf(c0, n0r, __builtin_fmaf(c1, n1r, c2 * lr[c]));
-			const float yi = __builtin_fmaf(c0, n0i, __builtin_fmaf(c1, n1i, c2 * li[c]));
-			if(i == ib) { sv[c][0] = n0r; sv[c][1] = n0i; sv[c][2] = n1r; sv[c][3] = n1i; }
-			if(cbase + c < a.nchan && kloc + i < a.D)
-				a.y[(size_t)(cbase + c) * a.cap + ((uint32_t)(a.k0 + kloc + i) & a.mask)] = cf32{yr, yi};
-		}
-	}
 
-	// wave-level scan of the lane end states: X_l = Q X_{l-1} + E_l, Q = P^R (Kogge-Stone, 6 steps)
-	#pragma unroll
-	for(int d = 0; d < 6; d++) {
-		const float q0 = bf.Q[d][0], q1 = bf.Q[d][1], q2 = bf.Q[d][2], q3 = bf.Q[d][3];
+		// wave-level scan of the lane end states: X_l = Q X_{l-1} + E_l, Q = P^R (Kogge-Stone, 6 steps), X_-1 = carry
 		#pragma unroll
-		for(int c = 0; c < CR; c++) {
-			const float o0r = __shfl_up(t0r[c], 1u << d), o0i = __shfl_up(t0i[c], 1u << d);
-			const float o1r = __shfl_up(t1r[c], 1u << d), o1i = __shfl_up(t1i[c], 1u << d);
-			if(lane >= (1 << d)) {
-				t0r[c] += q0 * o0r + q1 * o1r; t0i[c] += q0 * o0i + q1 * o1i;
-				t1r[c] += q2 * o0r + q3 * o1r; t1i[c] += q2 * o0i + q3 * o1i;
+		for(int d = 0; d < 6; d++) {
+			const float q0 = bf.Q[d][0], q1 = bf.Q[d][1], q2 = bf.Q[d][2], q3 = bf.Q[d][3];
+			#pragma unroll
+			for(int c = 0; c < CR; c++) {
+				const float o0r = __shfl_up(t0r[c], 1u << d), o0i = __shfl_up(t0i[c], 1u << d);
+				const float o1r = __shfl_up(t1r[c], 1u << d), o1i = __shfl_up(t1i[c], 1u << d);
+				if(lane >= (1 << d)) {
+					t0r[c] += q0 * o0r + q1 * o1r; t0i[c] += q0 * o0i + q1 * o1i;
+					t1r[c] += q2 * o0r + q3 * o1r; t1i[c] += q2 * o0i + q3 * o1i;
+				}
 			}
 		}
-	}
-	#pragma unroll
-	for(int c = 0; c < CR; c++) {
-		// state at the START of this lane's run (segment-local): what K2 adds back, decayed, to the lane's R outputs
-		float T0r = __shfl_up(t0r[c], 1), T0i = __shfl_up(t0i[c], 1), T1r = __shfl_up(t1r[c], 1), T1i = __shfl_up(t1i[c], 1);
-		if(lane == 0) { T0r = T0i = T1r = T1i = 0.f; }
-		if(cbase + c < a.nchan) {
-			if(kloc < a.D) a.run_start[(size_t)(cbase + c) * a.nrun_cap + (size_t)seg * 64 + lane] = make_float4(T0r, T0i, T1r, T1i);
-			if(lane == lb) {
+		const float4 qp = qpow[lane];
+		#pragma unroll
+		for(int c = 0; c < CR; c++) {
+			// add what the carried state contributes, then each lane needs the state at the START of its run
+			const float4 cy = carry[c];
+			t0r[c] += qp.x * cy.x + qp.y * cy.z; t0i[c] += qp.x * cy.y + qp.y * cy.w;
+			t1r[c] += qp.z * cy.x + qp.w * cy.z; t1i[c] += qp.z * cy.y + qp.w * cy.w;
+			float T0r = __shfl_up(t0r[c], 1), T0i = __shfl_up(t0i[c], 1), T1r = __shfl_up(t1r[c], 1), T1i = __shfl_up(t1i[c], 1);
+			if(lane == 0) { T0r = cy.x; T0i = cy.y; T1r = cy.z; T1i = cy.w; }
+			const bool cvalid = cbase + c < a.nchan;
+			const int64_t kloc = kbase + (int64_t)lane * R;
+			cf32 *yout = a.y + (size_t)(cbase + c) * a.cap;
+			// outputs of the run, completed with the decayed run-start state (cP[i] = (c0,c1) P^(i+1))
+			const float f0r = ya[c][0] + (bf.cP[0][0] * T0r + bf.cP[0][1] * T1r), f0i = ya[c][1] + (bf.cP[0][0] * T0i + bf.cP[0][1] * T1i);
+			if(cvalid && kloc < a.D) yout[(uint32_t)(a.k0 + kloc) & a.mask] = cf32{f0r, f0i};
+			if(R > 1) {
+				const float f1r = yb[c][0] + (bf.cP[1][0] * T0r + bf.cP[1][1] * T1r), f1i = yb[c][1] + (bf.cP[1][0] * T0i + bf.cP[1][1] * T1i);
+				if(cvalid && kloc + 1 < a.D) yout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = cf32{f1r, f1i};
+			}
+			if(cvalid && lane == lb && (rem <= L || ts == a.tiles - 1)) {
+				// state at the end of the segment's valid part, with zero state at the segment start
 				const float *Pp = bf.Pp[ib + 1];
 				float4 e;
-				e.x = sv[c][0] + (Pp[0] * T0r + Pp[1] * T1r); e.y = sv[c][1] + (Pp[0] * T0i + Pp[1] * T1i);
-				e.z = sv[c][2] + (Pp[2] * T0r + Pp[3] * T1r); e.w = sv[c][3] + (Pp[2] * T0i + Pp[3] * T1i);
+				const float4 sv = svp[c];
+				e.x = sv.x + (Pp[0] * T0r + Pp[1] * T1r); e.y = sv.y + (Pp[0] * T0i + Pp[1] * T1i);
+				e.z = sv.z + (Pp[2] * T0r + Pp[3] * T1r); e.w = sv.w + (Pp[2] * T0i + Pp[3] * T1i);
 				a.seg_end[(size_t)(cbase + c) * a.nseg_cap + seg] = e;
 			}
+			// carry into the next tile = state at the end of lane 63's run
+			if(lane == 63) carry[c] = make_float4(t0r[c], t0i[c], t1r[c], t1i[c]);
 		}
 	}
 }
 
 struct K2Args {
-	cf32 *y; float *phi; const float4 *seg_end; const float4 *run_start; const float4 *carry_in; float4 *carry_out;
+	cf32 *y; float *phi; const float4 *seg_end; const float4 *carry_in; float4 *carry_out;
 	const BlockForm *bf;
-	int64_t k0, D; uint32_t cap, mask, nseg_cap, nrun_cap; int32_t seglen, run;
+	int64_t k0, D; uint32_t cap, mask, nseg_cap; int32_t seglen;
 };
 
-// K2: complete K1's zero-start outputs with the decayed start states (lane run, then segment), then phase.
+// K2: add the decayed segment-start state to the first kFixW outputs of every workgroup segment, then phase.
 __global__ __launch_bounds__(256) void k_phase(K2Args a) {
 	const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	const int c = blockIdx.y;
@@ -228,18 +265,12 @@ __global__ __launch_bounds__(256) void k_phase(K2Args a) {
 	const uint32_t slot = (uint32_t)(a.k0 + k) & a.mask;
 	cf32 v = a.y[(size_t)c * a.cap + slot];
 	const int seg = (int)(k / a.seglen), i = (int)(k - (int64_t)seg * a.seglen);
-	{
-		const int64_t rho = k / a.run; const int ir = (int)(k - rho * a.run);
-		const float4 tr = a.run_start[(size_t)c * a.nrun_cap + rho];
-		v.re += bf.cP[ir][0] * tr.x + bf.cP[ir][1] * tr.z;
-		v.im += bf.cP[ir][0] * tr.y + bf.cP[ir][1] * tr.w;
-	}
 	if(i < kFixW) {
 		const float4 ts = seg ? a.seg_end[(size_t)c * a.nseg_cap + seg - 1] : a.carry_in[c];
 		v.re += bf.cP[i][0] * ts.x + bf.cP[i][1] * ts.z;
 		v.im += bf.cP[i][0] * ts.y + bf.cP[i][1] * ts.w;
+		a.y[(size_t)c * a.cap + slot] = v;
 	}
-	a.y[(size_t)c * a.cap + slot] = v;
 	a.phi[(size_t)c * a.cap + slot] = phase_of(v);
 	if(k == a.D - 1) {   // filter state handed to the next feed
 		const int len = i + 1;

@@ -59,7 +59,7 @@ struct vdl2hip_ctx {
 	cf32 *d_y = nullptr, *d_pf = nullptr; float *d_phi = nullptr; uint64_t *d_cand = nullptr;
 	uint32_t cap = 0;
 	float4 *d_segend = nullptr; uint32_t nseg_cap = 0;
-	float4 *d_runstart = nullptr; uint32_t nrun_cap = 0;
+	float4 *d_qpow = nullptr;
 	float4 *d_tcarry[2] = {nullptr, nullptr}; int tcarry_sel = 0;
 	WalkState *d_ws = nullptr; unsigned long long *d_cnt = nullptr;
 	NfState *d_nf = nullptr; EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
@@ -164,15 +164,25 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	K1Args a{};
 	a.in = dev_in; a.carry = c->d_carry[c->carry_sel]; a.ncarry = c->ncarry; a.nlogical = nlogical;
 	a.n0 = c->n_total - c->ncarry; a.k0 = c->k_total; a.D = D;
-	a.fmt = c->fmt; a.nchan = c->C; a.os = c->os; a.nseg = (int)((D + seglen - 1) / seglen); a.gy = 1;
+	a.fmt = c->fmt; a.nchan = c->C; a.os = c->os; a.nseg = 0; a.gy = 1;
 	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.seg_end = c->d_segend;
-	a.run_start = c->d_runstart; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap; a.nrun_cap = c->nrun_cap;
+	a.qpow = c->d_qpow; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap;
+	{
+		// tiles per workgroup segment: long segments save K2 work, but the grid should still offer several thousand
+		// workgroups (measured: tests/gpu_k1_tiles.sh - 2 is best at 8 channels, 8 at 256)
+		const int64_t ntile = (D + seglen - 1) / seglen;
+		const int groups = (c->C + c->cr - 1) / c->cr, gy = (groups + 3) / 4;
+		int64_t tiles = ntile * gy / 6144; if(tiles < 1) tiles = 1; if(tiles > 8) tiles = 8;
+		if(const char *e = getenv("VDL2HIP_K1_TILES")) { long v = atol(e); if(v >= 1 && v <= 64) tiles = v; }   // experiments only
+		a.tiles = (int)tiles;
+		a.nseg = (int)((ntile + tiles - 1) / tiles);
+	}
 
 	HIPCHK(hipMemcpyAsync(sl.d_ctl, c->h_ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, sb_));
 	sl.ev_valid = false;
 	if(D > 0) {
 		if(prof) HIPCHK(hipEventRecord(ev[0], st));
-		const size_t lds = 4096 + (size_t)c->run * c->os * 65 * sizeof(float2);
+		const size_t lds = 4096 + 2048 + (size_t)c->run * c->os * 65 * sizeof(float2);
 		if(c->specialised) {
 			switch(c->os) {
 				case 20: launch_chanfir<20, kRun>(c, a, c->cr, lds); break;
@@ -183,8 +193,8 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 			launch_chanfir<0, kRunGeneric>(c, a, c->cr, lds);
 		}
 		if(prof) HIPCHK(hipEventRecord(ev[1], st));
-		K2Args k2{ c->d_y, c->d_phi, c->d_segend, c->d_runstart, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
-		           c->k_total, D, c->cap, c->cap - 1, c->nseg_cap, c->nrun_cap, seglen, c->run };
+		K2Args k2{ c->d_y, c->d_phi, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
+		           c->k_total, D, c->cap, c->cap - 1, c->nseg_cap, seglen * a.tiles };
 		hipLaunchKernelGGL(k_phase, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), 0, st, k2);
 		c->tcarry_sel ^= 1;
 	}
@@ -266,7 +276,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_phi, c->d_cand, c->d_segend, c->d_runstart, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nfhist, c->d_lpbuf, c->d_nffeed, c->d_nfbase };
+	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nfhist, c->d_lpbuf, c->d_nffeed, c->d_nfbase };
 	for(auto &sl : c->slot) {
 		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl };
 		for(void *p : q) if(p) (void)hipFree(p);
@@ -318,7 +328,6 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	c->cap = cap;
 	c->in_cap = max_bytes;
 	c->nseg_cap = (uint32_t)(dmax / (64 * c->run) + 2);
-	c->nrun_cap = c->nseg_cap * 64;
 
 	#define DEV_ALLOC(ptr, bytes) do { if(hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_NOMEM; } } while(0)
 	#define DEV_CHK(expr) do { if((expr) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_DEVICE; } } while(0)
@@ -334,7 +343,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_y, nring * sizeof(cf32)); DEV_ALLOC(c->d_pf, nring * sizeof(cf32));
 	DEV_ALLOC(c->d_phi, nring * sizeof(float)); DEV_ALLOC(c->d_cand, nring / 8);
 	DEV_ALLOC(c->d_segend, (size_t)count * c->nseg_cap * sizeof(float4));
-	DEV_ALLOC(c->d_runstart, (size_t)count * c->nrun_cap * sizeof(float4));
+	DEV_ALLOC(c->d_qpow, 64 * sizeof(float4));
 	DEV_ALLOC(c->d_tcarry[0], count * sizeof(float4)); DEV_ALLOC(c->d_tcarry[1], count * sizeof(float4));
 	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, (size_t)count * kNumCounters * 8);
 	// a decodable burst occupies >= 22 symbols = 220 decimated samples (header + 3 data + 2 FEC octets)
@@ -363,6 +372,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	std::vector<WalkState> ws(count);
 	for(auto &w : ws) { memset(&w, 0, sizeof w); walk_state_init(w); }
 	DEV_CHK(hipMemcpy(c->d_bf, &c->bf, sizeof(BlockForm), hipMemcpyHostToDevice));
+	DEV_CHK(hipMemcpy(c->d_qpow, c->bf.Qpow, 64 * sizeof(float4), hipMemcpyHostToDevice));
 	DEV_CHK(hipMemcpy(c->d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
 	DEV_CHK(hipMemcpy(c->d_tab, tab, sizeof(Tables), hipMemcpyHostToDevice));
 	delete tab;
@@ -383,7 +393,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_CHK(hipMemset(c->d_cnt, 0, (size_t)count * kNumCounters * 8));
 	DEV_CHK(hipMemset(c->d_segend, 0, (size_t)count * c->nseg_cap * sizeof(float4)));
 	// the generic-oversample build may need more than the default dynamic LDS limit
-	const size_t lds = 4096 + (size_t)c->run * c->os * 65 * sizeof(float2);
+	const size_t lds = 4096 + 2048 + (size_t)c->run * c->os * 65 * sizeof(float2);
 	if(lds > 65536) { vdl2hip_destroy(c); return VDL2HIP_E_INVAL; }
 	DEV_CHK(hipDeviceSynchronize());
 	#undef DEV_ALLOC
