@@ -278,3 +278,52 @@ def test_cli_runner_and_raw_frame_archive(vh, oracle_mod, golden_wav, tmp_path):
         m = RawFrame(); m.ParseFromString(blob[off + 2:off + ln]); got.append(m); off += ln
     assert [m.data for m in got] == hexes
     assert all(m.metadata.station_id == "TEST" and m.metadata.frequency == CF and m.metadata.datalen_octets == 504 for m in got)
+
+
+def test_degenerate_feeds_and_errors(vh, golden_wav):
+    """Empty, sub-sample and tiny feeds; oversized blocks; bad channel numbers: same answers, clean errors."""
+    import ctypes as C
+    rx = vh.Receiver(CF, [CF], 10, vh.FMT_S16LE, max_block_bytes=400000)
+    ref = vh.Receiver(CF, [CF], 10, vh.FMT_S16LE, max_block_bytes=golden_wav.size)
+    ref.feed(golden_wav[:golden_wav.size - golden_wav.size % 4])
+    want = ref.drain()
+    rng = np.random.default_rng(0)
+    k = 0
+    wav = golden_wav[:golden_wav.size - golden_wav.size % 4]
+    rx.feed(wav[:0])                                            # len == 0 is a no-op (demod.c:341,358)
+    while k < wav.size:
+        m = int(rng.choice([4, 8, 36, 40, 44, 4000, 200000, 399996]))
+        m = min(m, wav.size - k)
+        rx.feed(wav[k:k + m]); k += m
+        if rng.random() < 0.3:
+            rx.sync()
+    got = rx.drain()
+    assert_frames_equal(want, got, label="tiny feeds")
+    assert list(ref.counters(0).values()) == list(rx.counters(0).values())
+    with pytest.raises(vh.Vdl2HipError, match="max_block_bytes"):
+        rx.feed(np.zeros(400004, dtype=np.uint8))
+    with pytest.raises(vh.Vdl2HipError, match="invalid argument"):
+        rx.counters(1)
+    with pytest.raises(vh.Vdl2HipError, match="invalid argument"):
+        vh.Receiver(CF, [CF, CF + 25000], 10, vh.FMT_S16LE, chan_first=1, chan_count=2)
+    with pytest.raises(vh.Vdl2HipError, match="invalid argument"):
+        vh.Receiver(CF, [CF], 33, vh.FMT_S16LE)
+    rx.close(); ref.close()
+
+
+def test_two_receivers_in_one_process(vh, oracle_mod, golden_wav):
+    """Contexts are independent (different oversampling, formats, channel counts) and can interleave their feeds."""
+    cfg, iq, _, gold = cases.load("config2_1s")
+    a = vh.Receiver(CF, [CF], 10, vh.FMT_S16LE, max_block_bytes=320000)
+    b = vh.Receiver(cfg.centerfreq, list(cfg.freqs), 20, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=1 << 21)
+    raw_b = iq.view(np.uint8)
+    ka = kb = 0
+    while ka < golden_wav.size or kb < raw_b.size:
+        if ka < golden_wav.size:
+            a.feed(golden_wav[ka:ka + 320000]); ka += 320000
+        if kb < raw_b.size:
+            b.feed(raw_b[kb:kb + (1 << 21)]); kb += 1 << 21
+    fa, fb = a.drain(), b.drain()
+    assert [len(f["octets"]) for f in fa] == [314, 186]
+    cases.check_against_golden(fb, [list(b.counters(c).values()) for c in range(8)], gold, label="interleaved", exact_diagnostics=False)
+    a.close(); b.close()
