@@ -4,7 +4,7 @@
 //   k_phase     K2  carry fix-up, atan2                              (src/demod.c:232,256)
 //   k_carry         saves the < oversample input samples left over for the next block
 //   k_sync      K3  got_sync() metric for every decimated sample + candidate bitmap (src/demod.c:105-171)
-//   k_walk      K4  per-channel FSM walker (vdl2_core.h)
+//   k_walk      K4  per-channel FSM walker (vdl2_core.h); k_walk_spec + k_walk_stitch: the same walk in speculative segments
 //   k_nf        K4b noise-floor replay from the walker's evaluation log (src/demod.c:238-243)
 //   k_burst     K5  wave-per-burst decoder (vdl2_core.h)
 //
@@ -360,6 +360,39 @@ __global__ __launch_bounds__(64) void k_walk(K4Args a) {
 	             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh);
 }
 
+// K4 in segments (vdl2_core.h "Speculative segments"): grid.x = 1 + 3*(nseg-1) walks per channel, then one stitcher per channel
+struct K4sArgs {
+	K4Args k; SpecOut *spec; uint32_t spec_stride; int32_t nseg; int64_t k0, seglen; uint32_t *seg_stats;
+};
+
+__global__ __launch_bounds__(64) void k_walk_spec(K4sArgs s) {
+	__shared__ WalkShared sh;
+	const K4Args &a = s.k;
+	const int c = blockIdx.y, x = blockIdx.x;
+	ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
+	if(x == 0) {
+		EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
+		walk_channel(c, a.freq[c], a.max_ppm, s.k0 + s.seglen, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
+		             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh);
+	} else {
+		const int seg = 1 + (x - 1) / 3, r = (x - 1) % 3;
+		const int64_t b = s.k0 + (int64_t)seg * s.seglen, kn = seg + 1 < s.nseg ? b + s.seglen : a.k_end;
+		spec_walk(c, a.freq[c], a.max_ppm, b, r, kn, *a.tab, v, s.spec + (size_t)c * s.spec_stride + (x - 1), sh);
+	}
+}
+
+__global__ __launch_bounds__(64) void k_walk_stitch(K4sArgs s) {
+	__shared__ WalkShared sh;
+	__shared__ StitchShared ss;
+	const K4Args &a = s.k;
+	const int c = blockIdx.x;
+	ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
+	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
+	stitch_channel(c, a.freq[c], a.max_ppm, s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
+	               a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg,
+	               s.spec + (size_t)c * s.spec_stride, sh, ss, s.seg_stats + 2 * c);
+}
+
 struct K4bArgs {
 	const cf32 *y; NfState *nf; WalkState *ws; EvalChunk *log; uint32_t *nlog; int64_t *sc_first; int64_t *sc_cum;
 	NfFeed *feed; float *lpbuf; float *hist; int64_t *hist_base; uint32_t cap, mask, cap_log, cap_comb, cap_hist;
@@ -370,7 +403,8 @@ __global__ __launch_bounds__(64) void k_nf_prepare(K4bArgs a) {
 	const int c = blockIdx.x;
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
-	nf_prepare(&a.nf[c], lg, sc, a.cap_comb, &a.feed[c]);
+	__shared__ NfShared sh;
+	nf_prepare(&a.nf[c], lg, sc, a.cap_comb, &a.feed[c], sh);
 }
 
 __global__ __launch_bounds__(64) void k_nf_replay(K4bArgs a) {
@@ -389,7 +423,8 @@ __global__ __launch_bounds__(64) void k_nf_finish(K4bArgs a) {
 	const int c = blockIdx.x;
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
-	nf_finish(&a.nf[c], lg, sc, a.feed[c], a.lpbuf + (size_t)c * a.cap_hist, a.hist + (size_t)c * a.cap_hist, a.cap_hist, a.hist_base + c, &a.ws[c]);
+	__shared__ NfShared sh;
+	nf_finish(&a.nf[c], lg, sc, a.feed[c], a.lpbuf + (size_t)c * a.cap_hist, a.hist + (size_t)c * a.cap_hist, a.cap_hist, a.hist_base + c, &a.ws[c], sh);
 }
 
 // Each channel's walker fills its own burst list (no atomics on its critical path); this one-wave kernel turns the
@@ -406,7 +441,6 @@ struct K5Args {
 	const cf32 *y; const float *phi; const Tables *tab; unsigned long long *cnt;
 	const Burst *bursts; const uint32_t *bbase; uint32_t cap_bursts_chan; int32_t nchan;
 	OutFrame *frames; uint8_t *pool; OutCtl *ctl; const uint32_t *freq;
-	const float *nf_hist; const int64_t *nf_base; uint32_t cap_hist;
 	uint32_t cap, mask;
 };
 
@@ -419,9 +453,17 @@ __global__ __launch_bounds__(64) void k_burst(K5Args a) {
 		const int c = lo;
 		const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - a.bbase[c])];
 		ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, nullptr, nullptr, a.mask };
-		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl,
-		             a.nf_hist + (size_t)c * a.cap_hist, a.cap_hist, a.nf_base[c], sh);
+		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
 		__syncthreads();
+	}
+}
+
+// after K4b and K5 have both finished: the noise-floor figure of every frame of this feed
+__global__ __launch_bounds__(256) void k_nf_stamp(OutFrame *frames, const OutCtl *ctl, const float *nf_hist, const int64_t *nf_base, uint32_t cap_hist) {
+	const uint32_t n = ctl->nframes < ctl->cap_frames ? ctl->nframes : ctl->cap_frames;
+	for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const int c = frames[i].chan;
+		stamp_noise_floor(frames[i], nf_hist + (size_t)c * cap_hist, cap_hist, nf_base[c]);
 	}
 }
 

@@ -99,6 +99,12 @@ constexpr int kNumIv = 32;                // DM_INIT interval history (160/6 < 3
 constexpr int kNfTail = 64;               // evaluation chunks remembered across feeds for the noise-floor lookback
 constexpr int kLpTerms = 256;             // 0.9^256 ~ 2e-12: below fp32 resolution of mag_lp
 constexpr int kNumCounters = 20;
+// segmented walk (see "Speculative segments" below)
+constexpr int kCleanAfter = 320;          // search state this far into an interval no longer depends on anything before the interval
+constexpr int kSpecBack = 4096;           // a speculative walker pretends its DM_INIT interval started this far before its segment
+constexpr int kSpecBursts = 48;           // per speculative segment; more than that and the segment is simply walked for real
+constexpr int kSpecLog = 128;
+constexpr int kMaxSeg = 32;
 
 enum { CNT_SYNC_GOOD = 0, CNT_CRC_GOOD, CNT_CRC_BAD, CNT_ERR_NO_HEADER, CNT_ERR_TOO_LONG, CNT_ERR_NO_FEC,
        CNT_ERR_DATA_TRUNCATED, CNT_ERR_FEC_TRUNCATED, CNT_ERR_DEINTERLEAVE_DATA, CNT_ERR_DEINTERLEAVE_FEC,
@@ -144,6 +150,7 @@ struct Burst {
 	float    prev_phi0, vdphi, ppm, mag_nf;   // mag_nf: stamped by the noise-floor kernel of the feed the sync happened in
 	uint32_t tl_bits, syndrome;
 	int64_t  nf_upd;                   // number of mag_nf updates that preceded the sync (v->mag_nf at decode_frame())
+	int64_t  sync_evals;               // got_sync() evaluations executed up to and including the one that fired (nf_upd = sync_evals / 1000)
 };
 
 struct OutFrame {
@@ -153,6 +160,7 @@ struct OutFrame {
 	int32_t  num_fec_corrections;
 	float    frame_pwr_dbfs, nf_pwr_dbfs, ppm_error;
 	int64_t  burst_ord, sync_sample, end_sample;
+	int64_t  nf_upd;                   // Burst::nf_upd; until stamp_noise_floor() has run, nf_pwr_dbfs holds Burst::mag_nf
 };
 
 struct OutCtl {
@@ -353,6 +361,7 @@ struct WalkShared {
 	// small read-only tables staged once per launch
 	uint32_t t_H[kHdrParBits], t_fix[32]; uint8_t t_gray[8], t_prbs[32];
 	uint32_t nb;                       // bursts emitted by this channel in this feed
+	int64_t first_fire;                // sample of the first got_sync() success (any outcome) since walk_load(); INT64_MAX if none
 };
 
 // lowest lane whose flag is set, or -1.  Call from wave-uniform code after a WAVE_END.
@@ -413,31 +422,67 @@ VDL2_HD void restart_search(WalkState &st, int64_t a) {
 	st.mode = 0;
 }
 
-// Process one channel up to (not including) decimated sample k_end.
-VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end, const Tables &T,
-		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
-		OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
-	K4_BEGIN();
+// Start of a walk: bring the channel's FSM state and the small tables into LDS.  `resume`: continue the burst list of
+// this feed (a previous walk_store() left its count in *nbursts_out) instead of starting it.
+VDL2_HD void walk_load(const WalkState *gstate, const EvalLog &lg, const uint32_t *nbursts_out, bool resume, const Tables &T, WalkShared &sh) {
 	LANE0
 		sh.st = *gstate;
 		sh.lg_n = *lg.n; sh.lg_first = 0; sh.lg_count = 0;
-		sh.spec_n = -1; sh.vring_a = -1; sh.nb = 0;
+		sh.spec_n = -1; sh.vring_a = -1; sh.nb = resume ? *nbursts_out : 0;
+		sh.first_fire = INT64_MAX;
 	LANE0_END
 	WAVE_FOR(l)
 		if(l < kHdrParBits) sh.t_H[l] = T.hdr_H[l];
 		if(l < 32) { sh.t_fix[l] = T.hdr_fix[l]; sh.t_prbs[l] = T.prbs[l]; }
 		if(l < 8) sh.t_gray[l] = T.gray[l];
 	WAVE_END
+}
+
+// the open evaluation chunk goes to the log
+VDL2_HD void walk_flush_log(WalkShared &sh, const EvalLog &lg, OutCtl *ctl) {
+	LANE0
+		if(sh.lg_count > 0) {
+			if(sh.lg_n < ctl->cap_log) { lg.chunks[sh.lg_n].first = sh.lg_first; lg.chunks[sh.lg_n].count = sh.lg_count; sh.lg_n++; }
+			else ctl->overflow = 1;
+			sh.lg_count = 0;
+		}
+	LANE0_END
+}
+
+VDL2_HD void walk_store(WalkShared &sh, WalkState *gstate, const EvalLog &lg, OutCtl *ctl, uint32_t *nbursts_out) {
+	walk_flush_log(sh, lg, ctl);
+	LANE0
+		*gstate = sh.st;
+		*lg.n = sh.lg_n;
+		*nbursts_out = sh.nb;
+	LANE0_END
+}
+
+// search state that depends on nothing but the sample streams and the evaluation grid (sh.st.e modulo 3)
+VDL2_HD bool walk_clean(const WalkState &st) { return st.mode == 0 && st.e >= st.a + kCleanAfter && st.e >= st.e0 + 6; }
+
+// Advance the FSM held in sh.st up to (not including) decimated sample k_end.  With `stop_clean` the walk also stops as
+// soon as the state is "clean" (walk_clean()).  Stopping anywhere is exact: it is what a feed boundary does.
+VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, bool stop_clean, const Tables &T,
+		const ChanView &v, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
+	K4_BEGIN();
 	K4_MARK(0);
 	for(;;) {
 		if(sh.st.mode == 0) {
 			const int64_t e = sh.st.e;
-			if(e >= k_end) break;
+			// evaluations run up to k_lim; sample reads stay bounded by k_end (what has been written)
+			int64_t k_lim = k_end;
+			if(stop_clean) {
+				int64_t c = sh.st.a + kCleanAfter; if(c < sh.st.e0 + 6) c = sh.st.e0 + 6;
+				if(e >= c) break;
+				if(c < k_lim) k_lim = c;
+			}
+			if(e >= k_lim) break;
 			int fired = 0;
 			int64_t fire_n = 0;
 			if(e < sh.st.a + kFreshAfter) {
 				// ---- explicit evaluations near an interval start (ring still holds pre-burst samples) ----
-				int64_t lim = sh.st.a + kFreshAfter; if(lim > k_end) lim = k_end;
+				int64_t lim = sh.st.a + kFreshAfter; if(lim > k_lim) lim = k_lim;
 				int64_t nb = (lim - e + 2) / 3; if(nb > 64) nb = 64;
 				// stage the reference's phase ring as it stands around this interval start: vring[160+t] = sample a+t,
 				// vring[159-r] = the (r+1)-th DM_INIT sample before a (through the interval history)
@@ -490,7 +535,7 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 				// the first evaluation of a run cannot fire (pherr[1] is still PHERR_MAX): start at max(e, e0+3)
 				const int64_t start = e > sh.st.e0 + 3 ? e : sh.st.e0 + 3;
 				int64_t w0 = start >> 6;
-				const int64_t wend = (k_end + 63) >> 6;
+				const int64_t wend = (k_lim + 63) >> 6;
 				for(; w0 < wend && !fired; w0 += 256) {
 					WAVE_FOR(l)
 						int32_t hit = -1;
@@ -500,12 +545,12 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 							const int64_t w = w0 + 4 * l + q;
 							uint64_t bits = wd[q];
 							if(bits) {
-								// keep bits with index >= start, < k_end, and congruent to e modulo 3
+								// keep bits with index >= start, < k_lim, and congruent to e modulo 3
 								const int64_t base = w << 6;
 								const int r = (((int)(e - base)) % 3 + 3) % 3;   // first bit position on the grid (|e - base| << 2^31)
 								bits &= 0x9249249249249249ull << r;                // bits r, r+3, ...
 								if(base < start) bits &= (start - base >= 64) ? 0ull : (~0ull << (start - base));
-								if(base + 64 > k_end) bits &= (k_end - base <= 0) ? 0ull : (~0ull >> (64 - (k_end - base)));
+								if(base + 64 > k_lim) bits &= (k_lim - base <= 0) ? 0ull : (~0ull >> (64 - (k_lim - base)));
 								if(bits) hit = 64 * q + __builtin_ctzll(bits);
 							}
 						}
@@ -536,8 +581,8 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 					log_evals(sh, lg, ctl, e, (n - e) / 3 + 1);
 					K4_MARK(2);
 				} else {
-					// nothing up to k_end: park just past the last evaluation that exists
-					const int64_t cnt_ev = (k_end - 1 - e) / 3 + 1;     // e < k_end here
+					// nothing up to k_lim: park just past the last evaluation that exists
+					const int64_t cnt_ev = (k_lim - 1 - e) / 3 + 1;     // e < k_lim here
 					const int64_t nl = e + 3 * (cnt_ev - 1);
 					log_evals(sh, lg, ctl, e, cnt_ev);
 					K4_MARK(2);
@@ -555,6 +600,7 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 				LANE0
 					WalkState &st = sh.st;
 					const int64_t n = fire_n;
+					if(sh.first_fire == INT64_MAX) sh.first_fire = n;
 					float vx = parabola_vertex(sh.u_y1, sh.u_y2, sh.u_y3);
 					int sclk = (int)(-roundf(vx));
 					float prev_phi0;
@@ -574,7 +620,7 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 						st.pb.chan = chan; st.pb.nsym = 0;
 						st.pb.t_first = n + (kSpsDec - sclk);
 						st.pb.sync_sample = n; st.pb.end_sample = 0; st.pb.ord = st.bursts++;
-						st.pb.prev_phi0 = prev_phi0; st.pb.vdphi = vdphi; st.pb.ppm = ppm; st.pb.mag_nf = 0.f; st.pb.nf_upd = st.evals / 1000;
+						st.pb.prev_phi0 = prev_phi0; st.pb.vdphi = vdphi; st.pb.ppm = ppm; st.pb.mag_nf = 0.f; st.pb.nf_upd = st.evals / 1000; st.pb.sync_evals = st.evals;
 						st.pb.tl_bits = 0; st.pb.syndrome = 0;
 						st.mode = 1;
 					}
@@ -632,16 +678,232 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 		}
 	}
 	K4_MARK(7);
+}
+
+// Process one channel up to (not including) decimated sample k_end.
+VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end, const Tables &T,
+		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
+		OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
+	walk_load(gstate, lg, nbursts_out, false, T, sh);
+	walk_run(chan, freq, max_ppm, k_end, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
+	walk_store(sh, gstate, lg, ctl, nbursts_out);
+}
+
+// ======================================================================
+// Speculative segments.  One channel's feed is cut into segments [b_s, b_s+1).  Segment 0 is walked
+// from the channel's real state.  For every later boundary three speculative walkers start in the
+// only kind of state a *clean* search can be in there - mode 0, far into its DM_INIT interval, next
+// evaluation at b_s + r (r = 0,1,2: the 3-sample evaluation grid) - and record what they do up to
+// b_s+1 in private buffers.  The stitcher then goes through the boundaries in order: when the real
+// state at b_s is clean, the speculative walk of the matching grid phase IS what the reference's FSM
+// does next (every later decision of a clean search depends only on the sample streams and the
+// grid), so its output is appended and its end state adopted; when it is not (a burst or a fresh
+// interval straddles the boundary) the real walker continues until the state is clean, which is
+// normally one burst later, and the speculative walk is joined there if it had not done anything
+// yet; otherwise the segment is walked for real.  Nothing is approximated: a speculative result is
+// either provably the real one or thrown away.
+// ======================================================================
+struct SpecHead {                      // what the stitcher needs to decide and chain; staged in LDS for all segments
+	int64_t n_first;                   // first got_sync() success of the speculative walk (INT64_MAX: none)
+	int64_t a, e, e0, evals, bursts;   // end state (evals, bursts relative to the segment start)
+	float   pherr1, pherr2, prev_dphi;
+	int32_t mode, niv;
+	uint32_t nb, nlog, ok;
+	EvalChunk c_first, c_last;         // first and last chunk of the evaluation log
+};
+
+struct SpecOut {
+	SpecHead h;
+	WalkState st;
+	unsigned long long cnt[kNumCounters];
+	OutCtl ctl;
+	uint32_t nlog, pad_;
+	Burst bursts[kSpecBursts];
+	EvalChunk chunks[kSpecLog];
+};
+
+struct StitchShared {
+	SpecHead head[(kMaxSeg - 1) * 3];
+	// accepted speculative segments whose bursts / log chunks / counters are copied at the end
+	int32_t  job_src[kMaxSeg]; uint32_t job_nb[kMaxSeg], job_dstb[kMaxSeg], job_logn[kMaxSeg], job_dstlog[kMaxSeg];
+	int64_t  job_base_b[kMaxSeg], job_base_e[kMaxSeg];
+	int32_t  njobs;
+	// parts of the adopted end state that still live in a SpecOut (fetched only if a real walk needs them)
+	int32_t  hist_src; int64_t hist_a, hist_sent;
+	int32_t  pb_src;   int64_t pb_base_b, pb_base_e;
+	int32_t  accepted, walked;           // statistics: segments adopted / walked for real
+	int32_t  u_ok;
+};
+
+// one speculative walk: segment [b, k_end), evaluation grid phase r
+VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, int64_t b, int r, int64_t k_end, const Tables &T,
+		const ChanView &v, SpecOut *o, WalkShared &sh) {
+	EvalLog lg{ o->chunks, &o->nlog };
 	LANE0
-		*gstate = sh.st;
-		if(sh.lg_count > 0) {
-			if(sh.lg_n < ctl->cap_log) { lg.chunks[sh.lg_n].first = sh.lg_first; lg.chunks[sh.lg_n].count = sh.lg_count; sh.lg_n++; }
-			else ctl->overflow = 1;
-		}
-		*lg.n = sh.lg_n;
-		*nbursts_out = sh.nb;
+		o->nlog = 0;
+		o->ctl.nbursts = o->ctl.nframes = o->ctl.pool_used = o->ctl.overflow = 0;
+		o->ctl.cap_bursts = kSpecBursts; o->ctl.cap_frames = 0; o->ctl.cap_pool = 0; o->ctl.cap_log = kSpecLog;
+		walk_state_init(o->st);
+		o->st.a = b - kSpecBack; o->st.e0 = o->st.a + 2; o->st.e = b + r;
 	LANE0_END
-	K4_MARK(0);
+	WAVE_FOR(l)
+		if(l < kNumCounters) o->cnt[l] = 0;
+	WAVE_END
+	uint32_t nb_dummy = 0;
+	walk_load(&o->st, lg, &nb_dummy, false, T, sh);
+	walk_run(chan, freq, max_ppm, k_end, false, T, v, o->cnt, o->bursts, kSpecBursts, &o->ctl, lg, sh);
+	walk_flush_log(sh, lg, &o->ctl);
+	LANE0
+		const WalkState &st = sh.st;
+		o->st = st; o->nlog = sh.lg_n;
+		SpecHead h;
+		h.n_first = sh.first_fire;
+		h.a = st.a; h.e = st.e; h.e0 = st.e0; h.evals = st.evals; h.bursts = st.bursts;
+		h.pherr1 = st.pherr1; h.pherr2 = st.pherr2; h.prev_dphi = st.prev_dphi;
+		h.mode = st.mode; h.niv = st.niv;
+		h.nb = sh.nb; h.nlog = sh.lg_n; h.ok = o->ctl.overflow ? 0u : 1u;
+		h.c_first.first = h.c_first.count = 0; h.c_last = h.c_first;
+		if(sh.lg_n > 0) { h.c_first = o->chunks[0]; h.c_last = o->chunks[sh.lg_n - 1]; }
+		o->h = h;
+	LANE0_END
+}
+
+// adopt speculative segment `idx` (boundary b, grid phase r) if the real state in sh.st allows it
+VDL2_HD bool stitch_try_accept(int64_t b, int64_t kn, int seg, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh, StitchShared &ss) {
+	LANE0
+		ss.u_ok = 0;
+		WalkState &st = sh.st;
+		if(walk_clean(st) && st.e >= b && st.e < kn) {
+			const int r = (int)((st.e - b) % 3);
+			const int idx = (seg - 1) * 3 + r;
+			const SpecHead &H = ss.head[idx];
+			const int64_t pre = (st.e - (b + r)) / 3;          // evaluations of the speculative walk that precede the join
+			if(H.ok && H.n_first >= st.e && ss.njobs < kMaxSeg && (H.nlog == 0 || H.c_first.count > pre)) {
+				const int64_t base_e = st.evals - pre, base_b = st.bursts;
+				const int64_t sent_a = b - kSpecBack;
+				const int j = ss.njobs++;
+				ss.job_src[j] = idx; ss.job_base_b[j] = base_b; ss.job_base_e[j] = base_e;
+				// --- evaluation log: first chunk joins the open one, last chunk stays open, the middle is copied later
+				ss.job_logn[j] = 0; ss.job_dstlog[j] = sh.lg_n;
+				if(H.nlog > 0) {
+					EvalChunk c0 = H.c_first; c0.first += 3 * pre; c0.count -= pre;
+					if(sh.lg_count > 0 && sh.lg_first + 3 * sh.lg_count == c0.first) { c0.first = sh.lg_first; c0.count += sh.lg_count; }
+					else if(sh.lg_count > 0) {
+						if(sh.lg_n < ctl->cap_log) { lg.chunks[sh.lg_n].first = sh.lg_first; lg.chunks[sh.lg_n].count = sh.lg_count; sh.lg_n++; }
+						else ctl->overflow = 1;
+					}
+					if(H.nlog == 1) { sh.lg_first = c0.first; sh.lg_count = c0.count; }
+					else {
+						if(sh.lg_n < ctl->cap_log) { lg.chunks[sh.lg_n] = c0; sh.lg_n++; } else ctl->overflow = 1;
+						uint32_t mid = H.nlog - 2;
+						if(sh.lg_n + mid > ctl->cap_log) { mid = ctl->cap_log > sh.lg_n ? ctl->cap_log - sh.lg_n : 0; ctl->overflow = 1; }
+						ss.job_logn[j] = mid; ss.job_dstlog[j] = sh.lg_n; sh.lg_n += mid;
+						sh.lg_first = H.c_last.first; sh.lg_count = H.c_last.count;
+					}
+				}
+				// --- bursts
+				uint32_t nb = H.nb;
+				if(sh.nb + nb > cap_bursts) { nb = cap_bursts > sh.nb ? cap_bursts - sh.nb : 0; ctl->overflow = 1; }
+				ss.job_nb[j] = nb; ss.job_dstb[j] = sh.nb; sh.nb += nb;
+				// --- state
+				if(H.niv > 0) { ss.hist_src = idx; ss.hist_a = st.a; ss.hist_sent = sent_a; }
+				if(H.a != sent_a) st.a = H.a;
+				if(H.e0 != sent_a + 2) st.e0 = H.e0;
+				st.e = H.e; st.pherr1 = H.pherr1; st.pherr2 = H.pherr2; st.prev_dphi = H.prev_dphi;
+				st.mode = H.mode; st.evals = base_e + H.evals; st.bursts = base_b + H.bursts;
+				if(H.mode != 0) { ss.pb_src = idx; ss.pb_base_b = base_b; ss.pb_base_e = base_e; } else ss.pb_src = -1;
+				sh.spec_n = -1; sh.vring_a = -1;
+				ss.accepted++;
+				ss.u_ok = 1;
+			}
+		}
+	LANE0_END
+	return ss.u_ok != 0;
+}
+
+// before the real walker runs again: fetch the interval history / pending burst an adopted end state left in its SpecOut.
+// Only the adopted walk's own intervals are taken: its oldest one is longer than kCleanAfter, and the 160-sample look-back
+// of a fresh interval (seq_index()) can never get past an interval that long.
+VDL2_HD void stitch_materialize(const SpecOut *spec, WalkShared &sh, StitchShared &ss) {
+	if(ss.hist_src >= 0) {
+		const SpecOut *o = spec + ss.hist_src;
+		const int niv = ss.head[ss.hist_src].niv;
+		WAVE_FOR(l)
+			if(l < niv && l < kNumIv) {
+				const int64_t ia = o->st.iva[l];
+				sh.st.iva[l] = ia == ss.hist_sent ? ss.hist_a : ia;
+				sh.st.ivb[l] = o->st.ivb[l];
+			}
+		WAVE_END
+		LANE0
+			sh.st.niv = niv; ss.hist_src = -1;
+		LANE0_END
+	}
+	if(ss.pb_src >= 0) {
+		LANE0
+			Burst pb = spec[ss.pb_src].st.pb;
+			pb.ord += ss.pb_base_b; pb.sync_evals += ss.pb_base_e; pb.nf_upd = pb.sync_evals / 1000;
+			sh.st.pb = pb; ss.pb_src = -1;
+		LANE0_END
+	}
+}
+
+// The feed [k0, k_end) of one channel in nseg segments of seglen samples; segment 0 has already been walked from the real
+// state (walk_channel() with k_end = k0 + seglen) and spec[(s-1)*3 + r] holds the speculative walks of segments 1..nseg-1.
+VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, int64_t k0, int64_t seglen, int nseg, int64_t k_end, const Tables &T,
+		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
+		OutCtl *ctl, const EvalLog &lg, const SpecOut *spec, WalkShared &sh, StitchShared &ss, uint32_t *seg_stats) {
+	walk_load(gstate, lg, nbursts_out, true, T, sh);
+	LANE0
+		ss.njobs = 0; ss.hist_src = -1; ss.pb_src = -1; ss.accepted = 0; ss.walked = 0;
+	LANE0_END
+	const int nspec = (nseg - 1) * 3;
+	WAVE_FOR(l)
+		for(int i = l; i < nspec; i += 64) ss.head[i] = spec[i].h;
+	WAVE_END
+	for(int s = 1; s < nseg; s++) {
+		const int64_t b = k0 + (int64_t)s * seglen;
+		const int64_t kn = s + 1 < nseg ? b + seglen : k_end;
+		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss)) continue;
+		stitch_materialize(spec, sh, ss);
+		walk_run(chan, freq, max_ppm, kn, true, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
+		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss)) continue;
+		walk_run(chan, freq, max_ppm, kn, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
+		LANE0
+			ss.walked++;
+		LANE0_END
+	}
+	stitch_materialize(spec, sh, ss);
+	// copy what the adopted segments produced
+	const int nj = ss.njobs;
+	WAVE_FOR(l)
+		// bursts: flattened over the jobs
+		uint32_t tot = 0;
+		for(int j = 0; j < nj; j++) tot += ss.job_nb[j];
+		for(uint32_t t = (uint32_t)l; t < tot; t += 64) {
+			uint32_t off = t; int j = 0;
+			while(off >= ss.job_nb[j]) { off -= ss.job_nb[j]; j++; }
+			Burst x = spec[ss.job_src[j]].bursts[off];
+			x.ord += ss.job_base_b[j]; x.sync_evals += ss.job_base_e[j]; x.nf_upd = x.sync_evals / 1000;
+			bursts[ss.job_dstb[j] + off] = x;
+		}
+		uint32_t totl = 0;
+		for(int j = 0; j < nj; j++) totl += ss.job_logn[j];
+		for(uint32_t t = (uint32_t)l; t < totl; t += 64) {
+			uint32_t off = t; int j = 0;
+			while(off >= ss.job_logn[j]) { off -= ss.job_logn[j]; j++; }
+			lg.chunks[ss.job_dstlog[j] + off] = spec[ss.job_src[j]].chunks[1 + off];
+		}
+		if(l < kNumCounters) {
+			unsigned long long acc = 0;
+			for(int j = 0; j < nj; j++) acc += spec[ss.job_src[j]].cnt[l];
+			if(acc) VDL2_CNT_ADD(cnt, l, acc);
+		}
+	WAVE_END
+	walk_store(sh, gstate, lg, ctl, nbursts_out);
+	LANE0
+		if(seg_stats) { seg_stats[0] += (uint32_t)ss.accepted; seg_stats[1] += (uint32_t)ss.walked; }
+	LANE0_END
 }
 
 // ======================================================================
@@ -652,7 +914,7 @@ VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end,
 // ======================================================================
 constexpr int kNfGroup = 16;               // updates replayed per wavefront pass (4 lanes gather for each)
 struct NfShared {
-	float mags[kNfGroup][kLpTerms + 1];    // +1: row padding keeps the per-lane replay off one LDS bank
+	alignas(16) float mags[kNfGroup][kLpTerms + 1];    // +1: row padding keeps the per-lane replay off one LDS bank
 };
 
 struct NfScratch { int64_t *first; int64_t *cum; };   // combined (tail + feed) chunk list: first sample, ordinal of first evaluation
@@ -660,17 +922,39 @@ struct NfScratch { int64_t *first; int64_t *cum; };   // combined (tail + feed) 
 // what the three noise-floor passes of one feed share (per channel)
 struct NfFeed { int64_t ev0, ev1, u0, u1, begin_ord; uint32_t ncomb, pad_; };
 
-// pass 1 (one lane): combined chunk list = remembered tail + this feed's log, with evaluation ordinals
-VDL2_HD void nf_prepare(const NfState *g, const EvalLog &lg, const NfScratch &sc, uint32_t cap_comb, NfFeed *fd) {
+// pass 1: combined chunk list = remembered tail + this feed's log, with evaluation ordinals (a prefix sum, 64 chunks at a time)
+VDL2_HD void nf_prepare(const NfState *g, const EvalLog &lg, const NfScratch &sc, uint32_t cap_comb, NfFeed *fd, NfShared &sh) {
+	int64_t *cnt64 = reinterpret_cast<int64_t *>(&sh.mags[0][0]);   // 64 counts, then 64 running ordinals
+	const uint32_t nlog = *lg.n;
+	const uint32_t ntail = (uint32_t)g->ntail;
+	uint32_t ntot = ntail + nlog; if(ntot > cap_comb) ntot = cap_comb;
 	LANE0
-		const uint32_t nlog = *lg.n;
-		int64_t ord = g->tail_ord;
-		uint32_t k = 0;
-		for(int i = 0; i < g->ntail && k < cap_comb; i++, k++) { sc.first[k] = g->tail[i].first; sc.cum[k] = ord; ord += g->tail[i].count; }
-		for(uint32_t i = 0; i < nlog && k < cap_comb; i++, k++) { sc.first[k] = lg.chunks[i].first; sc.cum[k] = ord; ord += lg.chunks[i].count; }
-		sc.cum[k] = ord;
-		fd->ncomb = k; fd->ev0 = g->evals; fd->ev1 = ord; fd->u0 = g->evals / 1000; fd->u1 = ord / 1000;
-		fd->begin_ord = k ? sc.cum[0] : ord;
+		cnt64[128] = g->tail_ord;
+	LANE0_END
+	for(uint32_t base = 0; base < ntot; base += 64) {
+		WAVE_FOR(l)
+			const uint32_t k = base + (uint32_t)l;
+			if(k < ntot) {
+				const EvalChunk ch = k < ntail ? g->tail[k] : lg.chunks[k - ntail];
+				sc.first[k] = ch.first; cnt64[l] = ch.count;
+			}
+		WAVE_END
+		LANE0
+			int64_t ord = cnt64[128];
+			const uint32_t m = ntot - base < 64 ? ntot - base : 64;
+			for(uint32_t i = 0; i < m; i++) { cnt64[64 + i] = ord; ord += cnt64[i]; }
+			cnt64[128] = ord;
+		LANE0_END
+		WAVE_FOR(l)
+			const uint32_t k = base + (uint32_t)l;
+			if(k < ntot) sc.cum[k] = cnt64[64 + l];
+		WAVE_END
+	}
+	LANE0
+		const int64_t ord = cnt64[128];
+		sc.cum[ntot] = ord;
+		fd->ncomb = ntot; fd->ev0 = g->evals; fd->ev1 = ord; fd->u0 = g->evals / 1000; fd->u1 = ord / 1000;
+		fd->begin_ord = ntot ? g->tail_ord : ord;
 	LANE0_END
 }
 
@@ -722,20 +1006,41 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 	WAVE_END
 }
 
-// pass 3 (one lane): the mag_nf chain over this feed's updates, history for the burst decoder, state for the next feed.
-// hist[i] = mag_nf after (u0 + i) updates
+// pass 3: the mag_nf chain over this feed's updates (sequential, so it runs out of LDS), history for the burst decoder,
+// state for the next feed.  hist[i] = mag_nf after (u0 + i) updates
 VDL2_HD void nf_finish(NfState *g, const EvalLog &lg, const NfScratch &sc, const NfFeed &fd, const float *lpbuf, float *hist,
-		uint32_t cap_hist, int64_t *hist_base, WalkState *ws) {
+		uint32_t cap_hist, int64_t *hist_base, WalkState *ws, NfShared &sh) {
+	float *buf = &sh.mags[0][0];
+	constexpr int kBatch = 2048;
+	int64_t nupd = fd.u1 - fd.u0;                       // updates of this feed: hist[1..nupd]
+	if(nupd > (int64_t)cap_hist - 1) nupd = (int64_t)cap_hist - 1;
+	// a burst that locked in this feed and is still in flight gets its noise floor now: hist[ti]
+	const int64_t ti = (ws->mode != 0 && ws->pb.nf_upd >= fd.u0) ? (ws->pb.nf_upd - fd.u0 < nupd ? ws->pb.nf_upd - fd.u0 : nupd) : -1;
 	LANE0
-		float nf = g->mag_nf;
-		hist[0] = nf;
+		buf[kBatch] = g->mag_nf; buf[kBatch + 1] = g->mag_nf;
+		hist[0] = g->mag_nf;
 		*hist_base = fd.u0;
-		for(int64_t U = fd.u0 + 1; U <= fd.u1; U++) {
-			const int64_t i = U - fd.u0;
-			if(i >= (int64_t)cap_hist) break;
-			nf = 0.85f * nf + (1.0f - 0.85f) * fminf(lpbuf[i], nf) + 0.0001f;
-			hist[i] = nf;
-		}
+	LANE0_END
+	for(int64_t i0 = 1; i0 <= nupd; i0 += kBatch) {
+		const int m = (int)(nupd - i0 + 1 < kBatch ? nupd - i0 + 1 : kBatch);
+		WAVE_FOR(l)
+			for(int i = l; i < m; i += 64) buf[i] = lpbuf[i0 + i];
+		WAVE_END
+		LANE0
+			float nf = buf[kBatch];
+			for(int i = 0; i < m; i++) {
+				nf = 0.85f * nf + (1.0f - 0.85f) * fminf(buf[i], nf) + 0.0001f;
+				buf[i] = nf;
+				if(i0 + i == ti) buf[kBatch + 1] = nf;
+			}
+			buf[kBatch] = nf;
+		LANE0_END
+		WAVE_FOR(l)
+			for(int i = l; i < m; i += 64) hist[i0 + i] = buf[i];
+		WAVE_END
+	}
+	LANE0
+		const float nf = buf[kBatch];
 		g->mag_nf = nf;
 		g->evals = fd.ev1;
 		// keep the newest chunks that cover the last kLpTerms evaluations
@@ -747,12 +1052,17 @@ VDL2_HD void nf_finish(NfState *g, const EvalLog &lg, const NfScratch &sc, const
 		g->ntail = nt;
 		g->tail_ord = ncomb ? sc.cum[first_keep] : fd.ev1;
 		*lg.n = 0;
-		// a burst that locked in this feed and is still in flight gets its noise floor now
-		if(ws->mode != 0 && ws->pb.nf_upd >= fd.u0) {
-			const int64_t i = ws->pb.nf_upd - fd.u0;
-			ws->pb.mag_nf = hist[i < (int64_t)cap_hist ? i : (int64_t)cap_hist - 1];
-		}
+		if(ti >= 0) ws->pb.mag_nf = buf[kBatch + 1];
 	LANE0_END
+}
+
+// v->mag_nf as decode_frame() sees it when a frame is output (decode.c:374): from this feed's update history if the
+// sync happened in this feed, else as stamped on the burst by the feed it did happen in.  Kept out of the burst decoder
+// so that the noise-floor replay and the burst decoder of a feed can run side by side.
+VDL2_HD void stamp_noise_floor(OutFrame &f, const float *nf_hist, uint32_t cap_hist, int64_t nf_base) {
+	float mag_nf = f.nf_pwr_dbfs;
+	if(f.nf_upd >= nf_base) { const int64_t i = f.nf_upd - nf_base; mag_nf = nf_hist[i < (int64_t)cap_hist ? i : (int64_t)cap_hist - 1]; }
+	f.nf_pwr_dbfs = 20.0f * log10f(mag_nf + 0.001f);
 }
 
 // ======================================================================
@@ -926,10 +1236,7 @@ VDL2_HD int ctz32(uint32_t v) { return __builtin_ctz(v); }
 
 // decode_vdl2_burst() DEC_DATA branch + decode_frame(): decode.c:259-380, 173-194
 VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const ChanView &v, unsigned long long *cnt,
-		OutFrame *frames, uint8_t *pool, OutCtl *ctl, const float *nf_hist, uint32_t cap_hist, int64_t nf_base, BurstShared &sh) {
-	// v->mag_nf at decode time: from this feed's update history if the sync happened in this feed, else as stamped earlier
-	float mag_nf = b.mag_nf;
-	if(b.nf_upd >= nf_base) { const int64_t i = b.nf_upd - nf_base; mag_nf = nf_hist[i < (int64_t)cap_hist ? i : (int64_t)cap_hist - 1]; }
+		OutFrame *frames, uint8_t *pool, OutCtl *ctl, BurstShared &sh) {
 	// geometry again from TL (decode.c:233-256)
 	const uint32_t octets = b.tl_bits / 8 + (b.tl_bits % 8 != 0);
 	uint32_t nblk = octets / kRsK, last = octets % kRsK;
@@ -1133,7 +1440,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 					f.synd_weight = T.hdr_weight[b.syndrome]; f.datalen_octets = octets;
 					f.num_fec_corrections = fec_fixed;
 					f.frame_pwr_dbfs = 10.0f * log10f(sh.u_pwr);
-					f.nf_pwr_dbfs = 20.0f * log10f(mag_nf + 0.001f);
+					f.nf_pwr_dbfs = b.mag_nf; f.nf_upd = b.nf_upd;      // turned into dBFS by stamp_noise_floor()
 					f.ppm_error = b.ppm;
 					f.burst_ord = b.ord; f.sync_sample = b.sync_sample; f.end_sample = b.end_sample;
 					sh.u_ok = 1; sh.u_off = off;

@@ -30,7 +30,8 @@ struct HostFrame {
 constexpr int kRun = VDL2_K1_RUN;        // decimated outputs per lane in K1 (specialised builds); 2 measured best: tests/gpu_k1_variants.sh
 constexpr int kRunGeneric = 2;
 constexpr int kHistory = 65536;          // decimated samples kept behind the newest block (> longest burst, 56 090)
-constexpr int kNumEv = 8;
+constexpr int kNumEv = 10;
+constexpr int kSlots = 3;             // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered)
 
 }  // namespace
 
@@ -65,9 +66,10 @@ struct vdl2hip_ctx {
 	NfState *d_nf = nullptr; EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
 	float *d_nfhist = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; int64_t *d_nfbase = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0;
 	uint32_t cap_bursts_chan = 0;
-	OutSlot slot[2];                       // per-feed output buffers: feed i+1's front runs while feed i's back still fills slot i&1
+	SpecOut *d_spec = nullptr; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
+	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
-	hipStream_t stream_back = nullptr; hipEvent_t ev_front = nullptr;
+	hipStream_t stream_back = nullptr, stream_nf = nullptr; hipEvent_t ev_front = nullptr, ev_walk = nullptr, ev_nf = nullptr;
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool overflowed = false;
 	std::vector<HostFrame> queue;
@@ -107,7 +109,7 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 		if(hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->stats.phase_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.sync_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[7], ev[6]) == hipSuccess) c->stats.walk_ms += ms;
-		if(hipEventElapsedTime(&ms, ev[6], ev[4]) == hipSuccess) c->stats.nf_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) c->stats.nf_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->stats.burst_ms += ms;
 	}
 	sl.ev_valid = false;
@@ -136,7 +138,7 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 // collect every feed except the `keep` most recent ones, oldest first
 static int collect_pending(vdl2hip_ctx *c, int keep = 0) {
 	int rc = VDL2HIP_OK;
-	for(int pass = 0; pass < 2; pass++) {
+	for(int pass = 0; pass < kSlots; pass++) {
 		OutSlot *oldest = nullptr;
 		int npend = 0;
 		for(auto &sl : c->slot) if(sl.pending) { npend++; if(!oldest || sl.seq < oldest->seq) oldest = &sl; }
@@ -155,7 +157,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	const int64_t D = (int64_t)(nlogical / (uint64_t)c->os);
 	const uint32_t nrem = (uint32_t)(nlogical - (uint64_t)D * c->os);
 	const int seglen = 64 * c->run;
-	OutSlot &sl = c->slot[c->feed_no & 1];
+	OutSlot &sl = c->slot[c->feed_no % kSlots];
 	{ int r = collect_slot(c, sl); if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r; }   // its buffers are about to be reused
 	hipStream_t st = c->stream, sb_ = c->stream_back;
 	hipEvent_t *ev = sl.ev;
@@ -215,20 +217,40 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		if(prof) HIPCHK(hipEventRecord(ev[7], sb_));
 		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           c->d_log, c->d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
-		hipLaunchKernelGGL(k_walk, dim3((unsigned)c->C), dim3(64), 0, sb_, k4);
+		// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
+		int nseg = (int)std::min<int64_t>(c->seg_max, D / c->seg_min);
+		if(nseg >= 2) {
+			const int64_t seglen = (D + nseg - 1) / nseg;
+			nseg = (int)((D + seglen - 1) / seglen);
+			K4sArgs k4s{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, c->k_total, seglen, c->d_segstats };
+			hipLaunchKernelGGL(k_walk_spec, dim3((unsigned)(1 + 3 * (nseg - 1)), (unsigned)c->C), dim3(64), 0, sb_, k4s);
+			hipLaunchKernelGGL(k_walk_stitch, dim3((unsigned)c->C), dim3(64), 0, sb_, k4s);
+		} else {
+			hipLaunchKernelGGL(k_walk, dim3((unsigned)c->C), dim3(64), 0, sb_, k4);
+		}
 		if(prof) HIPCHK(hipEventRecord(ev[6], sb_));
+		// the noise-floor replay (K4b) and the burst decoder (K5) both follow the walk and do not need each other:
+		// K4b goes to its own stream, and the frames get their noise-floor figure once both are done
+		hipStream_t sn_ = c->stream_nf;
+		HIPCHK(hipEventRecord(c->ev_walk, sb_));
+		HIPCHK(hipStreamWaitEvent(sn_, c->ev_walk, 0));
+		if(prof) HIPCHK(hipEventRecord(ev[8], sn_));
 		K4bArgs k4b{ c->d_y, c->d_nf, c->d_ws, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfhist, c->d_nfbase,
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist };
-		hipLaunchKernelGGL(k_nf_prepare, dim3((unsigned)c->C), dim3(64), 0, sb_, k4b);
+		hipLaunchKernelGGL(k_nf_prepare, dim3((unsigned)c->C), dim3(64), 0, sn_, k4b);
 		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup - 1) / kNfGroup);
-		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, sb_, k4b);
-		hipLaunchKernelGGL(k_nf_finish, dim3((unsigned)c->C), dim3(64), 0, sb_, k4b);
+		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, sn_, k4b);
+		hipLaunchKernelGGL(k_nf_finish, dim3((unsigned)c->C), dim3(64), 0, sn_, k4b);
+		if(prof) HIPCHK(hipEventRecord(ev[9], sn_));
+		HIPCHK(hipEventRecord(c->ev_nf, sn_));
 		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, sb_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl);
 		if(prof) HIPCHK(hipEventRecord(ev[4], sb_));
 		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
-		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->d_nfhist, c->d_nfbase, c->cap_hist, c->cap, c->cap - 1 };
+		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
 		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, sb_, k5);
 		if(prof) { HIPCHK(hipEventRecord(ev[5], sb_)); sl.ev_valid = true; }
+		HIPCHK(hipStreamWaitEvent(sb_, c->ev_nf, 0));
+		hipLaunchKernelGGL(k_nf_stamp, dim3(64), dim3(256), 0, sb_, sl.d_frames, (const OutCtl *)sl.d_ctl, (const float *)c->d_nfhist, (const int64_t *)c->d_nfbase, c->cap_hist);
 		c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C;
 	}
 	HIPCHK(hipMemcpyAsync(sl.h_ctl, sl.d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, sb_));
@@ -276,7 +298,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nfhist, c->d_lpbuf, c->d_nffeed, c->d_nfbase };
+	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nfhist, c->d_lpbuf, c->d_nffeed, c->d_nfbase, c->d_spec, c->d_segstats };
 	for(auto &sl : c->slot) {
 		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl };
 		for(void *p : q) if(p) (void)hipFree(p);
@@ -287,6 +309,9 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(c->h_ctl_template) (void)hipHostFree(c->h_ctl_template);
 	if(c->ev_front) (void)hipEventDestroy(c->ev_front);
 	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
+	if(c->stream_nf) { (void)hipStreamSynchronize(c->stream_nf); (void)hipStreamDestroy(c->stream_nf); }
+	if(c->ev_walk) (void)hipEventDestroy(c->ev_walk);
+	if(c->ev_nf) (void)hipEventDestroy(c->ev_nf);
 	for(void *p : ptrs) if(p) (void)hipFree(p);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -324,7 +349,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	const size_t sb = sample_bytes(c->fmt);
 	const uint64_t max_samples = max_bytes / sb + c->os;
 	const uint64_t dmax = max_samples / c->os + 1;
-	uint32_t cap = 1; while(cap < 2 * dmax + kHistory + 1024) cap <<= 1;   // two feeds may be in flight (front of i+1 over back of i)
+	uint32_t cap = 1; while(cap < kSlots * dmax + kHistory + 1024) cap <<= 1;   // kSlots feeds may be in flight (fronts of i+1, i+2 over back of i)
 	c->cap = cap;
 	c->in_cap = max_bytes;
 	c->nseg_cap = (uint32_t)(dmax / (64 * c->run) + 2);
@@ -333,7 +358,9 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	#define DEV_CHK(expr) do { if((expr) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_DEVICE; } } while(0)
 	DEV_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	DEV_CHK(hipStreamCreateWithFlags(&c->stream_back, hipStreamNonBlocking));
+	DEV_CHK(hipStreamCreateWithFlags(&c->stream_nf, hipStreamNonBlocking));
 	DEV_CHK(hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));
+	DEV_CHK(hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming)); DEV_CHK(hipEventCreateWithFlags(&c->ev_nf, hipEventDisableTiming));
 	for(auto &sl : c->slot) { DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i])); }
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
 	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count);
@@ -357,6 +384,19 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_nlog, count * 4); DEV_ALLOC(c->d_scfirst, (size_t)count * (c->cap_comb + 1) * 8); DEV_ALLOC(c->d_sccum, (size_t)count * (c->cap_comb + 1) * 8);
 	DEV_ALLOC(c->d_nfhist, (size_t)count * c->cap_hist * 4); DEV_ALLOC(c->d_nfbase, count * 8);
 	DEV_ALLOC(c->d_lpbuf, (size_t)count * c->cap_hist * 4); DEV_ALLOC(c->d_nffeed, count * sizeof(NfFeed));
+	{
+		// segments per feed: enough wavefronts to cover the walk's latency, not more than the chip holds at once
+		const char *e = getenv("VDL2HIP_SEG_MIN");
+		if(e && atoll(e) >= 64) c->seg_min = atoll(e);
+		int64_t smax = std::min<int64_t>(kMaxSeg, 8192 / (3 * (int64_t)count));
+		smax = std::min<int64_t>(smax, dmax / c->seg_min);
+		e = getenv("VDL2HIP_SEG_MAX");
+		if(e) smax = std::min<int64_t>(smax, atoll(e));
+		c->seg_max = (int)std::max<int64_t>(1, smax);
+		if(c->seg_max >= 2) DEV_ALLOC(c->d_spec, (size_t)count * 3 * (c->seg_max - 1) * sizeof(SpecOut));
+		DEV_ALLOC(c->d_segstats, (size_t)count * 2 * 4);
+		DEV_CHK(hipMemset(c->d_segstats, 0, (size_t)count * 2 * 4));
+	}
 	DEV_CHK(hipHostMalloc((void **)&c->h_ctl_template, sizeof(OutCtl), hipHostMallocDefault));
 	*c->h_ctl_template = c->ctl_template;
 	for(auto &sl : c->slot) {
@@ -523,6 +563,12 @@ int vdl2hip_set_profiling(vdl2hip_ctx *c, int on) {
 int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) {
 	if(!c || !out) return VDL2HIP_E_INVAL;
 	int r = collect_pending(c);
+	{
+		std::vector<uint32_t> ss((size_t)c->C * 2);
+		if(hipMemcpy(ss.data(), c->d_segstats, ss.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return VDL2HIP_E_DEVICE;
+		c->stats.seg_adopted = c->stats.seg_walked = 0;
+		for(int i = 0; i < c->C; i++) { c->stats.seg_adopted += ss[2 * i]; c->stats.seg_walked += ss[2 * i + 1]; }
+	}
 	*out = c->stats;
 	return r == VDL2HIP_E_OVERFLOW ? VDL2HIP_OK : r;
 }
@@ -530,7 +576,7 @@ int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) {
 void *vdl2hip_stream(vdl2hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int vdl2hip_set_drain_lag(vdl2hip_ctx *c, int lag) {
-	if(!c || lag < 0 || lag > 1) return VDL2HIP_E_INVAL;
+	if(!c || lag < 0 || lag > kSlots - 1) return VDL2HIP_E_INVAL;
 	c->drain_lag = lag;
 	return VDL2HIP_OK;
 }

@@ -111,6 +111,8 @@ typedef struct {
 	double   nf_ms;             /* noise-floor passes */
 	uint64_t bursts;            /* bursts handed to the burst decoder */
 	uint64_t frames;            /* frames produced */
+	uint64_t seg_adopted;       /* segmented walk: speculative segments adopted ... */
+	uint64_t seg_walked;        /* ... and segments walked sequentially because a burst straddled their start */
 } vdl2hip_stats;
 
 int  vdl2hip_abi_version(void);
@@ -128,10 +130,10 @@ int  vdl2hip_feed(vdl2hip_ctx *ctx, const void *buf, size_t nbytes);
  * (vdl2hip_sync(), or a drain that covers it - see vdl2hip_set_drain_lag). */
 int  vdl2hip_feed_device(vdl2hip_ctx *ctx, const void *dev_buf, size_t nbytes);
 
-/* Pipelining.  A feed call only queues work: the sample-rate front (K1-K3) of block i+1 may run while the burst-rate
- * back (K4-K5) of block i is still in flight.  By default the drain functions wait for everything (lag 0 = the
- * reference's blocking behaviour).  With lag 1 they deliver every block except the most recent one, so a
- * feed/drain loop keeps two blocks in flight; vdl2hip_sync() always completes everything. */
+/* Pipelining.  A feed call only queues work: the sample-rate front (K1-K3) of blocks i+1, i+2 may run while the
+ * burst-rate back (K4-K5) of block i is still in flight.  By default the drain functions wait for everything (lag 0 =
+ * the reference's blocking behaviour).  With lag L (1 or 2) they deliver every block except the L most recent ones,
+ * so a feed/drain loop keeps L+1 blocks in flight; vdl2hip_sync() always completes everything. */
 int  vdl2hip_set_drain_lag(vdl2hip_ctx *ctx, int lag);
 
 /* Wait for all queued blocks; moves finished frames to the host-side queue. */

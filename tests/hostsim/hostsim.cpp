@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #include "../../dumpvdl2_amd/csrc/vdl2_core.h"
 #include "../../dumpvdl2_amd/csrc/tables.h"
 
@@ -24,6 +25,8 @@ struct Sim {
 	std::vector<Burst> bursts; std::vector<OutFrame> frames; std::vector<uint8_t> pool;
 	std::vector<OutFrame> all_frames; std::vector<uint8_t> all_pool;
 	OutCtl ctl;
+	int64_t seg_min = 0; int seg_max = 1;          // segmented walk (off by default)
+	std::vector<SpecOut> spec; uint32_t seg_stats[2] = {0, 0};
 };
 
 extern "C" {
@@ -45,6 +48,10 @@ Sim *hostsim_create(int nchan, const uint32_t *freqs, float max_ppm, int cap_log
 }
 
 void hostsim_destroy(Sim *s) { delete s; }
+
+// walk feeds of at least 2*seg_min decimated samples in up to seg_max speculative segments (0 = plain sequential walk)
+void hostsim_set_segments(Sim *s, int64_t seg_min, int seg_max) { s->seg_min = seg_min; s->seg_max = seg_max < 1 ? 1 : seg_max > kMaxSeg ? kMaxSeg : seg_max; }
+void hostsim_segment_stats(Sim *s, uint32_t out[2]) { out[0] = s->seg_stats[0]; out[1] = s->seg_stats[1]; }
 
 // y: [nchan][D] complex (re,im) floats, channel-major
 int hostsim_feed(Sim *s, const float *yin, int64_t D) {
@@ -80,15 +87,32 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->phi[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
 		EvalLog lg{ &s->log[(size_t)c * s->cap_log], &s->nlog[c] };
 		uint32_t nbc = 0;
+		int nseg = s->seg_min > 0 ? (int)std::min<int64_t>(s->seg_max, D / s->seg_min) : 1;
+		if(nseg >= 2) {
+			// same three steps as k_walk_spec / k_walk_stitch
+			const int64_t seglen = (D + nseg - 1) / nseg;
+			nseg = (int)((D + seglen - 1) / seglen);
+			Burst *bdst = s->bursts.data() + s->ctl.nbursts; const uint32_t bcap = (uint32_t)s->bursts.size() - s->ctl.nbursts;
+			walk_channel(c, s->freqs[c], s->max_ppm, k0 + seglen, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], bdst, bcap, &nbc, &s->ctl, lg, wsh);
+			s->spec.resize((size_t)3 * (nseg - 1));
+			for(int x = 0; x < 3 * (nseg - 1); x++) {
+				const int seg = 1 + x / 3, r = x % 3;
+				const int64_t b = k0 + (int64_t)seg * seglen, kn = seg + 1 < nseg ? b + seglen : k1;
+				spec_walk(c, s->freqs[c], s->max_ppm, b, r, kn, s->T, v, &s->spec[x], wsh);
+			}
+			static StitchShared ssh;
+			stitch_channel(c, s->freqs[c], s->max_ppm, k0, seglen, nseg, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], bdst, bcap, &nbc,
+			               &s->ctl, lg, s->spec.data(), wsh, ssh, s->seg_stats);
+		} else
 		walk_channel(c, s->freqs[c], s->max_ppm, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], s->bursts.data() + s->ctl.nbursts,
 		             (uint32_t)s->bursts.size() - s->ctl.nbursts, &nbc, &s->ctl, lg, wsh);
 		s->ctl.nbursts += nbc;
 		static NfShared nsh;
 		NfScratch sc{ &s->scf[(size_t)c * (s->cap_comb + 1)], &s->scc[(size_t)c * (s->cap_comb + 1)] };
 		NfFeed fd;
-		nf_prepare(&s->nf[c], lg, sc, s->cap_comb, &fd);
+		nf_prepare(&s->nf[c], lg, sc, s->cap_comb, &fd, nsh);
 		for(int64_t g = 0; fd.u0 + 1 + kNfGroup * g <= fd.u1; g++) nf_replay_group(v, sc, fd, g, &s->lpbuf[(size_t)c * s->cap_hist], s->cap_hist, nsh);
-		nf_finish(&s->nf[c], lg, sc, fd, &s->lpbuf[(size_t)c * s->cap_hist], &s->hist[(size_t)c * s->cap_hist], s->cap_hist, &s->nfbase[c], &s->st[c]);
+		nf_finish(&s->nf[c], lg, sc, fd, &s->lpbuf[(size_t)c * s->cap_hist], &s->hist[(size_t)c * s->cap_hist], s->cap_hist, &s->nfbase[c], &s->st[c], nsh);
 	}
 	static BurstShared bsh;
 	uint32_t nb = s->ctl.nbursts;
@@ -96,10 +120,10 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		const Burst &b = s->bursts[i];
 		int c = b.chan;
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->phi[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
-		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl,
-		             &s->hist[(size_t)c * s->cap_hist], s->cap_hist, s->nfbase[c], bsh);
+		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl, bsh);
 	}
 	uint32_t nf = s->ctl.nframes < s->ctl.cap_frames ? s->ctl.nframes : s->ctl.cap_frames;
+	for(uint32_t i = 0; i < nf; i++) { const int c = s->frames[i].chan; stamp_noise_floor(s->frames[i], &s->hist[(size_t)c * s->cap_hist], s->cap_hist, s->nfbase[c]); }
 	for(uint32_t i = 0; i < nf; i++) {
 		OutFrame f = s->frames[i];
 		uint32_t off = (uint32_t)s->all_pool.size();

@@ -14,7 +14,7 @@ class OutFrame(C.Structure):
     _fields_ = [("chan", C.c_int32), ("idx", C.c_int32), ("len", C.c_uint32), ("pool_off", C.c_uint32),
                 ("synd_weight", C.c_uint32), ("datalen_octets", C.c_uint32), ("num_fec_corrections", C.c_int32),
                 ("frame_pwr_dbfs", C.c_float), ("nf_pwr_dbfs", C.c_float), ("ppm_error", C.c_float),
-                ("burst_ord", C.c_int64), ("sync_sample", C.c_int64), ("end_sample", C.c_int64)]
+                ("burst_ord", C.c_int64), ("sync_sample", C.c_int64), ("end_sample", C.c_int64), ("nf_upd", C.c_int64)]
 
 
 def build():
@@ -39,6 +39,8 @@ class HostSim:
         self.L.hostsim_pool.argtypes = [C.c_void_p]
         self.L.hostsim_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
         self.L.hostsim_destroy.argtypes = [C.c_void_p]
+        self.L.hostsim_set_segments.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+        self.L.hostsim_segment_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         assert self.L.hostsim_sizeof_outframe() == C.sizeof(OutFrame)
         self.n = len(freqs)
         self.h = self.L.hostsim_create(self.n, (C.c_uint32 * self.n)(*freqs), max_ppm, cap_log2)
@@ -64,6 +66,15 @@ class HostSim:
                             nf_pwr_dbfs=f.nf_pwr_dbfs, ppm_error=f.ppm_error, burst_ord=f.burst_ord,
                             sync_sample=f.sync_sample, end_sample=f.end_sample))
         return out
+
+    def set_segments(self, seg_min, seg_max=32):
+        """walk long feeds in speculative segments, as k_walk_spec / k_walk_stitch do on the device"""
+        self.L.hostsim_set_segments(self.h, seg_min, seg_max)
+
+    def segment_stats(self):
+        a = (C.c_uint32 * 2)()
+        self.L.hostsim_segment_stats(self.h, a)
+        return {"adopted": a[0], "walked": a[1]}
 
     def counters(self, chan):
         a = (C.c_ulonglong * NUM_COUNTERS)()

@@ -125,19 +125,22 @@ def test_drain_packed_equals_drain(vh):
     rx.close()
 
 
-def test_pipelined_feeds_with_drain_lag(vh):
-    """Streaming mode (drain lag 1): two blocks in flight, frames arrive one block late, nothing is lost or reordered."""
+@pytest.mark.parametrize("lag", [1, 2])
+def test_pipelined_feeds_with_drain_lag(vh, lag):
+    """Streaming mode (drain lag L): L+1 blocks in flight, frames arrive L blocks late, nothing is lost or reordered."""
     cfg, iq, _, gold = cases.load("config2_1s")
     raw = iq.view(np.uint8)
     rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=1 << 20)
-    rx.set_drain_lag(1)
+    rx.set_drain_lag(lag)
+    with pytest.raises(vh.Vdl2HipError):
+        rx.set_drain_lag(3)
     got = []
     for k in range(0, raw.size, 1 << 20):
         rx.feed(raw[k:k + (1 << 20)])
         got += rx.drain()
     rx.set_drain_lag(0)
     got += rx.drain()
-    cases.check_against_golden(got, [list(rx.counters(c).values()) for c in range(len(cfg.freqs))], gold, label="lag-1 streaming",
+    cases.check_against_golden(got, [list(rx.counters(c).values()) for c in range(len(cfg.freqs))], gold, label=f"lag-{lag} streaming",
                                exact_diagnostics=False)
     ends = [f["end_sample"] for f in got]
     assert ends == sorted(ends)
@@ -327,3 +330,23 @@ def test_two_receivers_in_one_process(vh, oracle_mod, golden_wav):
     assert [len(f["octets"]) for f in fa] == [314, 186]
     cases.check_against_golden(fb, [list(b.counters(c).values()) for c in range(8)], gold, label="interleaved", exact_diagnostics=False)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("name,seg_min,seg_max", [("config2_1s", 700, 32), ("config2_1s", 3000, 32), ("dirty25k_1s", 1000, 32),
+                                                  ("config4_0p4s", 2000, 7), ("config5_0p4s", 400, 32), ("os10_noisy_1s", 500, 32),
+                                                  ("config2_1s", 16384, 1)])
+def test_segmented_walk_is_exact(vh, monkeypatch, name, seg_min, seg_max):
+    """K4 in speculative segments (k_walk_spec / k_walk_stitch): whatever the segment length - down to a fraction of a
+    burst, so that most boundaries fall inside one - the frames, counters and metadata are those of the sequential walk
+    (the golden fixtures); seg_max = 1 is the sequential kernel itself."""
+    monkeypatch.setenv("VDL2HIP_SEG_MIN", str(seg_min)); monkeypatch.setenv("VDL2HIP_SEG_MAX", str(seg_max))
+    cfg, iq, bursts, gold = cases.load(name)
+    rx, fr, cnt = gpu_decode(vh, cfg, iq)
+    st = rx.stats()
+    cases.check_against_golden(fr, cnt, gold, label=f"{name} seg {seg_min}x{seg_max}", exact_diagnostics=False)
+    if seg_max > 1:
+        assert st["seg_adopted"] > 0
+        assert st["seg_adopted"] + st["seg_walked"] >= len(cfg.freqs)
+    else:
+        assert st["seg_adopted"] == st["seg_walked"] == 0
+    rx.close()

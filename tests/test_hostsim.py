@@ -9,7 +9,7 @@ import pyhostsim
 from util import assert_frames_equal
 
 
-def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None):
+def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None, segments=None):
     C = len(cfg.freqs)
     o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
     D = iq.size // 2 // cfg.oversample
@@ -17,6 +17,8 @@ def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None):
     o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=4)
     D = o.decimated_count(0)
     hs = pyhostsim.HostSim(list(cfg.freqs), cfg.rx_max_ppm, cap_log2=cap_log2 or int(np.ceil(np.log2(D + 70000))))
+    if segments:
+        hs.set_segments(*segments)
     if chunks is None:
         hs.feed(tr[:, :D, :])
     else:
@@ -26,6 +28,7 @@ def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None):
     fo, fh = o.frames(), hs.frames()
     cnt_o = [list(o.counters(c).values()) for c in range(C)]
     cnt_h = [hs.counters(c) for c in range(C)]
+    run_both.last_segment_stats = hs.segment_stats()
     hs.close()
     return fo, fh, cnt_o, cnt_h
 
@@ -44,6 +47,26 @@ def test_device_logic_matches_oracle(oracle_mod, name, chunks):
     fo = sorted(fo, key=lambda f: (f["chan"], f["burst_ord"], f["idx"])); fh = sorted(fh, key=lambda f: (f["chan"], f["burst_ord"], f["idx"]))
     assert [f["nf_pwr_dbfs"] for f in fo] == [f["nf_pwr_dbfs"] for f in fh]
     assert [f["ppm_error"] for f in fo] == [f["ppm_error"] for f in fh]
+
+
+@pytest.mark.parametrize("name,chunks,segments", [
+    ("config2_1s", None, (5000, 32)), ("config2_1s", None, (1500, 32)), ("config2_1s", (20000, 60000), (700, 32)),
+    ("config3_0p6s", None, (2500, 32)), ("config4_0p4s", None, (4000, 7)), ("config5_0p4s", None, (333, 32)),
+    ("dirty25k_1s", None, (1000, 32)), ("dirty25k_1s", (3000, 40000), (450, 5)), ("os10_noisy_1s", None, (2000, 32)),
+    ("os10_noisy_1s", None, (64, 32))])
+def test_segmented_walk_matches_oracle(oracle_mod, name, chunks, segments):
+    """The walk in speculative segments (k_walk_spec / k_walk_stitch) is exact: same frames, timing, counters and noise
+    floor as the sequential FSM, wherever the segment boundaries fall (inside bursts, inside headers, in fresh intervals)."""
+    cfg, iq, _, _ = cases.load(name)
+    fo, fh, co, ch = run_both(oracle_mod, cfg, iq, chunks, cap_log2=18 if chunks else None, segments=segments)
+    st = run_both.last_segment_stats
+    assert st["adopted"] + st["walked"] > 0
+    assert_frames_equal(fo, fh, label=name)
+    assert co == ch
+    fo = sorted(fo, key=lambda f: (f["chan"], f["burst_ord"], f["idx"])); fh = sorted(fh, key=lambda f: (f["chan"], f["burst_ord"], f["idx"]))
+    assert [f["nf_pwr_dbfs"] for f in fo] == [f["nf_pwr_dbfs"] for f in fh]
+    assert [f["ppm_error"] for f in fo] == [f["ppm_error"] for f in fh]
+    print(name, segments, st)
 
 
 def test_reference_wav(oracle_mod, golden_wav):
