@@ -306,42 +306,78 @@ struct K3Args {
 };
 
 // K3: got_sync() metric of every decimated sample (contiguous ring) + the candidate bitmap.
-// A block of 256 consecutive samples stages the 409 phases it needs (150 back + 3 for the n-3 neighbours) in LDS,
-// so the 16 taps are plain ds_reads at constant offsets.
+// A block stages the phases of kK3Tile consecutive samples (+150 back, +-3 for the neighbours) in LDS, so the 16 taps
+// are plain ds_reads at constant offsets.  Two tiers: every sample gets the cheap screening value; the exact reference
+// arithmetic (double-precision unwrap, centred regression) is redone only where it can matter to the walker - where the
+// value may be under the threshold, or 3 samples either side of such a place (those are y1/y3 of calc_para_vertex and
+// the right-hand side of the candidate test).  Everywhere else the stored value is only ever compared against the
+// threshold, and "well above it" is all that is used.  A sample whose right neighbour has not arrived yet is computed
+// exactly; the next feed redoes the last partial bitmap word anyway.
+constexpr int kK3Tile = 1024;
 __global__ __launch_bounds__(256) void k_sync(K3Args a) {
-	__shared__ float psh[256 + 3];
-	__shared__ float tile[256 + 153 + 3];
+	__shared__ float tile[kK3Tile + 156 + 3];       // phases of samples nblk-156 .. nblk+kK3Tile+2
+	__shared__ float psh[kK3Tile + 3];              // metric of samples nblk-3 .. nblk+kK3Tile-1 (kPherrBig where irrelevant)
+	__shared__ uint8_t fl[kK3Tile + 6];             // screening flag of samples nblk-3 .. nblk+kK3Tile+2
 	const int c = blockIdx.y, tid = threadIdx.x;
-	const int64_t nblk = a.nbase + (int64_t)blockIdx.x * 256;
-	const int64_t n = nblk + tid;
+	const int64_t nblk = a.nbase + (int64_t)blockIdx.x * kK3Tile;
 	const float *phi = a.phi + (size_t)c * a.cap;
 	const Tables &T = *a.tab;
-	for(int j = tid; j < 256 + 153; j += 256) {
-		const int64_t t = nblk - 153 + j;
+	for(int j = tid; j < kK3Tile + 156 + 3; j += 256) {
+		const int64_t t = nblk - 156 + j;
 		tile[j] = (t < 0 || t >= a.k1) ? 0.f : phi[(uint32_t)t & a.mask];
 	}
 	__syncthreads();
 	float ph[kPreamble];
+	float ps[kK3Tile / 256];
 	#pragma unroll
-	for(int i = 0; i < kPreamble; i++) ph[i] = tile[tid + 3 + 10 * i];
-	cf32 r{kPherrBig, 0.f};
-	if(n < a.k1) sync_metric(ph, T, r.re, r.im);
-	a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = r;
-	psh[tid + 3] = r.re;
-	if(tid < 3) {
+	for(int q = 0; q < kK3Tile / 256; q++) {
+		const int i0 = tid + 256 * q;               // sample nblk + i0: phases tile[i0 + 6 + 10 i]
+		#pragma unroll
+		for(int i = 0; i < kPreamble; i++) ph[i] = tile[i0 + 6 + 10 * i];
+		ps[q] = sync_metric_screen(ph, T);
+		fl[i0 + 3] = ps[q] < kScreenThr;
+	}
+	if(tid < 6) {                                   // the three neighbours on either side
+		const int i0 = tid < 3 ? tid - 3 : kK3Tile + tid - 3;
+		#pragma unroll
+		for(int i = 0; i < kPreamble; i++) ph[i] = tile[i0 + 6 + 10 * i];
+		fl[i0 + 3] = sync_metric_screen(ph, T) < kScreenThr;
+	}
+	__syncthreads();
+	#pragma unroll
+	for(int q = 0; q < kK3Tile / 256; q++) {
+		const int i0 = tid + 256 * q;
+		const int64_t n = nblk + i0;
+		cf32 r{ps[q], 0.f};
+		const bool need = fl[i0] | fl[i0 + 3] | (n + 3 < a.k1 ? fl[i0 + 6] : 1);
+		if(n >= a.k1) r = cf32{kPherrBig, 0.f};
+		else if(need) {
+			#pragma unroll
+			for(int i = 0; i < kPreamble; i++) ph[i] = tile[i0 + 6 + 10 * i];
+			sync_metric(ph, T, r.re, r.im);
+		}
+		if(n < a.k1) a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = r;
+		psh[i0 + 3] = r.re;
+	}
+	if(tid < 3) {                                   // left neighbours: only "under the threshold, and by how much" matters
 		const int64_t m = nblk - 3 + tid;
 		float pm = kPherrBig, fm;
-		if(m >= 0) {
+		if(m >= 0 && fl[tid]) {
 			#pragma unroll
-			for(int i = 0; i < kPreamble; i++) ph[i] = tile[tid + 10 * i];
+			for(int i = 0; i < kPreamble; i++) ph[i] = tile[tid - 3 + 6 + 10 * i];
 			sync_metric(ph, T, pm, fm);
 		}
 		psh[tid] = pm;
 	}
 	__syncthreads();
-	const bool cnd = n >= 3 && n < a.k1 && is_candidate(psh[tid], psh[tid + 3]);
-	const unsigned long long bits = __ballot(cnd);
-	if((tid & 63) == 0) a.cand[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
+	#pragma unroll
+	for(int q = 0; q < kK3Tile / 256; q++) {
+		const int i0 = tid + 256 * q;
+		const int64_t n = nblk + i0;
+		const bool cnd = n >= 3 && n < a.k1 && is_candidate(psh[i0], psh[i0 + 3]);
+		const unsigned long long bits = __ballot(cnd);
+		if((tid & 63) == 0 && n < a.k1) a.cand[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
+	}
 }
 
 struct K4Args {
@@ -394,8 +430,8 @@ __global__ __launch_bounds__(64) void k_walk_stitch(K4sArgs s) {
 }
 
 struct K4bArgs {
-	const cf32 *y; NfState *nf; WalkState *ws; EvalChunk *log; uint32_t *nlog; int64_t *sc_first; int64_t *sc_cum;
-	NfFeed *feed; float *lpbuf; float *hist; int64_t *hist_base; uint32_t cap, mask, cap_log, cap_comb, cap_hist;
+	const cf32 *y; NfState *nf; EvalChunk *log; uint32_t *nlog; int64_t *sc_first; int64_t *sc_cum;
+	NfFeed *feed; float *lpbuf; float *ring; uint32_t ring_mask; uint32_t cap, mask, cap_log, cap_comb, cap_hist;
 };
 
 // K4b: noise-floor replay from the walker's evaluation log, in three small passes
@@ -424,7 +460,7 @@ __global__ __launch_bounds__(64) void k_nf_finish(K4bArgs a) {
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
 	__shared__ NfShared sh;
-	nf_finish(&a.nf[c], lg, sc, a.feed[c], a.lpbuf + (size_t)c * a.cap_hist, a.hist + (size_t)c * a.cap_hist, a.cap_hist, a.hist_base + c, &a.ws[c], sh);
+	nf_finish(&a.nf[c], sc, a.feed[c], a.lpbuf + (size_t)c * a.cap_hist, a.ring + (size_t)c * (a.ring_mask + 1), a.ring_mask, a.cap_hist, sh);
 }
 
 // Each channel's walker fills its own burst list (no atomics on its critical path); this one-wave kernel turns the
@@ -459,11 +495,11 @@ __global__ __launch_bounds__(64) void k_burst(K5Args a) {
 }
 
 // after K4b and K5 have both finished: the noise-floor figure of every frame of this feed
-__global__ __launch_bounds__(256) void k_nf_stamp(OutFrame *frames, const OutCtl *ctl, const float *nf_hist, const int64_t *nf_base, uint32_t cap_hist) {
+__global__ __launch_bounds__(256) void k_nf_stamp(OutFrame *frames, const OutCtl *ctl, const float *ring, uint32_t ring_mask) {
 	const uint32_t n = ctl->nframes < ctl->cap_frames ? ctl->nframes : ctl->cap_frames;
 	for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const int c = frames[i].chan;
-		stamp_noise_floor(frames[i], nf_hist + (size_t)c * cap_hist, cap_hist, nf_base[c]);
+		stamp_noise_floor(frames[i], ring + (size_t)c * (ring_mask + 1), ring_mask);
 	}
 }
 

@@ -147,7 +147,7 @@ struct Burst {
 	int32_t  chan, nsym;
 	int64_t  t_first;                  // sample of the first symbol after the unique word
 	int64_t  sync_sample, end_sample, ord;
-	float    prev_phi0, vdphi, ppm, mag_nf;   // mag_nf: stamped by the noise-floor kernel of the feed the sync happened in
+	float    prev_phi0, vdphi, ppm, pad_;
 	uint32_t tl_bits, syndrome;
 	int64_t  nf_upd;                   // number of mag_nf updates that preceded the sync (v->mag_nf at decode_frame())
 	int64_t  sync_evals;               // got_sync() evaluations executed up to and including the one that fired (nf_upd = sync_evals / 1000)
@@ -160,7 +160,7 @@ struct OutFrame {
 	int32_t  num_fec_corrections;
 	float    frame_pwr_dbfs, nf_pwr_dbfs, ppm_error;
 	int64_t  burst_ord, sync_sample, end_sample;
-	int64_t  nf_upd;                   // Burst::nf_upd; until stamp_noise_floor() has run, nf_pwr_dbfs holds Burst::mag_nf
+	int64_t  nf_upd;                   // Burst::nf_upd: which entry of the noise-floor ring stamp_noise_floor() turns into nf_pwr_dbfs
 };
 
 struct OutCtl {
@@ -267,6 +267,25 @@ VDL2_HD void sync_metric(const float *ph, const Tables &T, float &pherr, float &
 		acc += r * r;
 	}
 	pherr = acc; slope_out = slope;
+}
+
+// Screening form of sync_metric(): the same unwrap decisions (they depend only on float differences), but the
+// unwrap offset accumulated in float and the residual taken from running sums, p = S2 - S0^2/16 - S1^2/den.  It differs
+// from the exact value by rounding only (< 0.1 for any phase sequence: |e| <= 16*pi, S2 <= 4e4), which is all the sync
+// kernel needs to know that a sample is nowhere near the threshold kSyncThr.
+constexpr float kScreenThr = 5.5f;
+VDL2_HD float sync_metric_screen(const float *ph, const Tables &T) {
+	float prev = ph[0] - T.pr_phase[0];
+	float s0 = prev, s1 = T.lrx[0] * prev, s2 = prev * prev, unwrap = 0.f;
+	for(int i = 1; i < kPreamble; i++) {
+		const float cur = ph[i] - T.pr_phase[i];
+		const float diff = cur - prev;
+		prev = cur;
+		unwrap += diff > kPiBelow ? -(float)(2.0 * M_PI) : (diff < -kPiBelow ? (float)(2.0 * M_PI) : 0.f);
+		const float e = cur + unwrap;
+		s0 += e; s1 = fmaf(T.lrx[i], e, s1); s2 = fmaf(e, e, s2);
+	}
+	return s2 - s0 * s0 * (1.0f / kPreamble) - s1 * s1 / T.lr_den;
 }
 
 // calc_para_vertex(v->sclk = 0, SYNC_SKIP, y1, y2, y3): demod.c:98-103,178
@@ -427,7 +446,7 @@ VDL2_HD void restart_search(WalkState &st, int64_t a) {
 VDL2_HD void walk_load(const WalkState *gstate, const EvalLog &lg, const uint32_t *nbursts_out, bool resume, const Tables &T, WalkShared &sh) {
 	LANE0
 		sh.st = *gstate;
-		sh.lg_n = *lg.n; sh.lg_first = 0; sh.lg_count = 0;
+		sh.lg_n = resume ? *lg.n : 0; sh.lg_first = 0; sh.lg_count = 0;
 		sh.spec_n = -1; sh.vring_a = -1; sh.nb = resume ? *nbursts_out : 0;
 		sh.first_fire = INT64_MAX;
 	LANE0_END
@@ -620,7 +639,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 						st.pb.chan = chan; st.pb.nsym = 0;
 						st.pb.t_first = n + (kSpsDec - sclk);
 						st.pb.sync_sample = n; st.pb.end_sample = 0; st.pb.ord = st.bursts++;
-						st.pb.prev_phi0 = prev_phi0; st.pb.vdphi = vdphi; st.pb.ppm = ppm; st.pb.mag_nf = 0.f; st.pb.nf_upd = st.evals / 1000; st.pb.sync_evals = st.evals;
+						st.pb.prev_phi0 = prev_phi0; st.pb.vdphi = vdphi; st.pb.ppm = ppm; st.pb.pad_ = 0.f; st.pb.nf_upd = st.evals / 1000; st.pb.sync_evals = st.evals;
 						st.pb.tl_bits = 0; st.pb.syndrome = 0;
 						st.mode = 1;
 					}
@@ -1006,20 +1025,18 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 	WAVE_END
 }
 
-// pass 3: the mag_nf chain over this feed's updates (sequential, so it runs out of LDS), history for the burst decoder,
-// state for the next feed.  hist[i] = mag_nf after (u0 + i) updates
-VDL2_HD void nf_finish(NfState *g, const EvalLog &lg, const NfScratch &sc, const NfFeed &fd, const float *lpbuf, float *hist,
-		uint32_t cap_hist, int64_t *hist_base, WalkState *ws, NfShared &sh) {
+// pass 3: the mag_nf chain over this feed's updates (sequential, so it runs out of LDS) into the per-channel history
+// ring - ring[U & ring_mask] = v->mag_nf after U updates, which is what decode_frame() reports for a burst that
+// synchronised after U updates - and the state for the next feed.
+VDL2_HD void nf_finish(NfState *g, const NfScratch &sc, const NfFeed &fd, const float *lpbuf, float *ring, uint32_t ring_mask,
+		uint32_t cap_hist, NfShared &sh) {
 	float *buf = &sh.mags[0][0];
 	constexpr int kBatch = 2048;
-	int64_t nupd = fd.u1 - fd.u0;                       // updates of this feed: hist[1..nupd]
+	int64_t nupd = fd.u1 - fd.u0;                       // updates of this feed
 	if(nupd > (int64_t)cap_hist - 1) nupd = (int64_t)cap_hist - 1;
-	// a burst that locked in this feed and is still in flight gets its noise floor now: hist[ti]
-	const int64_t ti = (ws->mode != 0 && ws->pb.nf_upd >= fd.u0) ? (ws->pb.nf_upd - fd.u0 < nupd ? ws->pb.nf_upd - fd.u0 : nupd) : -1;
 	LANE0
-		buf[kBatch] = g->mag_nf; buf[kBatch + 1] = g->mag_nf;
-		hist[0] = g->mag_nf;
-		*hist_base = fd.u0;
+		buf[kBatch] = g->mag_nf;
+		ring[(uint32_t)fd.u0 & ring_mask] = g->mag_nf;
 	LANE0_END
 	for(int64_t i0 = 1; i0 <= nupd; i0 += kBatch) {
 		const int m = (int)(nupd - i0 + 1 < kBatch ? nupd - i0 + 1 : kBatch);
@@ -1031,12 +1048,11 @@ VDL2_HD void nf_finish(NfState *g, const EvalLog &lg, const NfScratch &sc, const
 			for(int i = 0; i < m; i++) {
 				nf = 0.85f * nf + (1.0f - 0.85f) * fminf(buf[i], nf) + 0.0001f;
 				buf[i] = nf;
-				if(i0 + i == ti) buf[kBatch + 1] = nf;
 			}
 			buf[kBatch] = nf;
 		LANE0_END
 		WAVE_FOR(l)
-			for(int i = l; i < m; i += 64) hist[i0 + i] = buf[i];
+			for(int i = l; i < m; i += 64) ring[(uint32_t)(fd.u0 + i0 + i) & ring_mask] = buf[i];
 		WAVE_END
 	}
 	LANE0
@@ -1051,18 +1067,14 @@ VDL2_HD void nf_finish(NfState *g, const EvalLog &lg, const NfScratch &sc, const
 		for(int i = first_keep; i < ncomb; i++, nt++) { g->tail[nt].first = sc.first[i]; g->tail[nt].count = sc.cum[i + 1] - sc.cum[i]; }
 		g->ntail = nt;
 		g->tail_ord = ncomb ? sc.cum[first_keep] : fd.ev1;
-		*lg.n = 0;
-		if(ti >= 0) ws->pb.mag_nf = buf[kBatch + 1];
 	LANE0_END
 }
 
-// v->mag_nf as decode_frame() sees it when a frame is output (decode.c:374): from this feed's update history if the
-// sync happened in this feed, else as stamped on the burst by the feed it did happen in.  Kept out of the burst decoder
-// so that the noise-floor replay and the burst decoder of a feed can run side by side.
-VDL2_HD void stamp_noise_floor(OutFrame &f, const float *nf_hist, uint32_t cap_hist, int64_t nf_base) {
-	float mag_nf = f.nf_pwr_dbfs;
-	if(f.nf_upd >= nf_base) { const int64_t i = f.nf_upd - nf_base; mag_nf = nf_hist[i < (int64_t)cap_hist ? i : (int64_t)cap_hist - 1]; }
-	f.nf_pwr_dbfs = 20.0f * log10f(mag_nf + 0.001f);
+// v->mag_nf as decode_frame() sees it when a frame is output (decode.c:374): its value at the time of the sync, looked up
+// in the history ring.  Kept out of the burst decoder so that the noise-floor replay and the burst decoder of a feed can
+// run side by side.
+VDL2_HD void stamp_noise_floor(OutFrame &f, const float *ring, uint32_t ring_mask) {
+	f.nf_pwr_dbfs = 20.0f * log10f(ring[(uint32_t)f.nf_upd & ring_mask] + 0.001f);
 }
 
 // ======================================================================
@@ -1440,7 +1452,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 					f.synd_weight = T.hdr_weight[b.syndrome]; f.datalen_octets = octets;
 					f.num_fec_corrections = fec_fixed;
 					f.frame_pwr_dbfs = 10.0f * log10f(sh.u_pwr);
-					f.nf_pwr_dbfs = b.mag_nf; f.nf_upd = b.nf_upd;      // turned into dBFS by stamp_noise_floor()
+					f.nf_pwr_dbfs = 0.f; f.nf_upd = b.nf_upd;            // filled in by stamp_noise_floor()
 					f.ppm_error = b.ppm;
 					f.burst_ord = b.ord; f.sync_sample = b.sync_sample; f.end_sample = b.end_sample;
 					sh.u_ok = 1; sh.u_off = off;

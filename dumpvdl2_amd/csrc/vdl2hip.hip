@@ -38,8 +38,9 @@ constexpr int kSlots = 3;             // feeds in flight (vdl2hip_set_drain_lag:
 struct OutSlot {
 	Burst *d_bursts = nullptr; uint32_t *d_nbchan = nullptr, *d_bbase = nullptr;
 	OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
+	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
 	OutCtl *h_ctl = nullptr;               // pinned
-	hipEvent_t done = nullptr, ev[kNumEv] = {};
+	hipEvent_t done = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
 	bool pending = false, ev_valid = false;
 	uint64_t seq = 0;
 };
@@ -63,13 +64,13 @@ struct vdl2hip_ctx {
 	float4 *d_qpow = nullptr;
 	float4 *d_tcarry[2] = {nullptr, nullptr}; int tcarry_sel = 0;
 	WalkState *d_ws = nullptr; unsigned long long *d_cnt = nullptr;
-	NfState *d_nf = nullptr; EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
-	float *d_nfhist = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; int64_t *d_nfbase = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0;
+	NfState *d_nf = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
+	float *d_nfring = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0, nf_ring = 0;
 	uint32_t cap_bursts_chan = 0;
 	SpecOut *d_spec = nullptr; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
-	hipStream_t stream_back = nullptr, stream_nf = nullptr; hipEvent_t ev_front = nullptr, ev_walk = nullptr, ev_nf = nullptr;
+	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr; hipEvent_t ev_front = nullptr;
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool overflowed = false;
 	std::vector<HostFrame> queue;
@@ -206,17 +207,21 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		if(prof) HIPCHK(hipEventRecord(ev[2], st));
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
 		K3Args k3{ c->d_phi, c->d_pf, c->d_cand, c->d_tab, nbase, k1, c->cap, c->cap - 1 };
-		hipLaunchKernelGGL(k_sync, dim3((unsigned)((k1 - nbase + 255) / 256), (unsigned)c->C), dim3(256), 0, st, k3);
+		hipLaunchKernelGGL(k_sync, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(256), 0, st, k3);
 		if(prof) HIPCHK(hipEventRecord(ev[3], st));
 	}
-	// the burst-rate back end of this feed runs on its own stream, so the next feed's front can start under it
+	// The burst-rate back end runs on three more streams, so that consecutive feeds overlap stage by stage:
+	//   stream_back   K4   walk(i) -> walk(i+1) -> ...             (each needs the previous one's FSM state)
+	//   stream_nf     K4b  noise floor of feed i, after walk(i)    (each needs the previous one's NfState)
+	//   stream_burst  K5   bursts of feed i, after walk(i); the frames get their noise-floor figure when K4b(i) is done
+	hipStream_t sn_ = c->stream_nf, s5_ = c->stream_burst;
 	HIPCHK(hipEventRecord(c->ev_front, st));
 	HIPCHK(hipStreamWaitEvent(sb_, c->ev_front, 0));
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D;
 		if(prof) HIPCHK(hipEventRecord(ev[7], sb_));
 		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
-		           c->d_log, c->d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
+		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
 		// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
 		int nseg = (int)std::min<int64_t>(c->seg_max, D / c->seg_min);
 		if(nseg >= 2) {
@@ -229,32 +234,32 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 			hipLaunchKernelGGL(k_walk, dim3((unsigned)c->C), dim3(64), 0, sb_, k4);
 		}
 		if(prof) HIPCHK(hipEventRecord(ev[6], sb_));
-		// the noise-floor replay (K4b) and the burst decoder (K5) both follow the walk and do not need each other:
-		// K4b goes to its own stream, and the frames get their noise-floor figure once both are done
-		hipStream_t sn_ = c->stream_nf;
-		HIPCHK(hipEventRecord(c->ev_walk, sb_));
-		HIPCHK(hipStreamWaitEvent(sn_, c->ev_walk, 0));
+	}
+	HIPCHK(hipEventRecord(sl.ev_walk, sb_));
+	HIPCHK(hipStreamWaitEvent(sn_, sl.ev_walk, 0));
+	HIPCHK(hipStreamWaitEvent(s5_, sl.ev_walk, 0));
+	if(D > 0) {
 		if(prof) HIPCHK(hipEventRecord(ev[8], sn_));
-		K4bArgs k4b{ c->d_y, c->d_nf, c->d_ws, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfhist, c->d_nfbase,
+		K4bArgs k4b{ c->d_y, c->d_nf, sl.d_log, sl.d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfring, c->nf_ring - 1,
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist };
 		hipLaunchKernelGGL(k_nf_prepare, dim3((unsigned)c->C), dim3(64), 0, sn_, k4b);
 		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup - 1) / kNfGroup);
 		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, sn_, k4b);
 		hipLaunchKernelGGL(k_nf_finish, dim3((unsigned)c->C), dim3(64), 0, sn_, k4b);
 		if(prof) HIPCHK(hipEventRecord(ev[9], sn_));
-		HIPCHK(hipEventRecord(c->ev_nf, sn_));
-		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, sb_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl);
-		if(prof) HIPCHK(hipEventRecord(ev[4], sb_));
+		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
+		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl);
+		if(prof) HIPCHK(hipEventRecord(ev[4], s5_));
 		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
-		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, sb_, k5);
-		if(prof) { HIPCHK(hipEventRecord(ev[5], sb_)); sl.ev_valid = true; }
-		HIPCHK(hipStreamWaitEvent(sb_, c->ev_nf, 0));
-		hipLaunchKernelGGL(k_nf_stamp, dim3(64), dim3(256), 0, sb_, sl.d_frames, (const OutCtl *)sl.d_ctl, (const float *)c->d_nfhist, (const int64_t *)c->d_nfbase, c->cap_hist);
+		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, s5_, k5);
+		if(prof) { HIPCHK(hipEventRecord(ev[5], s5_)); sl.ev_valid = true; }
+		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
+		hipLaunchKernelGGL(k_nf_stamp, dim3(64), dim3(256), 0, s5_, sl.d_frames, (const OutCtl *)sl.d_ctl, (const float *)c->d_nfring, c->nf_ring - 1);
 		c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C;
 	}
-	HIPCHK(hipMemcpyAsync(sl.h_ctl, sl.d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, sb_));
-	HIPCHK(hipEventRecord(sl.done, sb_));
+	HIPCHK(hipMemcpyAsync(sl.h_ctl, sl.d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, s5_));
+	HIPCHK(hipEventRecord(sl.done, s5_));
 	HIPCHK(hipGetLastError());
 	sl.pending = true; sl.seq = c->feed_no++;
 	c->k_total += D; c->n_total += nnew;
@@ -298,20 +303,21 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_log, c->d_nlog, c->d_scfirst, c->d_sccum, c->d_nfhist, c->d_lpbuf, c->d_nffeed, c->d_nfbase, c->d_spec, c->d_segstats };
+	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats };
 	for(auto &sl : c->slot) {
-		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl };
+		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl, sl.d_log, sl.d_nlog };
 		for(void *p : q) if(p) (void)hipFree(p);
 		if(sl.h_ctl) (void)hipHostFree(sl.h_ctl);
 		if(sl.done) (void)hipEventDestroy(sl.done);
+		if(sl.ev_walk) (void)hipEventDestroy(sl.ev_walk);
+		if(sl.ev_nf) (void)hipEventDestroy(sl.ev_nf);
 		for(int i = 0; i < kNumEv; i++) if(sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
 	}
 	if(c->h_ctl_template) (void)hipHostFree(c->h_ctl_template);
 	if(c->ev_front) (void)hipEventDestroy(c->ev_front);
 	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
 	if(c->stream_nf) { (void)hipStreamSynchronize(c->stream_nf); (void)hipStreamDestroy(c->stream_nf); }
-	if(c->ev_walk) (void)hipEventDestroy(c->ev_walk);
-	if(c->ev_nf) (void)hipEventDestroy(c->ev_nf);
+	if(c->stream_burst) { (void)hipStreamSynchronize(c->stream_burst); (void)hipStreamDestroy(c->stream_burst); }
 	for(void *p : ptrs) if(p) (void)hipFree(p);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -356,12 +362,21 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 
 	#define DEV_ALLOC(ptr, bytes) do { if(hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_NOMEM; } } while(0)
 	#define DEV_CHK(expr) do { if((expr) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_DEVICE; } } while(0)
-	DEV_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-	DEV_CHK(hipStreamCreateWithFlags(&c->stream_back, hipStreamNonBlocking));
-	DEV_CHK(hipStreamCreateWithFlags(&c->stream_nf, hipStreamNonBlocking));
+	{
+		// the back end is a chain of small latency-bound kernels: it goes first whenever it competes with the
+		// channeliser of a later feed for compute units
+		int prio_low = 0, prio_high = 0;
+		DEV_CHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+		DEV_CHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_low));
+		DEV_CHK(hipStreamCreateWithPriority(&c->stream_back, hipStreamNonBlocking, prio_high));
+		DEV_CHK(hipStreamCreateWithPriority(&c->stream_nf, hipStreamNonBlocking, prio_high));
+		DEV_CHK(hipStreamCreateWithPriority(&c->stream_burst, hipStreamNonBlocking, prio_high));
+	}
 	DEV_CHK(hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));
-	DEV_CHK(hipEventCreateWithFlags(&c->ev_walk, hipEventDisableTiming)); DEV_CHK(hipEventCreateWithFlags(&c->ev_nf, hipEventDisableTiming));
-	for(auto &sl : c->slot) { DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i])); }
+	for(auto &sl : c->slot) {
+		DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i]));
+		DEV_CHK(hipEventCreateWithFlags(&sl.ev_walk, hipEventDisableTiming)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_nf, hipEventDisableTiming));
+	}
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
 	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count);
 	DEV_ALLOC(c->d_in, c->in_cap + 16);
@@ -380,9 +395,11 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	uint64_t cap_p = cap_b * 512; if(cap_p < (1u << 22)) cap_p = 1u << 22; if(cap_p > (1u << 30)) cap_p = 1u << 30;
 	c->cap_log = 8192; c->cap_comb = c->cap_log + kNfTail; c->cap_hist = (uint32_t)(dmax / 3000 + 8);
 	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, c->cap_log };
-	DEV_ALLOC(c->d_nf, count * sizeof(NfState)); DEV_ALLOC(c->d_log, (size_t)count * c->cap_log * sizeof(EvalChunk));
-	DEV_ALLOC(c->d_nlog, count * 4); DEV_ALLOC(c->d_scfirst, (size_t)count * (c->cap_comb + 1) * 8); DEV_ALLOC(c->d_sccum, (size_t)count * (c->cap_comb + 1) * 8);
-	DEV_ALLOC(c->d_nfhist, (size_t)count * c->cap_hist * 4); DEV_ALLOC(c->d_nfbase, count * 8);
+	DEV_ALLOC(c->d_nf, count * sizeof(NfState));
+	DEV_ALLOC(c->d_scfirst, (size_t)count * (c->cap_comb + 1) * 8); DEV_ALLOC(c->d_sccum, (size_t)count * (c->cap_comb + 1) * 8);
+	// noise-floor history: a frame looks up the value at its burst's sync, at most kSlots feeds + one burst ago
+	c->nf_ring = 64; while(c->nf_ring < (kSlots + 2) * c->cap_hist) c->nf_ring <<= 1;
+	DEV_ALLOC(c->d_nfring, (size_t)count * c->nf_ring * 4);
 	DEV_ALLOC(c->d_lpbuf, (size_t)count * c->cap_hist * 4); DEV_ALLOC(c->d_nffeed, count * sizeof(NfFeed));
 	{
 		// segments per feed: enough wavefronts to cover the walk's latency, not more than the chip holds at once
@@ -402,6 +419,8 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	for(auto &sl : c->slot) {
 		DEV_ALLOC(sl.d_bursts, cap_b * sizeof(Burst)); DEV_ALLOC(sl.d_nbchan, count * 4); DEV_ALLOC(sl.d_bbase, (count + 1) * 4);
 		DEV_ALLOC(sl.d_frames, cap_f * sizeof(OutFrame)); DEV_ALLOC(sl.d_pool, cap_p); DEV_ALLOC(sl.d_ctl, sizeof(OutCtl));
+		DEV_ALLOC(sl.d_log, (size_t)count * c->cap_log * sizeof(EvalChunk)); DEV_ALLOC(sl.d_nlog, count * 4);
+		DEV_CHK(hipMemset(sl.d_nlog, 0, count * 4));
 		DEV_CHK(hipHostMalloc((void **)&sl.h_ctl, sizeof(OutCtl), hipHostMallocDefault));
 		memset(sl.h_ctl, 0, sizeof(OutCtl));
 		DEV_CHK(hipMemset(sl.d_nbchan, 0, count * 4));
@@ -423,8 +442,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		std::vector<NfState> nfs(count);
 		for(auto &n : nfs) { memset(&n, 0, sizeof n); nf_state_init(n); }
 		DEV_CHK(hipMemcpy(c->d_nf, nfs.data(), count * sizeof(NfState), hipMemcpyHostToDevice));
-		DEV_CHK(hipMemset(c->d_nlog, 0, count * 4)); DEV_CHK(hipMemset(c->d_nfbase, 0, count * 8));
-		DEV_CHK(hipMemset(c->d_nfhist, 0, (size_t)count * c->cap_hist * 4)); DEV_CHK(hipMemset(c->d_lpbuf, 0, (size_t)count * c->cap_hist * 4));
+		DEV_CHK(hipMemset(c->d_nfring, 0, (size_t)count * c->nf_ring * 4)); DEV_CHK(hipMemset(c->d_lpbuf, 0, (size_t)count * c->cap_hist * 4));
 		DEV_CHK(hipMemset(c->d_nffeed, 0, count * sizeof(NfFeed)));
 	}
 	DEV_CHK(hipMemset(c->d_y, 0, nring * sizeof(cf32))); DEV_CHK(hipMemset(c->d_pf, 0, nring * sizeof(cf32)));

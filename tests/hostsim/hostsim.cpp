@@ -18,8 +18,8 @@ struct Sim {
 	std::vector<uint32_t> freqs;
 	std::vector<cf32> y, pf; std::vector<float> phi; std::vector<uint64_t> cand;
 	std::vector<WalkState> st; std::vector<unsigned long long> cnt;
-	std::vector<NfState> nf; std::vector<EvalChunk> log; std::vector<uint32_t> nlog; std::vector<int64_t> scf, scc, nfbase; std::vector<float> hist, lpbuf;
-	uint32_t cap_log = 8192, cap_comb = 8192 + kNfTail, cap_hist = 4096;
+	std::vector<NfState> nf; std::vector<EvalChunk> log; std::vector<uint32_t> nlog; std::vector<int64_t> scf, scc; std::vector<float> ring, lpbuf;
+	uint32_t cap_log = 8192, cap_comb = 8192 + kNfTail, cap_hist = 4096, nf_ring = 16384;
 	Tables T;
 	int64_t k_total = 0;
 	std::vector<Burst> bursts; std::vector<OutFrame> frames; std::vector<uint8_t> pool;
@@ -41,7 +41,7 @@ Sim *hostsim_create(int nchan, const uint32_t *freqs, float max_ppm, int cap_log
 	for(auto &w : s->st) { memset(&w, 0, sizeof w); walk_state_init(w); }
 	s->nf.resize(nchan); for(auto &n : s->nf) { memset(&n, 0, sizeof n); nf_state_init(n); }
 	s->log.resize((size_t)nchan * s->cap_log); s->nlog.assign(nchan, 0); s->scf.resize((size_t)nchan * (s->cap_comb + 1)); s->scc.resize((size_t)nchan * (s->cap_comb + 1));
-	s->nfbase.assign(nchan, 0); s->hist.assign((size_t)nchan * s->cap_hist, 0.f); s->lpbuf.assign((size_t)nchan * s->cap_hist, 0.f);
+	s->ring.assign((size_t)nchan * s->nf_ring, 0.f); s->lpbuf.assign((size_t)nchan * s->cap_hist, 0.f);
 	build_tables(s->T);
 	s->bursts.resize(65536); s->frames.resize(65536); s->pool.resize(1 << 24);
 	return s;
@@ -112,7 +112,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		NfFeed fd;
 		nf_prepare(&s->nf[c], lg, sc, s->cap_comb, &fd, nsh);
 		for(int64_t g = 0; fd.u0 + 1 + kNfGroup * g <= fd.u1; g++) nf_replay_group(v, sc, fd, g, &s->lpbuf[(size_t)c * s->cap_hist], s->cap_hist, nsh);
-		nf_finish(&s->nf[c], lg, sc, fd, &s->lpbuf[(size_t)c * s->cap_hist], &s->hist[(size_t)c * s->cap_hist], s->cap_hist, &s->nfbase[c], &s->st[c], nsh);
+		nf_finish(&s->nf[c], sc, fd, &s->lpbuf[(size_t)c * s->cap_hist], &s->ring[(size_t)c * s->nf_ring], s->nf_ring - 1, s->cap_hist, nsh);
 	}
 	static BurstShared bsh;
 	uint32_t nb = s->ctl.nbursts;
@@ -123,7 +123,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl, bsh);
 	}
 	uint32_t nf = s->ctl.nframes < s->ctl.cap_frames ? s->ctl.nframes : s->ctl.cap_frames;
-	for(uint32_t i = 0; i < nf; i++) { const int c = s->frames[i].chan; stamp_noise_floor(s->frames[i], &s->hist[(size_t)c * s->cap_hist], s->cap_hist, s->nfbase[c]); }
+	for(uint32_t i = 0; i < nf; i++) { const int c = s->frames[i].chan; stamp_noise_floor(s->frames[i], &s->ring[(size_t)c * s->nf_ring], s->nf_ring - 1); }
 	for(uint32_t i = 0; i < nf; i++) {
 		OutFrame f = s->frames[i];
 		uint32_t off = (uint32_t)s->all_pool.size();
