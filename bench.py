@@ -6,8 +6,10 @@ path (K1 channeliser ... K5 burst decoder, frames delivered to the host) over on
 synthetic 2.1 MS/s cs16 IQ that is already resident in HBM.  N=1 runs BASELINE configs[1]
 (8 VDL2 channels on one GPU).  With N>1 (one process per GPU, launched by torch.distributed.run)
 every rank decodes 8 channels of the same IQ stream (weak scaling: 8 channels per GPU); each raw IQ
-block is broadcast from rank 0 with RCCL inside the timed steps (double-buffered: the broadcast of
-block i+1 overlaps the demodulation of block i) - the path's only exchange.
+block is put on every GPU with RCCL inside the timed steps (double-buffered: the exchange of block
+i+1 overlaps the demodulation of block i) - the path's only exchange.  Default: the capture lies
+striped across the GPUs' HBM and the stripes are all-gathered (every xGMI link of a GPU carries part
+of the block); --exchange broadcast sends it from rank 0 instead (SURVEY 8.6's literal form).
 
 Prints ONE JSON line on rank 0.
 """
@@ -35,6 +37,9 @@ def main():
     ap.add_argument("--channels", type=int, default=8, help="channels per GPU (config2 only)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
                     help="BASELINE configs[1..4]; the headline line is config2 (8 channels)")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "broadcast"],
+                    help="N>1: how each rank gets the raw IQ block - all-gather of the stripes the ranks hold (capture striped "
+                         "over the GPUs' HBM) or broadcast from rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
@@ -80,14 +85,21 @@ def main():
 
     state = {"i": 0, "work": None}
     front = torch.cuda.ExternalStream(rx.stream()) if world > 1 else None
+    stripe = None
     if world > 1:       # block 0 arrives before the first step
         vdist.broadcast_block(bufs[0], src=0)
         torch.cuda.synchronize()
+        if args.exchange == "allgather" and nbytes % world == 0:
+            # the capture lies striped across the GPUs: every rank keeps its stripe of the block resident
+            b0, nb = vdist.stripe_of(nbytes, world, rank)
+            stripe = bufs[0].view(torch.uint8)[b0:b0 + nb].clone()
+        else:
+            args.exchange = "broadcast"
 
     def step():
-        """One pass of the hot path over one 16 s block; with N>1 the RCCL broadcast of the NEXT block runs
-        concurrently (its own stream) and is waited for before the step ends, so every step pays
-        max(compute, broadcast) - the exchange is inside the timed region."""
+        """One pass of the hot path over one 16 s block; with N>1 the RCCL exchange that puts the NEXT block on every GPU
+        (all-gather of the ranks' stripes, or broadcast from rank 0) runs concurrently on RCCL's stream and is waited for
+        before the step ends, so every step pays max(compute, exchange) - the exchange is inside the timed region."""
         i = state["i"]
         cur = bufs[i % len(bufs)]
         if world > 1:
@@ -95,7 +107,10 @@ def main():
             # `nxt` was the input of block i-1: its channeliser (front stream of the library) must have finished
             # reading it before RCCL overwrites it
             torch.cuda.current_stream().wait_event(front.record_event())
-            state["work"] = dist.broadcast(nxt.view(torch.uint8), src=0, async_op=True)
+            if stripe is not None:
+                state["work"] = vdist.allgather_block(nxt, stripe, async_op=True)
+            else:
+                state["work"] = dist.broadcast(nxt.view(torch.uint8), src=0, async_op=True)
         rx.feed_device(cur.data_ptr(), nbytes)
         out = rx.drain_packed()            # every frame of the step copied to host memory (records + octets)
         if world > 1:
@@ -183,8 +198,11 @@ def main():
                        "channel_MS_per_s": round(value * len(cfg.freqs), 1),
                        "realtime_channels_at_2.1MSps": round(value * len(cfg.freqs) / 2.1, 1),
                        "frames_per_step": nframes / args.steps,
-                       "parallelism": f"channel shard x{world}, RCCL broadcast of the IQ block" if world > 1 else "single GPU",
-                       "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}, "verified": verified,
+                       "parallelism": (f"channel shard x{world}, RCCL {'all-gather of the IQ block from the stripes resident on the GPUs' if args.exchange == 'allgather' else 'broadcast of the IQ block from rank 0'}, inside the timed steps") if world > 1 else "single GPU",
+                       "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+                       "walk_segments_per_step": {"adopted": (s1["seg_adopted"] - s0["seg_adopted"]) / args.steps,
+                                                  "walked_sequentially": (s1["seg_walked"] - s0["seg_walked"]) / args.steps},
+                       "verified": verified,
                        "synth_s": round(t_synth, 1)},
             "roofline": {"bound": "hbm", "kernel": "k_chanfir", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -64,9 +64,9 @@ inline uint32_t nco_step(uint32_t centerfreq, uint32_t freq, uint32_t fs) {
 	return (uint32_t)(int)(((float)centerfreq - (float)freq) / (float)fs * 256.0f * 65536.0f);
 }
 
-// LUT entry for the NCO: {sin[i], (sin[i+1]-sin[i]) * 2^-16, cos[i], (cos[i+1]-cos[i]) * 2^-16}
-// so that sincosf_lut()'s v1 + (v2 - v1) * fract becomes entry.x + entry.y * (float)(phi & 0xffff).
-struct Lut4 { float s, ds, c, dc; };
+// LUT entry for the NCO: {sin[i], cos[i], (sin[i+1]-sin[i]) * 2^-16, (cos[i+1]-cos[i]) * 2^-16}
+// so that sincosf_lut()'s v1 + (v2 - v1) * fract becomes (s, c) + (ds, dc) * (float)(phi & 0xffff): one packed FMA.
+struct Lut4 { float s, c, ds, dc; };
 inline void build_nco_lut(Lut4 out[256]) {
 	float s[257], c[257];
 	for(uint32_t i = 0; i < 256; i++) sincosf(2.0f * M_PI * (float)i / 256.0f, &s[i], &c[i]);

@@ -26,6 +26,7 @@
 namespace vdl2 {
 
 constexpr int kK1Unroll = VDL2_K1_UNROLL;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // the slice of BlockForm K1 needs, passed by value so that it lives in the kernarg segment
 // (constant address space -> scalar loads into SGPRs)
@@ -177,8 +178,8 @@ __global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
 					const uint32_t p = ph[c];
 					const float F = (float)(p & 0xffffu);                 // sincosf_lut(): fract * 65536
 					const float4 e = lut[(p >> 16) & 0xffu];
-					const float sn = __builtin_fmaf(e.y, F, e.x);
-					const float cs = __builtin_fmaf(e.w, F, e.z);
+					const v2f sc = __builtin_elementwise_fma(v2f{e.z, e.w}, v2f{F, F}, v2f{e.x, e.y});   // one v_pk_fma_f32
+					const float sn = sc.x, cs = sc.y;
 					const float mr = __builtin_fmaf(x.x, cs, -(x.y * sn)); // multiply(): re*cos - im*sin
 					const float mi = __builtin_fmaf(x.y, cs, x.x * sn);    //             im*cos + re*sin
 					a0r[c] = __builtin_fmaf(g0, mr, a0r[c]); a0i[c] = __builtin_fmaf(g0, mi, a0i[c]);

@@ -752,6 +752,7 @@ struct StitchShared {
 	int32_t  pb_src;   int64_t pb_base_b, pb_base_e;
 	int32_t  accepted, walked;           // statistics: segments adopted / walked for real
 	int32_t  u_ok;
+	uint32_t cap_log;                    // ctl->cap_log, read once
 };
 
 // one speculative walk: segment [b, k_end), evaluation grid phase r
@@ -808,14 +809,14 @@ VDL2_HD bool stitch_try_accept(int64_t b, int64_t kn, int seg, uint32_t cap_burs
 					EvalChunk c0 = H.c_first; c0.first += 3 * pre; c0.count -= pre;
 					if(sh.lg_count > 0 && sh.lg_first + 3 * sh.lg_count == c0.first) { c0.first = sh.lg_first; c0.count += sh.lg_count; }
 					else if(sh.lg_count > 0) {
-						if(sh.lg_n < ctl->cap_log) { lg.chunks[sh.lg_n].first = sh.lg_first; lg.chunks[sh.lg_n].count = sh.lg_count; sh.lg_n++; }
+						if(sh.lg_n < ss.cap_log) { lg.chunks[sh.lg_n].first = sh.lg_first; lg.chunks[sh.lg_n].count = sh.lg_count; sh.lg_n++; }
 						else ctl->overflow = 1;
 					}
 					if(H.nlog == 1) { sh.lg_first = c0.first; sh.lg_count = c0.count; }
 					else {
-						if(sh.lg_n < ctl->cap_log) { lg.chunks[sh.lg_n] = c0; sh.lg_n++; } else ctl->overflow = 1;
+						if(sh.lg_n < ss.cap_log) { lg.chunks[sh.lg_n] = c0; sh.lg_n++; } else ctl->overflow = 1;
 						uint32_t mid = H.nlog - 2;
-						if(sh.lg_n + mid > ctl->cap_log) { mid = ctl->cap_log > sh.lg_n ? ctl->cap_log - sh.lg_n : 0; ctl->overflow = 1; }
+						if(sh.lg_n + mid > ss.cap_log) { mid = ss.cap_log > sh.lg_n ? ss.cap_log - sh.lg_n : 0; ctl->overflow = 1; }
 						ss.job_logn[j] = mid; ss.job_dstlog[j] = sh.lg_n; sh.lg_n += mid;
 						sh.lg_first = H.c_last.first; sh.lg_count = H.c_last.count;
 					}
@@ -874,7 +875,7 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, int64_t k0, 
 		OutCtl *ctl, const EvalLog &lg, const SpecOut *spec, WalkShared &sh, StitchShared &ss, uint32_t *seg_stats) {
 	walk_load(gstate, lg, nbursts_out, true, T, sh);
 	LANE0
-		ss.njobs = 0; ss.hist_src = -1; ss.pb_src = -1; ss.accepted = 0; ss.walked = 0;
+		ss.njobs = 0; ss.hist_src = -1; ss.pb_src = -1; ss.accepted = 0; ss.walked = 0; ss.cap_log = ctl->cap_log;
 	LANE0_END
 	const int nspec = (nseg - 1) * 3;
 	WAVE_FOR(l)

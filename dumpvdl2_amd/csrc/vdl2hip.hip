@@ -367,6 +367,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		// channeliser of a later feed for compute units
 		int prio_low = 0, prio_high = 0;
 		DEV_CHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+		if(getenv("VDL2HIP_NO_PRIO")) prio_low = prio_high = 0;   // experiments only
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_low));
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_back, hipStreamNonBlocking, prio_high));
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_nf, hipStreamNonBlocking, prio_high));
@@ -405,7 +406,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		// segments per feed: enough wavefronts to cover the walk's latency, not more than the chip holds at once
 		const char *e = getenv("VDL2HIP_SEG_MIN");
 		if(e && atoll(e) >= 64) c->seg_min = atoll(e);
-		int64_t smax = std::min<int64_t>(kMaxSeg, 8192 / (3 * (int64_t)count));
+		int64_t smax = std::min<int64_t>(16, 8192 / (3 * (int64_t)count));   // measured: 8..24 are within noise of each other at 8 channels
 		smax = std::min<int64_t>(smax, dmax / c->seg_min);
 		e = getenv("VDL2HIP_SEG_MAX");
 		if(e) smax = std::min<int64_t>(smax, atoll(e));

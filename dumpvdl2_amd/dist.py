@@ -1,6 +1,7 @@
 """Multi-GPU layout of the hot path: channels are independent, so they shard statically across
-ranks (one process per GPU); the only exchange is a broadcast of each raw IQ block from the
-ingest rank to the others (RCCL over xGMI on GPUs, gloo in the CPU tests).  Frames never cross
+ranks (one process per GPU); the only exchange makes each raw IQ block available on every rank: a
+broadcast from the ingest rank, or - when the capture already lies striped across the GPUs - an
+all-gather of the stripes (RCCL over xGMI on GPUs, gloo in the CPU tests).  Frames never cross
 GPUs: every rank drains its own and rank 0 may gather them (tiny) for a deterministic merge.
 
 The reference's equivalent is "one pthread per channel over a shared sbuf" (src/dumpvdl2.c:117-135,
@@ -27,6 +28,29 @@ def broadcast_block(tensor, src: int = 0, group=None):
         # raw bytes: ncclUint8 / gloo uint8 exist on every backend (int16 does not on gloo)
         dist.broadcast(tensor.view(torch.uint8) if tensor.dtype != torch.uint8 else tensor, src=src, group=group)
     return tensor
+
+
+def stripe_of(nbytes: int, world: int, rank: int) -> Tuple[int, int]:
+    """Byte range [first, first+count) of a raw block that rank `rank` holds when the capture is striped over the GPUs
+    (equal stripes; the block length must be a multiple of the world size)."""
+    if nbytes % world:
+        raise ValueError(f"block of {nbytes} bytes does not split into {world} equal stripes")
+    return rank * (nbytes // world), nbytes // world
+
+
+def allgather_block(out, stripe, group=None, async_op: bool = False):
+    """Assemble one raw IQ block on every rank from the ranks' stripes (the capture lives striped across the GPUs' HBM).
+    Same end state as broadcast_block(), but the (N-1)/N of the block a GPU is missing arrives over all of its xGMI links at
+    once instead of down one broadcast tree.  `out`: the full block (uint8 view is taken), `stripe`: this rank's part."""
+    import torch
+    import torch.distributed as dist
+    o = out.view(torch.uint8) if out.dtype != torch.uint8 else out
+    s = stripe.view(torch.uint8) if stripe.dtype != torch.uint8 else stripe
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        o.copy_(s)
+        return None
+    assert o.numel() == s.numel() * dist.get_world_size(group)
+    return dist.all_gather_into_tensor(o, s, group=group, async_op=async_op)
 
 
 def merge_frames(per_rank: Sequence[Sequence[dict]]) -> List[dict]:

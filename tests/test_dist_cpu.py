@@ -34,6 +34,14 @@ def _worker(rank, world, port, q):
     cfg, iq, _, gold = cases.load("config2_1s")
     block = torch.from_numpy(iq.copy()) if rank == 0 else torch.zeros(iq.size, dtype=torch.int16)
     vd.broadcast_block(block, src=0)
+    # the other exchange: every rank holds one stripe of the capture, an all-gather rebuilds the block everywhere
+    first_b, count_b = vd.stripe_of(block.numel() * 2, world, rank)
+    stripe = block.view(torch.uint8)[first_b:first_b + count_b].clone()
+    rebuilt = torch.zeros_like(block)
+    w = vd.allgather_block(rebuilt, stripe, async_op=True)
+    w.wait()
+    assert torch.equal(rebuilt, torch.from_numpy(iq))
+    block = rebuilt
     first, count = vd.shard_channels(len(cfg.freqs), world, rank)
     o = po.Oracle(cfg.centerfreq, list(cfg.freqs)[first:first + count], oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
     o.process(block.numpy().view(np.uint8), block_bytes=1 << 24)
