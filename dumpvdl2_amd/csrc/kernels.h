@@ -7,6 +7,7 @@
 //   k_walk      K4  per-channel FSM walker (vdl2_core.h); k_walk_spec + k_walk_stitch: the same walk in speculative segments
 //   k_nf        K4b noise-floor replay from the walker's evaluation log (src/demod.c:238-243)
 //   k_burst     K5  wave-per-burst decoder (vdl2_core.h)
+//   k_frame_finish  wave-per-frame: noise-floor figure + AVLC front-door checks (src/avlc.c:163-236)
 //
 // K1 is the only kernel that touches every input sample; everything after it runs at
 // 1/oversample of that rate.  See DESIGN.md for the block-form derivation and the roofline.
@@ -458,7 +459,6 @@ __global__ __launch_bounds__(64) void k_nf_replay(K4bArgs a) {
 
 __global__ __launch_bounds__(64) void k_nf_finish(K4bArgs a) {
 	const int c = blockIdx.x;
-	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
 	__shared__ NfShared sh;
 	nf_finish(&a.nf[c], sc, a.feed[c], a.lpbuf + (size_t)c * a.cap_hist, a.ring + (size_t)c * (a.ring_mask + 1), a.ring_mask, a.cap_hist, sh);
@@ -495,12 +495,17 @@ __global__ __launch_bounds__(64) void k_burst(K5Args a) {
 	}
 }
 
-// after K4b and K5 have both finished: the noise-floor figure of every frame of this feed
-__global__ __launch_bounds__(256) void k_nf_stamp(OutFrame *frames, const OutCtl *ctl, const float *ring, uint32_t ring_mask) {
+// after K4b and K5 have both finished, one wavefront per frame: the noise-floor figure and the AVLC front-door checks
+__global__ __launch_bounds__(64) void k_frame_finish(OutFrame *frames, const uint8_t *pool, const OutCtl *ctl, const Tables *tab,
+		unsigned long long *acnt, const float *ring, uint32_t ring_mask) {
+	__shared__ FrameShared sh;
 	const uint32_t n = ctl->nframes < ctl->cap_frames ? ctl->nframes : ctl->cap_frames;
-	for(uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+	if(blockIdx.x >= n) return;
+	frame_shared_init(*tab, sh);
+	for(uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
 		const int c = frames[i].chan;
-		stamp_noise_floor(frames[i], ring + (size_t)c * (ring_mask + 1), ring_mask);
+		finish_frame(frames[i], pool, *tab, acnt + (size_t)c * kNumAvlcCounters, ring + (size_t)c * (ring_mask + 1), ring_mask, sh);
+		__syncthreads();
 	}
 }
 

@@ -5,6 +5,7 @@
 //                                            src/decode.c:55-100
 //   GF(2^8) log/antilog for poly 0x187       src/rs.c:28, src/libfec/init_rs.h:52-66
 //   descrambler PRBS x^15+x+1 from 0x6959    src/bitstream.c:94-107, src/decode.c:50
+//   FCS table (CRC-16-CCITT, reflected)      src/crc.c:21-64
 #pragma once
 #include <cstring>
 #include "vdl2_core.h"
@@ -56,6 +57,13 @@ inline void build_tables(Tables &T) {
 		sr &= 255;
 	}
 	for(int i = 255; i < 512; i++) T.gf_exp[i] = T.gf_exp[i - 255];
+
+	// reflected CRC-16-CCITT: one table step = eight shifts with the reversed polynomial 0x8408
+	for(uint32_t i = 0; i < 256; i++) {
+		uint32_t c = i;
+		for(int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ 0x8408u : c >> 1;
+		T.crc16[i] = (uint16_t)c;
+	}
 
 	uint32_t l = kLfsrIv;
 	for(int i = 0; i < kPrbsBits; i++) {

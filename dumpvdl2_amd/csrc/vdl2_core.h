@@ -99,6 +99,9 @@ constexpr int kNumIv = 32;                // DM_INIT interval history (160/6 < 3
 constexpr int kNfTail = 64;               // evaluation chunks remembered across feeds for the noise-floor lookback
 constexpr int kLpTerms = 256;             // 0.9^256 ~ 2e-12: below fp32 resolution of mag_lp
 constexpr int kNumCounters = 20;
+constexpr int kNumAvlcCounters = 10;
+constexpr int kMinAvlcLen = 11;           // avlc.c:39
+constexpr uint32_t kGoodFcs = 0xF0B8u;    // avlc.c:40
 // segmented walk (see "Speculative segments" below)
 constexpr int kCleanAfter = 320;          // search state this far into an interval no longer depends on anything before the interval
 constexpr int kSpecBack = 4096;           // a speculative walker pretends its DM_INIT interval started this far before its segment
@@ -110,6 +113,9 @@ enum { CNT_SYNC_GOOD = 0, CNT_CRC_GOOD, CNT_CRC_BAD, CNT_ERR_NO_HEADER, CNT_ERR_
        CNT_ERR_DATA_TRUNCATED, CNT_ERR_FEC_TRUNCATED, CNT_ERR_DEINTERLEAVE_DATA, CNT_ERR_DEINTERLEAVE_FEC,
        CNT_ERR_FEC_BAD, CNT_ERR_BITSTREAM, CNT_ERR_TRUNCATED_OCTETS, CNT_ERR_UNSTUFF, CNT_BLOCKS_PROCESSED,
        CNT_BLOCKS_FEC_OK, CNT_MSG_GOOD, CNT_MSG_GOOD_LOUD, CNT_PPM_REJECT, CNT_SLICER_NEG_IDX };
+// the per-channel counters of the AVLC front door (decode.c:466, avlc.c:170-233)
+enum { ACNT_PROCESSED = 0, ACNT_TOO_SHORT, ACNT_GOOD, ACNT_BAD_FCS, ACNT_AIR2GND, ACNT_AIR2AIR, ACNT_AIR2ALL, ACNT_GND2AIR, ACNT_GND2GND, ACNT_GND2ALL };
+enum { AVLC_OK = 0, AVLC_TOO_SHORT = 1, AVLC_BAD_FCS = 2 };
 
 struct cf32 { float re, im; };
 
@@ -127,6 +133,7 @@ struct Tables {
 	uint8_t  gf_exp[512];              // alpha^i, doubled: exp[a+b] valid for a,b <= 254
 	uint8_t  gf_log[256];              // log(0) = 255 marker
 	uint8_t  prbs[kPrbsBits];          // bitstream.c:94-107 from LFSR_IV, one bit per byte
+	uint16_t crc16[256];               // crc.c:23-57: reflected CRC-16-CCITT (x^16+x^12+x^5+1), one step per octet
 };
 
 // One channel's decimated-rate streams, ring-addressed by absolute sample index.
@@ -161,6 +168,7 @@ struct OutFrame {
 	float    frame_pwr_dbfs, nf_pwr_dbfs, ppm_error;
 	int64_t  burst_ord, sync_sample, end_sample;
 	int64_t  nf_upd;                   // Burst::nf_upd: which entry of the noise-floor ring stamp_noise_floor() turns into nf_pwr_dbfs
+	uint32_t avlc_status, dst_addr, src_addr, pad_;   // finish_frame(): avlc_parse()'s first checks
 };
 
 struct OutCtl {
@@ -1076,6 +1084,76 @@ VDL2_HD void nf_finish(NfState *g, const NfScratch &sc, const NfFeed &fd, const 
 // run side by side.
 VDL2_HD void stamp_noise_floor(OutFrame &f, const float *ring, uint32_t ring_mask) {
 	f.nf_pwr_dbfs = 20.0f * log10f(ring[(uint32_t)f.nf_upd & ring_mask] + 0.001f);
+}
+
+// ======================================================================
+// Frame finishing (one wavefront per frame, after K4b and K5): the noise-floor figure, and the first thing the
+// reference's decoder thread does with a frame (decode.c:466, avlc_parse() avlc.c:163-236): count it, drop it if it is
+// shorter than 11 octets or its FCS residue is not 0xF0B8, read the two link addresses and classify the direction.
+// ======================================================================
+struct FrameShared {
+	alignas(16) uint8_t buf[kMaxOctets + 64];
+	uint16_t tab[4][256];              // slicing tables: tab[k][b] = FCS register after octet b and k zero octets
+};
+
+// once per workgroup: tab[0] is the reference's table (crc.c:23-57), tab[k] = tab[k-1] advanced by one zero octet
+VDL2_HD void frame_shared_init(const Tables &T, FrameShared &sh) {
+	WAVE_FOR(l)
+		for(int b = l; b < 256; b += 64) {
+			uint16_t c = T.crc16[b];
+			sh.tab[0][b] = c;
+			for(int k = 1; k < 4; k++) { c = (uint16_t)((c >> 8) ^ T.crc16[c & 0xffu]); sh.tab[k][b] = c; }
+		}
+	WAVE_END
+}
+
+// parse_dlc_addr() (avlc.c:158-161): 4 address octets -> 28-bit value, bits reversed (addr:24 | type:3 | status:1)
+VDL2_HD uint32_t avlc_addr(const uint8_t *b) {
+	uint32_t v = (uint32_t)(b[0] >> 1) | ((uint32_t)b[1] << 6) | ((uint32_t)b[2] << 13) | ((uint32_t)(b[3] & 0xfe) << 20);
+	uint32_t r = 0;
+	for(int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);    // reverse(v, 28) of bitstream.c:152-164
+	return (r >> 4) & 0x0FFFFFFFu;
+}
+
+VDL2_HD void finish_frame(OutFrame &f, const uint8_t *pool, const Tables &T, unsigned long long *acnt, const float *ring, uint32_t ring_mask, FrameShared &sh) {
+	const uint32_t len = f.len;
+	const uint8_t *src = pool + f.pool_off;
+	const uint32_t n = len < (uint32_t)sizeof sh.buf ? len : (uint32_t)sizeof sh.buf;
+	WAVE_FOR(l)
+		for(uint32_t i = l; i < n; i += 64) sh.buf[i] = src[i];
+	WAVE_END
+	LANE0
+		stamp_noise_floor(f, ring, ring_mask);
+		VDL2_CNT_ADD(acnt, ACNT_PROCESSED, 1);
+		uint32_t status = AVLC_OK, dst = 0, sa = 0;
+		if(len < (uint32_t)kMinAvlcLen) { status = AVLC_TOO_SHORT; VDL2_CNT_ADD(acnt, ACNT_TOO_SHORT, 1); }
+		else {
+			// crc16_ccitt(buf, len, 0xFFFF) (crc.c:59-63), four octets per step: the 16-bit register is used up by the
+			// first two, so the four table reads of a step do not depend on each other
+			uint32_t crc = 0xFFFFu;
+			uint32_t i = 0;
+			for(; i + 4 <= n; i += 4) {
+				const uint32_t w = *reinterpret_cast<const uint32_t *>(sh.buf + i);   // octet i in the low byte (little endian)
+				const uint32_t x = crc ^ (w & 0xffffu);
+				crc = (uint32_t)(sh.tab[3][x & 0xffu] ^ sh.tab[2][x >> 8] ^ sh.tab[1][(w >> 16) & 0xffu] ^ sh.tab[0][w >> 24]);
+			}
+			for(; i < len; i++) {
+				const uint8_t b = i < n ? sh.buf[i] : src[i];
+				crc = (crc >> 8) ^ sh.tab[0][(crc ^ b) & 0xffu];
+			}
+			if(crc != kGoodFcs) { status = AVLC_BAD_FCS; VDL2_CNT_ADD(acnt, ACNT_BAD_FCS, 1); }
+			else {
+				VDL2_CNT_ADD(acnt, ACNT_GOOD, 1);
+				dst = avlc_addr(sh.buf); sa = avlc_addr(sh.buf + 4);
+				const uint32_t st = (sa >> 24) & 7u, dt = (dst >> 24) & 7u;  // a_addr.type
+				const bool s_air = st == 1, s_gnd = st == 4 || st == 5;
+				const int to = dt == 1 ? 0 : (dt == 4 || dt == 5) ? 1 : dt == 7 ? 2 : -1;    // aircraft / ground / all
+				if(s_air && to >= 0) VDL2_CNT_ADD(acnt, to == 1 ? ACNT_AIR2GND : to == 0 ? ACNT_AIR2AIR : ACNT_AIR2ALL, 1);
+				if(s_gnd && to >= 0) VDL2_CNT_ADD(acnt, to == 0 ? ACNT_GND2AIR : to == 1 ? ACNT_GND2GND : ACNT_GND2ALL, 1);
+			}
+		}
+		f.avlc_status = status; f.dst_addr = dst; f.src_addr = sa; f.pad_ = 0;
+	LANE0_END
 }
 
 // ======================================================================

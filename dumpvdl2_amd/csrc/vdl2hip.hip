@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 #include "../../include/vdl2hip.h"
 #include "kernels.h"
@@ -63,7 +64,7 @@ struct vdl2hip_ctx {
 	float4 *d_segend = nullptr; uint32_t nseg_cap = 0;
 	float4 *d_qpow = nullptr;
 	float4 *d_tcarry[2] = {nullptr, nullptr}; int tcarry_sel = 0;
-	WalkState *d_ws = nullptr; unsigned long long *d_cnt = nullptr;
+	WalkState *d_ws = nullptr; unsigned long long *d_cnt = nullptr, *d_acnt = nullptr;
 	NfState *d_nf = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
 	float *d_nfring = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0, nf_ring = 0;
 	uint32_t cap_bursts_chan = 0;
@@ -72,7 +73,8 @@ struct vdl2hip_ctx {
 	uint64_t feed_no = 0; int drain_lag = 0;
 	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr; hipEvent_t ev_front = nullptr;
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
-	bool overflowed = false;
+	bool overflowed = false, avlc_filter = false;
+	std::vector<uint64_t> statsd_prev;
 	std::vector<HostFrame> queue;
 	int64_t k_total = 0; uint64_t n_total = 0;
 	// profiling
@@ -130,7 +132,7 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 			batch[i].f = fr[i];
 			if(fr[i].pool_off + fr[i].len <= pool_n) batch[i].octets.assign(pool.begin() + fr[i].pool_off, pool.begin() + fr[i].pool_off + fr[i].len);
 		}
-		for(auto &h : batch) c->queue.push_back(std::move(h));
+		for(auto &h : batch) if(!c->avlc_filter || h.f.avlc_status == AVLC_OK) c->queue.push_back(std::move(h));
 		c->stats.frames += nf;
 	}
 	return c->overflowed ? VDL2HIP_E_OVERFLOW : VDL2HIP_OK;
@@ -255,7 +257,8 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, s5_, k5);
 		if(prof) { HIPCHK(hipEventRecord(ev[5], s5_)); sl.ev_valid = true; }
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
-		hipLaunchKernelGGL(k_nf_stamp, dim3(64), dim3(256), 0, s5_, sl.d_frames, (const OutCtl *)sl.d_ctl, (const float *)c->d_nfring, c->nf_ring - 1);
+		hipLaunchKernelGGL(k_frame_finish, dim3(1024), dim3(64), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, (const OutCtl *)sl.d_ctl, (const Tables *)c->d_tab,
+		                   c->d_acnt, (const float *)c->d_nfring, c->nf_ring - 1);
 		c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C;
 	}
 	HIPCHK(hipMemcpyAsync(sl.h_ctl, sl.d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, s5_));
@@ -281,6 +284,7 @@ static void fill_frame(const vdl2hip_ctx *c, const HostFrame &h, vdl2hip_frame &
 	f.synd_weight = h.f.synd_weight; f.datalen_octets = h.f.datalen_octets; f.num_fec_corrections = h.f.num_fec_corrections;
 	f.frame_pwr_dbfs = h.f.frame_pwr_dbfs; f.nf_pwr_dbfs = h.f.nf_pwr_dbfs; f.ppm_error = h.f.ppm_error;
 	f.burst_ord = h.f.burst_ord; f.sync_sample = h.f.sync_sample; f.end_sample = h.f.end_sample;
+	f.avlc_status = h.f.avlc_status; f.dst_addr = h.f.dst_addr; f.src_addr = h.f.src_addr;
 }
 
 extern "C" {
@@ -303,7 +307,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats };
+	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt };
 	for(auto &sl : c->slot) {
 		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl, sl.d_log, sl.d_nlog };
 		for(void *p : q) if(p) (void)hipFree(p);
@@ -389,6 +393,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_qpow, 64 * sizeof(float4));
 	DEV_ALLOC(c->d_tcarry[0], count * sizeof(float4)); DEV_ALLOC(c->d_tcarry[1], count * sizeof(float4));
 	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, (size_t)count * kNumCounters * 8);
+	DEV_ALLOC(c->d_acnt, (size_t)count * kNumAvlcCounters * 8);
 	// a decodable burst occupies >= 22 symbols = 220 decimated samples (header + 3 data + 2 FEC octets)
 	c->cap_bursts_chan = (uint32_t)(dmax / 220 + 4);
 	uint64_t cap_b = (uint64_t)count * c->cap_bursts_chan;
@@ -449,7 +454,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_CHK(hipMemset(c->d_y, 0, nring * sizeof(cf32))); DEV_CHK(hipMemset(c->d_pf, 0, nring * sizeof(cf32)));
 	DEV_CHK(hipMemset(c->d_phi, 0, nring * sizeof(float))); DEV_CHK(hipMemset(c->d_cand, 0, nring / 8));
 	DEV_CHK(hipMemset(c->d_tcarry[0], 0, count * sizeof(float4))); DEV_CHK(hipMemset(c->d_tcarry[1], 0, count * sizeof(float4)));
-	DEV_CHK(hipMemset(c->d_cnt, 0, (size_t)count * kNumCounters * 8));
+	DEV_CHK(hipMemset(c->d_cnt, 0, (size_t)count * kNumCounters * 8)); DEV_CHK(hipMemset(c->d_acnt, 0, (size_t)count * kNumAvlcCounters * 8));
 	DEV_CHK(hipMemset(c->d_segend, 0, (size_t)count * c->nseg_cap * sizeof(float4)));
 	// the generic-oversample build may need more than the default dynamic LDS limit
 	const size_t lds = 4096 + 2048 + (size_t)c->run * c->os * 65 * sizeof(float2);
@@ -570,6 +575,60 @@ int vdl2hip_counters(vdl2hip_ctx *c, uint32_t chan, uint64_t out[VDL2HIP_NUM_COU
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	HIPCHK(hipMemcpy(out, c->d_cnt + (size_t)(chan - c->chan_first) * kNumCounters, 8 * kNumCounters, hipMemcpyDeviceToHost));
 	return VDL2HIP_OK;
+}
+
+int vdl2hip_avlc_counters(vdl2hip_ctx *c, uint32_t chan, uint64_t out[VDL2HIP_NUM_AVLC_COUNTERS]) {
+	if(!c || !out || chan < (uint32_t)c->chan_first || chan >= (uint32_t)(c->chan_first + c->C)) return VDL2HIP_E_INVAL;
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	HIPCHK(hipMemcpy(out, c->d_acnt + (size_t)(chan - c->chan_first) * kNumAvlcCounters, 8 * kNumAvlcCounters, hipMemcpyDeviceToHost));
+	return VDL2HIP_OK;
+}
+
+int vdl2hip_set_avlc_filter(vdl2hip_ctx *c, int on) {
+	if(!c) return VDL2HIP_E_INVAL;
+	c->avlc_filter = on != 0;
+	return VDL2HIP_OK;
+}
+
+// counter names in the order of the VDL2HIP_CNT_* / VDL2HIP_ACNT_* enums (statsd.c:34-65); the two diagnostics this
+// implementation adds (ppm_reject, slicer_neg_idx) are exported under demod.* as well
+static const char *const kCounterNames[VDL2HIP_NUM_COUNTERS] = {
+	"demod.sync.good", "decoder.crc.good", "decoder.crc.bad", "decoder.errors.no_header", "decoder.errors.too_long",
+	"decoder.errors.no_fec", "decoder.errors.data_truncated", "decoder.errors.fec_truncated", "decoder.errors.deinterleave_data",
+	"decoder.errors.deinterleave_fec", "decoder.errors.fec_bad", "decoder.errors.bitstream", "decoder.errors.truncated_octets",
+	"decoder.errors.unstuff", "decoder.blocks.processed", "decoder.blocks.fec_ok", "decoder.msg.good", "decoder.msg.good_loud",
+	"demod.ppm_reject", "demod.slicer_neg_idx" };
+static const char *const kAvlcCounterNames[VDL2HIP_NUM_AVLC_COUNTERS] = {
+	"avlc.frames.processed", "avlc.errors.too_short", "avlc.frames.good", "avlc.errors.bad_fcs", "avlc.msg.air2gnd",
+	"avlc.msg.air2air", "avlc.msg.air2all", "avlc.msg.gnd2air", "avlc.msg.gnd2gnd", "avlc.msg.gnd2all" };
+
+int vdl2hip_statsd_lines(vdl2hip_ctx *c, const char *ns, char *out, size_t cap) {
+	if(!c || !ns || !out) return VDL2HIP_E_INVAL;
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	const size_t per = VDL2HIP_NUM_COUNTERS + VDL2HIP_NUM_AVLC_COUNTERS;
+	std::vector<uint64_t> now((size_t)c->C * per);
+	for(int ch = 0; ch < c->C; ch++) {
+		HIPCHK(hipMemcpy(&now[ch * per], c->d_cnt + (size_t)ch * kNumCounters, 8 * kNumCounters, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(&now[ch * per + kNumCounters], c->d_acnt + (size_t)ch * kNumAvlcCounters, 8 * kNumAvlcCounters, hipMemcpyDeviceToHost));
+	}
+	const bool first = c->statsd_prev.empty();
+	if(first) c->statsd_prev.assign(now.size(), 0);
+	std::string txt;
+	char line[320];
+	for(int ch = 0; ch < c->C; ch++)
+		for(size_t k = 0; k < per; k++) {
+			const uint64_t d = now[ch * per + k] - c->statsd_prev[ch * per + k];
+			if(!first && d == 0) continue;
+			const char *name = k < (size_t)kNumCounters ? kCounterNames[k] : kAvlcCounterNames[k - kNumCounters];
+			snprintf(line, sizeof line, "%s.%u.%s:%llu|c\n", ns, c->freqs[ch], name, (unsigned long long)d);
+			txt += line;
+		}
+	if(txt.size() + 1 > cap) { if(first) c->statsd_prev.clear(); return VDL2HIP_E_TOOBIG; }
+	memcpy(out, txt.c_str(), txt.size() + 1);
+	c->statsd_prev = now;
+	return (int)txt.size();
 }
 
 int vdl2hip_set_profiling(vdl2hip_ctx *c, int on) {

@@ -291,6 +291,7 @@ class SynthConfig:
     tdm_slots: int = 0                   # >0: channel k transmits only in slot k % tdm_slots
     tdm_slot_s: float = 0.2
     error_injection: bool = False        # config 5: RS byte errors + header bit flips
+    invalid_frame_rate: float = 0.0      # fraction of frames that are not valid AVLC (bad FCS or < 11 octets)
     first_burst_s: float = 0.02
 
     @property
@@ -312,6 +313,10 @@ def _random_frames(rng: np.random.Generator, cfg: SynthConfig) -> List[bytes]:
     frames = []
     for s in sizes:
         body = rng.integers(0, 256, size=max(s, 9), dtype=np.uint8).tobytes()
+        if cfg.invalid_frame_rate > 0 and rng.random() < cfg.invalid_frame_rate:
+            # what avlc_parse() refuses (avlc.c:168-187): a frame shorter than 11 octets, or one whose FCS does not check
+            frames.append(body[:int(rng.integers(1, 11))] if rng.random() < 0.4 else body + b"\x00\x00")
+            continue
         frames.append(make_avlc_frame(body))
     return frames
 

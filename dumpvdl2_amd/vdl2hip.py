@@ -27,10 +27,17 @@ COUNTER_NAMES = [
     "demod.ppm_reject", "demod.slicer_neg_idx",
 ]
 NUM_COUNTERS = len(COUNTER_NAMES)
+AVLC_COUNTER_NAMES = [
+    "avlc.frames.processed", "avlc.errors.too_short", "avlc.frames.good", "avlc.errors.bad_fcs",
+    "avlc.msg.air2gnd", "avlc.msg.air2air", "avlc.msg.air2all", "avlc.msg.gnd2air", "avlc.msg.gnd2gnd", "avlc.msg.gnd2all",
+]
+NUM_AVLC_COUNTERS = len(AVLC_COUNTER_NAMES)
+AVLC_OK, AVLC_TOO_SHORT, AVLC_BAD_FCS = 0, 1, 2
 EXPORTS = [
     "vdl2hip_abi_version", "vdl2hip_strerror", "vdl2hip_create", "vdl2hip_destroy", "vdl2hip_feed",
     "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
     "vdl2hip_drain_packed", "vdl2hip_pack_raw_frame", "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_set_drain_lag", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
+    "vdl2hip_avlc_counters", "vdl2hip_set_avlc_filter", "vdl2hip_statsd_lines",
 ]
 
 
@@ -46,7 +53,7 @@ class CFrame(C.Structure):
                 ("octets", C.POINTER(C.c_uint8)), ("synd_weight", C.c_uint32), ("datalen_octets", C.c_uint32),
                 ("num_fec_corrections", C.c_int32), ("frame_pwr_dbfs", C.c_float), ("nf_pwr_dbfs", C.c_float),
                 ("ppm_error", C.c_float), ("burst_ord", C.c_int64), ("sync_sample", C.c_int64),
-                ("end_sample", C.c_int64)]
+                ("end_sample", C.c_int64), ("avlc_status", C.c_uint32), ("dst_addr", C.c_uint32), ("src_addr", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -84,6 +91,9 @@ def load_library(path: str = LIB_PATH):
     L.vdl2hip_drain_packed.argtypes = [C.c_void_p, C.POINTER(PackedFrame), C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.vdl2hip_pack_raw_frame.argtypes = [C.POINTER(CFrame), C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t]
     L.vdl2hip_counters.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.vdl2hip_avlc_counters.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.vdl2hip_set_avlc_filter.argtypes = [C.c_void_p, C.c_int]
+    L.vdl2hip_statsd_lines.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
     L.vdl2hip_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.vdl2hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.vdl2hip_set_drain_lag.argtypes = [C.c_void_p, C.c_int]
@@ -108,7 +118,7 @@ def pack_raw_frame(frame: dict, station_id: Optional[str] = None, tv_sec: int = 
     f = CFrame(frame["chan"], frame["freq"], frame["idx"], len(octs), C.cast(buf, C.POINTER(C.c_uint8)),
                frame["synd_weight"], frame["datalen_octets"], frame["num_fec_corrections"], frame["frame_pwr_dbfs"],
                frame["nf_pwr_dbfs"], frame["ppm_error"], frame.get("burst_ord", 0), frame.get("sync_sample", 0),
-               frame.get("end_sample", 0))
+               frame.get("end_sample", 0), 0, 0, 0)
     out = (C.c_uint8 * (len(octs) + 600))()
     n = L.vdl2hip_pack_raw_frame(C.byref(f), station_id.encode() if station_id else None, tv_sec, tv_usec, out, len(out))
     if n < 0:
@@ -173,7 +183,8 @@ class Receiver:
                             synd_weight=f.synd_weight, datalen_octets=f.datalen_octets,
                             num_fec_corrections=f.num_fec_corrections, frame_pwr_dbfs=f.frame_pwr_dbfs,
                             nf_pwr_dbfs=f.nf_pwr_dbfs, ppm_error=f.ppm_error, burst_ord=f.burst_ord,
-                            sync_sample=f.sync_sample, end_sample=f.end_sample))
+                            sync_sample=f.sync_sample, end_sample=f.end_sample,
+                            avlc_status=f.avlc_status, dst_addr=f.dst_addr, src_addr=f.src_addr))
 
         self._cb = FRAME_CB(cb)
         self._chk(self.L.vdl2hip_drain(self.h, self._cb, None), "vdl2hip_drain")
@@ -198,8 +209,23 @@ class Receiver:
                             synd_weight=f.synd_weight, datalen_octets=f.datalen_octets,
                             num_fec_corrections=f.num_fec_corrections, frame_pwr_dbfs=f.frame_pwr_dbfs,
                             nf_pwr_dbfs=f.nf_pwr_dbfs, ppm_error=f.ppm_error, burst_ord=f.burst_ord,
-                            sync_sample=f.sync_sample, end_sample=f.end_sample))
+                            sync_sample=f.sync_sample, end_sample=f.end_sample,
+                            avlc_status=f.avlc_status, dst_addr=f.dst_addr, src_addr=f.src_addr))
         return out
+
+    def avlc_counters(self, chan: int) -> dict:
+        a = (C.c_uint64 * NUM_AVLC_COUNTERS)()
+        self._chk(self.L.vdl2hip_avlc_counters(self.h, chan, a), "vdl2hip_avlc_counters")
+        return dict(zip(AVLC_COUNTER_NAMES, list(a)))
+
+    def set_avlc_filter(self, on: bool) -> None:
+        self._chk(self.L.vdl2hip_set_avlc_filter(self.h, int(on)), "vdl2hip_set_avlc_filter")
+
+    def statsd_lines(self, ns: str = "dumpvdl2", cap: int = 1 << 20) -> List[str]:
+        """the reference's statsd counter traffic since the previous call, one "<ns>.<freq>.<counter>:<delta>|c" per line"""
+        buf = C.create_string_buffer(cap)
+        n = self._chk(self.L.vdl2hip_statsd_lines(self.h, ns.encode(), buf, cap), "vdl2hip_statsd_lines")
+        return buf.raw[:n].decode().splitlines()
 
     def counters(self, chan: int) -> dict:
         a = (C.c_uint64 * NUM_COUNTERS)()

@@ -97,7 +97,24 @@ typedef struct {
 	int64_t  burst_ord;         /* ordinal of the burst on its channel (0,1,...) */
 	int64_t  sync_sample;       /* decimated-sample index (105 kS/s clock) at which the preamble locked */
 	int64_t  end_sample;        /* decimated-sample index at which the burst was complete */
+	/* avlc_parse()'s first checks (src/avlc.c:163-199), done on the device: */
+	uint32_t avlc_status;       /* VDL2HIP_AVLC_OK / _TOO_SHORT (len < 11) / _BAD_FCS (crc16_ccitt residue != 0xF0B8) */
+	uint32_t dst_addr, src_addr;/* parse_dlc_addr() of octets 0-3 / 4-7: addr:24 | type:3 << 24 | status:1 << 27; 0 unless OK */
 } vdl2hip_frame;
+
+enum { VDL2HIP_AVLC_OK = 0, VDL2HIP_AVLC_TOO_SHORT = 1, VDL2HIP_AVLC_BAD_FCS = 2 };
+
+/* Per-channel counters of the AVLC front door = the reference's statsd counters of src/decode.c:466 and
+ * src/avlc.c:170-233, in this order */
+enum {
+	VDL2HIP_ACNT_FRAMES_PROCESSED = 0,  /* avlc.frames.processed */
+	VDL2HIP_ACNT_ERR_TOO_SHORT,         /* avlc.errors.too_short */
+	VDL2HIP_ACNT_FRAMES_GOOD,           /* avlc.frames.good */
+	VDL2HIP_ACNT_ERR_BAD_FCS,           /* avlc.errors.bad_fcs */
+	VDL2HIP_ACNT_MSG_AIR2GND, VDL2HIP_ACNT_MSG_AIR2AIR, VDL2HIP_ACNT_MSG_AIR2ALL,   /* avlc.msg.* */
+	VDL2HIP_ACNT_MSG_GND2AIR, VDL2HIP_ACNT_MSG_GND2GND, VDL2HIP_ACNT_MSG_GND2ALL,
+	VDL2HIP_NUM_AVLC_COUNTERS
+};
 
 typedef void (*vdl2hip_frame_cb)(const vdl2hip_frame *frame, void *user);
 
@@ -161,6 +178,16 @@ int  vdl2hip_pack_raw_frame(const vdl2hip_frame *frame, const char *station_id, 
 		uint8_t *out, size_t cap);
 
 int  vdl2hip_counters(vdl2hip_ctx *ctx, uint32_t chan, uint64_t out[VDL2HIP_NUM_COUNTERS]);
+int  vdl2hip_avlc_counters(vdl2hip_ctx *ctx, uint32_t chan, uint64_t out[VDL2HIP_NUM_AVLC_COUNTERS]);
+/* Deliver only frames that pass the AVLC front door (avlc_parse() returns NULL for the others, src/avlc.c:171,186): with
+ * `on` the drain functions skip frames whose avlc_status is not OK.  Counters are unaffected.  Default off: every frame
+ * reaches the callback, as every frame reaches avlc_decoder_queue_push() in the reference. */
+int  vdl2hip_set_avlc_filter(vdl2hip_ctx *ctx, int on);
+/* The reference's statsd traffic (src/statsd.c:34-65,153-160) in aggregate: one "<ns>.<freq>.<counter>:<delta>|c" line per
+ * counter that changed since the previous call (all counters, with :0, on the first call, like
+ * statsd_initialize_counters_per_channel()).  `ns` is the namespace ("dumpvdl2" or "dumpvdl2.<station_id>").  Returns the
+ * number of bytes written (excluding the terminating NUL) or VDL2HIP_E_TOOBIG if `cap` is too small (nothing is consumed). */
+int  vdl2hip_statsd_lines(vdl2hip_ctx *ctx, const char *ns, char *out, size_t cap);
 int  vdl2hip_set_profiling(vdl2hip_ctx *ctx, int on);   /* bracket kernels with HIP events on the ctx stream */
 int  vdl2hip_get_stats(vdl2hip_ctx *ctx, vdl2hip_stats *out);
 void *vdl2hip_stream(vdl2hip_ctx *ctx);                 /* the hipStream_t all work is queued on */

@@ -164,6 +164,40 @@ class Oracle:
         return self.L.vdl2o_get_dphi(self.h, chan)
 
 
+AVLC_COUNTER_NAMES = ["avlc.frames.processed", "avlc.errors.too_short", "avlc.frames.good", "avlc.errors.bad_fcs",
+                      "avlc.msg.air2gnd", "avlc.msg.air2air", "avlc.msg.air2all", "avlc.msg.gnd2air", "avlc.msg.gnd2gnd",
+                      "avlc.msg.gnd2all"]
+
+
+def avlc_screen(octets):
+    """(status, dst, src, dir) of avlc_parse()'s first checks: status 0 ok / 1 too short / 2 bad FCS"""
+    L = lib()
+    b = bytes(octets)
+    dst = C.c_uint32(); src = C.c_uint32(); d = C.c_int()
+    L.vdl2o_avlc_screen.restype = C.c_int
+    L.vdl2o_avlc_screen.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+    st = L.vdl2o_avlc_screen(b, len(b), C.byref(dst), C.byref(src), C.byref(d))
+    return st, dst.value, src.value, d.value
+
+
+def avlc_counters(frames, nchan):
+    """the reference's per-channel avlc.* statsd counters for a list of frames (dicts with chan, octets)"""
+    out = [[0] * len(AVLC_COUNTER_NAMES) for _ in range(nchan)]
+    for f in frames:
+        c = out[f["chan"]]
+        c[0] += 1
+        st, _, _, d = avlc_screen(f["octets"])
+        if st == 1:
+            c[1] += 1
+        elif st == 2:
+            c[3] += 1
+        else:
+            c[2] += 1
+            if d:
+                c[3 + d] += 1
+    return out
+
+
 def crc16_x25(data, init=0xFFFF):
     b = bytes(data)
     return lib().vdl2o_crc16(b, len(b), init)

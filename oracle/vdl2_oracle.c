@@ -291,6 +291,33 @@ uint16_t vdl2o_crc16(const uint8_t *data, uint32_t len, uint16_t init) {
 }
 
 /* ======================================================================
+ * The AVLC front door: what the decoder thread does first with a frame
+ * (decode.c:466, avlc_parse() avlc.c:163-236, parse_dlc_addr() avlc.c:158-161,
+ * reverse() bitstream.c:152-164).  Returns 0 = parsed on, 1 = too short, 2 = bad FCS;
+ * *dir: 0 none, 1 air2gnd, 2 air2air, 3 air2all, 4 gnd2air, 5 gnd2gnd, 6 gnd2all.
+ * ==================================================================== */
+static uint32_t dlc_addr(const uint8_t *b) {
+	uint32_t v = (uint32_t)(b[0] >> 1) | ((uint32_t)b[1] << 6) | ((uint32_t)b[2] << 13) | ((uint32_t)(b[3] & 0xfe) << 20);
+	/* reverse(v, 28): bit i of the 32-bit word goes to bit 31-i, then the top 28 bits are kept */
+	uint32_t r = v; int s = 31;
+	for(v >>= 1; v; v >>= 1) { r <<= 1; r |= v & 1; s--; }
+	r <<= s;
+	r >>= 32 - 28;
+	return r & ~(~0u << 28);
+}
+
+int vdl2o_avlc_screen(const uint8_t *buf, uint32_t len, uint32_t *dst, uint32_t *src, int *dir) {
+	*dst = *src = 0; *dir = 0;
+	if(len < 11) return 1;                                    /* MIN_AVLC_LEN, avlc.c:39,168 */
+	if(vdl2o_crc16(buf, len, 0xFFFFu) != 0xF0B8u) return 2;  /* GOOD_FCS, avlc.c:40,178-187 */
+	*dst = dlc_addr(buf); *src = dlc_addr(buf + 4);
+	const unsigned st = (*src >> 24) & 7u, dt = (*dst >> 24) & 7u;   /* a_addr.type, avlc.h:29-42 (little endian) */
+	if(st == 1) *dir = (dt == 4 || dt == 5) ? 1 : dt == 1 ? 2 : dt == 7 ? 3 : 0;           /* avlc.c:203-218 */
+	else if(st == 4 || st == 5) *dir = dt == 1 ? 4 : (dt == 4 || dt == 5) ? 5 : dt == 7 ? 6 : 0;   /* avlc.c:220-236 */
+	return 0;
+}
+
+/* ======================================================================
  * Header block code (25,20): decode.c:55-122
  * ==================================================================== */
 static const uint32_t hdr_H[K_HDR_PAR_BITS] = { /* parity-check rows, decode.c:55-61 */

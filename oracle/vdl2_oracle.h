@@ -102,6 +102,7 @@ uint32_t vdl2o_header_decode(uint32_t *word);                       /* decode.c:
 uint32_t vdl2o_header_parity(uint32_t upper20);                     /* 5 parity bits for a 20-bit field */
 uint16_t vdl2o_crc16(const uint8_t *data, uint32_t len, uint16_t init); /* crc.c:21-64 (own bitwise version) */
 void vdl2o_chebyshev(float fc, float ripple_pct, float A[3], float B[3]); /* chebyshev.c:67-119, 2 poles */
+int  vdl2o_avlc_screen(const uint8_t *buf, uint32_t len, uint32_t *dst, uint32_t *src, int *dir);  /* avlc.c:163-236 up to the addresses */
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ struct Sim {
 	int nchan; uint32_t cap, mask; float max_ppm;
 	std::vector<uint32_t> freqs;
 	std::vector<cf32> y, pf; std::vector<float> phi; std::vector<uint64_t> cand;
-	std::vector<WalkState> st; std::vector<unsigned long long> cnt;
+	std::vector<WalkState> st; std::vector<unsigned long long> cnt, acnt;
 	std::vector<NfState> nf; std::vector<EvalChunk> log; std::vector<uint32_t> nlog; std::vector<int64_t> scf, scc; std::vector<float> ring, lpbuf;
 	uint32_t cap_log = 8192, cap_comb = 8192 + kNfTail, cap_hist = 4096, nf_ring = 16384;
 	Tables T;
@@ -37,7 +37,7 @@ Sim *hostsim_create(int nchan, const uint32_t *freqs, float max_ppm, int cap_log
 	s->freqs.assign(freqs, freqs + nchan);
 	s->y.assign((size_t)nchan * s->cap, cf32{0, 0}); s->pf.assign((size_t)nchan * s->cap, cf32{0, 0});
 	s->phi.assign((size_t)nchan * s->cap, 0.f); s->cand.assign((size_t)nchan * (s->cap / 64), 0);
-	s->st.resize(nchan); s->cnt.assign((size_t)nchan * kNumCounters, 0);
+	s->st.resize(nchan); s->cnt.assign((size_t)nchan * kNumCounters, 0); s->acnt.assign((size_t)nchan * kNumAvlcCounters, 0);
 	for(auto &w : s->st) { memset(&w, 0, sizeof w); walk_state_init(w); }
 	s->nf.resize(nchan); for(auto &n : s->nf) { memset(&n, 0, sizeof n); nf_state_init(n); }
 	s->log.resize((size_t)nchan * s->cap_log); s->nlog.assign(nchan, 0); s->scf.resize((size_t)nchan * (s->cap_comb + 1)); s->scc.resize((size_t)nchan * (s->cap_comb + 1));
@@ -123,7 +123,12 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl, bsh);
 	}
 	uint32_t nf = s->ctl.nframes < s->ctl.cap_frames ? s->ctl.nframes : s->ctl.cap_frames;
-	for(uint32_t i = 0; i < nf; i++) { const int c = s->frames[i].chan; stamp_noise_floor(s->frames[i], &s->ring[(size_t)c * s->nf_ring], s->nf_ring - 1); }
+	static FrameShared fsh;
+	frame_shared_init(s->T, fsh);
+	for(uint32_t i = 0; i < nf; i++) {
+		const int c = s->frames[i].chan;
+		finish_frame(s->frames[i], s->pool.data(), s->T, &s->acnt[(size_t)c * kNumAvlcCounters], &s->ring[(size_t)c * s->nf_ring], s->nf_ring - 1, fsh);
+	}
 	for(uint32_t i = 0; i < nf; i++) {
 		OutFrame f = s->frames[i];
 		uint32_t off = (uint32_t)s->all_pool.size();
@@ -137,6 +142,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 int64_t hostsim_num_frames(Sim *s) { return (int64_t)s->all_frames.size(); }
 const OutFrame *hostsim_frames(Sim *s) { return s->all_frames.data(); }
 const uint8_t *hostsim_pool(Sim *s) { return s->all_pool.data(); }
+void hostsim_avlc_counters(Sim *s, int chan, unsigned long long *out) { memcpy(out, &s->acnt[(size_t)chan * kNumAvlcCounters], sizeof(unsigned long long) * kNumAvlcCounters); }
 void hostsim_counters(Sim *s, int chan, unsigned long long *out) { memcpy(out, &s->cnt[(size_t)chan * kNumCounters], sizeof(unsigned long long) * kNumCounters); }
 // phase_of() of the device code on n (re, im) pairs, for comparison with libm
 void hostsim_phase(const float *reim, float *out, int64_t n) { for(int64_t i = 0; i < n; i++) out[i] = phase_of(cf32{reim[2 * i], reim[2 * i + 1]}); }

@@ -14,7 +14,8 @@ class OutFrame(C.Structure):
     _fields_ = [("chan", C.c_int32), ("idx", C.c_int32), ("len", C.c_uint32), ("pool_off", C.c_uint32),
                 ("synd_weight", C.c_uint32), ("datalen_octets", C.c_uint32), ("num_fec_corrections", C.c_int32),
                 ("frame_pwr_dbfs", C.c_float), ("nf_pwr_dbfs", C.c_float), ("ppm_error", C.c_float),
-                ("burst_ord", C.c_int64), ("sync_sample", C.c_int64), ("end_sample", C.c_int64), ("nf_upd", C.c_int64)]
+                ("burst_ord", C.c_int64), ("sync_sample", C.c_int64), ("end_sample", C.c_int64), ("nf_upd", C.c_int64),
+                ("avlc_status", C.c_uint32), ("dst_addr", C.c_uint32), ("src_addr", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 def build():
@@ -38,6 +39,7 @@ class HostSim:
         self.L.hostsim_pool.restype = C.POINTER(C.c_uint8)
         self.L.hostsim_pool.argtypes = [C.c_void_p]
         self.L.hostsim_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
+        self.L.hostsim_avlc_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ulonglong)]
         self.L.hostsim_destroy.argtypes = [C.c_void_p]
         self.L.hostsim_set_segments.argtypes = [C.c_void_p, C.c_int64, C.c_int]
         self.L.hostsim_segment_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
@@ -64,7 +66,8 @@ class HostSim:
                             synd_weight=f.synd_weight, datalen_octets=f.datalen_octets,
                             num_fec_corrections=f.num_fec_corrections, frame_pwr_dbfs=f.frame_pwr_dbfs,
                             nf_pwr_dbfs=f.nf_pwr_dbfs, ppm_error=f.ppm_error, burst_ord=f.burst_ord,
-                            sync_sample=f.sync_sample, end_sample=f.end_sample))
+                            sync_sample=f.sync_sample, end_sample=f.end_sample,
+                            avlc_status=f.avlc_status, dst_addr=f.dst_addr, src_addr=f.src_addr))
         return out
 
     def set_segments(self, seg_min, seg_max=32):
@@ -79,6 +82,11 @@ class HostSim:
     def counters(self, chan):
         a = (C.c_ulonglong * NUM_COUNTERS)()
         self.L.hostsim_counters(self.h, chan, a)
+        return list(a)
+
+    def avlc_counters(self, chan):
+        a = (C.c_ulonglong * 10)()
+        self.L.hostsim_avlc_counters(self.h, chan, a)
         return list(a)
 
     def close(self):

@@ -350,3 +350,60 @@ def test_segmented_walk_is_exact(vh, monkeypatch, name, seg_min, seg_max):
     else:
         assert st["seg_adopted"] == st["seg_walked"] == 0
     rx.close()
+
+
+def test_avlc_front_door_on_device(vh, oracle_mod, golden_wav):
+    """SURVEY 8.7 rows 3+4: FCS / minimum length / link addresses per frame and the avlc.* counters, computed on the
+    device (k_frame_finish), against the oracle's restatement of src/avlc.c:163-236; the optional filter; the statsd lines."""
+    cfg, iq, _, gold = cases.load("config5_0p4s")
+    nch = len(cfg.freqs)
+    rx, fr, cnt = gpu_decode(vh, cfg, iq)
+    assert len(fr) > 50
+    for f in fr:
+        st, dst, src, _ = oracle_mod.avlc_screen(f["octets"])
+        assert (f["avlc_status"], f["dst_addr"], f["src_addr"]) == (st, dst, src)
+    want = oracle_mod.avlc_counters(fr, nch)
+    got = [list(rx.avlc_counters(c).values()) for c in range(nch)]
+    assert got == want
+    # statsd: first call announces every counter (statsd_initialize_counters_per_channel), deltas afterwards
+    lines = rx.statsd_lines("dumpvdl2.TEST")
+    assert len(lines) == nch * (vh.NUM_COUNTERS + vh.NUM_AVLC_COUNTERS)
+    table = dict(l.rsplit(":", 1) for l in lines)
+    for c in range(nch):
+        for k, v in {**rx.counters(c), **rx.avlc_counters(c)}.items():
+            assert table[f"dumpvdl2.TEST.{cfg.freqs[c]}.{k}"] == f"{v}|c"
+    assert rx.statsd_lines("dumpvdl2.TEST") == []               # nothing changed since
+    rx.close()
+
+    # the reference's own vector: both frames pass; with the filter on, a corrupted frame would not be delivered
+    rx = vh.Receiver(CF, [CF], 10, vh.FMT_S16LE, max_block_bytes=golden_wav.size)
+    rx.set_avlc_filter(True)
+    rx.feed(golden_wav[:golden_wav.size - golden_wav.size % 4])
+    fr = rx.drain()
+    assert [f["avlc_status"] for f in fr] == [0, 0] and [len(f["octets"]) for f in fr] == [314, 186]
+    assert list(rx.avlc_counters(0).values())[:4] == [2, 0, 2, 0]
+    assert sum(list(rx.avlc_counters(0).values())[4:]) == 2
+    rx.close()
+
+
+def test_avlc_filter_drops_what_avlc_parse_drops(vh, oracle_mod):
+    """Bursts whose payload is not a valid AVLC frame (no FCS, short frames) still decode (decoder.msg.good), but
+    avlc_parse() returns NULL for them: with the filter on they are counted and not delivered."""
+    from dumpvdl2_amd import synth
+    cfg = synth.SynthConfig(freqs=synth.channel_plan(2, spacing=100000), duration_s=1.5, mean_gap_s=0.05, max_payload=300,
+                            invalid_frame_rate=0.4, seed=77)
+    iq, bursts = synth.synthesize(cfg)
+    rx_all, fr_all, _ = gpu_decode(vh, cfg, iq)
+    status = [oracle_mod.avlc_screen(f["octets"])[0] for f in fr_all]
+    assert status.count(1) >= 3 and status.count(2) >= 3 and status.count(0) >= 3
+    assert [f["avlc_status"] for f in fr_all] == status
+    rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=iq.nbytes)
+    rx.set_avlc_filter(True)
+    rx.feed(iq.view(np.uint8))
+    fr = rx.drain()
+    assert len(fr) == status.count(0) and all(f["avlc_status"] == 0 for f in fr)
+    key = lambda f: (f["chan"], f["burst_ord"], f["idx"])
+    assert sorted(map(key, fr)) == sorted(key(f) for f, st in zip(fr_all, status) if st == 0)
+    tot = [sum(rx.avlc_counters(c)[k] for c in range(len(cfg.freqs))) for k in ("avlc.frames.processed", "avlc.errors.too_short", "avlc.errors.bad_fcs", "avlc.frames.good")]
+    assert tot == [len(fr_all), status.count(1), status.count(2), status.count(0)]
+    rx.close(); rx_all.close()
