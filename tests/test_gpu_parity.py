@@ -407,3 +407,29 @@ def test_avlc_filter_drops_what_avlc_parse_drops(vh, oracle_mod):
     tot = [sum(rx.avlc_counters(c)[k] for c in range(len(cfg.freqs))) for k in ("avlc.frames.processed", "avlc.errors.too_short", "avlc.errors.bad_fcs", "avlc.frames.good")]
     assert tot == [len(fr_all), status.count(1), status.count(2), status.count(0)]
     rx.close(); rx_all.close()
+
+
+def test_ring_wraps_many_times(vh, oracle_mod):
+    """Small blocks make the per-channel history ring small (2^17 samples here): over 5 s of signal it wraps 4 times, with
+    bursts, speculative segments and noise-floor look-backs straddling the wrap.  Same frames as the oracle."""
+    from dumpvdl2_amd import synth
+    cfg = synth.SynthConfig(freqs=synth.channel_plan(3, spacing=100000), duration_s=5.0, mean_gap_s=0.08, max_payload=600, seed=4242)
+    iq, bursts = synth.synthesize(cfg)
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample)
+    o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=3)
+    raw = iq.view(np.uint8)
+    blk = 1600000                                                   # 400 000 samples = 20 000 decimated per feed
+    rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, max_block_bytes=blk)
+    rx.set_drain_lag(2)
+    got = []
+    for k in range(0, raw.size, blk):
+        rx.feed(raw[k:k + blk])
+        got += rx.drain()
+    rx.set_drain_lag(0)
+    got += rx.drain()
+    assert 5 * 105000 > 4 * (1 << 17)
+    assert_frames_equal(o.frames(), got, label="ring wrap")
+    cases.assert_counters_equal([list(rx.counters(c).values()) for c in range(3)], [list(o.counters(c).values()) for c in range(3)],
+                                label="ring wrap", exact_diagnostics=False)
+    assert len(got) >= 60
+    rx.close()
