@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
 
 	lut[tid] = ((const float4 *)a.lut)[tid];
 	if(tid < 64) qpow[tid] = a.qpow[tid];
-	const int wave = tid >> 6, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform, so per-channel values stay in SGPRs
 	const int cbase = (gy * 4 + wave) * CR;
 	const bool wave_active = cbase < a.nchan;
 	const K1Consts &bf = a.bf;
@@ -134,12 +134,22 @@ __global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
 		if(kbase >= a.D) break;
 		const int64_t sbase = tix * tile_n;
 		if(ts) __syncthreads();                                  // everyone is done with the previous tile
-		for(int t = tid; t < tile_n; t += 256) {
-			const int64_t sidx = sbase + t;
-			float re = 0.f, im = 0.f;
-			if(sidx < (int64_t)a.nlogical) load_sample(a, sidx, re, im);
-			const int l = t / run, m = t - l * run;
-			tile[m * 65 + l] = make_float2(re, im);
+		if(a.fmt == 1 && sbase >= (int64_t)a.ncarry && sbase + tile_n <= (int64_t)a.nlogical) {
+			// the usual case - a cs16 tile that lies entirely inside this feed's block: no per-sample range or carry checks
+			const uint32_t *src = (const uint32_t *)a.in + (sbase - a.ncarry);
+			for(int t = tid; t < tile_n; t += 256) {
+				const uint32_t w = src[t];
+				const int l = t / run, m = t - l * run;
+				tile[m * 65 + l] = make_float2((float)(int16_t)(w & 0xffff) / 32768.0f, (float)(int16_t)(w >> 16) / 32768.0f);
+			}
+		} else {
+			for(int t = tid; t < tile_n; t += 256) {
+				const int64_t sidx = sbase + t;
+				float re = 0.f, im = 0.f;
+				if(sidx < (int64_t)a.nlogical) load_sample(a, sidx, re, im);
+				const int l = t / run, m = t - l * run;
+				tile[m * 65 + l] = make_float2(re, im);
+			}
 		}
 		__syncthreads();
 		if(!wave_active) continue;
@@ -213,8 +223,8 @@ __global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
 				const float o0r = __shfl_up(t0r[c], 1u << d), o0i = __shfl_up(t0i[c], 1u << d);
 				const float o1r = __shfl_up(t1r[c], 1u << d), o1i = __shfl_up(t1i[c], 1u << d);
 				if(lane >= (1 << d)) {
-					t0r[c] += q0 * o0r + q1 * o1r; t0i[c] += q0 * o0i + q1 * o1i;
-					t1r[c] += q2 * o0r + q3 * o1r; t1i[c] += q2 * o0i + q3 * o1i;
+					t0r[c] = __builtin_fmaf(q0, o0r, __builtin_fmaf(q1, o1r, t0r[c])); t0i[c] = __builtin_fmaf(q0, o0i, __builtin_fmaf(q1, o1i, t0i[c]));
+					t1r[c] = __builtin_fmaf(q2, o0r, __builtin_fmaf(q3, o1r, t1r[c])); t1i[c] = __builtin_fmaf(q2, o0i, __builtin_fmaf(q3, o1i, t1i[c]));
 				}
 			}
 		}
@@ -223,18 +233,18 @@ __global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
 		for(int c = 0; c < CR; c++) {
 			// add what the carried state contributes, then each lane needs the state at the START of its run
 			const float4 cy = carry[c];
-			t0r[c] += qp.x * cy.x + qp.y * cy.z; t0i[c] += qp.x * cy.y + qp.y * cy.w;
-			t1r[c] += qp.z * cy.x + qp.w * cy.z; t1i[c] += qp.z * cy.y + qp.w * cy.w;
+			t0r[c] = __builtin_fmaf(qp.x, cy.x, __builtin_fmaf(qp.y, cy.z, t0r[c])); t0i[c] = __builtin_fmaf(qp.x, cy.y, __builtin_fmaf(qp.y, cy.w, t0i[c]));
+			t1r[c] = __builtin_fmaf(qp.z, cy.x, __builtin_fmaf(qp.w, cy.z, t1r[c])); t1i[c] = __builtin_fmaf(qp.z, cy.y, __builtin_fmaf(qp.w, cy.w, t1i[c]));
 			float T0r = __shfl_up(t0r[c], 1), T0i = __shfl_up(t0i[c], 1), T1r = __shfl_up(t1r[c], 1), T1i = __shfl_up(t1i[c], 1);
 			if(lane == 0) { T0r = cy.x; T0i = cy.y; T1r = cy.z; T1i = cy.w; }
 			const bool cvalid = cbase + c < a.nchan;
 			const int64_t kloc = kbase + (int64_t)lane * R;
 			cf32 *yout = a.y + (size_t)(cbase + c) * a.cap;
 			// outputs of the run, completed with the decayed run-start state (cP[i] = (c0,c1) P^(i+1))
-			const float f0r = ya[c][0] + (bf.cP[0][0] * T0r + bf.cP[0][1] * T1r), f0i = ya[c][1] + (bf.cP[0][0] * T0i + bf.cP[0][1] * T1i);
+			const float f0r = __builtin_fmaf(bf.cP[0][0], T0r, __builtin_fmaf(bf.cP[0][1], T1r, ya[c][0])), f0i = __builtin_fmaf(bf.cP[0][0], T0i, __builtin_fmaf(bf.cP[0][1], T1i, ya[c][1]));
 			if(cvalid && kloc < a.D) yout[(uint32_t)(a.k0 + kloc) & a.mask] = cf32{f0r, f0i};
 			if(R > 1) {
-				const float f1r = yb[c][0] + (bf.cP[1][0] * T0r + bf.cP[1][1] * T1r), f1i = yb[c][1] + (bf.cP[1][0] * T0i + bf.cP[1][1] * T1i);
+				const float f1r = __builtin_fmaf(bf.cP[1][0], T0r, __builtin_fmaf(bf.cP[1][1], T1r, yb[c][0])), f1i = __builtin_fmaf(bf.cP[1][0], T0i, __builtin_fmaf(bf.cP[1][1], T1i, yb[c][1]));
 				if(cvalid && kloc + 1 < a.D) yout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = cf32{f1r, f1i};
 			}
 			if(cvalid && lane == lb && (rem <= L || ts == a.tiles - 1)) {

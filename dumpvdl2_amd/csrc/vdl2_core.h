@@ -1099,10 +1099,12 @@ struct FrameShared {
 // once per workgroup: tab[0] is the reference's table (crc.c:23-57), tab[k] = tab[k-1] advanced by one zero octet
 VDL2_HD void frame_shared_init(const Tables &T, FrameShared &sh) {
 	WAVE_FOR(l)
+		for(int b = l; b < 256; b += 64) sh.tab[0][b] = T.crc16[b];
+	WAVE_END
+	WAVE_FOR(l)
 		for(int b = l; b < 256; b += 64) {
-			uint16_t c = T.crc16[b];
-			sh.tab[0][b] = c;
-			for(int k = 1; k < 4; k++) { c = (uint16_t)((c >> 8) ^ T.crc16[c & 0xffu]); sh.tab[k][b] = c; }
+			uint16_t c = sh.tab[0][b];
+			for(int k = 1; k < 4; k++) { c = (uint16_t)((c >> 8) ^ sh.tab[0][c & 0xffu]); sh.tab[k][b] = c; }
 		}
 	WAVE_END
 }
