@@ -174,31 +174,35 @@ __global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
 		// The block loop stays rolled: one iteration = OS samples x CR channels of straight-line code.
 		#pragma unroll 1
 		for(int i = 0; i < R; i++) {
-			float a0r[CR], a0i[CR], a1r[CR], a1i[CR], lr[CR], li[CR];
+			// (re, im) pairs throughout, so that the mix and the two tap sums are packed FP32 operations
+			v2f A0[CR], A1[CR], M[CR];
 			#pragma unroll
-			for(int c = 0; c < CR; c++) { a0r[c] = a0i[c] = a1r[c] = a1i[c] = 0.f; lr[c] = li[c] = 0.f; }
+			for(int c = 0; c < CR; c++) { A0[c] = v2f{0.f, 0.f}; A1[c] = v2f{0.f, 0.f}; M[c] = v2f{0.f, 0.f}; }
 			const float2 *trow = tile + (size_t)(i * os) * 65 + lane;
 			// Partially unrolled on purpose: a fully unrolled run makes the scheduler hoist every LUT
 			// gather (4 VGPRs each) to the top and spill.  Taps come from scalar loads (uniform index).
 			#pragma unroll kK1Unroll
 			for(int j = 0; j < os; j++) {
 				const float2 x = trow[j * 65];
+				const v2f X = v2f{x.x, x.y}, Xr = v2f{-x.y, x.x};          // x and i*x, shared by the channels
 				const float g0 = bf.g0[j], g1 = bf.g1[j];
 				#pragma unroll
 				for(int c = 0; c < CR; c++) {
 					const uint32_t p = ph[c];
 					const float F = (float)(p & 0xffffu);                 // sincosf_lut(): fract * 65536
 					const float4 e = lut[(p >> 16) & 0xffu];
-					const v2f sc = __builtin_elementwise_fma(v2f{e.z, e.w}, v2f{F, F}, v2f{e.x, e.y});   // one v_pk_fma_f32
-					const float sn = sc.x, cs = sc.y;
-					const float mr = __builtin_fmaf(x.x, cs, -(x.y * sn)); // multiply(): re*cos - im*sin
-					const float mi = __builtin_fmaf(x.y, cs, x.x * sn);    //             im*cos + re*sin
-					a0r[c] = __builtin_fmaf(g0, mr, a0r[c]); a0i[c] = __builtin_fmaf(g0, mi, a0i[c]);
-					a1r[c] = __builtin_fmaf(g1, mr, a1r[c]); a1i[c] = __builtin_fmaf(g1, mi, a1i[c]);
-					lr[c] = mr; li[c] = mi;
+					const v2f sc = __builtin_elementwise_fma(v2f{e.z, e.w}, v2f{F, F}, v2f{e.x, e.y});   // (sin, cos)
+					// multiply(): (re*cos - im*sin, im*cos + re*sin) = cos * x + sin * (i x), the product rounded as before
+					const v2f m = __builtin_elementwise_fma(v2f{sc.y, sc.y}, X, v2f{sc.x, sc.x} * Xr);
+					A0[c] = __builtin_elementwise_fma(v2f{g0, g0}, m, A0[c]);
+					A1[c] = __builtin_elementwise_fma(v2f{g1, g1}, m, A1[c]);
+					M[c] = m;
 					ph[c] = p + dph[c];
 				}
 			}
+			float a0r[CR], a0i[CR], a1r[CR], a1i[CR], lr[CR], li[CR];
+			#pragma unroll
+			for(int c = 0; c < CR; c++) { a0r[c] = A0[c].x; a0i[c] = A0[c].y; a1r[c] = A1[c].x; a1i[c] = A1[c].y; lr[c] = M[c].x; li[c] = M[c].y; }
 			#pragma unroll
 			for(int c = 0; c < CR; c++) {
 				// state update t <- P t + acc, then y = c0*v[n] + c1*v[n-1] + c2*xm[n] (zero-start part)
