@@ -18,7 +18,7 @@
 
 // tuning knobs of K1 (overridable at build time for experiments: tests/gpu_k1_variants.sh)
 #ifndef VDL2_K1_UNROLL
-#define VDL2_K1_UNROLL 4
+#define VDL2_K1_UNROLL 5
 #endif
 #ifndef VDL2_K1_WAVES_PER_EU
 #define VDL2_K1_WAVES_PER_EU 3

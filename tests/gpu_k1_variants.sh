@@ -7,13 +7,9 @@ build() { hipcc $F $2 -o /tmp/$1.so dumpvdl2_amd/csrc/vdl2hip.hip; }
 build base "" &
 build u2 "-DVDL2_K1_UNROLL=2" &
 build u5 "-DVDL2_K1_UNROLL=5" &
-build w4 "-DVDL2_K1_WAVES_PER_EU=4" &
-build r2 "-DVDL2_K1_RUN=2" &
-build r2w5 "-DVDL2_K1_RUN=2 -DVDL2_K1_WAVES_PER_EU=5" &
+build u10 "-DVDL2_K1_UNROLL=10" &
+build u20 "-DVDL2_K1_UNROLL=20" &
 wait
-for v in base u2 u5 w4 r2 r2w5; do
-  for C in 8 64; do VDL2HIP_LIB=/tmp/$v.so python tests/gpu_k1_bench.py $C 16 4 | cut -c1-160; done
+for v in base u2 u5 u10 u20; do
+  for C in 8 64; do VDL2HIP_LIB=/tmp/$v.so python tests/gpu_k1_bench.py $C 16 4 | cut -c1-130; done
 done
-VDL2HIP_LIB=/tmp/base.so VDL2HIP_CR=1 python tests/gpu_k1_bench.py 8 16 4 | cut -c1-160
-VDL2HIP_LIB=/tmp/base.so VDL2HIP_CR=4 python tests/gpu_k1_bench.py 8 16 4 | cut -c1-160
-VDL2HIP_LIB=/tmp/base.so python tests/gpu_k1_bench.py 256 16 4 | cut -c1-160
