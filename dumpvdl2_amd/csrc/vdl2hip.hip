@@ -3,6 +3,7 @@
 // kernels of kernels.h.  There is deliberately no CPU fallback: without a HIP device
 // vdl2hip_create() fails with VDL2HIP_E_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -31,7 +32,7 @@ struct HostFrame {
 constexpr int kRun = VDL2_K1_RUN;        // decimated outputs per lane in K1 (specialised builds); 2 measured best: tests/gpu_k1_variants.sh
 constexpr int kRunGeneric = 2;
 constexpr int kHistory = 65536;          // decimated samples kept behind the newest block (> longest burst, 56 090)
-constexpr int kNumEv = 10;
+constexpr int kNumEv = 12;            // profiling: {start, stop} of K1, K2, K3, K4, K4b, K5
 constexpr int kSlots = 3;             // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered)
 
 }  // namespace
@@ -42,7 +43,7 @@ struct OutSlot {
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
 	OutCtl *h_ctl = nullptr;               // pinned
 	hipEvent_t done = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
-	bool pending = false, ev_valid = false;
+	bool pending = false, ev_valid = false; int ev_level = 0;
 	uint64_t seq = 0;
 };
 
@@ -78,7 +79,7 @@ struct vdl2hip_ctx {
 	std::vector<HostFrame> queue;
 	int64_t k_total = 0; uint64_t n_total = 0;
 	// profiling
-	bool profiling = false;
+	int profiling = 0;                     // 0 off, 1 channeliser only, 2 every stage
 	vdl2hip_stats stats{};
 };
 
@@ -87,17 +88,24 @@ struct vdl2hip_ctx {
 
 static size_t sample_bytes(int fmt) { return fmt == VDL2HIP_FMT_S16LE ? 4 : 2; }
 
+// Launch with the kernel's own start/stop stamped into two events (null: plain launch).  Used instead of hipEventRecord
+// pairs, which are separate queue entries and cost a few microseconds of stream time each.
+#define LAUNCH_EV(kernel, grid, block, stream, e0, e1, ...) hipExtLaunchKernelGGL(kernel, grid, block, 0u, stream, e0, e1, 0, __VA_ARGS__)
+#define EV(i) (prof_all ? ev[i] : (hipEvent_t) nullptr)
+
 template<int OS, int R>
-static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds) {
+static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds, hipEvent_t e0, hipEvent_t e1) {
 	const int groups = (c->C + cr - 1) / cr;
 	K1Args b = a;
 	b.gy = (groups + 3) / 4;
 	const int nseg8 = (a.nseg + 7) / 8 * 8;
 	dim3 grid((unsigned)(nseg8 * b.gy)), block(256);
+	// e0/e1 (profiling only, else null): the runtime stamps them with the kernel's own start and stop, so the roofline figure is
+	// the kernel's duration and not the time the launch spent queued behind other streams' work
 	switch(cr) {
-		case 4: hipLaunchKernelGGL((k_chanfir<OS, R, 4>), grid, block, lds, c->stream, b); break;
-		case 2: hipLaunchKernelGGL((k_chanfir<OS, R, 2>), grid, block, lds, c->stream, b); break;
-		default: hipLaunchKernelGGL((k_chanfir<OS, R, 1>), grid, block, lds, c->stream, b); break;
+		case 4: hipExtLaunchKernelGGL((k_chanfir<OS, R, 4>), grid, block, (uint32_t)lds, c->stream, e0, e1, 0, b); break;
+		case 2: hipExtLaunchKernelGGL((k_chanfir<OS, R, 2>), grid, block, (uint32_t)lds, c->stream, e0, e1, 0, b); break;
+		default: hipExtLaunchKernelGGL((k_chanfir<OS, R, 1>), grid, block, (uint32_t)lds, c->stream, e0, e1, 0, b); break;
 	}
 }
 
@@ -109,11 +117,13 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 		hipEvent_t *ev = sl.ev;
 		float ms = 0.f;
 		if(hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->stats.chanfir_ms += ms;
-		if(hipEventElapsedTime(&ms, ev[1], ev[2]) == hipSuccess) c->stats.phase_ms += ms;
-		if(hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.sync_ms += ms;
-		if(hipEventElapsedTime(&ms, ev[7], ev[6]) == hipSuccess) c->stats.walk_ms += ms;
+		if(sl.ev_level >= 2) {
+		if(hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.phase_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->stats.sync_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) c->stats.walk_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) c->stats.nf_ms += ms;
-		if(hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->stats.burst_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[10], ev[11]) == hipSuccess) c->stats.burst_ms += ms;
+		}
 	}
 	sl.ev_valid = false;
 	const OutCtl ctl = *sl.h_ctl;
@@ -164,7 +174,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	{ int r = collect_slot(c, sl); if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r; }   // its buffers are about to be reused
 	hipStream_t st = c->stream, sb_ = c->stream_back;
 	hipEvent_t *ev = sl.ev;
-	const bool prof = c->profiling;
+	const bool prof = c->profiling != 0, prof_all = c->profiling >= 2;
 
 	K1Args a{};
 	a.in = dev_in; a.carry = c->d_carry[c->carry_sel]; a.ncarry = c->ncarry; a.nlogical = nlogical;
@@ -186,31 +196,28 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	HIPCHK(hipMemcpyAsync(sl.d_ctl, c->h_ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, sb_));
 	sl.ev_valid = false;
 	if(D > 0) {
-		if(prof) HIPCHK(hipEventRecord(ev[0], st));
 		const size_t lds = 4096 + 2048 + (size_t)c->run * c->os * 65 * sizeof(float2);
+		hipEvent_t e0 = prof ? ev[0] : nullptr, e1 = prof ? ev[1] : nullptr;
 		if(c->specialised) {
 			switch(c->os) {
-				case 20: launch_chanfir<20, kRun>(c, a, c->cr, lds); break;
-				case 13: launch_chanfir<13, kRun>(c, a, c->cr, lds); break;
-				default: launch_chanfir<10, kRun>(c, a, c->cr, lds); break;
+				case 20: launch_chanfir<20, kRun>(c, a, c->cr, lds, e0, e1); break;
+				case 13: launch_chanfir<13, kRun>(c, a, c->cr, lds, e0, e1); break;
+				default: launch_chanfir<10, kRun>(c, a, c->cr, lds, e0, e1); break;
 			}
 		} else {
-			launch_chanfir<0, kRunGeneric>(c, a, c->cr, lds);
+			launch_chanfir<0, kRunGeneric>(c, a, c->cr, lds, e0, e1);
 		}
-		if(prof) HIPCHK(hipEventRecord(ev[1], st));
 		K2Args k2{ c->d_y, c->d_phi, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
 		           c->k_total, D, c->cap, c->cap - 1, c->nseg_cap, seglen * a.tiles };
-		hipLaunchKernelGGL(k_phase, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), 0, st, k2);
+		LAUNCH_EV(k_phase, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), st, EV(2), EV(3), k2);
 		c->tcarry_sel ^= 1;
 	}
 	if(nrem) hipLaunchKernelGGL(k_carry, dim3(1), dim3(64), 0, st, a, (void *)c->d_carry[c->carry_sel ^ 1], nrem);
 	c->carry_sel ^= 1; c->ncarry = nrem;
 	if(D > 0) {
-		if(prof) HIPCHK(hipEventRecord(ev[2], st));
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
 		K3Args k3{ c->d_phi, c->d_pf, c->d_cand, c->d_tab, nbase, k1, c->cap, c->cap - 1 };
-		hipLaunchKernelGGL(k_sync, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(256), 0, st, k3);
-		if(prof) HIPCHK(hipEventRecord(ev[3], st));
+		LAUNCH_EV(k_sync, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(256), st, EV(4), EV(5), k3);
 	}
 	// The burst-rate back end runs on three more streams, so that consecutive feeds overlap stage by stage:
 	//   stream_back   K4   walk(i) -> walk(i+1) -> ...             (each needs the previous one's FSM state)
@@ -221,7 +228,6 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	HIPCHK(hipStreamWaitEvent(sb_, c->ev_front, 0));
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D;
-		if(prof) HIPCHK(hipEventRecord(ev[7], sb_));
 		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
 		// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
@@ -230,32 +236,28 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 			const int64_t seglen = (D + nseg - 1) / nseg;
 			nseg = (int)((D + seglen - 1) / seglen);
 			K4sArgs k4s{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, c->k_total, seglen, c->d_segstats };
-			hipLaunchKernelGGL(k_walk_spec, dim3((unsigned)(1 + 3 * (nseg - 1)), (unsigned)c->C), dim3(64), 0, sb_, k4s);
-			hipLaunchKernelGGL(k_walk_stitch, dim3((unsigned)c->C), dim3(64), 0, sb_, k4s);
+			LAUNCH_EV(k_walk_spec, dim3((unsigned)(1 + 3 * (nseg - 1)), (unsigned)c->C), dim3(64), sb_, EV(6), (hipEvent_t) nullptr, k4s);
+			LAUNCH_EV(k_walk_stitch, dim3((unsigned)c->C), dim3(64), sb_, (hipEvent_t) nullptr, EV(7), k4s);
 		} else {
-			hipLaunchKernelGGL(k_walk, dim3((unsigned)c->C), dim3(64), 0, sb_, k4);
+			LAUNCH_EV(k_walk, dim3((unsigned)c->C), dim3(64), sb_, EV(6), EV(7), k4);
 		}
-		if(prof) HIPCHK(hipEventRecord(ev[6], sb_));
 	}
 	HIPCHK(hipEventRecord(sl.ev_walk, sb_));
 	HIPCHK(hipStreamWaitEvent(sn_, sl.ev_walk, 0));
 	HIPCHK(hipStreamWaitEvent(s5_, sl.ev_walk, 0));
 	if(D > 0) {
-		if(prof) HIPCHK(hipEventRecord(ev[8], sn_));
 		K4bArgs k4b{ c->d_y, c->d_nf, sl.d_log, sl.d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfring, c->nf_ring - 1,
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist };
-		hipLaunchKernelGGL(k_nf_prepare, dim3((unsigned)c->C), dim3(64), 0, sn_, k4b);
+		LAUNCH_EV(k_nf_prepare, dim3((unsigned)c->C), dim3(64), sn_, EV(8), (hipEvent_t) nullptr, k4b);
 		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup - 1) / kNfGroup);
 		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, sn_, k4b);
-		hipLaunchKernelGGL(k_nf_finish, dim3((unsigned)c->C), dim3(64), 0, sn_, k4b);
-		if(prof) HIPCHK(hipEventRecord(ev[9], sn_));
+		LAUNCH_EV(k_nf_finish, dim3((unsigned)c->C), dim3(64), sn_, (hipEvent_t) nullptr, EV(9), k4b);
 		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
 		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl);
-		if(prof) HIPCHK(hipEventRecord(ev[4], s5_));
 		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
-		hipLaunchKernelGGL(k_burst, dim3(2048), dim3(64), 0, s5_, k5);
-		if(prof) { HIPCHK(hipEventRecord(ev[5], s5_)); sl.ev_valid = true; }
+		LAUNCH_EV(k_burst, dim3(2048), dim3(64), s5_, EV(10), EV(11), k5);
+		sl.ev_valid = prof; sl.ev_level = c->profiling;
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
 		hipLaunchKernelGGL(k_frame_finish, dim3(1024), dim3(64), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, (const OutCtl *)sl.d_ctl, (const Tables *)c->d_tab,
 		                   c->d_acnt, (const float *)c->d_nfring, c->nf_ring - 1);
@@ -634,7 +636,7 @@ int vdl2hip_statsd_lines(vdl2hip_ctx *c, const char *ns, char *out, size_t cap) 
 int vdl2hip_set_profiling(vdl2hip_ctx *c, int on) {
 	if(!c) return VDL2HIP_E_INVAL;
 	int r = collect_pending(c);
-	c->profiling = on != 0;
+	c->profiling = on < 0 ? 0 : on > 2 ? 2 : on;
 	return r == VDL2HIP_E_OVERFLOW ? VDL2HIP_OK : r;
 }
 

@@ -232,8 +232,9 @@ class Receiver:
         self._chk(self.L.vdl2hip_counters(self.h, chan, a), "vdl2hip_counters")
         return dict(zip(COUNTER_NAMES, list(a)))
 
-    def set_profiling(self, on: bool) -> None:
-        self._chk(self.L.vdl2hip_set_profiling(self.h, int(on)), "vdl2hip_set_profiling")
+    def set_profiling(self, level) -> None:
+        """0/False off, 1/True: time the channeliser kernel only, 2: every stage (a few percent slower)"""
+        self._chk(self.L.vdl2hip_set_profiling(self.h, int(level)), "vdl2hip_set_profiling")
 
     def stats(self) -> dict:
         s = Stats()

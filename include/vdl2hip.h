@@ -188,7 +188,8 @@ int  vdl2hip_set_avlc_filter(vdl2hip_ctx *ctx, int on);
  * statsd_initialize_counters_per_channel()).  `ns` is the namespace ("dumpvdl2" or "dumpvdl2.<station_id>").  Returns the
  * number of bytes written (excluding the terminating NUL) or VDL2HIP_E_TOOBIG if `cap` is too small (nothing is consumed). */
 int  vdl2hip_statsd_lines(vdl2hip_ctx *ctx, const char *ns, char *out, size_t cap);
-int  vdl2hip_set_profiling(vdl2hip_ctx *ctx, int on);   /* bracket kernels with HIP events on the ctx stream */
+int  vdl2hip_set_profiling(vdl2hip_ctx *ctx, int level); /* 0 off; 1 time the channeliser kernel (start/stop events attached to
+                                                          * its launch); 2 time every stage the same way (costs ~5 % throughput) */
 int  vdl2hip_get_stats(vdl2hip_ctx *ctx, vdl2hip_stats *out);
 void *vdl2hip_stream(vdl2hip_ctx *ctx);                 /* the hipStream_t all work is queued on */
 

@@ -15,7 +15,7 @@ freqs = synth.channel_plan(C, cf, max(8000, min(100000, 2000000 // C)))
 n = int(secs * 2100000)
 iq = (torch.randn(2 * n, device="cuda") * 300).to(torch.int16)
 rx = vdl2hip.Receiver(cf, freqs, 20, 1, 3.0, max_block_bytes=iq.numel() * 2)
-rx.set_profiling(True)
+rx.set_profiling(2)
 rx.feed_device(iq.data_ptr(), iq.numel() * 2); rx.drain_packed()      # cold launch, not counted
 s0 = rx.stats()
 for _ in range(reps):

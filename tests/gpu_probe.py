@@ -19,7 +19,7 @@ def compare(name, raw, cf, freqs, os_, fmt, max_ppm=0.0, chunks=None, max_block=
     t = time.time(); o.process(raw, block_bytes=1 << 24, nthreads=8); t_or = time.time() - t
     fo = o.frames()
     rx = vdl2hip.Receiver(cf, freqs, os_, fmt, max_ppm, max_block_bytes=max_block or raw.size)
-    rx.set_profiling(True)
+    rx.set_profiling(2)
     t = time.time()
     if chunks is None:
         rx.feed(raw)

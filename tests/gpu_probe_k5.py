@@ -11,7 +11,7 @@ L = vdl2hip.load_library(lib)
 cfg = workloads.config2(4.0)
 iq, bursts = synth.synthesize(cfg)
 rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), 20, 1, 0.0, max_block_bytes=iq.nbytes)
-rx.set_profiling(True)
+rx.set_profiling(2)
 rx.feed(iq); fr = rx.drain()
 a = (C.c_ulonglong * 16)()
 print("rc", L.vdl2hip_debug_k5_prof(a), "frames", len(fr), "bursts", len(bursts), "burst_ms", rx.stats()["burst_ms"], "walk_ms", rx.stats()["walk_ms"])
