@@ -123,6 +123,13 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 		if(hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) c->stats.walk_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) c->stats.nf_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[10], ev[11]) == hipSuccess) c->stats.burst_ms += ms;
+		if(getenv("VDL2HIP_GAPS")) {   // development: idle time of the front stream between its kernels
+			float g12 = 0, g23 = 0, g31 = -1;
+			(void)hipEventElapsedTime(&g12, ev[1], ev[2]); (void)hipEventElapsedTime(&g23, ev[3], ev[4]);
+			OutSlot &pv = c->slot[(sl.seq + kSlots - 1) % kSlots];
+			if(sl.seq > 0 && pv.ev_level >= 2) (void)hipEventElapsedTime(&g31, pv.ev[5], ev[0]);
+			fprintf(stderr, "gaps feed %llu: K1->K2 %.1f us, K2->K3 %.1f us, K3(prev)->K1 %.1f us\n", (unsigned long long)sl.seq, g12 * 1e3, g23 * 1e3, g31 * 1e3);
+		}
 		}
 	}
 	sl.ev_valid = false;
