@@ -42,7 +42,7 @@ struct OutSlot {
 	OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
 	OutCtl *h_ctl = nullptr;               // pinned
-	hipEvent_t done = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
+	hipEvent_t done = nullptr, ev_front = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
 	bool pending = false, ev_valid = false; int ev_level = 0;
 	uint64_t seq = 0;
 };
@@ -72,7 +72,7 @@ struct vdl2hip_ctx {
 	SpecOut *d_spec = nullptr; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
-	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr; hipEvent_t ev_front = nullptr;
+	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr;
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool overflowed = false, avlc_filter = false;
 	std::vector<uint64_t> statsd_prev;
@@ -119,7 +119,7 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 		if(hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->stats.chanfir_ms += ms;
 		if(sl.ev_level >= 2) {
 		if(hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.phase_ms += ms;
-		if(hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) c->stats.sync_ms += ms;
+		if(hipEventElapsedTime(&ms, ev[4], sl.ev_front) == hipSuccess) c->stats.sync_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) c->stats.walk_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) c->stats.nf_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[10], ev[11]) == hipSuccess) c->stats.burst_ms += ms;
@@ -127,7 +127,7 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 			float g12 = 0, g23 = 0, g31 = -1;
 			(void)hipEventElapsedTime(&g12, ev[1], ev[2]); (void)hipEventElapsedTime(&g23, ev[3], ev[4]);
 			OutSlot &pv = c->slot[(sl.seq + kSlots - 1) % kSlots];
-			if(sl.seq > 0 && pv.ev_level >= 2) (void)hipEventElapsedTime(&g31, pv.ev[5], ev[0]);
+			if(sl.seq > 0 && pv.ev_level >= 2) (void)hipEventElapsedTime(&g31, pv.ev_front, ev[0]);
 			fprintf(stderr, "gaps feed %llu: K1->K2 %.1f us, K2->K3 %.1f us, K3(prev)->K1 %.1f us\n", (unsigned long long)sl.seq, g12 * 1e3, g23 * 1e3, g31 * 1e3);
 		}
 		}
@@ -224,15 +224,17 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
 		K3Args k3{ c->d_phi, c->d_pf, c->d_cand, c->d_tab, nbase, k1, c->cap, c->cap - 1 };
-		LAUNCH_EV(k_sync, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(256), st, EV(4), EV(5), k3);
+		// K3's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less on the
+		// front stream than a separate hipEventRecord
+		LAUNCH_EV(k_sync, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(256), st, EV(4), sl.ev_front, k3);
 	}
 	// The burst-rate back end runs on three more streams, so that consecutive feeds overlap stage by stage:
 	//   stream_back   K4   walk(i) -> walk(i+1) -> ...             (each needs the previous one's FSM state)
 	//   stream_nf     K4b  noise floor of feed i, after walk(i)    (each needs the previous one's NfState)
 	//   stream_burst  K5   bursts of feed i, after walk(i); the frames get their noise-floor figure when K4b(i) is done
 	hipStream_t sn_ = c->stream_nf, s5_ = c->stream_burst;
-	HIPCHK(hipEventRecord(c->ev_front, st));
-	HIPCHK(hipStreamWaitEvent(sb_, c->ev_front, 0));
+	if(D <= 0) HIPCHK(hipEventRecord(sl.ev_front, st));
+	HIPCHK(hipStreamWaitEvent(sb_, sl.ev_front, 0));
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D;
 		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
@@ -323,11 +325,11 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 		if(sl.h_ctl) (void)hipHostFree(sl.h_ctl);
 		if(sl.done) (void)hipEventDestroy(sl.done);
 		if(sl.ev_walk) (void)hipEventDestroy(sl.ev_walk);
+		if(sl.ev_front) (void)hipEventDestroy(sl.ev_front);
 		if(sl.ev_nf) (void)hipEventDestroy(sl.ev_nf);
 		for(int i = 0; i < kNumEv; i++) if(sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
 	}
 	if(c->h_ctl_template) (void)hipHostFree(c->h_ctl_template);
-	if(c->ev_front) (void)hipEventDestroy(c->ev_front);
 	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
 	if(c->stream_nf) { (void)hipStreamSynchronize(c->stream_nf); (void)hipStreamDestroy(c->stream_nf); }
 	if(c->stream_burst) { (void)hipStreamSynchronize(c->stream_burst); (void)hipStreamDestroy(c->stream_burst); }
@@ -386,10 +388,10 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_nf, hipStreamNonBlocking, prio_high));
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_burst, hipStreamNonBlocking, prio_high));
 	}
-	DEV_CHK(hipEventCreateWithFlags(&c->ev_front, hipEventDisableTiming));
 	for(auto &sl : c->slot) {
 		DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i]));
 		DEV_CHK(hipEventCreateWithFlags(&sl.ev_walk, hipEventDisableTiming)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_nf, hipEventDisableTiming));
+		DEV_CHK(hipEventCreate(&sl.ev_front));
 	}
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
 	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count);
