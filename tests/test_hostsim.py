@@ -79,3 +79,24 @@ def test_reference_wav(oracle_mod, golden_wav):
     for k in range(0, D, 7001):
         hs.feed(tr[:, k:min(D, k + 7001), :])
     assert_frames_equal(o.frames(), hs.frames(), label="wav")
+
+
+@pytest.mark.parametrize("name", ["config2_1s", "dirty25k_1s", "os10_noisy_1s", "config5_0p4s"])
+def test_segmented_walk_random_geometry(oracle_mod, name):
+    """Seeded sweep over segment lengths, segment counts and feed chunkings: the speculative walk must give the
+    oracle's frames and counters for every geometry (boundaries land in bursts, headers, fresh intervals, feed ends)."""
+    cfg, iq, _, _ = cases.load(name)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    tot = {"adopted": 0, "walked": 0}
+    for trial in range(5):
+        seg_min = int(rng.choice([64, 150, 400, 1000, 2500, 6000]))
+        seg_max = int(rng.integers(2, 33))
+        chunks = None if rng.random() < 0.4 else (int(rng.integers(2 * seg_min, 6 * seg_min)), int(rng.integers(8 * seg_min, 40 * seg_min)))
+        fo, fh, co, ch = run_both(oracle_mod, cfg, iq, chunks, cap_log2=19 if chunks else None, segments=(seg_min, seg_max))
+        label = f"{name} seg_min={seg_min} seg_max={seg_max} chunks={chunks}"
+        assert_frames_equal(fo, fh, label=label)
+        assert co == ch, label
+        st = run_both.last_segment_stats
+        tot["adopted"] += st["adopted"]; tot["walked"] += st["walked"]
+    assert tot["adopted"] > 0
