@@ -246,11 +246,17 @@ __global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
 			cf32 *yout = a.y + (size_t)(cbase + c) * a.cap;
 			// outputs of the run, completed with the decayed run-start state (cP[i] = (c0,c1) P^(i+1))
 			const float f0r = __builtin_fmaf(bf.cP[0][0], T0r, __builtin_fmaf(bf.cP[0][1], T1r, ya[c][0])), f0i = __builtin_fmaf(bf.cP[0][0], T0i, __builtin_fmaf(bf.cP[0][1], T1i, ya[c][1]));
-			if(cvalid && kloc < a.D) yout[(uint32_t)(a.k0 + kloc) & a.mask] = cf32{f0r, f0i};
 			if(R > 1) {
 				const float f1r = __builtin_fmaf(bf.cP[1][0], T0r, __builtin_fmaf(bf.cP[1][1], T1r, yb[c][0])), f1i = __builtin_fmaf(bf.cP[1][0], T0i, __builtin_fmaf(bf.cP[1][1], T1i, yb[c][1]));
-				if(cvalid && kloc + 1 < a.D) yout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = cf32{f1r, f1i};
-			}
+				const uint32_t s0 = (uint32_t)(a.k0 + kloc) & a.mask;
+				if(cvalid && kloc + 1 < a.D && (s0 & 1u) == 0) {
+					// both outputs of the run in one 16-byte store: a wavefront writes 1 KiB of contiguous, fully used lines
+					*reinterpret_cast<float4 *>(yout + s0) = make_float4(f0r, f0i, f1r, f1i);
+				} else {
+					if(cvalid && kloc < a.D) yout[s0] = cf32{f0r, f0i};
+					if(cvalid && kloc + 1 < a.D) yout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = cf32{f1r, f1i};
+				}
+			} else if(cvalid && kloc < a.D) yout[(uint32_t)(a.k0 + kloc) & a.mask] = cf32{f0r, f0i};
 			if(cvalid && lane == lb && (rem <= L || ts == a.tiles - 1)) {
 				// state at the end of the segment's valid part, with zero state at the segment start
 				const float *Pp = bf.Pp[ib + 1];
