@@ -1162,16 +1162,24 @@ VDL2_HD void finish_frame(OutFrame &f, const uint8_t *pool, const Tables &T, uns
 // Burst decoder: one wavefront per burst
 // ======================================================================
 struct BurstShared {
-	uint8_t sym[kMaxSyms];             // 3-bit Gray values, one per symbol
-	uint8_t oct[kMaxOctets];           // received data + FEC octets (still interleaved)
+	// sym/oct are dead once the RS table is filled; tpos/tG are first written by the un-stuffer: they share storage,
+	// which keeps a workgroup of this latency-bound kernel from taking LDS that the channeliser of the next feed wants
+	union {
+		struct {
+			uint8_t sym[kMaxSyms];     // 3-bit Gray values, one per symbol
+			uint8_t oct[kMaxOctets];   // received data + FEC octets (still interleaved)
+		};
+		struct {
+			uint16_t tpos[kMaxTerm];   // terminator positions, ascending
+			uint16_t tG[kMaxTerm];     // kept bits before each terminator
+		};
+	};
 	uint8_t tab[kMaxBlocks * 256];     // de-interleaved RS blocks, row stride 256
 	uint32_t xw[kMaxWords + 1];        // corrected data as 32-bit words, stream bit 32w+k = bit k of xw[w]
 	uint32_t keptw[kMaxWords + 1];     // bits that survive zero-deletion (valid and not a stuffed zero)
 	uint32_t termw[kMaxWords];         // flag terminators (a 0 after exactly six 1s)
 	uint16_t cumk[kMaxWords + 1];      // kept bits before word w
 	uint16_t cumt[kMaxWords + 1];      // terminators before word w
-	uint16_t tpos[kMaxTerm];           // terminator positions, ascending
-	uint16_t tG[kMaxTerm];             // kept bits before each terminator
 	uint32_t lanek[64], lanet[64];
 	int32_t  laneerr[64];
 	int32_t  flag_err[64];
