@@ -93,6 +93,21 @@ def main():
             # the capture lies striped across the GPUs: every rank keeps its stripe of the block resident
             b0, nb = vdist.stripe_of(nbytes, world, rank)
             stripe = bufs[0].view(torch.uint8)[b0:b0 + nb].clone()
+            # dry run (untimed): the all-gather must rebuild the block bit for bit on every rank, else fall back to broadcast
+            ok = 1
+            try:
+                w = vdist.allgather_block(bufs[1], stripe, async_op=True)
+                w.wait()
+                torch.cuda.synchronize()
+                ok = int(torch.equal(bufs[1], bufs[0]))
+            except Exception as e:            # noqa: BLE001 - any backend complaint means "use the other exchange"
+                print(f"[bench rank {rank}] all-gather exchange unavailable ({e}); using broadcast", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                stripe = None
+                args.exchange = "broadcast"
         else:
             args.exchange = "broadcast"
 
