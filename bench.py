@@ -85,31 +85,13 @@ def main():
 
     state = {"i": 0, "work": None}
     front = torch.cuda.ExternalStream(rx.stream()) if world > 1 else None
-    stripe = None
+    exchange = None
     if world > 1:       # block 0 arrives before the first step
         vdist.broadcast_block(bufs[0], src=0)
         torch.cuda.synchronize()
-        if args.exchange == "allgather" and nbytes % world == 0:
-            # the capture lies striped across the GPUs: every rank keeps its stripe of the block resident
-            b0, nb = vdist.stripe_of(nbytes, world, rank)
-            stripe = bufs[0].view(torch.uint8)[b0:b0 + nb].clone()
-            # dry run (untimed): the all-gather must rebuild the block bit for bit on every rank, else fall back to broadcast
-            ok = 1
-            try:
-                w = vdist.allgather_block(bufs[1], stripe, async_op=True)
-                w.wait()
-                torch.cuda.synchronize()
-                ok = int(torch.equal(bufs[1], bufs[0]))
-            except Exception as e:            # noqa: BLE001 - any backend complaint means "use the other exchange"
-                print(f"[bench rank {rank}] all-gather exchange unavailable ({e}); using broadcast", file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                stripe = None
-                args.exchange = "broadcast"
-        else:
-            args.exchange = "broadcast"
+        # default: the capture lies striped across the GPUs and is all-gathered; dry-run inside, falls back to broadcast
+        exchange = vdist.BlockExchange(bufs[0], mode=args.exchange, src=0, scratch=bufs[1])
+        args.exchange = exchange.mode
 
     def step():
         """One pass of the hot path over one 16 s block; with N>1 the RCCL exchange that puts the NEXT block on every GPU
@@ -122,10 +104,7 @@ def main():
             # `nxt` was the input of block i-1: its channeliser (front stream of the library) must have finished
             # reading it before RCCL overwrites it
             torch.cuda.current_stream().wait_event(front.record_event())
-            if stripe is not None:
-                state["work"] = vdist.allgather_block(nxt, stripe, async_op=True)
-            else:
-                state["work"] = dist.broadcast(nxt.view(torch.uint8), src=0, async_op=True)
+            state["work"] = exchange.start(nxt)
         rx.feed_device(cur.data_ptr(), nbytes)
         out = rx.drain_packed()            # every frame of the step copied to host memory (records + octets)
         if world > 1:

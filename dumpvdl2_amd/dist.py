@@ -53,6 +53,51 @@ def allgather_block(out, stripe, group=None, async_op: bool = False):
     return dist.all_gather_into_tensor(o, s, group=group, async_op=async_op)
 
 
+class BlockExchange:
+    """The path's only exchange, as bench.py drives it: puts the next raw IQ block on every rank while the current one is being
+    demodulated.  `mode` "allgather": every rank keeps its stripe of the capture resident and the block is rebuilt with one
+    all-gather; "broadcast": rank `src` sends it whole.  `block` is the block as it already lies on this rank (any rank's copy
+    is complete after the initial broadcast); on a backend/shape that cannot all-gather, or if the dry run does not rebuild
+    the block bit for bit on every rank, the exchange falls back to broadcast on all ranks together."""
+
+    def __init__(self, block, mode: str = "allgather", src: int = 0, group=None, scratch=None):
+        import torch
+        import torch.distributed as dist
+        self.group, self.src, self.mode, self.stripe = group, src, "broadcast", None
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        nbytes = block.numel() * block.element_size()
+        if mode == "allgather" and self.world > 1 and nbytes % self.world == 0:
+            b0, nb = stripe_of(nbytes, self.world, rank)
+            self.stripe = block.view(torch.uint8)[b0:b0 + nb].clone()
+            ok = 1
+            try:
+                dst = scratch if scratch is not None else torch.empty_like(block)
+                w = allgather_block(dst, self.stripe, group=group, async_op=True)
+                w.wait()
+                if block.is_cuda:
+                    torch.cuda.synchronize()
+                ok = int(torch.equal(dst.view(torch.uint8), block.view(torch.uint8)))
+            except Exception:                  # noqa: BLE001 - any backend complaint means "use the other exchange"
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=block.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()):
+                self.mode = "allgather"
+            else:
+                self.stripe = None
+
+    def start(self, dst):
+        """Begin filling `dst` (full-size block buffer) on every rank; returns the async work handle (None for one rank)."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return None
+        if self.mode == "allgather":
+            return allgather_block(dst, self.stripe, group=self.group, async_op=True)
+        return dist.broadcast(dst.view(torch.uint8) if dst.dtype != torch.uint8 else dst, src=self.src, group=self.group, async_op=True)
+
+
 def merge_frames(per_rank: Sequence[Sequence[dict]]) -> List[dict]:
     """Deterministic global order of frames from all shards: (end_sample, chan, idx)."""
     out = [f for fr in per_rank for f in fr]

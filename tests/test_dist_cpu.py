@@ -42,6 +42,17 @@ def _worker(rank, world, port, q):
     w.wait()
     assert torch.equal(rebuilt, torch.from_numpy(iq))
     block = rebuilt
+    # the exchange object bench.py uses, in both modes: the "next block" lands complete in the destination on every rank
+    for mode in ("allgather", "broadcast"):
+        ex = vd.BlockExchange(block, mode=mode, src=0)
+        assert ex.mode == mode
+        nxt = torch.zeros_like(block)
+        if mode == "broadcast" and rank == 0:
+            nxt.copy_(block)                                             # broadcast: the source rank's buffer holds the block
+        ex.start(nxt).wait()
+        assert torch.equal(nxt, torch.from_numpy(iq)), mode
+    odd = torch.arange(7, dtype=torch.uint8)                            # 7 bytes do not split into 2 stripes -> broadcast
+    assert vd.BlockExchange(odd, mode="allgather").mode == "broadcast"
     first, count = vd.shard_channels(len(cfg.freqs), world, rank)
     o = po.Oracle(cfg.centerfreq, list(cfg.freqs)[first:first + count], oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
     o.process(block.numpy().view(np.uint8), block_bytes=1 << 24)
