@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--duration", type=float, default=16.0, help="seconds of 2.1 MS/s signal per step")
     ap.add_argument("--channels", type=int, default=8, help="channels per GPU (config2 only)")
