@@ -66,6 +66,15 @@ struct K1Args {
 	float4 *seg_end;           // [nchan][nseg_cap] zero-start state at the end of each workgroup segment
 	const float4 *qpow;        // [64] Q^(l+1) row-major 2x2, Q = P^R
 	int32_t  tiles;            // tiles per workgroup segment
+	// fused phase stage (fuse != 0): K1 also applies the segment-start fix-up and writes phi, K2 is not launched
+	int32_t  fuse;
+	float *phi;                // [nchan][cap]
+	const float4 *carry_in;    // [nchan] true filter state at the end of the previous feed
+	float4 *carry_out;         // [nchan] ... at the end of this one
+	const BlockForm *bfd;      // full tables (cP[kFixW], Ppow[kFixW+1]) in device memory
+	unsigned long long *seg_pub; // [nchan][nseg_cap][4]: (epoch << 32 | float bits) of the zero-start segment end state
+	uint32_t epoch;
+	uint32_t *sync_timeouts;   // sticky count of look-back waits that gave up (never expected)
 	uint32_t cap, mask, nseg_cap;
 };
 
@@ -83,13 +92,35 @@ __device__ __forceinline__ void load_sample(const K1Args &a, int64_t s, float &r
 	}
 }
 
+// phases of one lane's run (R <= 2 consecutive outputs starting at feed-local index kloc)
+// atan2 out of line (two independent evaluations per call): inlined into the channeliser's epilogue once per channel it
+// pushes the kernel deep into scratch; a rolled single-instance loop was no better (tests/gpu_k1_variants.sh)
+__device__ __attribute__((noinline)) float2 phase_call2(float r0, float i0, float r1, float i1) {
+	return make_float2(phase_of(cf32{r0, i0}), phase_of(cf32{r1, i1}));
+}
+
+template<int R>
+__device__ __forceinline__ void store_phases(const K1Args &a, int ch, bool cvalid, int64_t kloc, float p0, float p1) {
+	float *pout = a.phi + (size_t)ch * a.cap;
+	const uint32_t s0 = (uint32_t)(a.k0 + kloc) & a.mask;
+	if(R > 1 && cvalid && kloc + 1 < a.D && (s0 & 1u) == 0) *reinterpret_cast<float2 *>(pout + s0) = make_float2(p0, p1);
+	else {
+		if(cvalid && kloc < a.D) pout[s0] = p0;
+		if(R > 1 && cvalid && kloc + 1 < a.D) pout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = p1;
+	}
+}
+
 // One workgroup = 4 waves that walk `a.tiles` consecutive time tiles (64*R blocks of OS samples each, staged in LDS
 // and shared by the waves); each wave owns CR channels; each lane owns R consecutive decimated outputs per tile.
 // Within a workgroup's segment the filter state is carried from tile to tile in registers, so the outputs it
 // stores are final except for the (decayed) state at the segment start, which K2 adds to the first kFixW of them.
 // OS == 0 selects the generic (run-time oversample) build of the same code.
+#ifndef VDL2_K1_MIN_BLOCKS
+#define VDL2_K1_MIN_BLOCKS 6
+#endif
 template<int OS, int R, int CR>
-__global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
+__global__ __launch_bounds__(256, (CR >= 4 ? 4 : VDL2_K1_MIN_BLOCKS)) void k_chanfir(K1Args a) {
+	static_assert(64 * R == kFixW || R == 1, "the fused fix-up assumes the fix window is the segment's first tile");
 	static_assert(R >= 1 && R <= 2, "the run's outputs are held in two register pairs");
 	extern __shared__ __align__(16) unsigned char smem[];
 	const int os = OS ? OS : a.os;
@@ -117,8 +148,13 @@ __global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
 	const int L = 64 * R;                         // decimated outputs per tile
 
 	uint32_t dph[CR];
-	float4 *carry = (float4 *)(park + wave * (2 * CR * 4));    // state carried into the current tile (zero at the segment start)
+	float4 *carry = (float4 *)(park + wave * (4 * CR * 4));    // state carried into the current tile (zero at the segment start)
 	float4 *svp = carry + CR;                                   // zero-start state after the feed's last valid block
+	float4 *sendp = svp + CR;                                   // zero-start state at the end of the segment (what seg_end gets)
+	float4 *tsp = sendp + CR;                                   // true state at the segment start (fused fix-up)
+	float hold[CR][4];                                          // fused: tile 0's outputs wait here for the segment-start state
+	#pragma unroll
+	for(int c = 0; c < CR; c++) hold[c][0] = hold[c][1] = hold[c][2] = hold[c][3] = 0.f;
 	#pragma unroll
 	for(int c = 0; c < CR; c++) {
 		const int ch = cbase + c < a.nchan ? cbase + c : a.nchan - 1;
@@ -249,14 +285,25 @@ __global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
 			if(R > 1) {
 				const float f1r = __builtin_fmaf(bf.cP[1][0], T0r, __builtin_fmaf(bf.cP[1][1], T1r, yb[c][0])), f1i = __builtin_fmaf(bf.cP[1][0], T0i, __builtin_fmaf(bf.cP[1][1], T1i, yb[c][1]));
 				const uint32_t s0 = (uint32_t)(a.k0 + kloc) & a.mask;
-				if(cvalid && kloc + 1 < a.D && (s0 & 1u) == 0) {
-					// both outputs of the run in one 16-byte store: a wavefront writes 1 KiB of contiguous, fully used lines
-					*reinterpret_cast<float4 *>(yout + s0) = make_float4(f0r, f0i, f1r, f1i);
+				if(a.fuse && ts == 0) {
+					hold[c][0] = f0r; hold[c][1] = f0i; hold[c][2] = f1r; hold[c][3] = f1i;      // stored after the fix-up below
 				} else {
-					if(cvalid && kloc < a.D) yout[s0] = cf32{f0r, f0i};
-					if(cvalid && kloc + 1 < a.D) yout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = cf32{f1r, f1i};
+					if(cvalid && kloc + 1 < a.D && (s0 & 1u) == 0) {
+						// both outputs of the run in one 16-byte store: a wavefront writes 1 KiB of contiguous, fully used lines
+						*reinterpret_cast<float4 *>(yout + s0) = make_float4(f0r, f0i, f1r, f1i);
+					} else {
+						if(cvalid && kloc < a.D) yout[s0] = cf32{f0r, f0i};
+						if(cvalid && kloc + 1 < a.D) yout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = cf32{f1r, f1i};
+					}
+					if(a.fuse) { const float2 pp = phase_call2(f0r, f0i, f1r, f1i); store_phases<R>(a, cbase + c, cvalid, kloc, pp.x, pp.y); }
 				}
-			} else if(cvalid && kloc < a.D) yout[(uint32_t)(a.k0 + kloc) & a.mask] = cf32{f0r, f0i};
+			} else {
+				if(a.fuse && ts == 0) { hold[c][0] = f0r; hold[c][1] = f0i; }
+				else {
+					if(cvalid && kloc < a.D) yout[(uint32_t)(a.k0 + kloc) & a.mask] = cf32{f0r, f0i};
+					if(a.fuse) { const float2 pp = phase_call2(f0r, f0i, 1.f, 0.f); store_phases<R>(a, cbase + c, cvalid, kloc, pp.x, 0.f); }
+				}
+			}
 			if(cvalid && lane == lb && (rem <= L || ts == a.tiles - 1)) {
 				// state at the end of the segment's valid part, with zero state at the segment start
 				const float *Pp = bf.Pp[ib + 1];
@@ -265,9 +312,73 @@ __global__ __launch_bounds__(256, (CR >= 4 ? 4 : 6)) void k_chanfir(K1Args a) {
 				e.x = sv.x + (Pp[0] * T0r + Pp[1] * T1r); e.y = sv.y + (Pp[0] * T0i + Pp[1] * T1i);
 				e.z = sv.z + (Pp[2] * T0r + Pp[3] * T1r); e.w = sv.w + (Pp[2] * T0i + Pp[3] * T1i);
 				a.seg_end[(size_t)(cbase + c) * a.nseg_cap + seg] = e;
+				sendp[c] = e;
+				if(a.fuse) {
+					// publish for the next segment's workgroup: each word carries the feed's epoch, so no flag and no fence
+					// (an agent-scope release would write back the whole L2 of this XCD)
+					unsigned long long *pub = a.seg_pub + ((size_t)(cbase + c) * a.nseg_cap + seg) * 4;
+					const unsigned long long ep = (unsigned long long)a.epoch << 32;
+					__hip_atomic_store(pub + 0, ep | __float_as_uint(e.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(pub + 1, ep | __float_as_uint(e.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(pub + 2, ep | __float_as_uint(e.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(pub + 3, ep | __float_as_uint(e.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 			}
 			// carry into the next tile = state at the end of lane 63's run
 			if(lane == 63) carry[c] = make_float4(t0r[c], t0i[c], t1r[c], t1i[c]);
+		}
+	}
+	if(!a.fuse || !wave_active) return;
+
+	// ---- fused K2: the first tile's outputs get the decayed state of the segment start, then every output its phase ----
+	// The state at the start of segment s is the zero-start state at the end of segment s-1 (a segment is >= kFixW blocks
+	// long, older history has decayed below fp32 resolution), which the workgroup of s-1 publishes before it waits for
+	// anything itself (in the epilogue of its last tile): a one-step look-back, no chain.  Workgroups are dispatched in
+	// block-id order and s-1 always has a smaller block id, so the producer is running or done whenever a consumer waits.
+	if(seg == 0) {
+		if(lane < CR) tsp[lane] = a.carry_in[cbase + lane < a.nchan ? cbase + lane : a.nchan - 1];
+	} else if(lane < 4 * CR) {
+		const int c = lane >> 2, ch = cbase + c < a.nchan ? cbase + c : a.nchan - 1;
+		const unsigned long long *src = a.seg_pub + ((size_t)ch * a.nseg_cap + seg - 1) * 4 + (lane & 3);
+		unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for(int spins = 0; (uint32_t)(w >> 32) != a.epoch; spins++) {
+			if(spins > (1 << 22)) { atomicAdd(a.sync_timeouts, 1u); break; }
+			__builtin_amdgcn_s_sleep(8);
+			w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		reinterpret_cast<float *>(tsp)[lane] = __uint_as_float((uint32_t)w);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const int64_t seglen = (int64_t)a.tiles * L;
+	const int64_t kloc0 = (int64_t)seg * seglen + (int64_t)lane * R;          // this lane's outputs in the segment's first tile
+	#pragma unroll
+	for(int c = 0; c < CR; c++) {
+		const bool cvalid = cbase + c < a.nchan;
+		const float4 ts = tsp[c];
+		const int i0 = lane * R;
+		// exactly K2's arithmetic: v += cP[i][0] * ts.(x|y) + cP[i][1] * ts.(z|w)
+		float v0r = hold[c][0], v0i = hold[c][1], v1r = hold[c][2], v1i = hold[c][3];
+		v0r += a.bfd->cP[i0][0] * ts.x + a.bfd->cP[i0][1] * ts.z; v0i += a.bfd->cP[i0][0] * ts.y + a.bfd->cP[i0][1] * ts.w;
+		if(R > 1) { v1r += a.bfd->cP[i0 + 1][0] * ts.x + a.bfd->cP[i0 + 1][1] * ts.z; v1i += a.bfd->cP[i0 + 1][0] * ts.y + a.bfd->cP[i0 + 1][1] * ts.w; }
+		cf32 *yout = a.y + (size_t)(cbase + c) * a.cap;
+		const uint32_t s0 = (uint32_t)(a.k0 + kloc0) & a.mask;
+		if(R > 1 && cvalid && kloc0 + 1 < a.D && (s0 & 1u) == 0) *reinterpret_cast<float4 *>(yout + s0) = make_float4(v0r, v0i, v1r, v1i);
+		else {
+			if(cvalid && kloc0 < a.D) yout[s0] = cf32{v0r, v0i};
+			if(R > 1 && cvalid && kloc0 + 1 < a.D) yout[(uint32_t)(a.k0 + kloc0 + 1) & a.mask] = cf32{v1r, v1i};
+		}
+		{ const float2 pp = phase_call2(v0r, v0i, v1r, v1i); store_phases<R>(a, cbase + c, cvalid, kloc0, pp.x, pp.y); }
+		// the filter state handed to the next feed (K2's k == D-1 branch)
+		if(cvalid && lane == 0 && (int64_t)(seg + 1) * seglen >= a.D) {
+			const int64_t len = a.D - (int64_t)seg * seglen;
+			float4 e = sendp[c];
+			if(len <= kFixW) {
+				const float *Pp = a.bfd->Ppow[len];
+				e.x += Pp[0] * ts.x + Pp[1] * ts.z; e.y += Pp[0] * ts.y + Pp[1] * ts.w;
+				e.z += Pp[2] * ts.x + Pp[3] * ts.z; e.w += Pp[2] * ts.y + Pp[3] * ts.w;
+			}
+			a.carry_out[cbase + c] = e;
 		}
 	}
 }

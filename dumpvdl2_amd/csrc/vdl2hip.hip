@@ -43,7 +43,7 @@ struct OutSlot {
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
 	OutCtl *h_ctl = nullptr;               // pinned
 	hipEvent_t done = nullptr, ev_front = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
-	bool pending = false, ev_valid = false; int ev_level = 0;
+	bool pending = false, ev_valid = false, fused = false; int ev_level = 0;
 	uint64_t seq = 0;
 };
 
@@ -65,6 +65,7 @@ struct vdl2hip_ctx {
 	float4 *d_segend = nullptr; uint32_t nseg_cap = 0;
 	float4 *d_qpow = nullptr;
 	float4 *d_tcarry[2] = {nullptr, nullptr}; int tcarry_sel = 0;
+	unsigned long long *d_segpub = nullptr; uint32_t *d_synctmo = nullptr; bool fuse_k2 = true;   // K2 fused into K1 (one-step look-back between segments)
 	WalkState *d_ws = nullptr; unsigned long long *d_cnt = nullptr, *d_acnt = nullptr;
 	NfState *d_nf = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
 	float *d_nfring = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0, nf_ring = 0;
@@ -118,14 +119,14 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 		float ms = 0.f;
 		if(hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->stats.chanfir_ms += ms;
 		if(sl.ev_level >= 2) {
-		if(hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.phase_ms += ms;
+		if(!sl.fused && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.phase_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[4], sl.ev_front) == hipSuccess) c->stats.sync_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) c->stats.walk_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) c->stats.nf_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[10], ev[11]) == hipSuccess) c->stats.burst_ms += ms;
 		if(getenv("VDL2HIP_GAPS")) {   // development: idle time of the front stream between its kernels
 			float g12 = 0, g23 = 0, g31 = -1;
-			(void)hipEventElapsedTime(&g12, ev[1], ev[2]); (void)hipEventElapsedTime(&g23, ev[3], ev[4]);
+			if(!sl.fused) { (void)hipEventElapsedTime(&g12, ev[1], ev[2]); (void)hipEventElapsedTime(&g23, ev[3], ev[4]); } else (void)hipEventElapsedTime(&g23, ev[1], ev[4]);
 			OutSlot &pv = c->slot[(sl.seq + kSlots - 1) % kSlots];
 			if(sl.seq > 0 && pv.ev_level >= 2) (void)hipEventElapsedTime(&g31, pv.ev_front, ev[0]);
 			fprintf(stderr, "gaps feed %llu: K1->K2 %.1f us, K2->K3 %.1f us, K3(prev)->K1 %.1f us\n", (unsigned long long)sl.seq, g12 * 1e3, g23 * 1e3, g31 * 1e3);
@@ -189,6 +190,8 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	a.fmt = c->fmt; a.nchan = c->C; a.os = c->os; a.nseg = 0; a.gy = 1;
 	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.seg_end = c->d_segend;
 	a.qpow = c->d_qpow; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap;
+	a.fuse = c->fuse_k2 && 64 * c->run == kFixW; a.phi = c->d_phi; a.carry_in = c->d_tcarry[c->tcarry_sel]; a.carry_out = c->d_tcarry[c->tcarry_sel ^ 1];
+	a.bfd = c->d_bf; a.seg_pub = c->d_segpub; a.epoch = (uint32_t)(c->feed_no + 1); a.sync_timeouts = c->d_synctmo;
 	{
 		// tiles per workgroup segment: long segments save K2 work, but the grid should still offer several thousand
 		// workgroups (measured: tests/gpu_k1_tiles.sh - 2 is best at 8 channels, 8 at 256)
@@ -214,9 +217,11 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		} else {
 			launch_chanfir<0, kRunGeneric>(c, a, c->cr, lds, e0, e1);
 		}
-		K2Args k2{ c->d_y, c->d_phi, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
-		           c->k_total, D, c->cap, c->cap - 1, c->nseg_cap, seglen * a.tiles };
-		LAUNCH_EV(k_phase, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), st, EV(2), EV(3), k2);
+		if(!a.fuse) {
+			K2Args k2{ c->d_y, c->d_phi, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
+			           c->k_total, D, c->cap, c->cap - 1, c->nseg_cap, seglen * a.tiles };
+			LAUNCH_EV(k_phase, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), st, EV(2), EV(3), k2);
+		}
 		c->tcarry_sel ^= 1;
 	}
 	if(nrem) hipLaunchKernelGGL(k_carry, dim3(1), dim3(64), 0, st, a, (void *)c->d_carry[c->carry_sel ^ 1], nrem);
@@ -266,7 +271,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
 		LAUNCH_EV(k_burst, dim3(2048), dim3(64), s5_, EV(10), EV(11), k5);
-		sl.ev_valid = prof; sl.ev_level = c->profiling;
+		sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0;
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
 		hipLaunchKernelGGL(k_frame_finish, dim3(1024), dim3(64), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, (const OutCtl *)sl.d_ctl, (const Tables *)c->d_tab,
 		                   c->d_acnt, (const float *)c->d_nfring, c->nf_ring - 1);
@@ -318,7 +323,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt };
+	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
 		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl, sl.d_log, sl.d_nlog };
 		for(void *p : q) if(p) (void)hipFree(p);
@@ -403,6 +408,9 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_segend, (size_t)count * c->nseg_cap * sizeof(float4));
 	DEV_ALLOC(c->d_qpow, 64 * sizeof(float4));
 	DEV_ALLOC(c->d_tcarry[0], count * sizeof(float4)); DEV_ALLOC(c->d_tcarry[1], count * sizeof(float4));
+	DEV_ALLOC(c->d_segpub, (size_t)count * c->nseg_cap * 4 * 8); DEV_ALLOC(c->d_synctmo, 4);
+	DEV_CHK(hipMemset(c->d_segpub, 0, (size_t)count * c->nseg_cap * 4 * 8)); DEV_CHK(hipMemset(c->d_synctmo, 0, 4));
+	c->fuse_k2 = getenv("VDL2HIP_NO_FUSE") == nullptr;
 	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, (size_t)count * kNumCounters * 8);
 	DEV_ALLOC(c->d_acnt, (size_t)count * kNumAvlcCounters * 8);
 	// a decodable burst occupies >= 22 symbols = 220 decimated samples (header + 3 data + 2 FEC octets)
@@ -656,6 +664,9 @@ int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) {
 		std::vector<uint32_t> ss((size_t)c->C * 2);
 		if(hipMemcpy(ss.data(), c->d_segstats, ss.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return VDL2HIP_E_DEVICE;
 		c->stats.seg_adopted = c->stats.seg_walked = 0;
+		uint32_t tmo = 0;
+		if(hipMemcpy(&tmo, c->d_synctmo, 4, hipMemcpyDeviceToHost) != hipSuccess) return VDL2HIP_E_DEVICE;
+		c->stats.front_sync_timeouts = tmo;
 		for(int i = 0; i < c->C; i++) { c->stats.seg_adopted += ss[2 * i]; c->stats.seg_walked += ss[2 * i + 1]; }
 	}
 	*out = c->stats;

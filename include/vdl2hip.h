@@ -130,6 +130,7 @@ typedef struct {
 	uint64_t frames;            /* frames produced */
 	uint64_t seg_adopted;       /* segmented walk: speculative segments adopted ... */
 	uint64_t seg_walked;        /* ... and segments walked sequentially because a burst straddled their start */
+	uint64_t front_sync_timeouts; /* channeliser workgroups that gave up waiting for their predecessor's state: always 0 */
 } vdl2hip_stats;
 
 int  vdl2hip_abi_version(void);

@@ -433,3 +433,26 @@ def test_ring_wraps_many_times(vh, oracle_mod):
                                 label="ring wrap", exact_diagnostics=False)
     assert len(got) >= 60
     rx.close()
+
+
+@pytest.mark.parametrize("name", ["config2_1s", "os10_noisy_1s", "config4_0p4s"])
+def test_separate_phase_kernel_gives_the_same_answer(vh, monkeypatch, name):
+    """By default K1 applies the segment-start fix-up and writes the phases itself (one-step look-back between workgroup
+    segments); VDL2HIP_NO_FUSE=1 runs the separate K2 instead.  Same arithmetic, so the decimated samples are bit-identical
+    and so is everything after them; and no look-back wait ever times out."""
+    cfg, iq, bursts, gold = cases.load(name)
+    rx, fr, cnt = gpu_decode(vh, cfg, iq, chunks=(50000, 400000), max_block=1600000)
+    assert rx.stats()["front_sync_timeouts"] == 0
+    D = iq.size // 2 // cfg.oversample
+    y_fused = [rx.read_decimated(c, max(0, D - 60000), 60000) for c in range(len(cfg.freqs))]
+    monkeypatch.setenv("VDL2HIP_NO_FUSE", "1")
+    rx2, fr2, cnt2 = gpu_decode(vh, cfg, iq, chunks=(50000, 400000), max_block=1600000)
+    y_sep = [rx2.read_decimated(c, max(0, D - 60000), 60000) for c in range(len(cfg.freqs))]
+    for a, b in zip(y_fused, y_sep):
+        assert a.tobytes() == b.tobytes()
+    key = lambda f: (f["chan"], f["burst_ord"], f["idx"])
+    assert [(key(f), f["octets"], f["sync_sample"], f["ppm_error"], f["frame_pwr_dbfs"], f["nf_pwr_dbfs"]) for f in sorted(fr, key=key)] == \
+           [(key(f), f["octets"], f["sync_sample"], f["ppm_error"], f["frame_pwr_dbfs"], f["nf_pwr_dbfs"]) for f in sorted(fr2, key=key)]
+    assert cnt == cnt2
+    cases.check_against_golden(fr2, cnt2, gold, label=f"{name} separate K2", exact_diagnostics=False)
+    rx.close(); rx2.close()
