@@ -115,11 +115,16 @@ __device__ __forceinline__ void store_phases(const K1Args &a, int ch, bool cvali
 // Within a workgroup's segment the filter state is carried from tile to tile in registers, so the outputs it
 // stores are final except for the (decayed) state at the segment start, which K2 adds to the first kFixW of them.
 // OS == 0 selects the generic (run-time oversample) build of the same code.
+// resident workgroups per CU the channeliser is compiled for: LDS allows 6, but with the fused phase stage 5 (96 VGPRs, no
+// scratch frame) is faster at CR = 2 (tests/gpu_k1_variants.sh: 0.262 -> 0.230 ms at 8 channels)
 #ifndef VDL2_K1_MIN_BLOCKS
-#define VDL2_K1_MIN_BLOCKS 6
+#define VDL2_K1_MIN_BLOCKS 5
+#endif
+#ifndef VDL2_K1_MIN_BLOCKS_CR4
+#define VDL2_K1_MIN_BLOCKS_CR4 4
 #endif
 template<int OS, int R, int CR>
-__global__ __launch_bounds__(256, (CR >= 4 ? 4 : VDL2_K1_MIN_BLOCKS)) void k_chanfir(K1Args a) {
+__global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MIN_BLOCKS)) void k_chanfir(K1Args a) {
 	static_assert(64 * R == kFixW || R == 1, "the fused fix-up assumes the fix window is the segment's first tile");
 	static_assert(R >= 1 && R <= 2, "the run's outputs are held in two register pairs");
 	extern __shared__ __align__(16) unsigned char smem[];
