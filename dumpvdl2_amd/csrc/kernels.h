@@ -95,7 +95,11 @@ __device__ __forceinline__ void load_sample(const K1Args &a, int64_t s, float &r
 // phases of one lane's run (R <= 2 consecutive outputs starting at feed-local index kloc)
 // atan2 out of line (two independent evaluations per call): inlined into the channeliser's epilogue once per channel it
 // pushes the kernel deep into scratch; a rolled single-instance loop was no better (tests/gpu_k1_variants.sh)
+#ifdef VDL2_K1_INLINE_PHASE
+__device__ __forceinline__ float2 phase_call2(float r0, float i0, float r1, float i1) {
+#else
 __device__ __attribute__((noinline)) float2 phase_call2(float r0, float i0, float r1, float i1) {
+#endif
 	return make_float2(phase_of(cf32{r0, i0}), phase_of(cf32{r1, i1}));
 }
 
