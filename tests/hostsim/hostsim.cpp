@@ -10,6 +10,7 @@
 #include <algorithm>
 #include "../../dumpvdl2_amd/csrc/vdl2_core.h"
 #include "../../dumpvdl2_amd/csrc/tables.h"
+#include "../../dumpvdl2_amd/csrc/design.h"
 
 using namespace vdl2;
 
@@ -149,6 +150,13 @@ void hostsim_phase(const float *reim, float *out, int64_t n) { for(int64_t i = 0
 double hostsim_atan2(double y, double x) { return atan2_f64(y, x); }
 
 int hostsim_sizeof_outframe() { return (int)sizeof(OutFrame); }
+
+// ---- init-time constants of the channeliser (design.h), for known-answer and consistency tests ----
+void hostsim_design_lpf(float fc, float ripple, float *A, float *B) { LpfCoeffs c = design_lpf(fc, ripple); memcpy(A, c.A, 12); memcpy(B, c.B, 12); }
+uint32_t hostsim_nco_step(uint32_t centerfreq, uint32_t freq, uint32_t fs) { return nco_step(centerfreq, freq, fs); }
+void hostsim_nco_lut(float *out /* [256][4] = s, c, ds, dc */) { Lut4 l[256]; build_nco_lut(l); memcpy(out, l, sizeof l); }
+int hostsim_sizeof_blockform() { return (int)sizeof(BlockForm); }
+void hostsim_block_form(const float *A, const float *B, int os, int run, BlockForm *out) { LpfCoeffs c; memcpy(c.A, A, 12); memcpy(c.B, B, 12); *out = derive_block_form(c, os, run); }
 
 // the burst decoder's RS stage on one 255-octet row (for direct comparison with libfec / the oracle)
 int hostsim_rs_decode(uint8_t *row, int npar) {

@@ -1,0 +1,115 @@
+"""Host-side constants of the channeliser (dumpvdl2_amd/csrc/design.h, compiled for the CPU by tests/hostsim): the filter
+design and the NCO against the oracle's restatement of chebyshev.c / demod.c, and the block form K1 evaluates against the
+direct-form recurrence it replaces."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pyhostsim
+
+K_FIX = 128
+K_MAXOS = 32
+
+
+class BlockForm(C.Structure):
+    _fields_ = [("os", C.c_int), ("run", C.c_int), ("g0", C.c_float * K_MAXOS), ("g1", C.c_float * K_MAXOS),
+                ("P", C.c_float * 4), ("c0", C.c_float), ("c1", C.c_float), ("c2", C.c_float),
+                ("cP", (C.c_float * 2) * K_FIX), ("Ppow", (C.c_float * 4) * (K_FIX + 1)), ("Q", (C.c_float * 4) * 6),
+                ("Qpow", (C.c_float * 4) * 64)]
+
+
+@pytest.fixture(scope="module")
+def hs():
+    L = C.CDLL(pyhostsim.build())
+    L.hostsim_nco_step.restype = C.c_uint32
+    L.hostsim_nco_step.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    L.hostsim_design_lpf.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.hostsim_block_form.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(BlockForm)]
+    assert L.hostsim_sizeof_blockform() == C.sizeof(BlockForm)
+    return L
+
+
+def lpf(hs, os_):
+    A = (C.c_float * 3)(); B = (C.c_float * 3)()
+    hs.hostsim_design_lpf(C.c_float(8000.0 / (105000.0 * os_)), C.c_float(0.5), A, B)     # input_lpf_init(), demod.c:367-370
+    return A, B
+
+
+@pytest.mark.parametrize("os_", [10, 13, 20])
+def test_filter_design_and_nco_step_match_the_oracle(hs, oracle_mod, os_):
+    cf = 136975000
+    freqs = [cf - 400000, cf - 12500, cf, cf + 25000, cf + 987654]
+    o = oracle_mod.Oracle(cf, freqs, oversample=os_)
+    A, B = lpf(hs, os_)
+    Ao, Bo = o.lpf()
+    assert bytes(A) == Ao.tobytes() and bytes(B) == Bo.tobytes()
+    for c, f in enumerate(freqs):
+        assert hs.hostsim_nco_step(cf, f, 105000 * os_) & 0xFFFFFF == o.dphi(c) & 0xFFFFFF
+
+
+def test_nco_lut_is_sincosf_lut(hs):
+    """entry i = {sin, cos, (sin[i+1]-sin[i]) 2^-16, (cos[i+1]-cos[i]) 2^-16} of the reference's 256-entry table (demod.c:372-377)"""
+    lut = np.zeros((256, 4), dtype=np.float32)
+    hs.hostsim_nco_lut(lut.ctypes.data_as(C.c_void_p))
+    i = np.arange(257, dtype=np.float64)
+    ang = (2.0 * np.pi * i / 256.0).astype(np.float32)      # "2.0f * M_PI * (float)i / 256.0f": evaluated in double, narrowed for sincosf()
+    s = np.sin(ang.astype(np.float64)).astype(np.float32); c = np.cos(ang.astype(np.float64)).astype(np.float32)
+    s[256] = s[0]; c[256] = c[0]
+    assert np.abs(lut[:, 0] - s[:256]).max() <= 1.2e-7 and np.abs(lut[:, 1] - c[:256]).max() <= 1.2e-7      # sincosf vs libm: 1 ulp
+    assert np.allclose(lut[:, 2] * 65536.0, lut[np.r_[1:256, 0], 0] - lut[:, 0], atol=1e-7)
+    assert np.allclose(lut[:, 3] * 65536.0, lut[np.r_[1:256, 0], 1] - lut[:, 1], atol=1e-7)
+
+
+@pytest.mark.parametrize("os_,run", [(20, 2), (10, 2), (13, 2), (7, 2)])
+def test_block_form_reproduces_the_direct_form(hs, os_, run):
+    """y[n] = A0 x[n] + A1 x[n-1] + A2 x[n-2] + B1 y[n-1] + B2 y[n-2] (chebyshev.c / demod.c:58-79), decimated by os, against
+    the block recurrence K1 runs: t_k = P t_{k-1} + sum_j (g0[j], g1[j]) x[os k + j], y_k = c0 t0 + c1 t1 + c2 x[last]."""
+    A, B = lpf(hs, os_)
+    bf = BlockForm()
+    hs.hostsim_block_form(A, B, os_, run, C.byref(bf))
+    a = np.array(A[:], dtype=np.float64); b = np.array(B[:], dtype=np.float64)
+    rng = np.random.default_rng(os_)
+    nblk = 600
+    x = rng.standard_normal(nblk * os_)
+    y = np.zeros_like(x)
+    for n in range(len(x)):
+        y[n] = a[0] * x[n] + (a[1] * x[n - 1] if n >= 1 else 0) + (a[2] * x[n - 2] if n >= 2 else 0) \
+            + (b[1] * y[n - 1] if n >= 1 else 0) + (b[2] * y[n - 2] if n >= 2 else 0)
+    want = y[os_ - 1::os_]
+    P = np.array(bf.P[:], dtype=np.float64).reshape(2, 2)
+    g0 = np.array(bf.g0[:os_], dtype=np.float64); g1 = np.array(bf.g1[:os_], dtype=np.float64)
+    t = np.zeros(2); got = np.zeros(nblk)
+    for k in range(nblk):
+        blk = x[k * os_:(k + 1) * os_]
+        t = P @ t + np.array([g0 @ blk, g1 @ blk])
+        got[k] = bf.c0 * t[0] + bf.c1 * t[1] + bf.c2 * blk[-1]
+    # fp32-rounded P, taps and c0..c2 in a filter whose poles sit at radius 0.985: the same ~1e-5 of the signal level that
+    # separates any two evaluation orders of this IIR in fp32
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    # the tables the wave scan and the fix-ups use are powers of the same P
+    # (derived in double from M = [[B1, B2], [1, 0]], P = M^os, then rounded once - so compare with the double powers)
+    Pd = np.linalg.matrix_power(np.array([[b[1], b[2]], [1.0, 0.0]]), os_)
+    assert np.abs(P - Pd).max() <= 6e-8 * np.abs(Pd).max()
+    Pp = np.array([list(r) for r in bf.Ppow], dtype=np.float64).reshape(-1, 2, 2)
+    c01 = np.array([a[0] + a[2] / b[2], a[1] - a[2] * b[1] / b[2]])
+    assert abs(bf.c0 - c01[0]) <= 1e-7 * abs(c01[0]) and abs(bf.c1 - c01[1]) <= 1e-7 * abs(c01[1]) and abs(bf.c2 + a[2] / b[2]) <= 1e-7 * abs(a[2] / b[2])
+    acc = np.eye(2)
+    for i in range(K_FIX + 1):
+        assert np.abs(Pp[i] - acc).max() <= 1e-7 * max(1e-30, np.abs(acc).max()) + 1e-37
+        if i < K_FIX:
+            nxt = acc @ Pd
+            cP = np.array(list(bf.cP[i]), dtype=np.float64)
+            ref = c01 @ nxt
+            assert np.abs(cP - ref).max() <= 1e-7 * max(1e-30, np.abs(nxt).max() * np.abs(c01).max()) + 1e-37
+        acc = acc @ Pd
+    P = Pd
+    Q1 = np.linalg.matrix_power(P, run)
+    for d in range(6):
+        Qd = np.linalg.matrix_power(Q1, 2 ** d)
+        assert np.abs(np.array(list(bf.Q[d])).reshape(2, 2) - Qd).max() <= 1e-7 * np.abs(Qd).max() + 1e-37
+    for l in (0, 1, 5, 63):
+        Ql = np.linalg.matrix_power(Q1, l + 1)
+        assert np.abs(np.array(list(bf.Qpow[l])).reshape(2, 2) - Ql).max() <= 1e-7 * np.abs(Ql).max() + 1e-37
+    # a start state has decayed below fp32 resolution after K_FIX blocks: what makes the one-step look-back exact
+    assert np.abs(np.linalg.matrix_power(P, K_FIX)).max() < 1e-12
