@@ -19,7 +19,7 @@ class OutFrame(C.Structure):
 
 
 def build():
-    srcs = [os.path.join(_HERE, "hostsim.cpp")] + [os.path.join(_ROOT, "dumpvdl2_amd", "csrc", f) for f in ("vdl2_core.h", "tables.h")]
+    srcs = [os.path.join(_HERE, "hostsim.cpp")] + [os.path.join(_ROOT, "dumpvdl2_amd", "csrc", f) for f in ("vdl2_core.h", "tables.h", "design.h")]
     if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
                                "-o", _LIB, srcs[0]])
