@@ -151,6 +151,16 @@ double hostsim_atan2(double y, double x) { return atan2_f64(y, x); }
 
 int hostsim_sizeof_outframe() { return (int)sizeof(OutFrame); }
 
+// got_sync() metric of n phase windows (16 taps each): the exact reference arithmetic and K3's screening form
+void hostsim_metric_pairs(const float *ph, int64_t n, float *exact, float *slope, float *screen) {
+	static Tables T; static bool init = false;
+	if(!init) { build_tables(T); init = true; }
+	for(int64_t i = 0; i < n; i++) {
+		sync_metric(ph + 16 * i, T, exact[i], slope[i]);
+		screen[i] = sync_metric_screen(ph + 16 * i, T);
+	}
+}
+
 // ---- init-time constants of the channeliser (design.h), for known-answer and consistency tests ----
 void hostsim_design_lpf(float fc, float ripple, float *A, float *B) { LpfCoeffs c = design_lpf(fc, ripple); memcpy(A, c.A, 12); memcpy(B, c.B, 12); }
 uint32_t hostsim_nco_step(uint32_t centerfreq, uint32_t freq, uint32_t fs) { return nco_step(centerfreq, freq, fs); }

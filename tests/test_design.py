@@ -113,3 +113,33 @@ def test_block_form_reproduces_the_direct_form(hs, os_, run):
         assert np.abs(np.array(list(bf.Qpow[l])).reshape(2, 2) - Ql).max() <= 1e-7 * np.abs(Ql).max() + 1e-37
     # a start state has decayed below fp32 resolution after K_FIX blocks: what makes the one-step look-back exact
     assert np.abs(np.linalg.matrix_power(P, K_FIX)).max() < 1e-12
+
+
+def test_sync_screening_never_hides_a_sub_threshold_metric(hs):
+    """K3 redoes the exact got_sync() arithmetic only where the screening value is under 5.5 (threshold 4).  That is safe iff
+    the screening value is within ~1 of the exact one wherever the exact one is small; it is within 0.2 everywhere here:
+    random windows, clean preambles with carrier offsets up to +-3 rad/symbol (large unwrapped excursions), preambles with
+    noise tuned to land around the threshold, and windows sitting right at the +-pi unwrap decision."""
+    hs.hostsim_metric_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    q = np.array([0, 3, -3, 1, 1, 2, 0, 4, -3, 4, -2, 3, 1, -2, -3, 0], dtype=np.float64) * np.pi / 4     # demod.c:107-124
+
+    def wrap(x):
+        return (x + np.pi) % (2 * np.pi) - np.pi
+
+    sets = [rng.uniform(-np.pi, np.pi, size=(200000, 16))]
+    for sigma in (0.0, 0.05, 0.3, 0.5, 0.6, 0.8):
+        n = 60000
+        slope = rng.uniform(-3.0, 3.0, size=(n, 1)); off = rng.uniform(-np.pi, np.pi, size=(n, 1))
+        sets.append(wrap(q[None, :] + off + slope * np.arange(16)[None, :] + sigma * rng.standard_normal((n, 16))))
+    edge = wrap(q[None, :] + np.pi * np.arange(16)[None, :] * rng.choice([-1.0, 1.0], size=(50000, 1)) + 1e-3 * rng.standard_normal((50000, 16)))
+    sets.append(edge)
+    ph = np.ascontiguousarray(np.concatenate(sets).astype(np.float32))
+    n = ph.shape[0]
+    exact = np.zeros(n, dtype=np.float32); slope = np.zeros(n, dtype=np.float32); screen = np.zeros(n, dtype=np.float32)
+    hs.hostsim_metric_pairs(ph.ctypes.data, n, exact.ctypes.data, slope.ctypes.data, screen.ctypes.data)
+    assert np.isfinite(exact).all() and np.isfinite(screen).all()
+    assert (exact < 4).sum() > 50000 and ((exact > 3) & (exact < 5)).sum() > 2000       # the interesting region is populated
+    err = np.abs(screen.astype(np.float64) - exact.astype(np.float64))
+    assert err.max() < 0.2, (err.max(), exact[err.argmax()], screen[err.argmax()])
+    assert not np.any((exact < 4.0) & (screen >= 5.5))
