@@ -61,3 +61,22 @@ def test_no_gpu_means_error_not_fallback(lib):
     from dumpvdl2_amd import vdl2hip
     with pytest.raises(vdl2hip.Vdl2HipError, match="HIP device error"):
         vdl2hip.Receiver(136975000, [136975000], 10)
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing that ships (package, C ABI sources, headers, tools) may import, include, link or
+    execute it - only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline / parity gate do."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for sub in ("dumpvdl2_amd", "include", "tools"):
+        for dp, _, files in os.walk(os.path.join(root, sub)):
+            for f in files:
+                if not f.endswith((".py", ".h", ".hip", ".c", ".cpp")):
+                    continue
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                for m in re.finditer(r"^.*(import\s+oracle|from\s+oracle|oracle/|libvdl2oracle|vdl2o_|pyoracle).*$", txt, re.M):
+                    if "test-only" in m.group(0) or "tests" in m.group(0):
+                        continue
+                    bad.append((os.path.relpath(os.path.join(dp, f), root), m.group(0).strip()[:100]))
+    assert not bad, bad
