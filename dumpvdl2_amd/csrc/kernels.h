@@ -476,7 +476,14 @@ __global__ __launch_bounds__(256) void k_sync(K3Args a) {
 		const int i0 = tid + 256 * q;               // sample nblk + i0: phases tile[i0 + 6 + 10 i]
 		#pragma unroll
 		for(int i = 0; i < kPreamble; i++) ph[i] = tile[i0 + 6 + 10 * i];
-		ps[q] = sync_metric_screen(ph, T);
+		// the first kScreenEarly taps bound the value from below: most wavefronts stop here
+		ScreenAcc acc;
+		screen_taps(ph, T, 0, kScreenEarly, acc);
+		ps[q] = screen_value(acc, kScreenEarly);
+		if(__any(ps[q] < kScreenEarlyThr)) {
+			screen_taps(ph, T, kScreenEarly, kPreamble, acc);
+			ps[q] = screen_value(acc, kPreamble);
+		}
 		fl[i0 + 3] = ps[q] < kScreenThr;
 	}
 	if(tid < 6) {                                   // the three neighbours on either side

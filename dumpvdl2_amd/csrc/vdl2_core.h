@@ -282,18 +282,40 @@ VDL2_HD void sync_metric(const float *ph, const Tables &T, float &pherr, float &
 // from the exact value by rounding only (< 0.1 for any phase sequence: |e| <= 16*pi, S2 <= 4e4), which is all the sync
 // kernel needs to know that a sample is nowhere near the threshold kSyncThr.
 constexpr float kScreenThr = 5.5f;
-VDL2_HD float sync_metric_screen(const float *ph, const Tables &T) {
-	float prev = ph[0] - T.pr_phase[0];
-	float s0 = prev, s1 = T.lrx[0] * prev, s2 = prev * prev, unwrap = 0.f;
-	for(int i = 1; i < kPreamble; i++) {
-		const float cur = ph[i] - T.pr_phase[i];
-		const float diff = cur - prev;
-		prev = cur;
-		unwrap += diff > kPiBelow ? -(float)(2.0 * M_PI) : (diff < -kPiBelow ? (float)(2.0 * M_PI) : 0.f);
-		const float e = cur + unwrap;
-		s0 += e; s1 = fmaf(T.lrx[i], e, s1); s2 = fmaf(e, e, s2);
+// The running sums are raw moments (sum e, sum i*e, sum e^2), so the value over the first n taps - the residual of the best
+// line through those n points, a lower bound of the residual over all 16 - is available along the way: the sync kernel stops
+// after kScreenEarly taps when no lane of the wavefront is still under the threshold (97 % of them on noise or data).
+constexpr int kScreenEarly = 12;
+constexpr float kScreenEarlyThr = 5.8f;   // early bound + its rounding slack must stay above kScreenThr
+struct ScreenAcc { float prev, unwrap, m0, m1, m2; };
+
+VDL2_HD void screen_taps(const float *ph, const Tables &T, int i0, int i1, ScreenAcc &a) {
+	if(i0 == 0) {
+		a.prev = ph[0] - T.pr_phase[0]; a.unwrap = 0.f;
+		a.m0 = a.prev; a.m1 = 0.f; a.m2 = a.prev * a.prev;
+		i0 = 1;
 	}
-	return s2 - s0 * s0 * (1.0f / kPreamble) - s1 * s1 / T.lr_den;
+	for(int i = i0; i < i1; i++) {
+		const float cur = ph[i] - T.pr_phase[i];
+		const float diff = cur - a.prev;
+		a.prev = cur;
+		a.unwrap += diff > kPiBelow ? -(float)(2.0 * M_PI) : (diff < -kPiBelow ? (float)(2.0 * M_PI) : 0.f);
+		const float e = cur + a.unwrap;
+		a.m0 += e; a.m1 = fmaf((float)i, e, a.m1); a.m2 = fmaf(e, e, a.m2);
+	}
+}
+
+// residual of the least-squares line through the first n points: m2 - m0^2/n - (m1 - xbar m0)^2 / Sxx, Sxx = n(n^2-1)/12
+VDL2_HD float screen_value(const ScreenAcc &a, int n) {
+	const float xbar = 0.5f * (float)(n - 1), sxx = (float)(n * (n * n - 1)) / 12.0f;
+	const float c = a.m1 - xbar * a.m0;
+	return a.m2 - a.m0 * a.m0 / (float)n - c * c / sxx;
+}
+
+VDL2_HD float sync_metric_screen(const float *ph, const Tables &T) {
+	ScreenAcc a;
+	screen_taps(ph, T, 0, kPreamble, a);
+	return screen_value(a, kPreamble);
 }
 
 // calc_para_vertex(v->sclk = 0, SYNC_SKIP, y1, y2, y3): demod.c:98-103,178

@@ -160,6 +160,13 @@ void hostsim_metric_pairs(const float *ph, int64_t n, float *exact, float *slope
 		screen[i] = sync_metric_screen(ph + 16 * i, T);
 	}
 }
+// the early bound the sync kernel tests after kScreenEarly taps
+void hostsim_metric_early(const float *ph, int64_t n, float *early) {
+	static Tables T; static bool init = false;
+	if(!init) { build_tables(T); init = true; }
+	for(int64_t i = 0; i < n; i++) { ScreenAcc a; screen_taps(ph + 16 * i, T, 0, kScreenEarly, a); early[i] = screen_value(a, kScreenEarly); }
+}
+int hostsim_screen_early_taps() { return kScreenEarly; }
 
 // ---- init-time constants of the channeliser (design.h), for known-answer and consistency tests ----
 void hostsim_design_lpf(float fc, float ripple, float *A, float *B) { LpfCoeffs c = design_lpf(fc, ripple); memcpy(A, c.A, 12); memcpy(B, c.B, 12); }

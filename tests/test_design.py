@@ -143,3 +143,12 @@ def test_sync_screening_never_hides_a_sub_threshold_metric(hs):
     err = np.abs(screen.astype(np.float64) - exact.astype(np.float64))
     assert err.max() < 0.2, (err.max(), exact[err.argmax()], screen[err.argmax()])
     assert not np.any((exact < 4.0) & (screen >= 5.5))
+    # the early exit after 12 taps: that partial value is a lower bound (up to rounding) of the 16-tap screening value, and a
+    # window that can matter (screening value under 5.5) is never dropped by the early test (under 5.8)
+    hs.hostsim_metric_early.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    early = np.zeros(n, dtype=np.float32)
+    hs.hostsim_metric_early(ph.ctypes.data, n, early.ctypes.data)
+    assert hs.hostsim_screen_early_taps() == 12
+    assert (early.astype(np.float64) - screen.astype(np.float64)).max() < 0.2
+    assert not np.any((screen < 5.5) & (early >= 5.8))
+    assert (early[:200000] >= 5.8).mean() > 0.99                      # random windows: almost all stop early
