@@ -262,9 +262,12 @@ def test_cli_runner_and_raw_frame_archive(vh, oracle_mod, golden_wav, tmp_path):
     from dumpvdl2_amd import build
     exe = build.build_cli(str(tmp_path / "vdl2hip_iqfile"))
     wav = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "vdl2_model_16b_1050kHz.wav")
-    raw = str(tmp_path / "frames.bin")
-    p = subprocess.run([exe, "--iq-file", wav, "--sample-format", "S16_LE", "--station-id", "TEST", "--raw-frames-out", raw],
-                       check=True, capture_output=True, text=True, timeout=120)
+    raw = str(tmp_path / "frames.bin"); statsd = str(tmp_path / "statsd.txt")
+    p = subprocess.run([exe, "--iq-file", wav, "--sample-format", "S16_LE", "--station-id", "TEST", "--raw-frames-out", raw,
+                        "--avlc-filter", "--statsd-out", statsd], check=True, capture_output=True, text=True, timeout=120)
+    table = dict(l.rsplit(":", 1) for l in open(statsd).read().splitlines())
+    assert table[f"dumpvdl2.TEST.{CF}.decoder.msg.good"] == "2|c" and table[f"dumpvdl2.TEST.{CF}.avlc.frames.good"] == "2|c"
+    assert table[f"dumpvdl2.TEST.{CF}.demod.sync.good"] == "1|c" and table[f"dumpvdl2.TEST.{CF}.avlc.errors.bad_fcs"] == "0|c"
     lines = [l for l in p.stdout.splitlines() if "[S:" in l]
     assert len(lines) == 2 and all("[S:0] [L:504] [F:0]" in l for l in lines)
     hexes = [bytes.fromhex(l.rsplit(" ", 1)[1]) for l in lines]

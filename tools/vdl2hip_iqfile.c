@@ -6,6 +6,9 @@
  *   --iq-file <path|->            raw IQ file, read in FILE_BUFSIZE (320000-byte) blocks; sets oversample 10 and U8
  *   --sample-format U8|S16_LE     (the reference's token is S16_LE, src/dumpvdl2.c:849)
  *   --oversample <n>  --centerfreq <Hz>  --max-ppm <x>  --station-id <s>
+ *   --avlc-filter                 deliver only frames that pass avlc_parse()'s first checks (length, FCS) - src/avlc.c:168-187
+ *   --statsd-out <path>           at exit, write the per-channel counters in the reference's statsd names
+ *                                 ("dumpvdl2[.<station-id>].<freq>.<counter>:<n>|c", src/statsd.c:34-65,153-160)
  *   --raw-frames-out <path>       write every frame in the reference's raw-frame archive format, so that a stock
  *                                 `dumpvdl2 --raw-frames-file <path>` decodes them through the full protocol stack
  *   freq [freq ...]               channel frequencies in Hz; default: the CSC, 136975000
@@ -46,7 +49,8 @@ static void on_frame(const vdl2hip_frame *f, void *user) {
 }
 
 int main(int argc, char **argv) {
-	const char *infile = NULL, *rawpath = NULL;
+	const char *infile = NULL, *rawpath = NULL, *statsd_path = NULL;
+	int avlc_filter = 0;
 	uint32_t oversample = 0, centerfreq = 0, fmt = VDL2HIP_FMT_U8, freqs[1024], nfreq = 0;
 	float max_ppm = 0.f;
 	int fmt_set = 0;
@@ -65,12 +69,14 @@ int main(int argc, char **argv) {
 		else if(!strcmp(a, "--max-ppm")) { NEEDARG(); max_ppm = strtof(argv[++i], NULL); }
 		else if(!strcmp(a, "--station-id")) { NEEDARG(); station_id = argv[++i]; }
 		else if(!strcmp(a, "--raw-frames-out")) { NEEDARG(); rawpath = argv[++i]; }
+		else if(!strcmp(a, "--statsd-out")) { NEEDARG(); statsd_path = argv[++i]; }
+		else if(!strcmp(a, "--avlc-filter")) avlc_filter = 1;
 		else if(a[0] == '-' && a[1]) { fprintf(stderr, "unknown option %s\n", a); return 1; }
 		else if(nfreq < 1024) freqs[nfreq++] = (uint32_t)strtoul(a, NULL, 10);
 	}
 	(void)fmt_set;
 	if(!infile) { fprintf(stderr, "usage: %s --iq-file <file|-> [--sample-format U8|S16_LE] [--oversample n] [--centerfreq Hz] "
-			"[--max-ppm x] [--station-id s] [--raw-frames-out file] [freq ...]\n", argv[0]); return 1; }
+			"[--max-ppm x] [--station-id s] [--raw-frames-out file] [--avlc-filter] [--statsd-out file] [freq ...]\n", argv[0]); return 1; }
 	if(nfreq == 0) {
 		fprintf(stderr, "Warning: frequency not set - using VDL2 Common Signalling Channel as a default (%u Hz)\n", CSC_FREQ);
 		freqs[nfreq++] = CSC_FREQ;
@@ -95,6 +101,8 @@ int main(int argc, char **argv) {
 	int r = vdl2hip_create(&cfg, &rx);
 	if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_create: %s\n", vdl2hip_strerror(r)); return 3; }
 
+	if(avlc_filter) vdl2hip_set_avlc_filter(rx, 1);
+
 	static unsigned char buf[FILE_BUFSIZE];
 	size_t len;
 	do {                                                                        /* process_iq_file(), src/dumpvdl2.c:353-356 */
@@ -109,6 +117,15 @@ int main(int argc, char **argv) {
 					freqs[c], cnt[VDL2HIP_CNT_SYNC_GOOD], cnt[VDL2HIP_CNT_CRC_GOOD], cnt[VDL2HIP_CNT_BLOCKS_FEC_OK],
 					cnt[VDL2HIP_CNT_BLOCKS_PROCESSED], cnt[VDL2HIP_CNT_MSG_GOOD], cnt[VDL2HIP_CNT_ERR_FEC_BAD]);
 	fprintf(stderr, "%lu frames\n", nframes);
+	if(statsd_path) {
+		static char lines[1 << 20];
+		char ns[300];
+		if(station_id) snprintf(ns, sizeof ns, "dumpvdl2.%s", station_id); else snprintf(ns, sizeof ns, "dumpvdl2");    /* statsd.c:103-108 */
+		int n = vdl2hip_statsd_lines(rx, ns, lines, sizeof lines);
+		FILE *so = n >= 0 ? fopen(statsd_path, "w") : NULL;
+		if(so) { fwrite(lines, 1, (size_t)n, so); fclose(so); }
+		else fprintf(stderr, "statsd counters not written: %s\n", n < 0 ? vdl2hip_strerror(n) : "cannot open file");
+	}
 	vdl2hip_destroy(rx);
 	if(raw_out) fclose(raw_out);
 	if(f != stdin) fclose(f);
