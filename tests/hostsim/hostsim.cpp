@@ -168,6 +168,18 @@ void hostsim_metric_early(const float *ph, int64_t n, float *early) {
 }
 int hostsim_screen_early_taps() { return kScreenEarly; }
 
+// finish_frame() on one frame's octets: returns avlc_status, fills dst/src (direct fuzzing of the FCS slicing and the address parse)
+int hostsim_finish_frame(const uint8_t *octets, uint32_t len, uint32_t *dst, uint32_t *src, unsigned long long *acnt /* [10] */) {
+	static Tables T; static bool init = false; static FrameShared fsh;
+	if(!init) { build_tables(T); frame_shared_init(T, fsh); init = true; }
+	OutFrame f; memset(&f, 0, sizeof f);
+	f.len = len; f.pool_off = 0; f.nf_upd = 0;
+	float ring[1] = { 2.0f };
+	finish_frame(f, octets, T, acnt, ring, 0, fsh);
+	*dst = f.dst_addr; *src = f.src_addr;
+	return (int)f.avlc_status;
+}
+
 // ---- init-time constants of the channeliser (design.h), for known-answer and consistency tests ----
 void hostsim_design_lpf(float fc, float ripple, float *A, float *B) { LpfCoeffs c = design_lpf(fc, ripple); memcpy(A, c.A, 12); memcpy(B, c.B, 12); }
 uint32_t hostsim_nco_step(uint32_t centerfreq, uint32_t freq, uint32_t fs) { return nco_step(centerfreq, freq, fs); }

@@ -84,3 +84,35 @@ def test_device_front_door_matches_oracle(oracle_mod, name):
     assert [hs.avlc_counters(c) for c in range(nch)] == oracle_mod.avlc_counters(fh, nch)
     assert sum(f["avlc_status"] == 0 for f in fh) > 0
     hs.close()
+
+
+def test_device_fcs_and_addresses_fuzz(oracle_mod):
+    """finish_frame() (four octets per step from slicing tables, tail octets singly) against the oracle's bitwise FCS for every
+    length 0..70 and random lengths up to the largest frame, valid and corrupted, with random address octets."""
+    import ctypes as C
+    from dumpvdl2_amd import synth
+    L = C.CDLL(pyhostsim.build())
+    L.hostsim_finish_frame.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_ulonglong)]
+    rng = np.random.default_rng(11)
+    acnt = (C.c_ulonglong * 10)()
+    want_cnt = [0] * 10
+    lens = list(range(0, 71)) + [int(x) for x in rng.integers(71, 2100, size=150)] + [2047, 2048, 2099]
+    for n in lens:
+        for variant in range(3):
+            body = rng.integers(0, 256, size=max(n, 0), dtype=np.uint8).tobytes()
+            if variant == 1 and n >= 3:
+                body = synth.make_avlc_frame(body[:n - 2])                  # valid FCS, same total length
+            elif variant == 2 and n >= 12:
+                fr = bytearray(synth.make_avlc_frame(body[:n - 2])); fr[int(rng.integers(0, n))] ^= 1 << int(rng.integers(0, 8)); body = bytes(fr)
+            dst = C.c_uint32(); src = C.c_uint32()
+            st = L.hostsim_finish_frame(body, len(body), C.byref(dst), C.byref(src), acnt)
+            ost, odst, osrc, odir = oracle_mod.avlc_screen(body)
+            assert (st, dst.value, src.value) == (ost, odst, osrc), (n, variant)
+            want_cnt[0] += 1
+            if ost == 1: want_cnt[1] += 1
+            elif ost == 2: want_cnt[3] += 1
+            else:
+                want_cnt[2] += 1
+                if odir: want_cnt[3 + odir] += 1
+    assert list(acnt) == want_cnt
+    assert want_cnt[2] > 100 and want_cnt[3] > 100 and want_cnt[1] > 20
