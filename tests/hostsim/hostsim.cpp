@@ -27,6 +27,7 @@ struct Sim {
 	std::vector<OutFrame> all_frames; std::vector<uint8_t> all_pool;
 	OutCtl ctl;
 	int64_t seg_min = 0; int seg_max = 1;          // segmented walk (off by default)
+	bool two_tier = false; int64_t n_exact = 0, n_total = 0;   // K3's screening rule instead of the exact metric everywhere
 	std::vector<SpecOut> spec; uint32_t seg_stats[2] = {0, 0};
 };
 
@@ -52,6 +53,8 @@ void hostsim_destroy(Sim *s) { delete s; }
 
 // walk feeds of at least 2*seg_min decimated samples in up to seg_max speculative segments (0 = plain sequential walk)
 void hostsim_set_segments(Sim *s, int64_t seg_min, int seg_max) { s->seg_min = seg_min; s->seg_max = seg_max < 1 ? 1 : seg_max > kMaxSeg ? kMaxSeg : seg_max; }
+void hostsim_set_two_tier(Sim *s, int on) { s->two_tier = on != 0; }
+void hostsim_two_tier_stats(Sim *s, int64_t out[2]) { out[0] = s->n_exact; out[1] = s->n_total; }
 void hostsim_segment_stats(Sim *s, uint32_t out[2]) { out[0] = s->seg_stats[0]; out[1] = s->seg_stats[1]; }
 
 // y: [nchan][D] complex (re,im) floats, channel-major
@@ -66,9 +69,36 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 			phi[(uint32_t)k & s->mask] = phase_of(v);
 		}
 		// sync kernel: whole 64-aligned words covering [k0, k1)
-		for(int64_t n = k0 & ~63ll; n < ((k1 + 63) & ~63ll); n++) {
-			cf32 r = (n < k1) ? metric_contiguous(phi, s->mask, n, s->T) : cf32{kPherrBig, 0.f};
-			pf[(uint32_t)n & s->mask] = r;
+		if(!s->two_tier) {
+			for(int64_t n = k0 & ~63ll; n < ((k1 + 63) & ~63ll); n++) {
+				cf32 r = (n < k1) ? metric_contiguous(phi, s->mask, n, s->T) : cf32{kPherrBig, 0.f};
+				pf[(uint32_t)n & s->mask] = r;
+			}
+		} else {
+			// K3's rule (kernels.h:k_sync): screening value everywhere, the exact arithmetic only where the screening value is
+			// under kScreenThr or 3 samples either side of such a place, or where the right neighbour has not arrived yet
+			const int64_t nb = (k0 & ~63ll) - 3, ne = (k1 + 63) & ~63ll;
+			std::vector<float> scr((size_t)(ne + 3 - nb));
+			auto screen_at = [&](int64_t n) -> float {
+				if(n < 0 || n >= k1) return kPherrBig;
+				float ph[kPreamble];
+				for(int i = 0; i < kPreamble; i++) { int64_t t = n - 150 + 10 * i; ph[i] = t < 0 ? 0.f : phi[(uint32_t)t & s->mask]; }
+				ScreenAcc a; screen_taps(ph, s->T, 0, kScreenEarly, a);
+				float v = screen_value(a, kScreenEarly);
+				if(v < kScreenEarlyThr) { screen_taps(ph, s->T, kScreenEarly, kPreamble, a); v = screen_value(a, kPreamble); }
+				return v;
+			};
+			for(int64_t n = nb; n < ne + 3; n++) scr[(size_t)(n - nb)] = screen_at(n);
+			auto fl = [&](int64_t n) -> bool { return n >= 0 && n < k1 && scr[(size_t)(n - nb)] < kScreenThr; };
+			for(int64_t n = k0 & ~63ll; n < ne; n++) {
+				cf32 r{kPherrBig, 0.f};
+				if(n < k1) {
+					const bool need = fl(n - 3) || fl(n) || (n + 3 < k1 ? fl(n + 3) : true);
+					r = need ? metric_contiguous(phi, s->mask, n, s->T) : cf32{scr[(size_t)(n - nb)], 0.f};
+					s->n_exact += need; s->n_total++;
+				}
+				pf[(uint32_t)n & s->mask] = r;
+			}
 		}
 		for(int64_t w = k0 >> 6; w < ((k1 + 63) >> 6); w++) {
 			uint64_t bits = 0;

@@ -74,6 +74,17 @@ class HostSim:
         """walk long feeds in speculative segments, as k_walk_spec / k_walk_stitch do on the device"""
         self.L.hostsim_set_segments(self.h, seg_min, seg_max)
 
+    def set_two_tier(self, on=True):
+        """compute the sync metric the way k_sync does: screening value everywhere, exact arithmetic only where it can matter"""
+        self.L.hostsim_set_two_tier.argtypes = [C.c_void_p, C.c_int]
+        self.L.hostsim_set_two_tier(self.h, int(on))
+
+    def two_tier_stats(self):
+        a = (C.c_int64 * 2)()
+        self.L.hostsim_two_tier_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        self.L.hostsim_two_tier_stats(self.h, a)
+        return {"exact": a[0], "total": a[1]}
+
     def segment_stats(self):
         a = (C.c_uint32 * 2)()
         self.L.hostsim_segment_stats(self.h, a)

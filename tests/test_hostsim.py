@@ -9,7 +9,7 @@ import pyhostsim
 from util import assert_frames_equal
 
 
-def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None, segments=None):
+def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None, segments=None, two_tier=False):
     C = len(cfg.freqs)
     o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
     D = iq.size // 2 // cfg.oversample
@@ -19,6 +19,8 @@ def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None, segments=None):
     hs = pyhostsim.HostSim(list(cfg.freqs), cfg.rx_max_ppm, cap_log2=cap_log2 or int(np.ceil(np.log2(D + 70000))))
     if segments:
         hs.set_segments(*segments)
+    if two_tier:
+        hs.set_two_tier(True)
     if chunks is None:
         hs.feed(tr[:, :D, :])
     else:
@@ -29,6 +31,7 @@ def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None, segments=None):
     cnt_o = [list(o.counters(c).values()) for c in range(C)]
     cnt_h = [hs.counters(c) for c in range(C)]
     run_both.last_segment_stats = hs.segment_stats()
+    run_both.last_two_tier_stats = hs.two_tier_stats()
     hs.close()
     return fo, fh, cnt_o, cnt_h
 
@@ -100,3 +103,23 @@ def test_segmented_walk_random_geometry(oracle_mod, name):
         st = run_both.last_segment_stats
         tot["adopted"] += st["adopted"]; tot["walked"] += st["walked"]
     assert tot["adopted"] > 0
+
+
+@pytest.mark.parametrize("name,chunks,segments", [("config2_1s", None, None), ("config2_1s", (1, 3000), (700, 32)), ("config3_0p6s", None, (2500, 16)),
+                                                  ("config4_0p4s", (3000, 50000), None), ("config5_0p4s", None, (1000, 32)),
+                                                  ("dirty25k_1s", (500, 20000), None), ("os10_noisy_1s", (64, 5000), (64, 32))])
+def test_two_tier_sync_metric_changes_nothing(oracle_mod, name, chunks, segments):
+    """K3 stores the exact got_sync() value only where it can reach the walker (under the screening threshold, or 3 samples
+    either side of such a place, or at the end of the data so far) and a cheaper screening value elsewhere.  Same rule on the
+    CPU: frames, timing, counters, ppm and noise floor stay those of the oracle, for any chunking / segmentation, while only a
+    small fraction of the samples gets the exact arithmetic."""
+    cfg, iq, _, _ = cases.load(name)
+    fo, fh, co, ch = run_both(oracle_mod, cfg, iq, chunks, cap_log2=17 if chunks else None, segments=segments, two_tier=True)
+    assert_frames_equal(fo, fh, label=name)
+    assert co == ch
+    fo = sorted(fo, key=lambda f: (f["chan"], f["burst_ord"], f["idx"])); fh = sorted(fh, key=lambda f: (f["chan"], f["burst_ord"], f["idx"]))
+    assert [f["nf_pwr_dbfs"] for f in fo] == [f["nf_pwr_dbfs"] for f in fh]
+    assert [f["ppm_error"] for f in fo] == [f["ppm_error"] for f in fh]
+    st = run_both.last_two_tier_stats
+    assert st["total"] > 0 and st["exact"] < 0.2 * st["total"]
+    print(name, st, st["exact"] / st["total"])
