@@ -198,6 +198,19 @@ void hostsim_metric_early(const float *ph, int64_t n, float *early) {
 }
 int hostsim_screen_early_taps() { return kScreenEarly; }
 
+// more of tables.h: preamble phases (units of pi/4 are checked by the caller), Gray map, FCS table, first PRBS bits, RS field
+void hostsim_misc_tables(float *pr_phase16, uint8_t *gray8, uint16_t *crc256, uint8_t *prbs64, uint8_t *gf_exp8) {
+	static Tables T; build_tables(T);
+	memcpy(pr_phase16, T.pr_phase, sizeof T.pr_phase); memcpy(gray8, T.gray, 8); memcpy(crc256, T.crc16, sizeof T.crc16);
+	memcpy(prbs64, T.prbs, 64); memcpy(gf_exp8, T.gf_exp, 8);
+}
+
+// the header-code tables the walker uses (tables.h), for comparison with the reference's own
+void hostsim_header_tables(uint32_t *H, uint32_t *fix, uint32_t *weight) {
+	static Tables T; build_tables(T);
+	memcpy(H, T.hdr_H, sizeof T.hdr_H); memcpy(fix, T.hdr_fix, sizeof T.hdr_fix); memcpy(weight, T.hdr_weight, sizeof T.hdr_weight);
+}
+
 // finish_frame() on one frame's octets: returns avlc_status, fills dst/src (direct fuzzing of the FCS slicing and the address parse)
 int hostsim_finish_frame(const uint8_t *octets, uint32_t len, uint32_t *dst, uint32_t *src, unsigned long long *acnt /* [10] */) {
 	static Tables T; static bool init = false; static FrameShared fsh;

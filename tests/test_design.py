@@ -152,3 +152,67 @@ def test_sync_screening_never_hides_a_sub_threshold_metric(hs):
     assert (early.astype(np.float64) - screen.astype(np.float64)).max() < 0.2
     assert not np.any((screen < 5.5) & (early >= 5.8))
     assert (early[:200000] >= 5.8).mean() > 0.99                      # random windows: almost all stop early
+
+
+def test_header_code_tables_are_the_reference_tables(hs, oracle_mod):
+    """The (25,20) header code: parity-check rows, syndrome -> error-pattern table and syndrome weights, read from the
+    reference's source where it lies (src/decode.c:55-100; skipped where /root/reference is not mounted), against the tables
+    the device builds from the parity-check matrix (tables.h) and against the oracle's decoder."""
+    import os, re
+    path = "/root/reference/src/decode.c"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not mounted here")
+    src = open(path).read()
+
+    def table(name):
+        body = re.search(name + r"\s*\[[^\]]*\]\s*=\s*\{([^}]*)\}", src).group(1)
+        return [int(t, 0) for t in re.findall(r"0b[01]+|\b\d+\b", body)]
+
+    H_ref, fix_ref, w_ref = table("H"), table("syndtable"), table("synd_weight")
+    assert len(H_ref) == 5 and len(fix_ref) == 32 and len(w_ref) == 32
+    H = (C.c_uint32 * 5)(); fix = (C.c_uint32 * 32)(); w = (C.c_uint32 * 32)()
+    hs.hostsim_header_tables(H, fix, w)
+    assert list(H) == H_ref and list(fix) == fix_ref and list(w) == w_ref
+    # the oracle corrects every table pattern (an error on the all-zero codeword) back to zero and reports its syndrome
+    L = oracle_mod.lib()
+    L.vdl2o_header_decode.restype = C.c_uint32
+    L.vdl2o_header_decode.argtypes = [C.POINTER(C.c_uint32)]
+    for s_, e in enumerate(fix_ref):
+        word = C.c_uint32(e)
+        assert L.vdl2o_header_decode(C.byref(word)) == s_ and word.value == 0
+
+
+def test_other_tables_are_the_reference_constants(hs):
+    """Preamble phases (demod.c:107-124), Gray map (demod.c:223), FCS table (crc.c:23-57), descrambler seed (decode.c:50) and RS
+    field (rs.c:28), read from the reference's source where it lies, against what tables.h derives."""
+    import os, re
+    root = "/root/reference/src"
+    if not os.path.exists(root):
+        pytest.skip("reference tree not mounted here")
+    pr = (C.c_float * 16)(); gray = (C.c_uint8 * 8)(); crc = (C.c_uint16 * 256)(); prbs = (C.c_uint8 * 64)(); gfe = (C.c_uint8 * 8)()
+    hs.hostsim_misc_tables(pr, gray, crc, prbs, gfe)
+    demod = open(os.path.join(root, "demod.c")).read()
+    body = re.search(r"pr_phase\[PREAMBLE_SYMS\]\s*=\s*\{([^}]*)\}", demod).group(1)
+    quarters = [int(m) for m in re.findall(r"(-?\d+)\s*\*\s*M_PI\s*/\s*4", body)]
+    assert len(quarters) == 16
+    assert [np.float32(q * np.pi / 4) for q in quarters] == [np.float32(x) for x in pr]
+    g = [int(x) for x in re.search(r"graycode\[ARITY\]\s*=\s*\{([^}]*)\}", demod).group(1).split(",")]
+    assert g == list(gray)
+    crcsrc = open(os.path.join(root, "crc.c")).read()
+    tab = [int(x, 16) for x in re.findall(r"0x[0-9A-Fa-f]{4}", re.search(r"crctable\[256\]\s*=\s*\{([^}]*)\}", crcsrc, re.S).group(1))]
+    assert len(tab) == 256 and tab == list(crc)
+    iv = int(re.search(r"#define\s+LFSR_IV\s+(0x[0-9a-fA-F]+)", open(os.path.join(root, "decode.c")).read()).group(1), 16)
+    l, want = iv, []
+    for _ in range(64):                                   # bitstream_descramble(), bitstream.c:94-107: x^15 + x + 1
+        bit = (l ^ (l >> 14)) & 1
+        l = (l >> 1) | (bit << 14)
+        want.append(bit)
+    assert want == list(prbs)
+    m = re.search(r"init_rs_char\(\s*8\s*,\s*(0x[0-9a-fA-F]+)\s*,\s*(\d+)\s*,\s*1\s*,", open(os.path.join(root, "rs.c")).read())
+    poly, fcr = int(m.group(1), 16), int(m.group(2))
+    assert (poly, fcr) == (0x187, 120)
+    x, exp = 1, []
+    for _ in range(8):
+        exp.append(x); x <<= 1
+        if x & 0x100: x ^= poly
+    assert exp == list(gfe)
