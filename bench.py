@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_CHAN_SAMPLE = 4.0 + 8.0 / 20.0 + 4.0 / 20.0   # cs16 I+Q read per channel + (float2 decimated sample + float phase, which the
                                                             # channeliser writes too since the phase stage is fused into it) / oversample
+if os.environ.get("VDL2HIP_NO_FUSE"):             # experiments: with the separate phase kernel K1 does not write the phases
+    ALGO_BYTES_PER_CHAN_SAMPLE = 4.0 + 8.0 / 20.0
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s spec
 
 
