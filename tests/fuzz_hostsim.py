@@ -1,0 +1,51 @@
+"""Development aid (CPU only): random synthetic captures through the host-compiled device logic (tests/hostsim, with the
+speculative walk, K3's two-tier rule and random chunking) against the oracle.  usage: python tests/fuzz_hostsim.py [n] [seed0]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
+import numpy as np
+from dumpvdl2_amd import synth
+from oracle import pyoracle as po
+import pyhostsim
+from util import assert_frames_equal
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+po.build()
+bad = 0
+for k in range(n):
+    seed = seed0 + k
+    rng = np.random.default_rng(seed)
+    nch = int(rng.choice([1, 2, 3, 5]))
+    os_ = int(rng.choice([10, 13, 20]))
+    spacing = int(rng.choice([25000, 50000, 100000]))
+    cfg = synth.SynthConfig(freqs=synth.channel_plan(nch, spacing=spacing), oversample=os_, duration_s=float(rng.uniform(0.6, 1.6)),
+                            seed=seed, mean_gap_s=float(rng.choice([0.01, 0.05, 0.15])), max_payload=int(rng.choice([60, 300, 1000, 1980])),
+                            noise_sigma=float(rng.choice([0.0005, 0.002, 0.01, 0.02])), error_injection=bool(rng.random() < 0.4),
+                            invalid_frame_rate=float(rng.choice([0.0, 0.3])), max_ppm=float(rng.choice([0.5, 2.0, 8.0])),
+                            rx_max_ppm=float(rng.choice([0.0, 0.0, 3.0])))
+    iq, bursts = synth.synthesize(cfg)
+    o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+    D = iq.size // 2 // cfg.oversample
+    tr = o.trace_all(D + 4)
+    o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=4)
+    D = o.decimated_count(0)
+    hs = pyhostsim.HostSim(list(cfg.freqs), cfg.rx_max_ppm, cap_log2=19)
+    seg_min = int(rng.choice([64, 300, 1500, 6000])); hs.set_segments(seg_min, int(rng.integers(2, 33)))
+    hs.set_two_tier(bool(rng.random() < 0.7))
+    t = 0
+    while t < D:
+        m = min(D - t, int(rng.integers(2 * seg_min, 60 * seg_min)) if rng.random() < 0.8 else int(rng.integers(1, 500)))
+        hs.feed(tr[:, t:t + m, :]); t += m
+    fo, fh = o.frames(), hs.frames()
+    try:
+        assert_frames_equal(fo, fh, label=f"seed {seed}")
+        assert [list(o.counters(c).values()) for c in range(nch)] == [hs.counters(c) for c in range(nch)]
+        assert po.avlc_counters(fh, nch) == [hs.avlc_counters(c) for c in range(nch)]
+        print(f"seed {seed}: ok  ch={nch} os={os_} sp={spacing} frames={len(fo)} bursts={len(bursts)} seg={hs.segment_stats()}", flush=True)
+    except AssertionError as e:
+        bad += 1
+        print(f"seed {seed}: MISMATCH {str(e)[:300]}", flush=True)
+    hs.close()
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
