@@ -515,6 +515,11 @@ VDL2_HD bool walk_clean(const WalkState &st) { return st.mode == 0 && st.e >= st
 VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, bool stop_clean, const Tables &T,
 		const ChanView &v, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
 	K4_BEGIN();
+	LANE0
+		// a speculative gather left by an earlier call was bounded by that call's k_end (phases beyond it read as zero): the
+		// stitcher calls this function several times per feed with growing k_end
+		sh.spec_n = -1;
+	LANE0_END
 	K4_MARK(0);
 	for(;;) {
 		if(sh.st.mode == 0) {

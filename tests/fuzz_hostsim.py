@@ -9,12 +9,10 @@ from oracle import pyoracle as po
 import pyhostsim
 from util import assert_frames_equal
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-po.build()
-bad = 0
-for k in range(n):
-    seed = seed0 + k
+
+def run_seed(seed):
+    """one random capture through hostsim (random segmentation, two-tier on/off, random chunking) against the oracle;
+    returns a description string, raises AssertionError on any difference"""
     rng = np.random.default_rng(seed)
     nch = int(rng.choice([1, 2, 3, 5]))
     os_ = int(rng.choice([10, 13, 20]))
@@ -40,12 +38,23 @@ for k in range(n):
     fo, fh = o.frames(), hs.frames()
     try:
         assert_frames_equal(fo, fh, label=f"seed {seed}")
-        assert [list(o.counters(c).values()) for c in range(nch)] == [hs.counters(c) for c in range(nch)]
-        assert po.avlc_counters(fh, nch) == [hs.avlc_counters(c) for c in range(nch)]
-        print(f"seed {seed}: ok  ch={nch} os={os_} sp={spacing} frames={len(fo)} bursts={len(bursts)} seg={hs.segment_stats()}", flush=True)
-    except AssertionError as e:
-        bad += 1
-        print(f"seed {seed}: MISMATCH {str(e)[:300]}", flush=True)
-    hs.close()
-print("mismatches:", bad)
-sys.exit(1 if bad else 0)
+        assert [list(o.counters(c).values()) for c in range(nch)] == [hs.counters(c) for c in range(nch)], f"seed {seed}: counters differ"
+        assert po.avlc_counters(fh, nch) == [hs.avlc_counters(c) for c in range(nch)], f"seed {seed}: avlc counters differ"
+        return f"ch={nch} os={os_} sp={spacing} frames={len(fo)} bursts={len(bursts)} seg={hs.segment_stats()}"
+    finally:
+        hs.close()
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    po.build()
+    bad = 0
+    for k in range(n):
+        try:
+            print(f"seed {seed0 + k}: ok  {run_seed(seed0 + k)}", flush=True)
+        except AssertionError as e:
+            bad += 1
+            print(f"seed {seed0 + k}: MISMATCH {str(e)[:300]}", flush=True)
+    print("mismatches:", bad)
+    sys.exit(1 if bad else 0)

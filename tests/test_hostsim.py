@@ -123,3 +123,13 @@ def test_two_tier_sync_metric_changes_nothing(oracle_mod, name, chunks, segments
     st = run_both.last_two_tier_stats
     assert st["total"] > 0 and st["exact"] < 0.2 * st["total"]
     print(name, st, st["exact"] / st["total"])
+
+
+@pytest.mark.parametrize("seed", [5019, 5029, 5041, 1002, 1018])
+def test_fuzz_regressions(oracle_mod, seed):
+    """Seeds of tests/fuzz_hostsim.py kept as regressions.  5019/5029/5041: a sync fired just before a segment end while the
+    stitcher was walking sequentially; the header phases gathered speculatively at the fire were bounded by that segment's end
+    (zeros beyond it) and were still used when the next call, with a later end, decoded the header.  1002/1018: heavy
+    cross-talk with many sequentially walked segments."""
+    import fuzz_hostsim
+    fuzz_hostsim.run_seed(seed)
