@@ -1,5 +1,5 @@
 """Development aid (CPU only): random synthetic captures through the host-compiled device logic (tests/hostsim, with the
-speculative walk, K3's two-tier rule and random chunking) against the oracle.  usage: python tests/fuzz_hostsim.py [n] [seed0]"""
+speculative walk, K3's two-tier rule and random chunking) against the oracle.  usage: python tests/fuzz_hostsim.py [n] [seed0] [extreme]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
@@ -10,7 +10,7 @@ import pyhostsim
 from util import assert_frames_equal
 
 
-def run_seed(seed):
+def run_seed(seed, extreme=False):
     """one random capture through hostsim (random segmentation, two-tier on/off, random chunking) against the oracle;
     returns a description string, raises AssertionError on any difference"""
     rng = np.random.default_rng(seed)
@@ -22,6 +22,11 @@ def run_seed(seed):
                             noise_sigma=float(rng.choice([0.0005, 0.002, 0.01, 0.02])), error_injection=bool(rng.random() < 0.4),
                             invalid_frame_rate=float(rng.choice([0.0, 0.3])), max_ppm=float(rng.choice([0.5, 2.0, 8.0])),
                             rx_max_ppm=float(rng.choice([0.0, 0.0, 3.0])))
+    if extreme:      # back-to-back bursts, many frames per burst, loud and faint signals, a burst right at the start, longer runs
+        cfg.mean_gap_s = float(rng.choice([0.001, 0.004, 0.02])); cfg.max_frames = int(rng.choice([1, 3, 8]))
+        cfg.amplitude = float(rng.choice([0.01, 0.05, 0.4])); cfg.first_burst_s = float(rng.choice([0.0, 0.0005, 0.02]))
+        cfg.duration_s = float(rng.uniform(0.3, 2.5)); cfg.min_payload = int(rng.choice([9, 20]))
+        cfg.noise_sigma = float(rng.choice([0.0005, 0.004, 0.012, 0.03]))
     iq, bursts = synth.synthesize(cfg)
     o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
     D = iq.size // 2 // cfg.oversample
@@ -57,11 +62,12 @@ def run_seed(seed):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    extreme = len(sys.argv) > 3 and sys.argv[3] == "extreme"
     po.build()
     bad = 0
     for k in range(n):
         try:
-            print(f"seed {seed0 + k}: ok  {run_seed(seed0 + k)}", flush=True)
+            print(f"seed {seed0 + k}: ok  {run_seed(seed0 + k, extreme)}", flush=True)
         except AssertionError as e:
             bad += 1
             print(f"seed {seed0 + k}: MISMATCH {str(e)[:300]}", flush=True)
