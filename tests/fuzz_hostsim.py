@@ -34,11 +34,11 @@ def run_seed(seed, extreme=False):
     o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=4)
     D = o.decimated_count(0)
     hs = pyhostsim.HostSim(list(cfg.freqs), cfg.rx_max_ppm, cap_log2=19)
-    seg_min = int(rng.choice([64, 300, 1500, 6000])); hs.set_segments(seg_min, int(rng.integers(2, 33)))
+    seg_min = int(rng.choice([64, 300, 1500, 6000, 25000] if extreme else [64, 300, 1500, 6000])); hs.set_segments(seg_min, int(rng.integers(2, 33)))
     hs.set_two_tier(bool(rng.random() < 0.7))
     t = 0
     while t < D:
-        m = min(D - t, int(rng.integers(2 * seg_min, 60 * seg_min)) if rng.random() < 0.8 else int(rng.integers(1, 500)))
+        m = min(D - t, int(rng.integers(2 * seg_min, max(2 * seg_min + 1, min(60 * seg_min, 400000)))) if rng.random() < 0.8 else int(rng.integers(1, 500)))
         hs.feed(tr[:, t:t + m, :]); t += m
     fo, fh = o.frames(), hs.frames()
     try:
