@@ -44,7 +44,13 @@
 #define LANE0_END } WAVE_SYNC();
 #else
 #define WAVE_SYNC() do {} while(0)
+// Host build: the lanes of a phase run one after the other.  A phase must not depend on that order (on the device the
+// lanes run together): -DVDL2_HOST_REVERSE_LANES runs them backwards, and the CPU tests must give the same answers.
+#ifdef VDL2_HOST_REVERSE_LANES
+#define WAVE_FOR(l) for(int l##_fw_ = 0; l##_fw_ < 64; l##_fw_++) { const int l = 63 - l##_fw_;
+#else
 #define WAVE_FOR(l) for(int l = 0; l < 64; l++) {
+#endif
 #define WAVE_END }
 #define LANE0 {
 #define LANE0_END }

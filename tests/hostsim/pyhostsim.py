@@ -18,17 +18,20 @@ class OutFrame(C.Structure):
                 ("avlc_status", C.c_uint32), ("dst_addr", C.c_uint32), ("src_addr", C.c_uint32), ("pad_", C.c_uint32)]
 
 
-def build():
+def build(reverse_lanes=False):
+    """reverse_lanes: compile with -DVDL2_HOST_REVERSE_LANES - the 64 lanes of every wave phase run in the opposite order, which
+    must not change any result (a phase whose lanes depended on each other would be a race on the device)"""
+    lib = _LIB.replace(".so", "_rev.so") if reverse_lanes else _LIB
     srcs = [os.path.join(_HERE, "hostsim.cpp")] + [os.path.join(_ROOT, "dumpvdl2_amd", "csrc", f) for f in ("vdl2_core.h", "tables.h", "design.h")]
-    if not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
-                               "-o", _LIB, srcs[0]])
-    return _LIB
+    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared"]
+                              + (["-DVDL2_HOST_REVERSE_LANES"] if reverse_lanes else []) + ["-o", lib, srcs[0]])
+    return lib
 
 
 class HostSim:
-    def __init__(self, freqs, max_ppm=0.0, cap_log2=21):
-        self.L = C.CDLL(build())
+    def __init__(self, freqs, max_ppm=0.0, cap_log2=21, reverse_lanes=False):
+        self.L = C.CDLL(build(reverse_lanes))
         self.L.hostsim_create.restype = C.c_void_p
         self.L.hostsim_create.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_float, C.c_int]
         self.L.hostsim_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]

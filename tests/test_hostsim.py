@@ -9,14 +9,14 @@ import pyhostsim
 from util import assert_frames_equal
 
 
-def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None, segments=None, two_tier=False):
+def run_both(oracle_mod, cfg, iq, chunks=None, cap_log2=None, segments=None, two_tier=False, reverse_lanes=False):
     C = len(cfg.freqs)
     o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
     D = iq.size // 2 // cfg.oversample
     tr = o.trace_all(D + 4)
     o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=4)
     D = o.decimated_count(0)
-    hs = pyhostsim.HostSim(list(cfg.freqs), cfg.rx_max_ppm, cap_log2=cap_log2 or int(np.ceil(np.log2(D + 70000))))
+    hs = pyhostsim.HostSim(list(cfg.freqs), cfg.rx_max_ppm, cap_log2=cap_log2 or int(np.ceil(np.log2(D + 70000))), reverse_lanes=reverse_lanes)
     if segments:
         hs.set_segments(*segments)
     if two_tier:
@@ -133,3 +133,16 @@ def test_fuzz_regressions(oracle_mod, seed):
     cross-talk with many sequentially walked segments."""
     import fuzz_hostsim
     fuzz_hostsim.run_seed(seed)
+
+
+@pytest.mark.parametrize("name,chunks,segments", [("config2_1s", (100, 30000), (700, 32)), ("config5_0p4s", None, (1000, 16)),
+                                                  ("dirty25k_1s", None, None), ("os10_noisy_1s", (64, 5000), (500, 32))])
+def test_lane_order_does_not_matter(oracle_mod, name, chunks, segments):
+    """On the device the 64 lanes of a wave phase run together; the host build runs them one after the other.  Run backwards
+    (-DVDL2_HOST_REVERSE_LANES) the walker, the stitcher, the noise-floor replay, the burst decoder and the frame finisher
+    must give the same frames and counters - a phase in which one lane consumed what another lane produced would be a race
+    on the GPU that the forward host order hides."""
+    cfg, iq, _, _ = cases.load(name)
+    fo, fh, co, ch = run_both(oracle_mod, cfg, iq, chunks, cap_log2=17 if chunks else None, segments=segments, two_tier=True, reverse_lanes=True)
+    assert_frames_equal(fo, fh, label=name)
+    assert co == ch
