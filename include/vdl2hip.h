@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VDL2HIP_ABI_VERSION 1
+#define VDL2HIP_ABI_VERSION 2   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added */
 
 /* enum sample_formats, src/dumpvdl2.h:319 */
 #define VDL2HIP_FMT_U8     0
