@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the MI355X-native VDL2 hot path.
 
-Metric (BASELINE.json): IQ MS/s demodulated end-to-end.  One "step" = one pass of the whole hot
-path (K1 channeliser ... K5 burst decoder, frames delivered to the host) over one 16 s batch of
-synthetic 2.1 MS/s cs16 IQ that is already resident in HBM.  N=1 runs BASELINE configs[1]
-(8 VDL2 channels on one GPU).  With N>1 (one process per GPU, launched by torch.distributed.run)
-every rank decodes 8 channels of the same IQ stream (weak scaling: 8 channels per GPU); each raw IQ
-block is put on every GPU with RCCL inside the timed steps (double-buffered: the exchange of block
-i+1 overlaps the demodulation of block i) - the path's only exchange.  Default: the capture lies
-striped across the GPUs' HBM and the stripes are all-gathered (every xGMI link of a GPU carries part
-of the block); --exchange broadcast sends it from rank 0 instead (SURVEY 8.6's literal form).
+Metric (BASELINE.json): IQ MS/s demodulated end-to-end.  One "step" = one pass of the whole hot path (K1 channeliser ...
+K5 burst decoder, frames delivered to host memory) over one 16 s block of synthetic 2.1 MS/s cs16 IQ, demodulated on ALL
+channels of the workload.  Default workload: north_star's 256-channel configuration (BASELINE configs[3], "config4") - the
+largest configuration, which fits one GPU.  The same command runs at any N:
+
+  N = 1   one GPU demodulates all 256 channels;
+  N > 1   (one process per GPU, launched by torch.distributed.run) rank r demodulates channels [r*256/N, (r+1)*256/N) of
+          the same stream (32 per GPU at N = 8); the only exchange puts every raw IQ block on every GPU with RCCL, inside
+          the timed steps and overlapped with the demodulation of the previous block: broadcast from the ingest rank
+          (north_star's form) or all-gather of per-rank stripes (each rank ingests 1/N of the block over its own PCIe
+          link).  `--exchange auto` (default) times both bare exchanges during warm-up and uses the faster one.
+
+So total work is fixed ("scaling": "strong") and value(N=8) / value(N=1) is the 8-GPU speed-up north_star asks for.
+
+`value` is the host-fed rate (cs16 block in page-locked host memory -> all frames of the block delivered):
+the block crosses PCIe inside every timed step, overlapped with compute by the library's copy stream.  The same K steps
+are then repeated with the block already resident in HBM (`value_hbm_resident`).  At N = 1 two smaller configurations
+(64 and 8 channels) are measured the same way and reported under config.secondary.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import platform
+import subprocess
 import sys
 import time
 
@@ -23,33 +34,179 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-ALGO_BYTES_PER_CHAN_SAMPLE = 4.0 + 8.0 / 20.0 + 4.0 / 20.0   # cs16 I+Q read per channel + (float2 decimated sample + float phase, which the
-                                                            # channeliser writes too since the phase stage is fused into it) / oversample
-if os.environ.get("VDL2HIP_NO_FUSE"):             # experiments: with the separate phase kernel K1 does not write the phases
-    ALGO_BYTES_PER_CHAN_SAMPLE = 4.0 + 8.0 / 20.0
+OS = 20
+# algorithmic bytes per channel-sample = 4 B (cs16 I+Q, read per channel as the reference does) + 8/os B (one
+# float2 decimated output).  The kernel also writes the phase stream (4/os B) since the phase stage is fused into it: the
+# figure including it is reported separately, never as `frac`.
+ALGO_BYTES = 4.0 + 8.0 / OS
+ALGO_BYTES_WITH_PHASE = ALGO_BYTES + 4.0 / OS
+FLOP_PER_CHAN_SAMPLE = 30.0                       # LUT interpolation 6 + mix 6 + 2 x 9 IIR
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: peak FP32 vector
+WORKLOAD_INDEX = {"config2": 1, "config3": 2, "config4": 3, "config5": 4}
+
+
+def cpu_info():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        cc = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:  # noqa: BLE001
+        cc = "gcc ?"
+    return {"nproc": os.cpu_count(), "cpu_model": model or platform.processor(), "compiler": cc}
+
+
+class Case:
+    """One workload on this rank: receiver over the rank's channel shard + the feeder that brings the blocks."""
+
+    def __init__(self, name, duration, world, rank, local, torch, channels=None):
+        from dumpvdl2_amd import synth, workloads, vdl2hip
+        from dumpvdl2_amd import dist as vdist
+        self.torch, self.vdist, self.vdl2hip = torch, vdist, vdl2hip
+        self.name, self.world, self.rank, self.local = name, world, rank, local
+        cfg = getattr(workloads, name)(duration)
+        if name == "config2" and channels and channels != 8:
+            cfg.freqs = synth.channel_plan(channels, cfg.centerfreq, max(8000, min(100000, 2000000 // channels)))
+        self.cfg = cfg
+        t0 = time.time()
+        # every rank synthesises the capture itself (seeded: identical bytes, checked below) - each needs it in its own
+        # page-locked memory for the striped ingest, and nothing large has to cross process boundaries
+        self.iq, self.bursts = synth.synthesize(cfg)
+        self.t_synth = time.time() - t0
+        self.nvals = self.iq.size
+        self.nbytes = self.nvals * 2
+        self.nsamples = self.nvals // 2
+        self.C = len(cfg.freqs)
+        self.first, self.count = vdist.shard_channels(self.C, world, rank)
+        self.device = torch.device("cuda", local)
+        self.rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm,
+                                   device=local, max_block_bytes=self.nbytes, chan_first=self.first, chan_count=self.count)
+        self.front = torch.cuda.ExternalStream(self.rx.stream(), device=self.device)
+        self.host = torch.from_numpy(self.iq)
+
+    def feeder(self, mode, source):
+        return self.vdist.ShardedFeeder(self.rx, self.host, self.world, self.rank, mode=mode, source=source, device=self.device,
+                                        front_stream=self.front)
+
+    def frames_of_step(self, feeder):
+        """one synchronous step: every frame this rank's channels produce for one block"""
+        self.rx.set_drain_lag(0)
+        n, recs, octs = feeder.step()
+        return self.vdl2hip.Receiver.unpack(n, recs, octs)
+
+    def timed(self, feeder, steps, dist):
+        """exactly `steps` steps in streaming mode (three blocks in flight); every block fully delivered inside the region"""
+        torch = self.torch
+        self.rx.set_profiling(1)           # start/stop events on the channeliser launch only: its duration is the roofline figure
+        self.rx.set_drain_lag(2)
+        s0 = self.rx.stats()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nframes = 0
+        for _ in range(steps):
+            nframes += feeder.step()[0]
+        self.rx.set_drain_lag(0)
+        nframes += self.rx.drain_packed()[0]
+        feeder.finish()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        s1 = self.rx.stats()
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            nf = torch.tensor([nframes], dtype=torch.int64, device=self.device)
+            dist.all_reduce(nf)
+            nframes = int(nf.item())
+        launches = max(1, s1["chanfir_launches"] - s0["chanfir_launches"])
+        k1_ms = (s1["chanfir_ms"] - s0["chanfir_ms"]) / launches
+        k1_cs = (s1["chan_samples"] - s0["chan_samples"]) / launches
+        assert s1["front_sync_timeouts"] == 0 and s1["overflow_feeds"] == s0["overflow_feeds"], "device-side overflow or look-back timeout"
+        return {"dt": dt, "frames": nframes, "k1_ms": k1_ms, "k1_chan_samples": k1_cs,
+                "seg_adopted": (s1["seg_adopted"] - s0["seg_adopted"]) / steps, "seg_walked": (s1["seg_walked"] - s0["seg_walked"]) / steps}
+
+    def stage_times(self, feeder, nstage=4):
+        """per-stage kernel times (informational): a short untimed pass with every stage's launch timed"""
+        self.rx.set_profiling(2)
+        self.rx.set_drain_lag(2)
+        sa = self.rx.stats()
+        for _ in range(nstage):
+            feeder.step()
+        self.rx.set_drain_lag(0)
+        self.rx.drain_packed()
+        feeder.finish()
+        self.torch.cuda.synchronize()
+        sb = self.rx.stats()
+        self.rx.set_profiling(1)
+        return {k: round((sb[k] - sa[k]) / nstage, 4) for k in ("chanfir_ms", "phase_ms", "sync_ms", "walk_ms", "nf_ms", "burst_ms")}
+
+    def close(self):
+        self.rx.close()
+
+
+def roofline_of(t, case, traffic):
+    k1_ms, cs = t["k1_ms"], t["k1_chan_samples"]
+    ach = cs * ALGO_BYTES / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+    tf = cs * FLOP_PER_CHAN_SAMPLE / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": "k_chanfir", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_chan_sample": ALGO_BYTES, "algorithmic_bytes_per_launch": cs * ALGO_BYTES,
+            "avg_launch_ms": round(k1_ms, 5), "chan_samples_per_launch": cs,
+            "frac_counting_phase_stream": round(cs * ALGO_BYTES_WITH_PHASE / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k1_ms > 0 else 0.0,
+            # the kernel is instruction-issue bound, not HBM bound (DESIGN 3): the same launch against the FP32 vector peak
+            "valu": {"flop_per_chan_sample": FLOP_PER_CHAN_SAMPLE, "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / VALU_PEAK_TFLOPS, 4)}}
+
+
+def pmc_traffic(workload, case):
+    """HBM traffic of K1 per launch: PMC counters cannot be read from inside this process; the number measured with
+    rocprofv3 on this same command (tests/gpu_pmc_traffic.sh) is kept under profiles/ and quoted only for the workload and
+    shard size it was taken on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+        for e in pt.get("k_chanfir_by_workload", []):
+            w = e["workload"]
+            if (w["name"], w["channels_per_gpu"], float(w["duration_s"])) == (workload, case.count, float(case.cfg.duration_s)):
+                return e["traffic_bytes"]
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--duration", type=float, default=16.0, help="seconds of 2.1 MS/s signal per step")
-    ap.add_argument("--channels", type=int, default=8, help="channels per GPU (config2 only)")
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config4", "config5"],
-                    help="BASELINE configs[1..4]; the headline line is config2 (8 channels)")
-    ap.add_argument("--exchange", default="allgather", choices=["allgather", "broadcast"],
-                    help="N>1: how each rank gets the raw IQ block - all-gather of the stripes the ranks hold (capture striped "
-                         "over the GPUs' HBM) or broadcast from rank 0")
+    ap.add_argument("--channels", type=int, default=8, help="channel count of config2 (experiments)")
+    ap.add_argument("--workload", default="config4", choices=["config2", "config3", "config4", "config5"],
+                    help="BASELINE configs[1..4]; default config4 = north_star's 256 channels")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "broadcast", "allgather"],
+                    help="N>1: how each rank gets the raw IQ block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the 64- and 8-channel configurations")
+    ap.add_argument("--oracle-threads", type=int, default=0)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from dumpvdl2_amd import synth, workloads, vdl2hip
+    from dumpvdl2_amd import vdl2hip
     from dumpvdl2_amd import dist as vdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -62,183 +219,157 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    # ---- workload: BASELINE configs[1] ----
-    cfg = getattr(workloads, args.workload)(args.duration)
-    if args.workload == "config2" and args.channels != 8:
-        cfg.freqs = synth.channel_plan(args.channels, cfg.centerfreq, max(8000, min(100000, 2000000 // args.channels)))
-    nvals = 2 * (int(round(cfg.duration_s * cfg.sample_rate)) // 2 * 2)
-    bursts = None
-    if rank == 0:
-        t0 = time.time()
-        iq, bursts = synth.synthesize(cfg)
-        assert iq.size == nvals
-        t_synth = time.time() - t0
-        bufs = [torch.from_numpy(iq).cuda()]
-    else:
-        iq = None
-        t_synth = 0.0
-        bufs = [torch.zeros(nvals, dtype=torch.int16, device="cuda")]
-    if world > 1:       # double buffer: block i+1 is broadcast over xGMI while block i is being demodulated
-        bufs.append(bufs[0].clone())
-    nbytes = nvals * 2
-    nsamples = nvals // 2
+    case = Case(args.workload, args.duration, world, rank, local, torch, channels=args.channels)
+    cfg = case.cfg
+    if world > 1:        # every rank must hold the very same capture
+        h = torch.tensor([int(np.bitwise_xor.reduce(case.iq.view(np.uint64))) & 0x7fffffffffffffff], dtype=torch.int64, device=case.device)
+        lo, hi = h.clone(), h.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert int(lo.item()) == int(hi.item()), "ranks synthesised different captures"
 
-    rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm,
-                          device=local, max_block_bytes=nbytes)
-
-    state = {"i": 0, "work": None}
-    front = torch.cuda.ExternalStream(rx.stream()) if world > 1 else None
-    exchange = None
-    if world > 1:       # block 0 arrives before the first step
-        vdist.broadcast_block(bufs[0], src=0)
-        torch.cuda.synchronize()
-        # default: the capture lies striped across the GPUs and is all-gathered; dry-run inside, falls back to broadcast
-        exchange = vdist.BlockExchange(bufs[0], mode=args.exchange, src=0, scratch=bufs[1])
-        args.exchange = exchange.mode
-
-    def step():
-        """One pass of the hot path over one 16 s block; with N>1 the RCCL exchange that puts the NEXT block on every GPU
-        (all-gather of the ranks' stripes, or broadcast from rank 0) runs concurrently on RCCL's stream and is waited for
-        before the step ends, so every step pays max(compute, exchange) - the exchange is inside the timed region."""
-        i = state["i"]
-        cur = bufs[i % len(bufs)]
-        if world > 1:
-            nxt = bufs[(i + 1) % len(bufs)]
-            # `nxt` was the input of block i-1: its channeliser (front stream of the library) must have finished
-            # reading it before RCCL overwrites it
-            torch.cuda.current_stream().wait_event(front.record_event())
-            state["work"] = exchange.start(nxt)
-        rx.feed_device(cur.data_ptr(), nbytes)
-        out = rx.drain_packed()            # every frame of the step copied to host memory (records + octets)
-        if world > 1:
-            state["work"].wait()
-            torch.cuda.current_stream().synchronize()
-        state["i"] = i + 1
-        return out
+    # ---- exchange: measured, not assumed ----
+    exchange_info = None
+    mode = "broadcast"
+    if world > 1:
+        cands = ["broadcast", "allgather"] if args.exchange == "auto" else [args.exchange]
+        if case.nbytes % world:
+            cands = ["broadcast"]
+        exchange_info = {}
+        for src_kind in ("host", "hbm"):
+            for m in cands:
+                secs, ok = vdist.time_exchange(case.host, world, rank, m, src_kind, case.device)
+                exchange_info[f"{m}_{src_kind}_ms"] = round(secs * 1e3, 4) if ok else None
+        best = {m: exchange_info.get(f"{m}_host_ms") for m in cands}
+        mode = min((m for m in cands if best[m] is not None), key=lambda m: best[m])
+        exchange_info["chosen"] = mode
 
     # ---- warm-up, with the parity gate on the first pass ----
+    f_host = case.feeder(mode, "host")
     verified = None
-    for w in range(max(args.warmup, 1)):
-        n, recs, octs = step()
-        if w == 0 and rank == 0 and not args.no_verify:
-            fr = vdl2hip.Receiver.unpack(n, recs, octs)
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from util import truth_is_subset, assert_frames_equal
-            missing = truth_is_subset(bursts, fr)
-            want = sum(len(b.frames) for b in bursts if b.decodable)
-            # with injected errors some bursts pushed past the nominal RS capacity still decode (both here and in the oracle)
-            exact = not cfg.error_injection
-            assert missing == 0 and (len(fr) == want if exact else len(fr) >= want), \
-                f"parity gate: {missing} transmitted frames missing, {len(fr)} decoded vs {want} sent"
-            # bounded oracle check on the first 2 s of the very same bytes
-            from oracle import pyoracle as po
-            n2 = min(nvals, 2 * cfg.sample_rate * 2)
-            o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
-            o.process(iq[:n2].view(np.uint8), block_bytes=1 << 24, nthreads=min(len(cfg.freqs), os.cpu_count() or 8))
-            lim = n2 // 2 // cfg.oversample - 200
-            assert_frames_equal([f for f in o.frames() if f["end_sample"] < lim], [f for f in fr if f["end_sample"] < lim], label="bench oracle gate")
-            verified = {"tx_frames": want, "decoded": len(fr), "oracle_window_s": n2 / 2 / cfg.sample_rate}
-
-    # ---- timed region: exactly K steps ----
-    # Streaming mode: a step queues its block and collects the frames of the previous one, so the sample-rate
-    # front of block i+1 overlaps the burst-rate back of block i; the frames of the last block are collected before
-    # the clock stops (vdl2hip_sync + drain), so all K blocks are fully delivered inside the timed region.
-    rx.set_profiling(1)                # start/stop events on the channeliser launch only: its duration is the roofline figure
-    rx.set_drain_lag(2)
-    s0 = rx.stats()
+    cpu_baseline = None
+    fr = case.frames_of_step(f_host)
+    allfr = vdist.gather_frames(fr, dst=0) if world > 1 else fr
+    if rank == 0 and not args.no_verify:
+        from util import truth_is_subset, assert_frames_equal
+        missing = truth_is_subset(case.bursts, allfr)
+        want = sum(len(b.frames) for b in case.bursts if b.decodable)
+        # with injected errors some bursts pushed past the nominal RS capacity still decode (both here and in the oracle)
+        exact = not cfg.error_injection
+        assert missing == 0 and (len(allfr) == want if exact else len(allfr) >= want), \
+            f"parity gate: {missing} transmitted frames missing, {len(allfr)} decoded vs {want} sent"
+        verified = {"tx_frames": want, "decoded": len(allfr)}
+        # the oracle on the WHOLE block (all channels, all 16 s) on this box's host cores: the parity gate and, at N = 1, the
+        # CPU baseline in one pass
+        from oracle import pyoracle as po
+        nth = args.oracle_threads or min(case.C, os.cpu_count() or 1)
+        o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+        t0 = time.perf_counter()
+        o.process(case.iq.view(np.uint8), block_bytes=320000, nthreads=nth)
+        tc = time.perf_counter() - t0
+        ofr = o.frames()
+        assert_frames_equal(ofr, allfr, label="bench oracle gate")
+        for ch in range(case.first, case.first + case.count, max(1, case.count // 8)):
+            assert list(o.counters(ch).values()) == list(case.rx.counters(ch).values()), f"counters of channel {ch} differ from the oracle's"
+        o.close()
+        verified.update({"oracle_window_s": cfg.duration_s, "oracle_frames": len(ofr), "oracle_identical": True})
+        if world == 1 and not args.no_cpu_baseline:
+            ci = cpu_info()
+            cpu_baseline = {"value": round(case.nsamples / tc / 1e6, 4), "unit": "MS/s", "cores": nth, "kind": "port",
+                            "channel_MS_per_s": round(case.nsamples * case.C / tc / 1e6, 1),
+                            "sample": f"the same {cfg.duration_s:g} s x {case.C}-channel block, one pass ({tc:.1f} s); CPU restatement of the "
+                                      f"reference (oracle/), {nth} threads over the channels + serial sample conversion, 320000-byte blocks "
+                                      f"as process_iq_file()",
+                            "flags": "-O2 -fno-fast-math -ffp-contract=off (oracle/Makefile)", **ci}
+            try:
+                of = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm, variant="fast")
+                n_fast = min(case.nbytes, 4 * cfg.sample_rate * 4)          # 4 s of the block: bounded
+                t0 = time.perf_counter()
+                of.process(case.iq.view(np.uint8)[:n_fast], block_bytes=320000, nthreads=nth)
+                tf = time.perf_counter() - t0
+                of.close()
+                cpu_baseline["fast_math"] = {"value": round(n_fast / 4 / tf / 1e6, 4), "unit": "MS/s", "flags": "-O3 -ffast-math (mirrors src/CMakeLists.txt:35-38)",
+                                             "sample": f"first {n_fast / 4 / cfg.sample_rate:g} s of the block"}
+            except Exception as e:  # noqa: BLE001 - the fast-math build is optional
+                cpu_baseline["fast_math"] = {"error": str(e)[:200]}
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    nframes = 0
-    for _ in range(args.steps):
-        nframes += step()[0]
-    rx.set_drain_lag(0)
-    nframes += rx.drain_packed()[0]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    s1 = rx.stats()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    for _ in range(max(0, args.warmup - 1)):
+        f_host.step()
+    case.rx.sync()
 
-    k1_ms = (s1["chanfir_ms"] - s0["chanfir_ms"]) / max(1, s1["chanfir_launches"] - s0["chanfir_launches"])
-    k1_chan_samples = (s1["chan_samples"] - s0["chan_samples"]) / max(1, s1["chanfir_launches"] - s0["chanfir_launches"])
-    achieved = k1_chan_samples * ALGO_BYTES_PER_CHAN_SAMPLE / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-    # per-stage kernel times (informational): a short untimed pass with every stage's launch timed - doing that inside the
-    # timed region costs ~5 % of the throughput being measured
-    rx.set_profiling(2)
-    rx.set_drain_lag(2)
-    sa = rx.stats()
-    nstage = 4
-    for _ in range(nstage):
-        step()
-    rx.set_drain_lag(0)
-    rx.drain_packed()
-    torch.cuda.synchronize()
-    sb = rx.stats()
-    stage_ms = {k: (sb[k] - sa[k]) / nstage for k in ("chanfir_ms", "phase_ms", "sync_ms", "walk_ms", "nf_ms", "burst_ms")}
-    if world > 1:
-        dist.barrier()
+    # ---- timed region: exactly K steps, host-fed ----
+    t_host = case.timed(f_host, args.steps, dist)
+    stage_ms = case.stage_times(f_host)
+    del f_host
+    # ---- the same K steps with the block resident in HBM ----
+    f_hbm = case.feeder(mode, "hbm")
+    for _ in range(2):
+        f_hbm.step()
+    case.rx.set_drain_lag(0); case.rx.drain_packed()
+    t_hbm = case.timed(f_hbm, args.steps, dist)
+    del f_hbm
 
-    # HBM traffic of K1 per launch: PMC counters cannot be read from inside this process; the number measured with
-    # rocprofv3 on this same command is kept under profiles/ and quoted when the workload is the one it was taken on
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pt = json.load(f)["k_chanfir"]
-        w = pt["workload"]
-        if args.workload == "config2" and (w["channels_per_gpu"], w["duration_s"], w["oversample"]) == (len(cfg.freqs), float(cfg.duration_s), cfg.oversample):
-            traffic = pt["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    secondary = []
+    if world == 1 and not args.no_secondary and args.workload == "config4":
+        case.close()
+        for name in ("config3", "config2"):
+            c2 = Case(name, args.duration, 1, 0, local, torch)
+            fh = c2.feeder("broadcast", "host")
+            fr2 = c2.frames_of_step(fh)
+            from util import truth_is_subset
+            miss = truth_is_subset(c2.bursts, fr2)
+            want2 = sum(len(b.frames) for b in c2.bursts if b.decodable)
+            assert miss == 0 and len(fr2) == want2, f"{name}: {miss} transmitted frames missing, {len(fr2)} decoded vs {want2} sent"
+            fh.step(); c2.rx.sync()
+            th = c2.timed(fh, args.steps, dist)
+            del fh
+            fd = c2.feeder("broadcast", "hbm")
+            fd.step(); fd.step(); c2.rx.set_drain_lag(0); c2.rx.drain_packed()
+            td = c2.timed(fd, args.steps, dist)
+            del fd
+            rl = roofline_of(td, c2, pmc_traffic(name, c2))
+            secondary.append({"workload": f"configs[{WORKLOAD_INDEX[name]}] ({name}): {c2.C} channels, {c2.cfg.duration_s:g} s",
+                              "value": round(c2.nsamples * args.steps / th["dt"] / 1e6, 3),
+                              "value_hbm_resident": round(c2.nsamples * args.steps / td["dt"] / 1e6, 3),
+                              "ms_per_step": round(th["dt"] / args.steps * 1e3, 4), "ms_per_step_hbm_resident": round(td["dt"] / args.steps * 1e3, 4),
+                              "frames_per_step": th["frames"] / args.steps, "tx_frames_all_recovered": True,
+                              "k_chanfir_ms": rl["avg_launch_ms"], "roofline_frac": rl["frac"], "valu_frac": rl["valu"]["frac"]})
+            c2.close()
 
     if rank == 0:
-        value = world * nsamples * args.steps / dt / 1e6
+        value = case.nsamples * args.steps / t_host["dt"] / 1e6
+        value_hbm = case.nsamples * args.steps / t_hbm["dt"] / 1e6
+        widx = WORKLOAD_INDEX[args.workload]
         out = {
             "metric": "IQ MS/s demodulated end-to-end",
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(t_host["dt"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[{int(args.workload[-1]) - 1}] ({args.workload}): synthetic 2.1 MS/s cs16 IQ, {cfg.duration_s:g} s, "
-                                   f"{len(cfg.freqs)} VDL2 channels per GPU, input resident in HBM, three blocks in flight",
-                       "channels_per_gpu": len(cfg.freqs), "samples_per_step": nsamples,
-                       "channel_MS_per_s": round(value * len(cfg.freqs), 1),
-                       "realtime_channels_at_2.1MSps": round(value * len(cfg.freqs) / 2.1, 1),
-                       "frames_per_step": nframes / args.steps,
-                       "parallelism": (f"channel shard x{world}, RCCL {'all-gather of the IQ block from the stripes resident on the GPUs' if args.exchange == 'allgather' else 'broadcast of the IQ block from rank 0'}, inside the timed steps") if world > 1 else "single GPU",
-                       "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
-                       "walk_segments_per_step": {"adopted": (s1["seg_adopted"] - s0["seg_adopted"]) / args.steps,
-                                                  "walked_sequentially": (s1["seg_walked"] - s0["seg_walked"]) / args.steps},
+            "value_hbm_resident": round(value_hbm, 3), "ms_per_step_hbm_resident": round(t_hbm["dt"] / args.steps * 1e3, 4),
+            "config": {"workload": f"configs[{widx}] ({args.workload}): synthetic 2.1 MS/s cs16 IQ, {cfg.duration_s:g} s per step, {case.C} VDL2 channels "
+                                   f"in total, {case.count} per GPU; value = block in page-locked host memory -> frames in host memory "
+                                   f"(H2D inside the step, overlapped); three blocks in flight",
+                       "channels_total": case.C, "channels_per_gpu": case.count, "samples_per_step": case.nsamples,
+                       "channel_MS_per_s": round(value * case.C, 1),
+                       "realtime_channels_at_2.1MSps": round(value * case.C / 2.1, 1),
+                       "frames_per_step": t_host["frames"] / args.steps,
+                       "parallelism": (f"channels sharded x{world} ({case.count} per GPU), RCCL {mode} of every IQ block inside the timed steps"
+                                       if world > 1 else "single GPU, all channels"),
+                       "exchange": exchange_info,
+                       "stage_ms_per_step": stage_ms,
+                       "walk_segments_per_step": {"adopted": t_host["seg_adopted"], "walked_sequentially": t_host["seg_walked"]},
                        "verified": verified,
-                       "synth_s": round(t_synth, 1)},
-            "roofline": {"bound": "hbm", "kernel": "k_chanfir", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": k1_chan_samples * ALGO_BYTES_PER_CHAN_SAMPLE,
-                         "avg_launch_ms": round(k1_ms, 5)},
+                       "synth_s": round(case.t_synth, 1),
+                       "secondary": secondary},
+            "roofline": roofline_of(t_hbm, case, pmc_traffic(args.workload, case)),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import pyoracle as po
-            nth = min(len(cfg.freqs), os.cpu_count() or 1)
-            best, nfr = None, 0
-            for _ in range(3):                                  # best of 3: shared host, noisy neighbours
-                o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
-                t0 = time.perf_counter()
-                o.process(iq.view(np.uint8), block_bytes=320000, nthreads=nth)
-                tc1 = time.perf_counter() - t0
-                nfr = len(o.frames())
-                o.close()
-                best = tc1 if best is None else min(best, tc1)
-            tc = best
-            out["cpu_baseline"] = {"value": round(nsamples / tc / 1e6, 3), "unit": "MS/s", "cores": nth, "kind": "port",
-                                   "sample": f"the same {cfg.duration_s:g} s x {len(cfg.freqs)}-channel batch, best of 3 passes; CPU restatement of the reference "
-                                             f"(oracle/), one thread per channel + serial sample conversion, 320000-byte blocks as process_iq_file()",
-                                   "frames": nfr}
+        out["roofline"]["measured_in"] = "the HBM-resident timed region (HIP start/stop events attached to each k_chanfir launch)"
+        out["roofline"]["avg_launch_ms_host_fed"] = round(t_host["k1_ms"], 5)
+        if cpu_baseline is not None:
+            out["cpu_baseline"] = cpu_baseline
         print(json.dumps(out), flush=True)
-    rx.close()
+    if not (world == 1 and secondary):
+        case.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -74,6 +74,8 @@ struct K1Args {
 	const BlockForm *bfd;      // full tables (cP[kFixW], Ppow[kFixW+1]) in device memory
 	unsigned long long *seg_pub; // [nchan][nseg_cap][4]: (epoch << 32 | float bits) of the zero-start segment end state
 	uint32_t epoch;
+	uint32_t pub_epoch;        // = epoch (differs only when a test forces the look-back to time out)
+	uint32_t spin_limit;
 	uint32_t *sync_timeouts;   // sticky count of look-back waits that gave up (never expected)
 	uint32_t cap, mask, nseg_cap;
 };
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 					// publish for the next segment's workgroup: each word carries the feed's epoch, so no flag and no fence
 					// (an agent-scope release would write back the whole L2 of this XCD)
 					unsigned long long *pub = a.seg_pub + ((size_t)(cbase + c) * a.nseg_cap + seg) * 4;
-					const unsigned long long ep = (unsigned long long)a.epoch << 32;
+					const unsigned long long ep = (unsigned long long)a.pub_epoch << 32;
 					__hip_atomic_store(pub + 0, ep | __float_as_uint(e.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					__hip_atomic_store(pub + 1, ep | __float_as_uint(e.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					__hip_atomic_store(pub + 2, ep | __float_as_uint(e.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 		const unsigned long long *src = a.seg_pub + ((size_t)ch * a.nseg_cap + seg - 1) * 4 + (lane & 3);
 		unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		for(int spins = 0; (uint32_t)(w >> 32) != a.epoch; spins++) {
-			if(spins > (1 << 22)) { atomicAdd(a.sync_timeouts, 1u); break; }
+			if((uint32_t)spins > a.spin_limit) { atomicAdd(a.sync_timeouts, 1u); break; }
 			__builtin_amdgcn_s_sleep(8);
 			w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
@@ -613,8 +615,9 @@ __global__ __launch_bounds__(64) void k_nf_finish(K4bArgs a) {
 
 // Each channel's walker fills its own burst list (no atomics on its critical path); this one-wave kernel turns the
 // per-channel counts into offsets so that K5 can spread all bursts of the feed over its workgroups.
-__global__ __launch_bounds__(64) void k_burst_index(const uint32_t *nb_chan, uint32_t *bbase, int nchan, OutCtl *ctl) {
+__global__ __launch_bounds__(64) void k_burst_index(const uint32_t *nb_chan, uint32_t *bbase, int nchan, OutCtl *ctl, const uint32_t *front_timeouts) {
 	if(threadIdx.x != 0) return;
+	ctl->front_timeouts = *front_timeouts;   // runs after this feed's front: what the host checks before it trusts the feed
 	uint32_t acc = 0;
 	for(int c = 0; c < nchan; c++) { bbase[c] = acc; acc += nb_chan[c]; }
 	bbase[nchan] = acc;
@@ -651,6 +654,7 @@ __global__ __launch_bounds__(64) void k_frame_finish(OutFrame *frames, const uin
 	frame_shared_init(*tab, sh);
 	for(uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
 		const int c = frames[i].chan;
+		if(c < 0) continue;                              // tombstone (octet pool overflow): wave-uniform
 		finish_frame(frames[i], pool, *tab, acnt + (size_t)c * kNumAvlcCounters, ring + (size_t)c * (ring_mask + 1), ring_mask, sh);
 		__syncthreads();
 	}

@@ -180,6 +180,8 @@ struct OutFrame {
 struct OutCtl {
 	uint32_t nbursts, nframes, pool_used, overflow;
 	uint32_t cap_bursts, cap_frames, cap_pool, cap_log;
+	uint32_t front_timeouts;           // channeliser workgroups that gave up waiting for their predecessor's state (must be 0)
+	uint32_t pad_[3];
 };
 
 // A stretch of executed got_sync() evaluations: samples first, first+3, ..., first+3*(count-1).
@@ -1578,7 +1580,10 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 					f.ppm_error = b.ppm;
 					f.burst_ord = b.ord; f.sync_sample = b.sync_sample; f.end_sample = b.end_sample;
 					sh.u_ok = 1; sh.u_off = off;
-				} else ctl->overflow = 1;
+				} else {
+					ctl->overflow = 1;
+					if(slot < ctl->cap_frames) { OutFrame &f = frames[slot]; f.chan = -1; f.len = 0; f.pool_off = 0; f.nf_upd = 0; }   // tombstone: skipped downstream
+				}
 			}
 		LANE0_END
 		if(sh.u_kind != 1) { if(sh.u_kind == 4) break; return; }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -21,9 +22,11 @@ static_assert(VDL2HIP_NUM_COUNTERS == kNumCounters, "counter enum out of sync");
 
 namespace {
 
+// a delivered frame: its record plus the octet pool of the feed it came from (one allocation per feed, shared by its frames)
 struct HostFrame {
 	OutFrame f;
-	std::vector<uint8_t> octets;
+	std::shared_ptr<std::vector<uint8_t>> pool;
+	const uint8_t *octets() const { return pool && f.pool_off + f.len <= pool->size() ? pool->data() + f.pool_off : nullptr; }
 };
 
 #ifndef VDL2_K1_RUN
@@ -58,7 +61,12 @@ struct vdl2hip_ctx {
 	// device memory
 	BlockForm *d_bf = nullptr; Lut4 *d_lut = nullptr; Tables *d_tab = nullptr;
 	uint32_t *d_dphi = nullptr, *d_freq = nullptr;
-	uint8_t *d_in = nullptr; size_t in_cap = 0;
+	// host-fed input: one device buffer + "copy done" event per slot, filled on a copy stream of its own so that the H2D of
+	// block i+1 runs beside the channeliser of block i (process_buf_*() hands over host memory: src/demod.c:356-365)
+	uint8_t *d_in[kSlots] = {}; hipEvent_t ev_copied[kSlots] = {}; size_t in_cap = 0;
+	hipStream_t stream_copy = nullptr, stream_out = nullptr;
+	hipEvent_t pinned_pending = nullptr;   // copy event of the last vdl2hip_feed_pinned() whose source buffer the caller may not touch yet
+	uint8_t *h_stage = nullptr; size_t stage_cap = 0;   // pinned D2H staging for frame records + octets
 	uint8_t *d_carry[2] = {nullptr, nullptr}; int carry_sel = 0; uint32_t ncarry = 0;
 	cf32 *d_y = nullptr, *d_pf = nullptr; float *d_phi = nullptr; uint64_t *d_cand = nullptr;
 	uint32_t cap = 0;
@@ -75,7 +83,7 @@ struct vdl2hip_ctx {
 	uint64_t feed_no = 0; int drain_lag = 0;
 	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr;
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
-	bool overflowed = false, avlc_filter = false;
+	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
 	std::vector<uint64_t> statsd_prev;
 	std::vector<HostFrame> queue;
 	int64_t k_total = 0; uint64_t n_total = 0;
@@ -135,25 +143,43 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 	}
 	sl.ev_valid = false;
 	const OutCtl ctl = *sl.h_ctl;
-	if(ctl.overflow) c->overflowed = true;
+	if(ctl.front_timeouts) {
+		// a channeliser workgroup gave up waiting for its predecessor's filter state (kernels.h, fused look-back) and went on with
+		// a stale one: part of this feed's decimated stream is wrong.  Never seen (workgroups are dispatched in order), but the
+		// guarantee is an observation, not a promise of the runtime: the context is dead from here on, nothing more is delivered.
+		if(!c->failed) fprintf(stderr, "vdl2hip: channeliser look-back timed out (%u workgroups) - context disabled\n", ctl.front_timeouts);
+		c->failed = true;
+		return VDL2HIP_E_DEVICE;
+	}
+	if(ctl.overflow) c->stats.overflow_feeds++;
 	c->stats.bursts += std::min(ctl.nbursts, ctl.cap_bursts);
 	const uint32_t nf = std::min(ctl.nframes, ctl.cap_frames);
 	if(nf) {
-		std::vector<OutFrame> fr(nf);
+		// one pinned staging buffer, two asynchronous copies on a stream of their own (the burst stream may already hold the
+		// next feeds' kernels), one wait
 		const uint32_t pool_n = std::min(ctl.pool_used, ctl.cap_pool);
-		std::vector<uint8_t> pool(pool_n ? pool_n : 1);
-		HIPCHK(hipMemcpy(fr.data(), sl.d_frames, sizeof(OutFrame) * nf, hipMemcpyDeviceToHost));
-		if(pool_n) HIPCHK(hipMemcpy(pool.data(), sl.d_pool, pool_n, hipMemcpyDeviceToHost));
-		// frames of one feed are sorted here, so that feeds can be appended to the queue in order
-		std::vector<HostFrame> batch(nf);
-		for(uint32_t i = 0; i < nf; i++) {
-			batch[i].f = fr[i];
-			if(fr[i].pool_off + fr[i].len <= pool_n) batch[i].octets.assign(pool.begin() + fr[i].pool_off, pool.begin() + fr[i].pool_off + fr[i].len);
+		const size_t fr_bytes = sizeof(OutFrame) * (size_t)nf, need = fr_bytes + pool_n;
+		if(need > c->stage_cap) {
+			if(c->h_stage) (void)hipHostFree(c->h_stage);
+			c->h_stage = nullptr; c->stage_cap = 0;
+			size_t cap = std::max<size_t>(need + need / 2, 1u << 20);
+			HIPCHK(hipHostMalloc((void **)&c->h_stage, cap, hipHostMallocDefault));
+			c->stage_cap = cap;
 		}
-		for(auto &h : batch) if(!c->avlc_filter || h.f.avlc_status == AVLC_OK) c->queue.push_back(std::move(h));
+		HIPCHK(hipMemcpyAsync(c->h_stage, sl.d_frames, fr_bytes, hipMemcpyDeviceToHost, c->stream_out));
+		if(pool_n) HIPCHK(hipMemcpyAsync(c->h_stage + fr_bytes, sl.d_pool, pool_n, hipMemcpyDeviceToHost, c->stream_out));
+		HIPCHK(hipStreamSynchronize(c->stream_out));
+		const OutFrame *fr = reinterpret_cast<const OutFrame *>(c->h_stage);
+		auto pool = std::make_shared<std::vector<uint8_t>>(c->h_stage + fr_bytes, c->h_stage + fr_bytes + pool_n);
+		// frames of one feed are sorted when they are drained, so that feeds can be appended to the queue in order
+		c->queue.reserve(c->queue.size() + nf);
+		for(uint32_t i = 0; i < nf; i++) {
+			if(fr[i].chan < 0 || fr[i].chan >= c->C) continue;           // a slot reserved past the octet pool's end (overflow): decode_burst() left a tombstone
+			if(!c->avlc_filter || fr[i].avlc_status == AVLC_OK) c->queue.push_back(HostFrame{ fr[i], pool });
+		}
 		c->stats.frames += nf;
 	}
-	return c->overflowed ? VDL2HIP_E_OVERFLOW : VDL2HIP_OK;
+	return ctl.overflow ? VDL2HIP_E_OVERFLOW : VDL2HIP_OK;
 }
 
 // collect every feed except the `keep` most recent ones, oldest first
@@ -178,6 +204,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	const int64_t D = (int64_t)(nlogical / (uint64_t)c->os);
 	const uint32_t nrem = (uint32_t)(nlogical - (uint64_t)D * c->os);
 	const int seglen = 64 * c->run;
+	if(c->failed) return VDL2HIP_E_DEVICE;
 	OutSlot &sl = c->slot[c->feed_no % kSlots];
 	{ int r = collect_slot(c, sl); if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r; }   // its buffers are about to be reused
 	hipStream_t st = c->stream, sb_ = c->stream_back;
@@ -192,6 +219,8 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	a.qpow = c->d_qpow; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap;
 	a.fuse = c->fuse_k2 && 64 * c->run == kFixW; a.phi = c->d_phi; a.carry_in = c->d_tcarry[c->tcarry_sel]; a.carry_out = c->d_tcarry[c->tcarry_sel ^ 1];
 	a.bfd = c->d_bf; a.seg_pub = c->d_segpub; a.epoch = (uint32_t)(c->feed_no + 1); a.sync_timeouts = c->d_synctmo;
+	a.pub_epoch = a.epoch; a.spin_limit = 1 << 22;
+	if(c->debug_force_timeout) { a.pub_epoch = a.epoch ^ 0x40000000u; a.spin_limit = 16; }   // tests only: the look-back must fail loudly
 	{
 		// tiles per workgroup segment: long segments save K2 work, but the grid should still offer several thousand
 		// workgroups (measured: tests/gpu_k1_tiles.sh - 2 is best at 8 channels, 8 at 256)
@@ -267,7 +296,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, sn_, k4b);
 		LAUNCH_EV(k_nf_finish, dim3((unsigned)c->C), dim3(64), sn_, (hipEvent_t) nullptr, EV(9), k4b);
 		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
-		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl);
+		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl, (const uint32_t *)c->d_synctmo);
 		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
 		LAUNCH_EV(k_burst, dim3(2048), dim3(64), s5_, EV(10), EV(11), k5);
@@ -296,7 +325,7 @@ static void sort_queue(vdl2hip_ctx *c) {
 
 static void fill_frame(const vdl2hip_ctx *c, const HostFrame &h, vdl2hip_frame &f) {
 	f.chan = (uint32_t)(h.f.chan + c->chan_first); f.freq = c->freqs[h.f.chan]; f.idx = h.f.idx;
-	f.len = h.f.len; f.octets = h.octets.data();
+	f.len = h.f.len; f.octets = h.octets();
 	f.synd_weight = h.f.synd_weight; f.datalen_octets = h.f.datalen_octets; f.num_fec_corrections = h.f.num_fec_corrections;
 	f.frame_pwr_dbfs = h.f.frame_pwr_dbfs; f.nf_pwr_dbfs = h.f.nf_pwr_dbfs; f.ppm_error = h.f.ppm_error;
 	f.burst_ord = h.f.burst_ord; f.sync_sample = h.f.sync_sample; f.end_sample = h.f.end_sample;
@@ -322,7 +351,7 @@ const char *vdl2hip_strerror(int err) {
 void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
+	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
 	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
 		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl, sl.d_log, sl.d_nlog };
@@ -335,6 +364,10 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 		for(int i = 0; i < kNumEv; i++) if(sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
 	}
 	if(c->h_ctl_template) (void)hipHostFree(c->h_ctl_template);
+	if(c->h_stage) (void)hipHostFree(c->h_stage);
+	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
+	if(c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
+	if(c->stream_out) { (void)hipStreamSynchronize(c->stream_out); (void)hipStreamDestroy(c->stream_out); }
 	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
 	if(c->stream_nf) { (void)hipStreamSynchronize(c->stream_nf); (void)hipStreamDestroy(c->stream_nf); }
 	if(c->stream_burst) { (void)hipStreamSynchronize(c->stream_burst); (void)hipStreamDestroy(c->stream_burst); }
@@ -392,6 +425,8 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_back, hipStreamNonBlocking, prio_high));
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_nf, hipStreamNonBlocking, prio_high));
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_burst, hipStreamNonBlocking, prio_high));
+		DEV_CHK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
 	}
 	for(auto &sl : c->slot) {
 		DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i]));
@@ -400,7 +435,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	}
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
 	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count);
-	DEV_ALLOC(c->d_in, c->in_cap + 16);
+	static_assert(kSlots == 3, "vdl2hip_destroy() lists the input buffers one by one");
 	DEV_ALLOC(c->d_carry[0], 4 * kMaxOversample); DEV_ALLOC(c->d_carry[1], 4 * kMaxOversample);
 	const size_t nring = (size_t)count * cap;
 	DEV_ALLOC(c->d_y, nring * sizeof(cf32)); DEV_ALLOC(c->d_pf, nring * sizeof(cf32));
@@ -411,6 +446,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_segpub, (size_t)count * c->nseg_cap * 4 * 8); DEV_ALLOC(c->d_synctmo, 4);
 	DEV_CHK(hipMemset(c->d_segpub, 0, (size_t)count * c->nseg_cap * 4 * 8)); DEV_CHK(hipMemset(c->d_synctmo, 0, 4));
 	c->fuse_k2 = getenv("VDL2HIP_NO_FUSE") == nullptr;
+	c->debug_force_timeout = getenv("VDL2HIP_DEBUG_FORCE_TIMEOUT") != nullptr;   // tests only (tests/test_gpu_parity.py::test_lookback_timeout_fails_loudly)
 	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, (size_t)count * kNumCounters * 8);
 	DEV_ALLOC(c->d_acnt, (size_t)count * kNumAvlcCounters * 8);
 	// a decodable burst occupies >= 22 symbols = 220 decimated samples (header + 3 data + 2 FEC octets)
@@ -419,7 +455,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	uint64_t cap_f = cap_b * 2; if(cap_f < 4096) cap_f = 4096;
 	uint64_t cap_p = cap_b * 512; if(cap_p < (1u << 22)) cap_p = 1u << 22; if(cap_p > (1u << 30)) cap_p = 1u << 30;
 	c->cap_log = 8192; c->cap_comb = c->cap_log + kNfTail; c->cap_hist = (uint32_t)(dmax / 3000 + 8);
-	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, c->cap_log };
+	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, c->cap_log, 0, {0, 0, 0} };
 	DEV_ALLOC(c->d_nf, count * sizeof(NfState));
 	DEV_ALLOC(c->d_scfirst, (size_t)count * (c->cap_comb + 1) * 8); DEV_ALLOC(c->d_sccum, (size_t)count * (c->cap_comb + 1) * 8);
 	// noise-floor history: a frame looks up the value at its burst's sync, at most kSlots feeds + one burst ago
@@ -485,15 +521,33 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	return VDL2HIP_OK;
 }
 
-int vdl2hip_feed(vdl2hip_ctx *c, const void *buf, size_t nbytes) {
+// Host-fed blocks: the copy into the device goes to one of kSlots input buffers on the copy stream, the channeliser of the
+// block waits for it on the front stream; the buffer was last read by the channeliser of feed i - kSlots, which
+// collect_slot() has seen complete.  So the H2D of block i+1 overlaps the kernels of block i (and i-1, i-2 further down).
+static int feed_host(vdl2hip_ctx *c, const void *buf, size_t nbytes, bool wait_copy) {
 	if(!c || (!buf && nbytes)) return VDL2HIP_E_INVAL;
+	if(c->failed) return VDL2HIP_E_DEVICE;
 	if(nbytes == 0) return VDL2HIP_OK;                             // process_buf_*: len == 0 is a no-op (demod.c:341,358)
 	if(nbytes > c->in_cap) return VDL2HIP_E_TOOBIG;
 	nbytes -= nbytes % sample_bytes(c->fmt);
-	HIPCHK(hipMemcpyAsync(c->d_in, buf, nbytes, hipMemcpyHostToDevice, c->stream));   // ordered behind the previous block's K1 on the front stream
-	HIPCHK(hipStreamSynchronize(c->stream));                       // `buf` is only ours during the call
-	return feed_common(c, c->d_in, nbytes);
+	if(c->pinned_pending) { HIPCHK(hipEventSynchronize(c->pinned_pending)); c->pinned_pending = nullptr; }
+	const int k = (int)(c->feed_no % kSlots);
+	{ int r = collect_slot(c, c->slot[k]); if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r; }
+	if(!c->d_in[k]) {
+		if(hipMalloc((void **)&c->d_in[k], c->in_cap + 16) != hipSuccess) return VDL2HIP_E_NOMEM;
+		HIPCHK(hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming));
+	}
+	HIPCHK(hipMemcpyAsync(c->d_in[k], buf, nbytes, hipMemcpyHostToDevice, c->stream_copy));
+	HIPCHK(hipEventRecord(c->ev_copied[k], c->stream_copy));
+	if(wait_copy) HIPCHK(hipEventSynchronize(c->ev_copied[k]));    // `buf` is only ours during the call
+	else c->pinned_pending = c->ev_copied[k];
+	HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copied[k], 0));
+	return feed_common(c, c->d_in[k], nbytes);
 }
+
+int vdl2hip_feed(vdl2hip_ctx *c, const void *buf, size_t nbytes) { return feed_host(c, buf, nbytes, true); }
+
+int vdl2hip_feed_pinned(vdl2hip_ctx *c, const void *buf, size_t nbytes) { return feed_host(c, buf, nbytes, false); }
 
 int vdl2hip_feed_device(vdl2hip_ctx *c, const void *dev_buf, size_t nbytes) {
 	if(!c || (!dev_buf && nbytes)) return VDL2HIP_E_INVAL;
@@ -506,11 +560,14 @@ int vdl2hip_feed_device(vdl2hip_ctx *c, const void *dev_buf, size_t nbytes) {
 
 int vdl2hip_sync(vdl2hip_ctx *c) {
 	if(!c) return VDL2HIP_E_INVAL;
+	if(c->pinned_pending) { HIPCHK(hipEventSynchronize(c->pinned_pending)); c->pinned_pending = nullptr; }
+	if(c->failed) return VDL2HIP_E_DEVICE;
 	return collect_pending(c);
 }
 
 int vdl2hip_drain(vdl2hip_ctx *c, vdl2hip_frame_cb cb, void *user) {
 	if(!c) return VDL2HIP_E_INVAL;
+	if(c->failed) return VDL2HIP_E_DEVICE;
 	int r = collect_pending(c, c->drain_lag);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	sort_queue(c);
@@ -530,6 +587,7 @@ int vdl2hip_drain(vdl2hip_ctx *c, vdl2hip_frame_cb cb, void *user) {
 int vdl2hip_drain_packed(vdl2hip_ctx *c, vdl2hip_packed_frame *frames, size_t cap_frames,
 		uint8_t *octets, size_t cap_octets, size_t *octets_used) {
 	if(!c || (!frames && cap_frames) || (!octets && cap_octets)) return VDL2HIP_E_INVAL;
+	if(c->failed) return VDL2HIP_E_DEVICE;
 	int r = collect_pending(c, c->drain_lag);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	sort_queue(c);
@@ -539,7 +597,7 @@ int vdl2hip_drain_packed(vdl2hip_ctx *c, vdl2hip_packed_frame *frames, size_t ca
 		fill_frame(c, h, frames[n].frame);
 		frames[n].frame.octets = nullptr;
 		frames[n].octets_off = used;
-		if(h.f.len) memcpy(octets + used, h.octets.data(), h.f.len);
+		if(h.f.len && h.octets()) memcpy(octets + used, h.octets(), h.f.len);
 		used += h.f.len;
 		n++;
 	}
@@ -670,7 +728,7 @@ int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) {
 		for(int i = 0; i < c->C; i++) { c->stats.seg_adopted += ss[2 * i]; c->stats.seg_walked += ss[2 * i + 1]; }
 	}
 	*out = c->stats;
-	return r == VDL2HIP_E_OVERFLOW ? VDL2HIP_OK : r;
+	return (r == VDL2HIP_E_OVERFLOW || c->failed) ? VDL2HIP_OK : r;   // a disabled context still reports why (front_sync_timeouts)
 }
 
 void *vdl2hip_stream(vdl2hip_ctx *c) { return c ? (void *)c->stream : nullptr; }

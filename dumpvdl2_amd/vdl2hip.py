@@ -37,7 +37,7 @@ EXPORTS = [
     "vdl2hip_abi_version", "vdl2hip_strerror", "vdl2hip_create", "vdl2hip_destroy", "vdl2hip_feed",
     "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
     "vdl2hip_drain_packed", "vdl2hip_pack_raw_frame", "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_set_drain_lag", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
-    "vdl2hip_avlc_counters", "vdl2hip_set_avlc_filter", "vdl2hip_statsd_lines",
+    "vdl2hip_avlc_counters", "vdl2hip_set_avlc_filter", "vdl2hip_statsd_lines", "vdl2hip_feed_pinned",
 ]
 
 
@@ -61,7 +61,8 @@ class Stats(C.Structure):
                 ("chanfir_launches", C.c_uint64), ("chanfir_ms", C.c_double), ("phase_ms", C.c_double),
                 ("sync_ms", C.c_double), ("walk_ms", C.c_double), ("burst_ms", C.c_double), ("nf_ms", C.c_double),
                 ("bursts", C.c_uint64), ("frames", C.c_uint64),
-                ("seg_adopted", C.c_uint64), ("seg_walked", C.c_uint64), ("front_sync_timeouts", C.c_uint64)]
+                ("seg_adopted", C.c_uint64), ("seg_walked", C.c_uint64), ("front_sync_timeouts", C.c_uint64),
+                ("overflow_feeds", C.c_uint64)]
 
 
 class PackedFrame(C.Structure):
@@ -86,6 +87,7 @@ def load_library(path: str = LIB_PATH):
     L.vdl2hip_destroy.argtypes = [C.c_void_p]
     L.vdl2hip_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.vdl2hip_feed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.vdl2hip_feed_pinned.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.vdl2hip_sync.argtypes = [C.c_void_p]
     L.vdl2hip_drain.argtypes = [C.c_void_p, FRAME_CB, C.c_void_p]
     L.vdl2hip_drain_packed.argtypes = [C.c_void_p, C.POINTER(PackedFrame), C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -164,8 +166,20 @@ class Receiver:
         a = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
         self._chk(self.L.vdl2hip_feed(self.h, a.ctypes.data, a.size), "vdl2hip_feed")
 
+    def feed_pinned(self, host_ptr: int, nbytes: int) -> None:
+        """one block from page-locked host memory, queued without waiting for the copy (see vdl2hip.h for the lifetime rule)"""
+        self._chk(self.L.vdl2hip_feed_pinned(self.h, C.c_void_p(host_ptr), nbytes), "vdl2hip_feed_pinned")
+
     def feed_device(self, dev_ptr: int, nbytes: int) -> None:
         self._chk(self.L.vdl2hip_feed_device(self.h, C.c_void_p(dev_ptr), nbytes), "vdl2hip_feed_device")
+
+    def feed_tensor(self, t) -> None:
+        """a block resident on this receiver's device (torch tensor of raw bytes / int16 values)"""
+        self.feed_device(t.data_ptr(), t.numel() * t.element_size())
+
+    def feed_pinned_tensor(self, t) -> None:
+        """a block in page-locked host memory (torch tensor made with pin_memory())"""
+        self.feed_pinned(t.data_ptr(), t.numel() * t.element_size())
 
     def set_drain_lag(self, lag: int) -> None:
         self._chk(self.L.vdl2hip_set_drain_lag(self.h, lag), "vdl2hip_set_drain_lag")

@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define VDL2HIP_ABI_VERSION 2   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added */
+#define VDL2HIP_ABI_VERSION 3   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added
+                                 * 3: vdl2hip_feed_pinned(); vdl2hip_stats.overflow_feeds; a look-back timeout is VDL2HIP_E_DEVICE */
 
 /* enum sample_formats, src/dumpvdl2.h:319 */
 #define VDL2HIP_FMT_U8     0
@@ -130,7 +131,10 @@ typedef struct {
 	uint64_t frames;            /* frames produced */
 	uint64_t seg_adopted;       /* segmented walk: speculative segments adopted ... */
 	uint64_t seg_walked;        /* ... and segments walked sequentially because a burst straddled their start */
-	uint64_t front_sync_timeouts; /* channeliser workgroups that gave up waiting for their predecessor's state: always 0 */
+	uint64_t front_sync_timeouts; /* channeliser workgroups that gave up waiting for their predecessor's state: always 0
+	                               * (non-zero disables the context: every later call returns VDL2HIP_E_DEVICE) */
+	uint64_t overflow_feeds;    /* feeds in which a device-side burst/frame/octet buffer ran out (bursts or frames were dropped);
+	                             * vdl2hip_sync() returns VDL2HIP_E_OVERFLOW for those, the drain calls only count here */
 } vdl2hip_stats;
 
 int  vdl2hip_abi_version(void);
@@ -141,8 +145,13 @@ int  vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out);
 void vdl2hip_destroy(vdl2hip_ctx *ctx);
 
 /* = process_buf_uchar()/process_buf_short(): one block of raw IQ from host memory.
- * Returns after the block has been queued on the device (the copy out of `buf` is complete). */
+ * Returns after the block has been queued on the device (the copy out of `buf` is complete).  The copy runs on a
+ * stream of its own into one of three device buffers, so it overlaps the kernels of the blocks fed before. */
 int  vdl2hip_feed(vdl2hip_ctx *ctx, const void *buf, size_t nbytes);
+/* Same for page-locked host memory (hipHostMalloc / hipHostRegister), without waiting for the copy: the call only queues.
+ * `buf` must stay unmodified until the NEXT vdl2hip_feed*() call or vdl2hip_sync() has returned - i.e. a producer
+ * alternating between two pinned buffers never waits for the device. */
+int  vdl2hip_feed_pinned(vdl2hip_ctx *ctx, const void *buf, size_t nbytes);
 /* Same, for a block that already lives in this device's memory (e.g. the
  * destination of an RCCL broadcast).  The block must stay valid until it has been drained
  * (vdl2hip_sync(), or a drain that covers it - see vdl2hip_set_drain_lag). */

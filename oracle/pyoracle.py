@@ -10,6 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libvdl2oracle.so")
+_LIB_FAST = os.path.join(_HERE, "libvdl2oracle_fast.so")     # the same source built -O3 -ffast-math, as upstream builds the reference
 
 COUNTER_NAMES = [
     "demod.sync.good", "decoder.crc.good", "decoder.crc.bad", "decoder.errors.no_header",
@@ -36,20 +37,32 @@ class Frame(C.Structure):
 
 def build(force=False):
     """Compile the oracle (and oracle/_ref when the reference tree is present)."""
-    if force or not os.path.exists(_LIB) or \
-            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "vdl2_oracle.c")):
+    src_t = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("vdl2_oracle.c", "vdl2_oracle.h", "Makefile"))
+    if force or any(not os.path.exists(p) or os.path.getmtime(p) < src_t for p in (_LIB, _LIB_FAST)):
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
     return _LIB
 
 
 _lib = None
+_libs = {}
 
 
-def lib():
+def lib(variant="strict"):
+    """variant "strict" (default: the oracle proper) or "fast" (-O3 -ffast-math build of the same source)"""
     global _lib
+    if variant != "strict":
+        if variant not in _libs:
+            build()
+            _libs[variant] = _bind(C.CDLL(_LIB_FAST))
+        return _libs[variant]
     if _lib is None:
         build()
-        L = C.CDLL(_LIB)
+        _lib = _bind(C.CDLL(_LIB))
+    return _lib
+
+
+def _bind(L):
+    if True:
         L.vdl2o_create.restype = C.c_void_p
         L.vdl2o_create.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.c_int, C.c_uint32, C.c_int, C.c_float]
         L.vdl2o_destroy.argtypes = [C.c_void_p]
@@ -82,15 +95,14 @@ def lib():
         L.vdl2o_crc16.restype = C.c_uint16
         L.vdl2o_crc16.argtypes = [C.c_void_p, C.c_uint32, C.c_uint16]
         L.vdl2o_chebyshev.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        _lib = L
-    return _lib
+    return L
 
 
 class Oracle:
     """One reference-equivalent receiver: nchan channels fed with raw IQ blocks."""
 
-    def __init__(self, centerfreq, freqs, oversample=20, sample_fmt=FMT_S16LE, max_ppm=0.0):
-        self.L = lib()
+    def __init__(self, centerfreq, freqs, oversample=20, sample_fmt=FMT_S16LE, max_ppm=0.0, variant="strict"):
+        self.L = lib(variant)
         self.freqs = list(freqs)
         arr = (C.c_uint32 * len(freqs))(*freqs)
         self.h = self.L.vdl2o_create(centerfreq, arr, len(freqs), oversample, sample_fmt, max_ppm)

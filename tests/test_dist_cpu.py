@@ -24,6 +24,26 @@ def test_shard_channels_partitions():
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
 
 
+class OracleRx:
+    """stands in for vdl2hip.Receiver on a CPU rank: same three calls the feeder makes, decoding with the oracle"""
+
+    def __init__(self, po, cfg, first, count):
+        self.o = po.Oracle(cfg.centerfreq, list(cfg.freqs)[first:first + count], oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+        self.first, self.blocks = first, 0
+
+    def feed_tensor(self, t):
+        self.o.process(t.numpy().view(np.uint8), block_bytes=1 << 24)
+        self.blocks += 1
+
+    feed_pinned_tensor = feed_tensor
+
+    def drain_packed(self):
+        fr = self.o.frames()
+        for f in fr:
+            f["chan"] += self.first
+        return fr
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -32,38 +52,52 @@ def _worker(rank, world, port, q):
     from oracle import pyoracle as po
     import cases
     cfg, iq, _, gold = cases.load("config2_1s")
-    block = torch.from_numpy(iq.copy()) if rank == 0 else torch.zeros(iq.size, dtype=torch.int16)
-    vd.broadcast_block(block, src=0)
-    # the other exchange: every rank holds one stripe of the capture, an all-gather rebuilds the block everywhere
-    first_b, count_b = vd.stripe_of(block.numel() * 2, world, rank)
-    stripe = block.view(torch.uint8)[first_b:first_b + count_b].clone()
-    rebuilt = torch.zeros_like(block)
-    w = vd.allgather_block(rebuilt, stripe, async_op=True)
-    w.wait()
-    assert torch.equal(rebuilt, torch.from_numpy(iq))
-    block = rebuilt
-    # the exchange object bench.py uses, in both modes: the "next block" lands complete in the destination on every rank
-    for mode in ("allgather", "broadcast"):
-        ex = vd.BlockExchange(block, mode=mode, src=0)
-        assert ex.mode == mode
-        nxt = torch.zeros_like(block)
-        if mode == "broadcast" and rank == 0:
-            nxt.copy_(block)                                             # broadcast: the source rank's buffer holds the block
-        ex.start(nxt).wait()
-        assert torch.equal(nxt, torch.from_numpy(iq)), mode
-    odd = torch.arange(7, dtype=torch.uint8)                            # 7 bytes do not split into 2 stripes -> broadcast
-    assert vd.BlockExchange(odd, mode="allgather").mode == "broadcast"
+    host = torch.from_numpy(iq.copy())
+    cpu = torch.device("cpu")
     first, count = vd.shard_channels(len(cfg.freqs), world, rank)
-    o = po.Oracle(cfg.centerfreq, list(cfg.freqs)[first:first + count], oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
-    o.process(block.numpy().view(np.uint8), block_bytes=1 << 24)
-    fr = o.frames()
-    for f in fr:
-        f["chan"] += first
-    merged = vd.gather_frames(fr, dst=0)
+    # bench.py's step function, in every exchange form: after each step the block this rank would feed next is the capture,
+    # bit for bit, and the rank has decoded exactly its own channels of one block
+    merged_by_mode = {}
+    for mode in ("broadcast", "allgather"):
+        for source in ("host", "hbm"):
+            # ranks other than the source start from garbage in broadcast mode: only what the exchange delivers counts
+            mine = host if (mode == "allgather" or rank == 0) else torch.randint(-99, 99, host.shape, dtype=torch.int16)
+            rx = OracleRx(po, cfg, first, count)
+            f = vd.ShardedFeeder(rx, mine, world, rank, mode=mode, source=source, device=cpu)
+            fr = f.step()
+            assert rx.blocks == 1
+            assert torch.equal(vd._u8(f.current_block()), vd._u8(host)), (mode, source)
+            assert all(first <= x["chan"] < first + count for x in fr)
+            merged_by_mode[(mode, source)] = vd.gather_frames(fr, dst=0)
+            for _ in range(4):                 # the ring of buffers wraps: blocks keep arriving complete
+                f._start_exchange((f.i + 1) % len(f.bufs)); f.i += 1
+                assert torch.equal(vd._u8(f.current_block()), vd._u8(host)), (mode, source)
+            f.finish()
+    secs, ok = vd.time_exchange(host, world, rank, "allgather", "host", cpu, iters=2)
+    assert ok and secs > 0
+    secs, ok = vd.time_exchange(host, world, rank, "broadcast", "hbm", cpu, iters=2)
+    assert ok and secs > 0
+    with pytest.raises(ValueError):
+        vd.ShardedFeeder(OracleRx(po, cfg, first, count), torch.arange(7, dtype=torch.uint8), world, rank, mode="allgather", device=cpu)
     if rank == 0:
-        q.put([(f["chan"], f["burst_ord"], f["idx"], f["octets"]) for f in merged])
+        ref = merged_by_mode[("broadcast", "host")]
+        key = lambda m: [(f["chan"], f["burst_ord"], f["idx"], f["octets"]) for f in m]
+        assert all(key(m) == key(ref) for m in merged_by_mode.values())
+        q.put(key(ref))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_one_rank_feeder_needs_no_process_group(oracle_mod):
+    """world 1: the same step function feeds from host memory or from the resident copy, no collective involved"""
+    import cases
+    from dumpvdl2_amd import dist as vd
+    cfg, iq, _, gold = cases.load("config2_1s")
+    for source in ("host", "hbm"):
+        rx = OracleRx(oracle_mod, cfg, 0, len(cfg.freqs))
+        f = vd.ShardedFeeder(rx, torch.from_numpy(iq.copy()), 1, 0, mode="broadcast", source=source)
+        fr = f.step()
+        cases.check_against_golden(fr, None, gold, 1e-3, 1e-4, "one-rank feeder")
 
 
 def test_two_rank_shard_broadcast_merge(oracle_mod):

@@ -13,3 +13,28 @@ def test_oracle_reproduces_golden(oracle_mod, name):
     o.process(iq.view(np.uint8), block_bytes=320000, nthreads=2)     # the reference's FILE_BUFSIZE blocks
     cases.check_against_golden(o.frames(), [list(o.counters(c).values()) for c in range(len(cfg.freqs))], gold, 1e-3, 1e-4, name)
     assert gold["n_tx_bursts"] == len(bursts)
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_fast_math_build_gives_the_same_frames(oracle_mod, name):
+    """Upstream builds the reference with -O3 -ffast-math when the compiler takes it (src/CMakeLists.txt:12-15,35-38), which
+    changes the filter coefficients (A0 moves by 4e-4 and A0 != A2) and every float after them.  SURVEY 8.4
+    requires frame parity against both builds: the same restatement compiled that way must reproduce the golden frames -
+    octets, integer metadata and burst timing exactly, float metadata within the SURVEY 8.5 tolerances."""
+    cfg, iq, bursts, gold = cases.load(name)
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm, variant="fast")
+    A, _ = o.lpf()
+    s = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample).lpf()[0]
+    assert not np.array_equal(A, s) and np.allclose(A, s, rtol=2e-3)      # really a different arithmetic, and only slightly
+    o.process(iq.view(np.uint8), block_bytes=320000, nthreads=2)
+    cases.check_against_golden(o.frames(), None, gold, 0.05, 0.01, name + " (fast-math)")
+
+
+def test_fast_math_build_on_the_reference_wav(oracle_mod, golden_wav):
+    cf = 136975000
+    out = []
+    for v in ("strict", "fast"):
+        o = oracle_mod.Oracle(cf, [cf], oversample=10, variant=v)
+        o.process(golden_wav)
+        out.append([(f["octets"], f["sync_sample"], f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"]) for f in o.frames()])
+    assert out[0] == out[1] and len(out[0]) == 2
