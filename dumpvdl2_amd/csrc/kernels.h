@@ -1,9 +1,10 @@
 // kernels.h - the HIP kernels of the hot path (gfx950 / CDNA4, wave64).
 //
 //   k_chanfir   K1  NCO mix + 2-pole Chebyshev low-pass + decimate  (src/demod.c:58-79,200-203,302-329)
-//   k_phase     K2  carry fix-up, atan2                              (src/demod.c:232,256)
+//   k_fixup     K2  segment-start fix-up as a kernel of its own (only with VDL2HIP_NO_FUSE: K1 normally does it itself)
 //   k_carry         saves the < oversample input samples left over for the next block
-//   k_sync      K3  got_sync() metric for every decimated sample + candidate bitmap (src/demod.c:105-171)
+//   k_sync      K3  phase (screening precision) + got_sync() metric of every decimated sample + candidate bitmap
+//                   (src/demod.c:232,105-171); the exact double-precision phases only where a preamble is near
 //   k_walk      K4  per-channel FSM walker (vdl2_core.h); k_walk_spec + k_walk_stitch: the same walk in speculative segments
 //   k_nf        K4b noise-floor replay from the walker's evaluation log (src/demod.c:238-243)
 //   k_burst     K5  wave-per-burst decoder (vdl2_core.h)
@@ -66,9 +67,8 @@ struct K1Args {
 	float4 *seg_end;           // [nchan][nseg_cap] zero-start state at the end of each workgroup segment
 	const float4 *qpow;        // [64] Q^(l+1) row-major 2x2, Q = P^R
 	int32_t  tiles;            // tiles per workgroup segment
-	// fused phase stage (fuse != 0): K1 also applies the segment-start fix-up and writes phi, K2 is not launched
+	// fused fix-up (fuse != 0): K1 also adds the decayed segment-start state to its first tile (one-step look-back), K2 is not launched
 	int32_t  fuse;
-	float *phi;                // [nchan][cap]
 	const float4 *carry_in;    // [nchan] true filter state at the end of the previous feed
 	float4 *carry_out;         // [nchan] ... at the end of this one
 	const BlockForm *bfd;      // full tables (cP[kFixW], Ppow[kFixW+1]) in device memory
@@ -94,37 +94,14 @@ __device__ __forceinline__ void load_sample(const K1Args &a, int64_t s, float &r
 	}
 }
 
-// phases of one lane's run (R <= 2 consecutive outputs starting at feed-local index kloc)
-// atan2 out of line (two independent evaluations per call): inlined into the channeliser's epilogue once per channel it
-// pushes the kernel deep into scratch; a rolled single-instance loop was no better (tests/gpu_k1_variants.sh)
-#ifdef VDL2_K1_INLINE_PHASE
-__device__ __forceinline__ float2 phase_call2(float r0, float i0, float r1, float i1) {
-#else
-__device__ __attribute__((noinline)) float2 phase_call2(float r0, float i0, float r1, float i1) {
-#endif
-	return make_float2(phase_of(cf32{r0, i0}), phase_of(cf32{r1, i1}));
-}
-
-template<int R>
-__device__ __forceinline__ void store_phases(const K1Args &a, int ch, bool cvalid, int64_t kloc, float p0, float p1) {
-	float *pout = a.phi + (size_t)ch * a.cap;
-	const uint32_t s0 = (uint32_t)(a.k0 + kloc) & a.mask;
-	if(R > 1 && cvalid && kloc + 1 < a.D && (s0 & 1u) == 0) *reinterpret_cast<float2 *>(pout + s0) = make_float2(p0, p1);
-	else {
-		if(cvalid && kloc < a.D) pout[s0] = p0;
-		if(R > 1 && cvalid && kloc + 1 < a.D) pout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = p1;
-	}
-}
-
 // One workgroup = 4 waves that walk `a.tiles` consecutive time tiles (64*R blocks of OS samples each, staged in LDS
 // and shared by the waves); each wave owns CR channels; each lane owns R consecutive decimated outputs per tile.
 // Within a workgroup's segment the filter state is carried from tile to tile in registers, so the outputs it
 // stores are final except for the (decayed) state at the segment start, which K2 adds to the first kFixW of them.
 // OS == 0 selects the generic (run-time oversample) build of the same code.
-// resident workgroups per CU the channeliser is compiled for: LDS allows 6, but with the fused phase stage 5 (96 VGPRs, no
-// scratch frame) is faster at CR = 2 (tests/gpu_k1_variants.sh: 0.262 -> 0.230 ms at 8 channels)
+// resident workgroups per CU the channeliser is compiled for (LDS allows 6; tests/gpu_k1_variants.sh sweeps the choices)
 #ifndef VDL2_K1_MIN_BLOCKS
-#define VDL2_K1_MIN_BLOCKS 5
+#define VDL2_K1_MIN_BLOCKS 6
 #endif
 #ifndef VDL2_K1_MIN_BLOCKS_CR4
 #define VDL2_K1_MIN_BLOCKS_CR4 4
@@ -306,13 +283,11 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 						if(cvalid && kloc < a.D) yout[s0] = cf32{f0r, f0i};
 						if(cvalid && kloc + 1 < a.D) yout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = cf32{f1r, f1i};
 					}
-					if(a.fuse) { const float2 pp = phase_call2(f0r, f0i, f1r, f1i); store_phases<R>(a, cbase + c, cvalid, kloc, pp.x, pp.y); }
 				}
 			} else {
 				if(a.fuse && ts == 0) { hold[c][0] = f0r; hold[c][1] = f0i; }
 				else {
 					if(cvalid && kloc < a.D) yout[(uint32_t)(a.k0 + kloc) & a.mask] = cf32{f0r, f0i};
-					if(a.fuse) { const float2 pp = phase_call2(f0r, f0i, 1.f, 0.f); store_phases<R>(a, cbase + c, cvalid, kloc, pp.x, 0.f); }
 				}
 			}
 			if(cvalid && lane == lb && (rem <= L || ts == a.tiles - 1)) {
@@ -341,7 +316,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	}
 	if(!a.fuse || !wave_active) return;
 
-	// ---- fused K2: the first tile's outputs get the decayed state of the segment start, then every output its phase ----
+	// ---- fused K2: the first tile's outputs get the decayed state of the segment start ----
 	// The state at the start of segment s is the zero-start state at the end of segment s-1 (a segment is >= kFixW blocks
 	// long, older history has decayed below fp32 resolution), which the workgroup of s-1 publishes before it waits for
 	// anything itself (in the epilogue of its last tile): a one-step look-back, no chain.  Workgroups are dispatched in
@@ -379,7 +354,6 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			if(cvalid && kloc0 < a.D) yout[s0] = cf32{v0r, v0i};
 			if(R > 1 && cvalid && kloc0 + 1 < a.D) yout[(uint32_t)(a.k0 + kloc0 + 1) & a.mask] = cf32{v1r, v1i};
 		}
-		{ const float2 pp = phase_call2(v0r, v0i, v1r, v1i); store_phases<R>(a, cbase + c, cvalid, kloc0, pp.x, pp.y); }
 		// the filter state handed to the next feed (K2's k == D-1 branch)
 		if(cvalid && lane == 0 && (int64_t)(seg + 1) * seglen >= a.D) {
 			const int64_t len = a.D - (int64_t)seg * seglen;
@@ -395,27 +369,26 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 }
 
 struct K2Args {
-	cf32 *y; float *phi; const float4 *seg_end; const float4 *carry_in; float4 *carry_out;
+	cf32 *y; const float4 *seg_end; const float4 *carry_in; float4 *carry_out;
 	const BlockForm *bf;
 	int64_t k0, D; uint32_t cap, mask, nseg_cap; int32_t seglen;
 };
 
-// K2: add the decayed segment-start state to the first kFixW outputs of every workgroup segment, then phase.
-__global__ __launch_bounds__(256) void k_phase(K2Args a) {
+// K2 (VDL2HIP_NO_FUSE only): add the decayed segment-start state to the first kFixW outputs of every workgroup segment.
+__global__ __launch_bounds__(256) void k_fixup(K2Args a) {
 	const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
 	const int c = blockIdx.y;
 	if(k >= a.D) return;
 	const BlockForm &bf = *a.bf;
 	const uint32_t slot = (uint32_t)(a.k0 + k) & a.mask;
-	cf32 v = a.y[(size_t)c * a.cap + slot];
 	const int seg = (int)(k / a.seglen), i = (int)(k - (int64_t)seg * a.seglen);
 	if(i < kFixW) {
+		cf32 v = a.y[(size_t)c * a.cap + slot];
 		const float4 ts = seg ? a.seg_end[(size_t)c * a.nseg_cap + seg - 1] : a.carry_in[c];
 		v.re += bf.cP[i][0] * ts.x + bf.cP[i][1] * ts.z;
 		v.im += bf.cP[i][0] * ts.y + bf.cP[i][1] * ts.w;
 		a.y[(size_t)c * a.cap + slot] = v;
 	}
-	a.phi[(size_t)c * a.cap + slot] = phase_of(v);
 	if(k == a.D - 1) {   // filter state handed to the next feed
 		const int len = i + 1;
 		float4 e = a.seg_end[(size_t)c * a.nseg_cap + seg];
@@ -444,95 +417,116 @@ __global__ void k_carry(K1Args a, void *carry_out, uint32_t nrem) {
 }
 
 struct K3Args {
-	const float *phi; cf32 *pf; uint64_t *cand; const Tables *tab;
+	const cf32 *y; cf32 *pf; uint64_t *cand; uint64_t *flag; const Tables *tab;
 	int64_t nbase, k1;        // first sample to (re)compute (multiple of 64); one past the last valid sample
 	uint32_t cap, mask;
 };
 
-// K3: got_sync() metric of every decimated sample (contiguous ring) + the candidate bitmap.
-// A block stages the phases of kK3Tile consecutive samples (+150 back, +-3 for the neighbours) in LDS, so the 16 taps
-// are plain ds_reads at constant offsets.  Two tiers: every sample gets the cheap screening value; the exact reference
-// arithmetic (double-precision unwrap, centred regression) is redone only where it can matter to the walker - where the
-// value may be under the threshold, or 3 samples either side of such a place (those are y1/y3 of calc_para_vertex and
-// the right-hand side of the candidate test).  Everywhere else the stored value is only ever compared against the
-// threshold, and "well above it" is all that is used.  A sample whose right neighbour has not arrived yet is computed
-// exactly; the next feed redoes the last partial bitmap word anyway.
+// K3: got_sync() metric (contiguous ring) + the candidate bitmap, in two tiers and two kernels.
+//
+// k_sync_screen - every decimated sample.  A block turns kK3Tile consecutive outputs (+150 back) into screening-precision
+// phases (phase_fast) in LDS, so the 16 taps are plain ds_reads at constant offsets, and gives every sample the cheap
+// screening value of the metric (vdl2_core.h: same unwrap decisions, running sums, float only).  Output: one flag bit per
+// sample - "the exact value may be under the threshold".
+//
+// k_sync_exact - only where a flag is set (on noise 3e-5 of the samples): the reference's arithmetic - atan2 in double on the
+// 16 taps, the double-precision unwrap, the centred regression - for the flagged samples and 3 samples either side (those are
+// y1/y3 of calc_para_vertex and the right-hand side of the candidate test), stored in pf, and the candidate bit
+// pherr(n-3) < 4 && pherr(n) > pherr(n-3) of every sample.  The walker reads the metric nowhere else.  A sample whose right
+// neighbour has not arrived yet is computed exactly; the next feed redoes the last partial bitmap word anyway.
 constexpr int kK3Tile = 1024;
-__global__ __launch_bounds__(256) void k_sync(K3Args a) {
-	__shared__ float tile[kK3Tile + 156 + 3];       // phases of samples nblk-156 .. nblk+kK3Tile+2
-	__shared__ float psh[kK3Tile + 3];              // metric of samples nblk-3 .. nblk+kK3Tile-1 (kPherrBig where irrelevant)
-	__shared__ uint8_t fl[kK3Tile + 6];             // screening flag of samples nblk-3 .. nblk+kK3Tile+2
+
+__global__ __launch_bounds__(256) void k_sync_screen(K3Args a) {
+	__shared__ float tile[kK3Tile + 150];           // screening phases of samples nblk-150 .. nblk+kK3Tile-1
 	const int c = blockIdx.y, tid = threadIdx.x;
 	const int64_t nblk = a.nbase + (int64_t)blockIdx.x * kK3Tile;
-	const float *phi = a.phi + (size_t)c * a.cap;
+	const cf32 *y = a.y + (size_t)c * a.cap;
 	const Tables &T = *a.tab;
-	for(int j = tid; j < kK3Tile + 156 + 3; j += 256) {
-		const int64_t t = nblk - 156 + j;
-		tile[j] = (t < 0 || t >= a.k1) ? 0.f : phi[(uint32_t)t & a.mask];
+	for(int j = tid; j < kK3Tile + 150; j += 256) {
+		const int64_t t = nblk - 150 + j;
+		tile[j] = (t < 0 || t >= a.k1) ? 0.f : phase_fast(y[(uint32_t)t & a.mask]);
 	}
 	__syncthreads();
 	float ph[kPreamble];
-	float ps[kK3Tile / 256];
 	#pragma unroll
 	for(int q = 0; q < kK3Tile / 256; q++) {
-		const int i0 = tid + 256 * q;               // sample nblk + i0: phases tile[i0 + 6 + 10 i]
+		const int i0 = tid + 256 * q;               // sample nblk + i0: phases tile[i0 + 10 i]
+		const int64_t n = nblk + i0;
 		#pragma unroll
-		for(int i = 0; i < kPreamble; i++) ph[i] = tile[i0 + 6 + 10 * i];
+		for(int i = 0; i < kScreenEarly; i++) ph[i] = tile[i0 + 10 * i];
 		// the first kScreenEarly taps bound the value from below: most wavefronts stop here
 		ScreenAcc acc;
 		screen_taps(ph, T, 0, kScreenEarly, acc);
-		ps[q] = screen_value(acc, kScreenEarly);
-		if(__any(ps[q] < kScreenEarlyThr)) {
+		float ps = screen_value(acc, kScreenEarly);
+		if(__any(ps < kScreenEarlyThr)) {
+			#pragma unroll
+			for(int i = kScreenEarly; i < kPreamble; i++) ph[i] = tile[i0 + 10 * i];
 			screen_taps(ph, T, kScreenEarly, kPreamble, acc);
-			ps[q] = screen_value(acc, kPreamble);
+			ps = screen_value(acc, kPreamble);
 		}
-		fl[i0 + 3] = ps[q] < kScreenThr;
+		const unsigned long long bits = __ballot(n < a.k1 && ps < kScreenThr);
+		if((tid & 63) == 0 && n < a.k1) a.flag[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
 	}
-	if(tid < 6) {                                   // the three neighbours on either side
-		const int i0 = tid < 3 ? tid - 3 : kK3Tile + tid - 3;
-		#pragma unroll
-		for(int i = 0; i < kPreamble; i++) ph[i] = tile[i0 + 6 + 10 * i];
-		fl[i0 + 3] = sync_metric_screen(ph, T) < kScreenThr;
+}
+
+__device__ __forceinline__ void k3_exact(const cf32 *y, uint32_t mask, int64_t n, int64_t k1, const Tables &T, float &p, float &f) {
+	float ph[kPreamble];
+	#pragma unroll 1
+	for(int i = 0; i < kPreamble; i++) {
+		const int64_t t = n - 150 + 10 * i;
+		ph[i] = (t < 0 || t >= k1) ? 0.f : phase_of(y[(uint32_t)t & mask]);
 	}
-	__syncthreads();
-	#pragma unroll
-	for(int q = 0; q < kK3Tile / 256; q++) {
-		const int i0 = tid + 256 * q;
-		const int64_t n = nblk + i0;
-		cf32 r{ps[q], 0.f};
-		const bool need = fl[i0] | fl[i0 + 3] | (n + 3 < a.k1 ? fl[i0 + 6] : 1);
-		if(n >= a.k1) r = cf32{kPherrBig, 0.f};
-		else if(need) {
-			#pragma unroll
-			for(int i = 0; i < kPreamble; i++) ph[i] = tile[i0 + 6 + 10 * i];
-			sync_metric(ph, T, r.re, r.im);
+	sync_metric(ph, T, p, f);
+}
+
+// one lane per 64-sample word; a wavefront then gathers on each of its words that holds work, one lane per sample
+__global__ __launch_bounds__(256) void k_sync_exact(K3Args a) {
+	const int c = blockIdx.y, lane = threadIdx.x & 63;
+	const cf32 *y = a.y + (size_t)c * a.cap;
+	const uint64_t *flag = a.flag + (size_t)c * (a.cap >> 6);
+	uint64_t *cand = a.cand + (size_t)c * (a.cap >> 6);
+	const uint32_t wmask = a.mask >> 6;
+	const Tables &T = *a.tab;
+	const int64_t w0 = a.nbase >> 6, w1 = (a.k1 + 63) >> 6;
+	const int64_t w = w0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+	uint64_t need = 0, fprev = 0;
+	if(w < w1) {
+		const uint64_t f0 = flag[(uint32_t)w & wmask];
+		fprev = w > 0 ? flag[(uint32_t)(w - 1) & wmask] : 0ull;          // words before nbase hold the previous feed's flags
+		const uint64_t fnext = w + 1 < w1 ? flag[(uint32_t)(w + 1) & wmask] : 0ull;
+		need = f0 | (f0 << 3) | (f0 >> 3) | (fprev >> 61) | (fnext << 61);
+		const int64_t base = w << 6;
+		if(a.k1 - 3 < base + 64) {                                          // right neighbour n+3 not there yet
+			const int64_t lo = a.k1 - 3 - base;
+			need |= lo <= 0 ? ~0ull : (~0ull << lo);
 		}
-		if(n < a.k1) a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = r;
-		psh[i0 + 3] = r.re;
+		if(a.k1 < base + 64) need &= (a.k1 - base <= 0) ? 0ull : (~0ull >> (64 - (a.k1 - base)));   // samples that exist
+		if(need == 0) cand[(uint32_t)w & wmask] = 0;
 	}
-	if(tid < 3) {                                   // left neighbours: only "under the threshold, and by how much" matters
-		const int64_t m = nblk - 3 + tid;
-		float pm = kPherrBig, fm;
-		if(m >= 0 && fl[tid]) {
-			#pragma unroll
-			for(int i = 0; i < kPreamble; i++) ph[i] = tile[tid - 3 + 6 + 10 * i];
-			sync_metric(ph, T, pm, fm);
+	unsigned long long busy = __ballot(need != 0);
+	while(busy) {
+		const int j = __builtin_ctzll(busy); busy &= busy - 1;
+		const uint64_t needj = __shfl(need, j), fprevj = __shfl(fprev, j);
+		const int64_t wj = w - lane + j;                                   // every lane of the wavefront turns to lane j's word
+		const int64_t n = (wj << 6) + lane;
+		float p = kPherrBig, f = 0.f;
+		if((needj >> lane) & 1ull) {
+			k3_exact(y, a.mask, n, a.k1, T, p, f);
+			a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = cf32{p, f};
 		}
-		psh[tid] = pm;
-	}
-	__syncthreads();
-	#pragma unroll
-	for(int q = 0; q < kK3Tile / 256; q++) {
-		const int i0 = tid + 256 * q;
-		const int64_t n = nblk + i0;
-		const bool cnd = n >= 3 && n < a.k1 && is_candidate(psh[i0], psh[i0 + 3]);
-		const unsigned long long bits = __ballot(cnd);
-		if((tid & 63) == 0 && n < a.k1) a.cand[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
+		float pm3 = __shfl_up(p, 3);
+		if(lane < 3) {                                                      // n-3 lies in the previous word
+			pm3 = kPherrBig;
+			float fm;
+			if(n >= 3 && ((fprevj >> (61 + lane)) & 1ull)) k3_exact(y, a.mask, n - 3, a.k1, T, pm3, fm);
+		}
+		const unsigned long long bits = __ballot(n >= 3 && n < a.k1 && is_candidate(pm3, p));
+		if(lane == 0) cand[(uint32_t)wj & wmask] = bits;
 	}
 }
 
 struct K4Args {
-	const cf32 *y; const float *phi; const cf32 *pf; const uint64_t *cand; const Tables *tab;
+	const cf32 *y; const cf32 *pf; const uint64_t *cand; const Tables *tab;
 	WalkState *ws; unsigned long long *cnt; Burst *bursts; uint32_t *nb_chan; uint32_t cap_bursts_chan; OutCtl *ctl; const uint32_t *freq;
 	EvalChunk *log; uint32_t *nlog; uint32_t cap_log;
 	int64_t k_end; float max_ppm; uint32_t cap, mask; int32_t chan_first;
@@ -541,7 +535,7 @@ struct K4Args {
 __global__ __launch_bounds__(64) void k_walk(K4Args a) {
 	__shared__ WalkShared sh;
 	const int c = blockIdx.x;
-	ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	walk_channel(c, a.freq[c], a.max_ppm, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh);
@@ -556,7 +550,7 @@ __global__ __launch_bounds__(64) void k_walk_spec(K4sArgs s) {
 	__shared__ WalkShared sh;
 	const K4Args &a = s.k;
 	const int c = blockIdx.y, x = blockIdx.x;
-	ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
 	if(x == 0) {
 		EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 		walk_channel(c, a.freq[c], a.max_ppm, s.k0 + s.seglen, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
@@ -573,7 +567,7 @@ __global__ __launch_bounds__(64) void k_walk_stitch(K4sArgs s) {
 	__shared__ StitchShared ss;
 	const K4Args &a = s.k;
 	const int c = blockIdx.x;
-	ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	stitch_channel(c, a.freq[c], a.max_ppm, s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	               a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg,
@@ -597,7 +591,7 @@ __global__ __launch_bounds__(64) void k_nf_prepare(K4bArgs a) {
 __global__ __launch_bounds__(64) void k_nf_replay(K4bArgs a) {
 	__shared__ NfShared sh;
 	const int c = blockIdx.y;
-	ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, nullptr, a.mask };
+	ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask };
 	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
 	const NfFeed fd = a.feed[c];
 	for(int64_t g = blockIdx.x; fd.u0 + 1 + kNfGroup * g <= fd.u1; g += gridDim.x) {
@@ -625,7 +619,7 @@ __global__ __launch_bounds__(64) void k_burst_index(const uint32_t *nb_chan, uin
 }
 
 struct K5Args {
-	const cf32 *y; const float *phi; const Tables *tab; unsigned long long *cnt;
+	const cf32 *y; const Tables *tab; unsigned long long *cnt;
 	const Burst *bursts; const uint32_t *bbase; uint32_t cap_bursts_chan; int32_t nchan;
 	OutFrame *frames; uint8_t *pool; OutCtl *ctl; const uint32_t *freq;
 	uint32_t cap, mask;
@@ -639,7 +633,7 @@ __global__ __launch_bounds__(64) void k_burst(K5Args a) {
 		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(a.bbase[mid] <= g) lo = mid; else hi = mid; }
 		const int c = lo;
 		const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - a.bbase[c])];
-		ChanView v{ a.y + (size_t)c * a.cap, a.phi + (size_t)c * a.cap, nullptr, nullptr, a.mask };
+		ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask };
 		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
 		__syncthreads();
 	}

@@ -123,9 +123,6 @@ enum { CNT_SYNC_GOOD = 0, CNT_CRC_GOOD, CNT_CRC_BAD, CNT_ERR_NO_HEADER, CNT_ERR_
 enum { ACNT_PROCESSED = 0, ACNT_TOO_SHORT, ACNT_GOOD, ACNT_BAD_FCS, ACNT_AIR2GND, ACNT_AIR2AIR, ACNT_AIR2ALL, ACNT_GND2AIR, ACNT_GND2GND, ACNT_GND2ALL };
 enum { AVLC_OK = 0, AVLC_TOO_SHORT = 1, AVLC_BAD_FCS = 2 };
 
-struct cf32 { float re, im; };
-
-
 // Read-only tables, built on the host once per context (tables.h) and kept in device memory.
 struct Tables {
 	float    pr_phase[kPreamble];      // demod.c:107-124
@@ -142,15 +139,20 @@ struct Tables {
 	uint16_t crc16[256];               // crc.c:23-57: reflected CRC-16-CCITT (x^16+x^12+x^5+1), one step per octet
 };
 
-// One channel's decimated-rate streams, ring-addressed by absolute sample index.
+struct cf32 { float re, im; };
+VDL2_HD float phase_of(cf32 y);
+
+// One channel's decimated-rate streams, ring-addressed by absolute sample index.  There is no stored phase stream: the
+// reference's atan2 (double, narrowed to float: demod.c:232,256) is evaluated where a decision reads a phase - the exact
+// tier of the sync kernel, the walker, the burst decoder - which is a few percent of the samples; the sync kernel's
+// screening tier works on a cheap single-precision phase of its own (phase_fast()).
 struct ChanView {
 	const cf32     *y;                 // filtered + decimated samples (lp_re, lp_im)
-	const float    *phi;               // atan2 of y (demod.c:232,256)
-	const cf32     *pf;                // {pherr[0], freq_err} of got_sync() evaluated at every n (contiguous ring)
+	const cf32     *pf;                // {pherr[0], freq_err} of got_sync() evaluated at n (contiguous ring) - valid where a preamble is near
 	const uint64_t *cand;              // bit n: pf[n-3].p < 4 && pf[n].p > pf[n-3].p
 	uint32_t        mask;              // capacity - 1 (capacity is a power of two)
-	VDL2_HD float Phi(int64_t n) const { return n < 0 ? 0.f : phi[(uint32_t)n & mask]; }
 	VDL2_HD cf32  Y(int64_t n) const { return y[(uint32_t)n & mask]; }
+	VDL2_HD float Phi(int64_t n) const { return n < 0 ? 0.f : phase_of(y[(uint32_t)n & mask]); }   // atan2(lp_im, lp_re); 0 before the stream starts
 	VDL2_HD cf32  PF(int64_t n) const { return pf[(uint32_t)n & mask]; }
 	VDL2_HD uint64_t Cand(int64_t word) const { return cand[(uint32_t)word & (mask >> 6)]; }
 };
@@ -252,6 +254,28 @@ VDL2_HD double atan2_f64(double y, double x) {
 }
 VDL2_HD float phase_of(cf32 y) { return (float)atan2_f64((double)y.im, (double)y.re); }
 
+// Single-precision phase for the sync kernel's screening tier only: odd minimax polynomial of degree 13 on min/max, error
+// < 5e-7 rad (tests/test_phase.py).  No decision is taken on it: a window whose screening value is near the threshold, or
+// in which one of its unwrap decisions could go the other way with the exact phases, is redone exactly (kScreenGuard).
+VDL2_HD float phase_fast(cf32 y) {
+	const float ax = fabsf(y.re), ay = fabsf(y.im);
+	const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+	if(!(mx > 0.f)) return 0.f;
+#if VDL2_DEVICE_PASS
+	const float t = mn * __builtin_amdgcn_rcpf(mx);
+#else
+	const float t = mn / mx;
+#endif
+	const float z = t * t;
+	float p = 0.006811664905399084f;
+	p = fmaf(p, z, -0.03360380604863167f); p = fmaf(p, z, 0.07962316274642944f); p = fmaf(p, z, -0.13233311474323273f);
+	p = fmaf(p, z, 0.19807806611061096f); p = fmaf(p, z, -0.3331736624240875f); p = fmaf(p, z, 0.9999961256980896f);
+	float a = p * t;
+	if(ay > ax) a = 1.5707963267948966f - a;
+	if(y.re < 0.f) a = 3.141592653589793f - a;
+	return copysignf(a, y.im);
+}
+
 // hypotf() as glibc evaluates it (double intermediate), demod.c:238
 VDL2_HD float mag_of(cf32 y) { return (float)sqrt((double)y.re * (double)y.re + (double)y.im * (double)y.im); }
 
@@ -295,12 +319,16 @@ constexpr float kScreenThr = 5.5f;
 // after kScreenEarly taps when no lane of the wavefront is still under the threshold (97 % of them on noise or data).
 constexpr int kScreenEarly = 12;
 constexpr float kScreenEarlyThr = 5.8f;   // early bound + its rounding slack must stay above kScreenThr
-struct ScreenAcc { float prev, unwrap, m0, m1, m2; };
+// The screening tier runs on phase_fast() phases (error < 5e-7 rad each), so an unwrap decision - "is the difference of two
+// taps beyond +-pi" - could differ from the one the exact phases give when the difference is within ~2e-6 of +-pi.  `guard`
+// is the smallest distance of any difference from +-pi: a window where it is under kScreenGuard is treated as flagged.
+constexpr float kScreenGuard = 2e-5f;
+struct ScreenAcc { float prev, unwrap, m0, m1, m2, guard; };
 
 VDL2_HD void screen_taps(const float *ph, const Tables &T, int i0, int i1, ScreenAcc &a) {
 	if(i0 == 0) {
 		a.prev = ph[0] - T.pr_phase[0]; a.unwrap = 0.f;
-		a.m0 = a.prev; a.m1 = 0.f; a.m2 = a.prev * a.prev;
+		a.m0 = a.prev; a.m1 = 0.f; a.m2 = a.prev * a.prev; a.guard = 1.f;
 		i0 = 1;
 	}
 	for(int i = i0; i < i1; i++) {
@@ -308,16 +336,19 @@ VDL2_HD void screen_taps(const float *ph, const Tables &T, int i0, int i1, Scree
 		const float diff = cur - a.prev;
 		a.prev = cur;
 		a.unwrap += diff > kPiBelow ? -(float)(2.0 * M_PI) : (diff < -kPiBelow ? (float)(2.0 * M_PI) : 0.f);
+		a.guard = fminf(a.guard, fabsf(fabsf(diff) - kPiBelow));
 		const float e = cur + a.unwrap;
 		a.m0 += e; a.m1 = fmaf((float)i, e, a.m1); a.m2 = fmaf(e, e, a.m2);
 	}
 }
 
 // residual of the least-squares line through the first n points: m2 - m0^2/n - (m1 - xbar m0)^2 / Sxx, Sxx = n(n^2-1)/12
+// (n is a constant at every call site: the reciprocals fold, no division is executed - it is a screening value)
 VDL2_HD float screen_value(const ScreenAcc &a, int n) {
-	const float xbar = 0.5f * (float)(n - 1), sxx = (float)(n * (n * n - 1)) / 12.0f;
+	const float xbar = 0.5f * (float)(n - 1), inv_n = 1.0f / (float)n, inv_sxx = 12.0f / (float)(n * (n * n - 1));
 	const float c = a.m1 - xbar * a.m0;
-	return a.m2 - a.m0 * a.m0 / (float)n - c * c / sxx;
+	const float v = a.m2 - a.m0 * a.m0 * inv_n - c * c * inv_sxx;
+	return a.guard < kScreenGuard ? 0.f : v;        // an unwrap decision too close to call: let the exact tier look
 }
 
 VDL2_HD float sync_metric_screen(const float *ph, const Tables &T) {
@@ -347,13 +378,10 @@ VDL2_HD int slice_symbol(float phi, float prev_phi, float vdphi, int &neg) {
 }
 
 // got_sync() metric at decimated sample n assuming the phase ring holds the 160 most recent
-// samples contiguously (taps n-150, n-140, ..., n): what the sync kernel tabulates for every n.
-VDL2_HD cf32 metric_contiguous(const float *phi, uint32_t mask, int64_t n, const Tables &T) {
+// samples contiguously (taps n-150, n-140, ..., n): what the sync kernel's exact tier tabulates.
+VDL2_HD cf32 metric_contiguous(const ChanView &v, int64_t n, const Tables &T) {
 	float ph[kPreamble];
-	for(int i = 0; i < kPreamble; i++) {
-		int64_t t = n - 150 + 10 * i;
-		ph[i] = t < 0 ? 0.f : phi[(uint32_t)t & mask];
-	}
+	for(int i = 0; i < kPreamble; i++) ph[i] = v.Phi(n - 150 + 10 * i);
 	cf32 r;
 	sync_metric(ph, T, r.re, r.im);
 	return r;
@@ -643,15 +671,20 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 					log_evals(sh, lg, ctl, e, (n - e) / 3 + 1);
 					K4_MARK(2);
 				} else {
-					// nothing up to k_lim: park just past the last evaluation that exists
+					// nothing up to k_lim: park just past the last evaluation that exists.  v->pherr[1], pherr[2] and prev_dphi
+					// as that evaluation leaves them are computed here (two lanes, one round trip): the sync kernel stores
+					// metric values only where a preamble is near, and an arbitrary stopping place is not one
 					const int64_t cnt_ev = (k_lim - 1 - e) / 3 + 1;     // e < k_lim here
 					const int64_t nl = e + 3 * (cnt_ev - 1);
 					log_evals(sh, lg, ctl, e, cnt_ev);
 					K4_MARK(2);
+					WAVE_FOR(l)
+						if(l < 2) { const cf32 r = metric_contiguous(v, nl - 3 * l, T); sh.p[l] = r.re; sh.f[l] = r.im; }
+					WAVE_END
 					LANE0
-						sh.st.pherr1 = v.PF(nl).re;
-						sh.st.pherr2 = (nl - 3 >= sh.st.e0) ? v.PF(nl - 3).re : kPherrBig;
-						sh.st.prev_dphi = v.PF(nl).im;
+						sh.st.pherr1 = sh.p[0];
+						sh.st.pherr2 = (nl - 3 >= sh.st.e0) ? sh.p[1] : kPherrBig;
+						sh.st.prev_dphi = sh.f[0];
 						sh.st.e = nl + 3;
 					LANE0_END
 				}
@@ -1388,14 +1421,20 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		for(int i = l; i < 256; i += 64) sh.gf_log[i] = T.gf_log[i];
 	WAVE_END
 
-	// 1. slice every symbol (demod.c:252-274); decisions are independent because prev_phi is the raw phase
+	// 1. slice every symbol (demod.c:252-274); decisions are independent because prev_phi is the raw phase.  A lane takes
+	//    a run of consecutive symbols, so that the phase of a symbol (one double-precision atan2, evaluated here: there is no
+	//    stored phase stream) also serves as the next symbol's prev_phi
+	const int per_lane = (nsym + 63) / 64;
 	WAVE_FOR(l)
 		float pw = 0.f; int neg = 0;
-		for(int m = l; m < nsym; m += 64) {
-			int64_t t = b.t_first + (int64_t)m * kSpsDec;
-			float prev = m ? v.Phi(t - kSpsDec) : b.prev_phi0;
-			sh.sym[m] = T.gray[slice_symbol(v.Phi(t), prev, b.vdphi, neg)];
-			cf32 y = v.Y(t);
+		const int m0 = l * per_lane, m1 = m0 + per_lane < nsym ? m0 + per_lane : nsym;
+		float prev = b.prev_phi0;
+		if(m0 > 0 && m0 < nsym) prev = v.Phi(b.t_first + (int64_t)(m0 - 1) * kSpsDec);
+		for(int m = m0; m < m1; m++) {
+			const cf32 y = v.Y(b.t_first + (int64_t)m * kSpsDec);
+			const float cur = phase_of(y);
+			sh.sym[m] = T.gray[slice_symbol(cur, prev, b.vdphi, neg)];
+			prev = cur;
 			pw += y.re * y.re + y.im * y.im;
 		}
 		sh.pw[l] = pw; sh.neg[l] = neg;

@@ -68,7 +68,7 @@ struct vdl2hip_ctx {
 	hipEvent_t pinned_pending = nullptr;   // copy event of the last vdl2hip_feed_pinned() whose source buffer the caller may not touch yet
 	uint8_t *h_stage = nullptr; size_t stage_cap = 0;   // pinned D2H staging for frame records + octets
 	uint8_t *d_carry[2] = {nullptr, nullptr}; int carry_sel = 0; uint32_t ncarry = 0;
-	cf32 *d_y = nullptr, *d_pf = nullptr; float *d_phi = nullptr; uint64_t *d_cand = nullptr;
+	cf32 *d_y = nullptr, *d_pf = nullptr; uint64_t *d_cand = nullptr, *d_flag = nullptr;
 	uint32_t cap = 0;
 	float4 *d_segend = nullptr; uint32_t nseg_cap = 0;
 	float4 *d_qpow = nullptr;
@@ -217,7 +217,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	a.fmt = c->fmt; a.nchan = c->C; a.os = c->os; a.nseg = 0; a.gy = 1;
 	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.seg_end = c->d_segend;
 	a.qpow = c->d_qpow; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap;
-	a.fuse = c->fuse_k2 && 64 * c->run == kFixW; a.phi = c->d_phi; a.carry_in = c->d_tcarry[c->tcarry_sel]; a.carry_out = c->d_tcarry[c->tcarry_sel ^ 1];
+	a.fuse = c->fuse_k2 && 64 * c->run == kFixW; a.carry_in = c->d_tcarry[c->tcarry_sel]; a.carry_out = c->d_tcarry[c->tcarry_sel ^ 1];
 	a.bfd = c->d_bf; a.seg_pub = c->d_segpub; a.epoch = (uint32_t)(c->feed_no + 1); a.sync_timeouts = c->d_synctmo;
 	a.pub_epoch = a.epoch; a.spin_limit = 1 << 22;
 	if(c->debug_force_timeout) { a.pub_epoch = a.epoch ^ 0x40000000u; a.spin_limit = 16; }   // tests only: the look-back must fail loudly
@@ -247,9 +247,9 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 			launch_chanfir<0, kRunGeneric>(c, a, c->cr, lds, e0, e1);
 		}
 		if(!a.fuse) {
-			K2Args k2{ c->d_y, c->d_phi, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
+			K2Args k2{ c->d_y, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
 			           c->k_total, D, c->cap, c->cap - 1, c->nseg_cap, seglen * a.tiles };
-			LAUNCH_EV(k_phase, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), st, EV(2), EV(3), k2);
+			LAUNCH_EV(k_fixup, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), st, EV(2), EV(3), k2);
 		}
 		c->tcarry_sel ^= 1;
 	}
@@ -257,10 +257,12 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	c->carry_sel ^= 1; c->ncarry = nrem;
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
-		K3Args k3{ c->d_phi, c->d_pf, c->d_cand, c->d_tab, nbase, k1, c->cap, c->cap - 1 };
-		// K3's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less on the
-		// front stream than a separate hipEventRecord
-		LAUNCH_EV(k_sync, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(256), st, EV(4), sl.ev_front, k3);
+		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1 };
+		LAUNCH_EV(k_sync_screen, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(256), st, EV(4), (hipEvent_t) nullptr, k3);
+		// the exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry
+		// less on the front stream than a separate hipEventRecord
+		const int64_t nwords = ((k1 + 63) >> 6) - (nbase >> 6);
+		LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + 255) / 256), (unsigned)c->C), dim3(256), st, (hipEvent_t) nullptr, sl.ev_front, k3);
 	}
 	// The burst-rate back end runs on three more streams, so that consecutive feeds overlap stage by stage:
 	//   stream_back   K4   walk(i) -> walk(i+1) -> ...             (each needs the previous one's FSM state)
@@ -271,7 +273,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	HIPCHK(hipStreamWaitEvent(sb_, sl.ev_front, 0));
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D;
-		K4Args k4{ c->d_y, c->d_phi, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
+		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
 		// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
 		int nseg = (int)std::min<int64_t>(c->seg_max, D / c->seg_min);
@@ -297,7 +299,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		LAUNCH_EV(k_nf_finish, dim3((unsigned)c->C), dim3(64), sn_, (hipEvent_t) nullptr, EV(9), k4b);
 		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
 		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl, (const uint32_t *)c->d_synctmo);
-		K5Args k5{ c->d_y, c->d_phi, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
+		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
 		LAUNCH_EV(k_burst, dim3(2048), dim3(64), s5_, EV(10), EV(11), k5);
 		sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0;
@@ -352,7 +354,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_phi, c->d_cand, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
+	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
 		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl, sl.d_log, sl.d_nlog };
 		for(void *p : q) if(p) (void)hipFree(p);
@@ -439,7 +441,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_carry[0], 4 * kMaxOversample); DEV_ALLOC(c->d_carry[1], 4 * kMaxOversample);
 	const size_t nring = (size_t)count * cap;
 	DEV_ALLOC(c->d_y, nring * sizeof(cf32)); DEV_ALLOC(c->d_pf, nring * sizeof(cf32));
-	DEV_ALLOC(c->d_phi, nring * sizeof(float)); DEV_ALLOC(c->d_cand, nring / 8);
+	DEV_ALLOC(c->d_cand, nring / 8); DEV_ALLOC(c->d_flag, nring / 8);
 	DEV_ALLOC(c->d_segend, (size_t)count * c->nseg_cap * sizeof(float4));
 	DEV_ALLOC(c->d_qpow, 64 * sizeof(float4));
 	DEV_ALLOC(c->d_tcarry[0], count * sizeof(float4)); DEV_ALLOC(c->d_tcarry[1], count * sizeof(float4));
@@ -507,7 +509,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipMemset(c->d_nffeed, 0, count * sizeof(NfFeed)));
 	}
 	DEV_CHK(hipMemset(c->d_y, 0, nring * sizeof(cf32))); DEV_CHK(hipMemset(c->d_pf, 0, nring * sizeof(cf32)));
-	DEV_CHK(hipMemset(c->d_phi, 0, nring * sizeof(float))); DEV_CHK(hipMemset(c->d_cand, 0, nring / 8));
+	DEV_CHK(hipMemset(c->d_cand, 0, nring / 8)); DEV_CHK(hipMemset(c->d_flag, 0, nring / 8));
 	DEV_CHK(hipMemset(c->d_tcarry[0], 0, count * sizeof(float4))); DEV_CHK(hipMemset(c->d_tcarry[1], 0, count * sizeof(float4)));
 	DEV_CHK(hipMemset(c->d_cnt, 0, (size_t)count * kNumCounters * 8)); DEV_CHK(hipMemset(c->d_acnt, 0, (size_t)count * kNumAvlcCounters * 8));
 	DEV_CHK(hipMemset(c->d_segend, 0, (size_t)count * c->nseg_cap * sizeof(float4)));

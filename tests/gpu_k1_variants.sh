@@ -1,13 +1,11 @@
 #!/bin/bash
 # Development aid: build K1 variants on the GPU box and time them (python tests/gpu_k1_bench.py).
-set -e
+# usage: tests/gpu_k1_variants.sh "<name>:<flags>" ...   (default set below); channel counts from $CHANS (default "8 64 256")
 cd "$(dirname "$0")/.."
 F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared"
-build() { hipcc $F $2 -o /tmp/$1.so dumpvdl2_amd/csrc/vdl2hip.hip; }
-build base "" &
-build inl5 "-DVDL2_K1_INLINE_PHASE" &
-build inl4 "-DVDL2_K1_INLINE_PHASE -DVDL2_K1_MIN_BLOCKS=4" &
+if [ $# -eq 0 ]; then set -- "base:" "mb5:-DVDL2_K1_MIN_BLOCKS=5" "cr4mb5:-DVDL2_K1_MIN_BLOCKS_CR4=5" "cr4mb3:-DVDL2_K1_MIN_BLOCKS_CR4=3" "unr4:-DVDL2_K1_UNROLL=4" "unr10:-DVDL2_K1_UNROLL=10"; fi
+for v in "$@"; do ( hipcc $F ${v#*:} -o /tmp/k1_${v%%:*}.so dumpvdl2_amd/csrc/vdl2hip.hip 2>/dev/null || echo "build of $v failed" ) & done
 wait
-for v in base inl5 inl4; do
-  for C in 8; do VDL2HIP_LIB=/tmp/$v.so python tests/gpu_k1_bench.py $C 16 3 | cut -c1-110; done
+for v in "$@"; do
+  for C in ${CHANS:-8 64 256}; do VDL2HIP_LIB=/tmp/k1_${v%%:*}.so timeout 300 python tests/gpu_k1_bench.py $C 16 3 | sed "s|^/tmp/k1_||" | cut -c1-230; done
 done

@@ -17,7 +17,7 @@ using namespace vdl2;
 struct Sim {
 	int nchan; uint32_t cap, mask; float max_ppm;
 	std::vector<uint32_t> freqs;
-	std::vector<cf32> y, pf; std::vector<float> phi; std::vector<uint64_t> cand;
+	std::vector<cf32> y, pf; std::vector<uint64_t> cand;
 	std::vector<WalkState> st; std::vector<unsigned long long> cnt, acnt;
 	std::vector<NfState> nf; std::vector<EvalChunk> log; std::vector<uint32_t> nlog; std::vector<int64_t> scf, scc; std::vector<float> ring, lpbuf;
 	uint32_t cap_log = 8192, cap_comb = 8192 + kNfTail, cap_hist = 4096, nf_ring = 16384;
@@ -38,7 +38,7 @@ Sim *hostsim_create(int nchan, const uint32_t *freqs, float max_ppm, int cap_log
 	s->nchan = nchan; s->cap = 1u << cap_log2; s->mask = s->cap - 1; s->max_ppm = max_ppm;
 	s->freqs.assign(freqs, freqs + nchan);
 	s->y.assign((size_t)nchan * s->cap, cf32{0, 0}); s->pf.assign((size_t)nchan * s->cap, cf32{0, 0});
-	s->phi.assign((size_t)nchan * s->cap, 0.f); s->cand.assign((size_t)nchan * (s->cap / 64), 0);
+	s->cand.assign((size_t)nchan * (s->cap / 64), 0);
 	s->st.resize(nchan); s->cnt.assign((size_t)nchan * kNumCounters, 0); s->acnt.assign((size_t)nchan * kNumAvlcCounters, 0);
 	for(auto &w : s->st) { memset(&w, 0, sizeof w); walk_state_init(w); }
 	s->nf.resize(nchan); for(auto &n : s->nf) { memset(&n, 0, sizeof n); nf_state_init(n); }
@@ -61,28 +61,29 @@ void hostsim_segment_stats(Sim *s, uint32_t out[2]) { out[0] = s->seg_stats[0]; 
 int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 	const int64_t k0 = s->k_total, k1 = k0 + D;
 	for(int c = 0; c < s->nchan; c++) {
-		cf32 *y = &s->y[(size_t)c * s->cap]; float *phi = &s->phi[(size_t)c * s->cap];
+		cf32 *y = &s->y[(size_t)c * s->cap];
 		cf32 *pf = &s->pf[(size_t)c * s->cap]; uint64_t *cand = &s->cand[(size_t)c * (s->cap / 64)];
 		for(int64_t k = k0; k < k1; k++) {
 			cf32 v{ yin[((size_t)c * D + (k - k0)) * 2], yin[((size_t)c * D + (k - k0)) * 2 + 1] };
 			y[(uint32_t)k & s->mask] = v;
-			phi[(uint32_t)k & s->mask] = phase_of(v);
 		}
+		const ChanView cv{ y, pf, cand, s->mask };
 		// sync kernel: whole 64-aligned words covering [k0, k1)
 		if(!s->two_tier) {
 			for(int64_t n = k0 & ~63ll; n < ((k1 + 63) & ~63ll); n++) {
-				cf32 r = (n < k1) ? metric_contiguous(phi, s->mask, n, s->T) : cf32{kPherrBig, 0.f};
+				cf32 r = (n < k1) ? metric_contiguous(cv, n, s->T) : cf32{kPherrBig, 0.f};
 				pf[(uint32_t)n & s->mask] = r;
 			}
 		} else {
-			// K3's rule (kernels.h:k_sync): screening value everywhere, the exact arithmetic only where the screening value is
-			// under kScreenThr or 3 samples either side of such a place, or where the right neighbour has not arrived yet
+			// K3's rule (kernels.h:k_sync_screen / k_sync_exact): the screening value, from single-precision phases, everywhere;
+			// the exact arithmetic only where the screening value is under kScreenThr or 3 samples either side of such a place,
+			// or where the right neighbour has not arrived yet
 			const int64_t nb = (k0 & ~63ll) - 3, ne = (k1 + 63) & ~63ll;
 			std::vector<float> scr((size_t)(ne + 3 - nb));
 			auto screen_at = [&](int64_t n) -> float {
 				if(n < 0 || n >= k1) return kPherrBig;
 				float ph[kPreamble];
-				for(int i = 0; i < kPreamble; i++) { int64_t t = n - 150 + 10 * i; ph[i] = t < 0 ? 0.f : phi[(uint32_t)t & s->mask]; }
+				for(int i = 0; i < kPreamble; i++) { int64_t t = n - 150 + 10 * i; ph[i] = t < 0 ? 0.f : phase_fast(y[(uint32_t)t & s->mask]); }
 				ScreenAcc a; screen_taps(ph, s->T, 0, kScreenEarly, a);
 				float v = screen_value(a, kScreenEarly);
 				if(v < kScreenEarlyThr) { screen_taps(ph, s->T, kScreenEarly, kPreamble, a); v = screen_value(a, kPreamble); }
@@ -94,7 +95,9 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 				cf32 r{kPherrBig, 0.f};
 				if(n < k1) {
 					const bool need = fl(n - 3) || fl(n) || (n + 3 < k1 ? fl(n + 3) : true);
-					r = need ? metric_contiguous(phi, s->mask, n, s->T) : cf32{scr[(size_t)(n - nb)], 0.f};
+					// the kernel stores a metric value only where it computed the exact one; everywhere else the ring keeps whatever
+					// an earlier lap left there, which the walker must never look at: the simulation puts poison there
+					r = need ? metric_contiguous(cv, n, s->T) : cf32{12345.f, 54321.f};
 					s->n_exact += need; s->n_total++;
 				}
 				pf[(uint32_t)n & s->mask] = r;
@@ -115,7 +118,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 	s->ctl.cap_bursts = (uint32_t)s->bursts.size(); s->ctl.cap_frames = (uint32_t)s->frames.size(); s->ctl.cap_pool = (uint32_t)s->pool.size(); s->ctl.cap_log = s->cap_log;
 	static WalkShared wsh;
 	for(int c = 0; c < s->nchan; c++) {
-		ChanView v{ &s->y[(size_t)c * s->cap], &s->phi[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
+		ChanView v{ &s->y[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
 		EvalLog lg{ &s->log[(size_t)c * s->cap_log], &s->nlog[c] };
 		uint32_t nbc = 0;
 		int nseg = s->seg_min > 0 ? (int)std::min<int64_t>(s->seg_max, D / s->seg_min) : 1;
@@ -150,7 +153,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 	for(uint32_t i = 0; i < nb; i++) {
 		const Burst &b = s->bursts[i];
 		int c = b.chan;
-		ChanView v{ &s->y[(size_t)c * s->cap], &s->phi[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
+		ChanView v{ &s->y[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
 		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl, bsh);
 	}
 	uint32_t nf = s->ctl.nframes < s->ctl.cap_frames ? s->ctl.nframes : s->ctl.cap_frames;
@@ -177,6 +180,9 @@ void hostsim_avlc_counters(Sim *s, int chan, unsigned long long *out) { memcpy(o
 void hostsim_counters(Sim *s, int chan, unsigned long long *out) { memcpy(out, &s->cnt[(size_t)chan * kNumCounters], sizeof(unsigned long long) * kNumCounters); }
 // phase_of() of the device code on n (re, im) pairs, for comparison with libm
 void hostsim_phase(const float *reim, float *out, int64_t n) { for(int64_t i = 0; i < n; i++) out[i] = phase_of(cf32{reim[2 * i], reim[2 * i + 1]}); }
+// the screening-tier phase of the sync kernel
+void hostsim_phase_fast(const float *reim, float *out, int64_t n) { for(int64_t i = 0; i < n; i++) out[i] = phase_fast(cf32{reim[2 * i], reim[2 * i + 1]}); }
+float hostsim_screen_guard() { return kScreenGuard; }
 double hostsim_atan2(double y, double x) { return atan2_f64(y, x); }
 
 int hostsim_sizeof_outframe() { return (int)sizeof(OutFrame); }

@@ -140,8 +140,13 @@ def test_sync_screening_never_hides_a_sub_threshold_metric(hs):
     hs.hostsim_metric_pairs(ph.ctypes.data, n, exact.ctypes.data, slope.ctypes.data, screen.ctypes.data)
     assert np.isfinite(exact).all() and np.isfinite(screen).all()
     assert (exact < 4).sum() > 50000 and ((exact > 3) & (exact < 5)).sum() > 2000       # the interesting region is populated
-    err = np.abs(screen.astype(np.float64) - exact.astype(np.float64))
-    assert err.max() < 0.2, (err.max(), exact[err.argmax()], screen[err.argmax()])
+    # a screening value of exactly 0 is the unwrap guard speaking: one of the window's tap differences lies within kScreenGuard of
+    # +-pi, where the single-precision phases the kernel screens with could unwrap the other way - such a window goes to the
+    # exact tier whatever it looks like (the "edge" set above is made of them)
+    guarded = screen == 0.0
+    assert guarded[-50000:].mean() > 0.001 and guarded[:200000].mean() < 1e-3
+    err = np.abs(screen.astype(np.float64) - exact.astype(np.float64))[~guarded]
+    assert err.max() < 0.2, err.max()
     assert not np.any((exact < 4.0) & (screen >= 5.5))
     # the early exit after 12 taps: that partial value is a lower bound (up to rounding) of the 16-tap screening value, and a
     # window that can matter (screening value under 5.5) is never dropped by the early test (under 5.8)
@@ -149,8 +154,11 @@ def test_sync_screening_never_hides_a_sub_threshold_metric(hs):
     early = np.zeros(n, dtype=np.float32)
     hs.hostsim_metric_early(ph.ctypes.data, n, early.ctypes.data)
     assert hs.hostsim_screen_early_taps() == 12
-    assert (early.astype(np.float64) - screen.astype(np.float64)).max() < 0.2
-    assert not np.any((screen < 5.5) & (early >= 5.8))
+    assert (early.astype(np.float64) - screen.astype(np.float64))[~guarded].max() < 0.2
+    assert not np.any((screen < 5.5) & ~guarded & (early >= 5.8))
+    # a guard that only trips in taps 12..15 is never seen when the window has already stopped after 12: harmless, the first 12
+    # unwrapped errors do not depend on later decisions and already put the exact value over the threshold
+    assert not np.any((exact < 4.0) & (early >= 5.8))
     assert (early[:200000] >= 5.8).mean() > 0.99                      # random windows: almost all stop early
 
 

@@ -34,3 +34,28 @@ def test_atan2_matches_libm_after_narrowing():
     for y, x in [(0.3, -2.0), (-7.5, 0.01), (1e-200, 1e-190), (5.0, 5.0), (-0.0, -1.0), (0.0, -1.0)]:
         a, b = H.hostsim_atan2(y, x), math.atan2(y, x)
         assert abs(a - b) <= 4 * np.spacing(abs(b)) and math.copysign(1, a) == math.copysign(1, b)
+
+
+def test_screening_phase_is_within_its_guard():
+    """phase_fast() (the sync kernel's screening tier) against the exact phase: the error of a difference of two such phases
+    must stay far inside kScreenGuard, the margin within which an unwrap decision is handed to the exact tier."""
+    H = C.CDLL(pyhostsim.build())
+    H.hostsim_phase.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    H.hostsim_phase_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    H.hostsim_screen_guard.restype = C.c_float
+    rng = np.random.default_rng(10)
+    n = 2_000_000
+    mag = np.exp(rng.uniform(-20, 2, n))
+    ang = rng.uniform(-np.pi, np.pi, n)
+    xy = np.empty((n, 2), dtype=np.float32)
+    xy[:, 0] = mag * np.cos(ang); xy[:, 1] = mag * np.sin(ang)
+    edge = np.array([[1, 0], [0, 1], [-1, 0], [0, -1], [1, 1], [-1, 1], [1, -1], [-1, -1], [1e-30, 1], [1, 1e-30], [-2, 1e-38],
+                     [0, 0], [-1, -0.0], [5e-39, 1e-45]], dtype=np.float32)
+    xy = np.concatenate([xy, edge])
+    a = np.empty(len(xy), dtype=np.float32); b = np.empty(len(xy), dtype=np.float32)
+    H.hostsim_phase(xy.ctypes.data, a.ctypes.data, len(xy))
+    H.hostsim_phase_fast(xy.ctypes.data, b.ctypes.data, len(xy))
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    d = np.minimum(d, 2 * np.pi - d)                       # +pi and -pi are the same direction
+    assert d.max() < 1e-6, d.max()
+    assert 2 * d.max() + 4 * np.spacing(np.float32(2 * np.pi)) < 0.25 * H.hostsim_screen_guard()
