@@ -578,12 +578,15 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 				// vring[159-r] = the (r+1)-th DM_INIT sample before a (through the interval history)
 				const int64_t a0 = sh.st.a;
 				WAVE_FOR(l)
-					for(int j = l; j < 320; j += 64) {
-						float val = 0.f;
-						if(j >= 160) { const int64_t n = a0 + (j - 160); if(n < k_end) val = v.Phi(n); }
-						else val = v.Phi(seq_index(sh.st, a0, 160 - j));
-						sh.vring[j] = val;
+					cf32 yv[5]; bool ok[5];
+					for(int q = 0; q < 5; q++) {                  // the five loads of a lane first, then the five phases
+						const int j = l + 64 * q;
+						int64_t n;
+						if(j >= 160) { n = a0 + (j - 160); ok[q] = n < k_end; }
+						else { n = seq_index(sh.st, a0, 160 - j); ok[q] = n >= 0; }
+						yv[q] = ok[q] ? v.Y(n) : cf32{0.f, 0.f};
 					}
+					for(int q = 0; q < 5; q++) sh.vring[l + 64 * q] = ok[q] ? phase_of(yv[q]) : 0.f;
 					if(l == 0) sh.vring_a = a0;
 				WAVE_END
 				WAVE_FOR(l)
@@ -672,15 +675,21 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 					K4_MARK(2);
 				} else {
 					// nothing up to k_lim: park just past the last evaluation that exists.  v->pherr[1], pherr[2] and prev_dphi
-					// as that evaluation leaves them are computed here (two lanes, one round trip): the sync kernel stores
+					// as that evaluation leaves them are computed here (one round trip for the 32 phases): the sync kernel stores
 					// metric values only where a preamble is near, and an arbitrary stopping place is not one
 					const int64_t cnt_ev = (k_lim - 1 - e) / 3 + 1;     // e < k_lim here
 					const int64_t nl = e + 3 * (cnt_ev - 1);
 					log_evals(sh, lg, ctl, e, cnt_ev);
 					K4_MARK(2);
 					WAVE_FOR(l)
-						if(l < 2) { const cf32 r = metric_contiguous(v, nl - 3 * l, T); sh.p[l] = r.re; sh.f[l] = r.im; }
+						if(l < 32) sh.spec[l] = v.Phi(nl - 3 * (l >> 4) - 150 + 10 * (l & 15));   // one round trip for both windows
 					WAVE_END
+					WAVE_FOR(l)
+						if(l < 2) sync_metric(&sh.spec[16 * l], T, sh.p[l], sh.f[l]);
+					WAVE_END
+					LANE0
+						sh.spec_n = -1;                 // sh.spec no longer holds a fire-path gather
+					LANE0_END
 					LANE0
 						sh.st.pherr1 = sh.p[0];
 						sh.st.pherr2 = (nl - 3 >= sh.st.e0) ? sh.p[1] : kPherrBig;
@@ -1430,12 +1439,15 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		const int m0 = l * per_lane, m1 = m0 + per_lane < nsym ? m0 + per_lane : nsym;
 		float prev = b.prev_phi0;
 		if(m0 > 0 && m0 < nsym) prev = v.Phi(b.t_first + (int64_t)(m0 - 1) * kSpsDec);
-		for(int m = m0; m < m1; m++) {
-			const cf32 y = v.Y(b.t_first + (int64_t)m * kSpsDec);
-			const float cur = phase_of(y);
-			sh.sym[m] = T.gray[slice_symbol(cur, prev, b.vdphi, neg)];
-			prev = cur;
-			pw += y.re * y.re + y.im * y.im;
+		for(int mb = m0; mb < m1; mb += 4) {
+			cf32 yv[4];
+			for(int q = 0; q < 4; q++) yv[q] = mb + q < m1 ? v.Y(b.t_first + (int64_t)(mb + q) * kSpsDec) : cf32{0.f, 0.f};   // loads first
+			for(int q = 0; q < 4 && mb + q < m1; q++) {
+				const float cur = phase_of(yv[q]);
+				sh.sym[mb + q] = T.gray[slice_symbol(cur, prev, b.vdphi, neg)];
+				prev = cur;
+				pw += yv[q].re * yv[q].re + yv[q].im * yv[q].im;
+			}
 		}
 		sh.pw[l] = pw; sh.neg[l] = neg;
 	WAVE_END

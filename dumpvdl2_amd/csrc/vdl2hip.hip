@@ -235,7 +235,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	HIPCHK(hipMemcpyAsync(sl.d_ctl, c->h_ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, sb_));
 	sl.ev_valid = false;
 	if(D > 0) {
-		const size_t lds = 4096 + 2048 + (size_t)c->run * c->os * 65 * sizeof(float2);
+		const size_t lds = ((size_t)c->run * c->os + 1) * 65 * sizeof(float2);   // the tile; the tables are static LDS
 		hipEvent_t e0 = prof ? ev[0] : nullptr, e1 = prof ? ev[1] : nullptr;
 		if(c->specialised) {
 			switch(c->os) {
@@ -514,7 +514,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_CHK(hipMemset(c->d_cnt, 0, (size_t)count * kNumCounters * 8)); DEV_CHK(hipMemset(c->d_acnt, 0, (size_t)count * kNumAvlcCounters * 8));
 	DEV_CHK(hipMemset(c->d_segend, 0, (size_t)count * c->nseg_cap * sizeof(float4)));
 	// the generic-oversample build may need more than the default dynamic LDS limit
-	const size_t lds = 4096 + 2048 + (size_t)c->run * c->os * 65 * sizeof(float2);
+	const size_t lds = ((size_t)c->run * c->os + 1) * 65 * sizeof(float2) + 8192;
 	if(lds > 65536) { vdl2hip_destroy(c); return VDL2HIP_E_INVAL; }
 	DEV_CHK(hipDeviceSynchronize());
 	#undef DEV_ALLOC

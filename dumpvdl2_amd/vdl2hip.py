@@ -73,10 +73,12 @@ FRAME_CB = C.CFUNCTYPE(None, C.POINTER(CFrame), C.c_void_p)
 _lib = None
 
 
-def load_library(path: str = LIB_PATH):
+def load_library(path: str = None):
+    """path: default = the in-tree build; VDL2HIP_LIB in the environment points development runs at a variant build"""
     global _lib
     if _lib is not None:
         return _lib
+    path = path or os.environ.get("VDL2HIP_LIB") or LIB_PATH
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing - build it with dumpvdl2_amd.build.build(); there is no CPU fallback")
     L = C.CDLL(path)

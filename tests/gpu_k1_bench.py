@@ -26,4 +26,4 @@ s = {k: s[k] - s0[k] for k in s}
 ms = s["chanfir_ms"] / s["chanfir_launches"]
 cs = s["chan_samples"] / s["chanfir_launches"]
 print(os.environ.get("VDL2HIP_LIB", "default"), os.environ.get("VDL2HIP_CR", ""), f"C={C} secs={secs}: k_chanfir {ms:.4f} ms/launch, {cs / ms * 1e3:.3e} chan-samples/s, algorithmic {cs * 4.4 / ms / 1e6:.1f} GB/s = {cs * 4.4 / ms / 1e6 / 8000 * 100:.1f}% of 8 TB/s | "
-      f"K2 {s["phase_ms"] / reps:.3f} K3 {s['sync_ms'] / reps:.3f} K4 {s['walk_ms'] / reps:.3f} nf {s['nf_ms'] / reps:.3f} K5 {s['burst_ms'] / reps:.3f} ms")
+      f"K2 {s['phase_ms'] / reps:.3f} K3 {s['sync_ms'] / reps:.3f} K4 {s['walk_ms'] / reps:.3f} nf {s['nf_ms'] / reps:.3f} K5 {s['burst_ms'] / reps:.3f} ms")
