@@ -35,7 +35,8 @@ static struct {
 	uint32_t centerfreq, source_rate, oversample;
 	uint32_t freqs[MAX_CHANNELS];
 	uint32_t nchan;
-	vdl2hip_ctx *ctx;
+	vdl2hip_group *grp;            /* one member per GPU listed in VDL2HIP_DEVICES (default: device 0) */
+	uint64_t overflow_seen;
 	int fmt;
 #ifndef VDL2HIP_IN_TREE
 	float max_ppm;
@@ -109,8 +110,26 @@ static void push_frame(const vdl2hip_frame *f, void *user) {
 	avlc_decoder_queue_push(m, os, 0);
 }
 
+/* VDL2HIP_DEVICES=0,1,2,...: the GPUs the channels are spread over (contiguous ranges, src/dumpvdl2.c:117-135 has one worker
+ * per channel; here the workers are grouped by device).  A device may be listed more than once. */
+static uint32_t parse_devices(int32_t *dev, uint32_t cap) {
+	const char *e = getenv("VDL2HIP_DEVICES");
+	uint32_t n = 0;
+	if(e) {
+		char *end;
+		while(*e && n < cap) {
+			long v = strtol(e, &end, 10);
+			if(end == e) break;
+			dev[n++] = (int32_t)v;
+			e = (*end == ',') ? end + 1 : end;
+		}
+	}
+	if(n == 0) dev[n++] = 0;
+	return n;
+}
+
 static void feed_block(unsigned char *buf, uint32_t len, int fmt) {
-	if(!G.ctx) {
+	if(!G.grp) {
 		vdl2hip_cfg cfg;
 		memset(&cfg, 0, sizeof cfg);
 		cfg.struct_size = sizeof cfg;
@@ -120,19 +139,28 @@ static void feed_block(unsigned char *buf, uint32_t len, int fmt) {
 		cfg.nchan = G.nchan;
 		cfg.freqs = G.freqs;
 		cfg.max_ppm = cfg_max_ppm();
-		cfg.device = 0;
 		cfg.max_block_bytes = BLOCK_MAX;
-		int r = vdl2hip_create(&cfg, &G.ctx);
-		if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_create: %s\n", vdl2hip_strerror(r)); _exit(2); }
+		int32_t dev[64];
+		uint32_t ndev = parse_devices(dev, 64);
+		if(ndev > G.nchan) ndev = G.nchan;
+		int r = vdl2hip_group_create(&cfg, dev, ndev, &G.grp);
+		if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_group_create: %s\n", vdl2hip_strerror(r)); _exit(2); }
 		G.fmt = fmt;
 	}
 	for(uint32_t off = 0; off < len; off += BLOCK_MAX) {
 		uint32_t n = len - off < BLOCK_MAX ? len - off : BLOCK_MAX;
-		int r = vdl2hip_feed(G.ctx, buf + off, n);
-		if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_feed: %s\n", vdl2hip_strerror(r)); _exit(2); }
+		int r = vdl2hip_group_feed(G.grp, buf + off, n);
+		if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_group_feed: %s\n", vdl2hip_strerror(r)); _exit(2); }
 	}
-	int r = vdl2hip_drain(G.ctx, push_frame, NULL);
-	if(r < 0) fprintf(stderr, "vdl2hip_drain: %s\n", vdl2hip_strerror(r));
+	int r = vdl2hip_group_drain(G.grp, push_frame, NULL);
+	if(r < 0) { fprintf(stderr, "vdl2hip_group_drain: %s\n", vdl2hip_strerror(r)); _exit(2); }
+	/* the drain calls only count device-side buffer overflows (bursts or frames dropped): say so once per occurrence */
+	uint64_t ov = 0;
+	for(uint32_t i = 0; i < vdl2hip_group_size(G.grp); i++) {
+		vdl2hip_stats st;
+		if(vdl2hip_get_stats(vdl2hip_group_ctx(G.grp, i), &st) == VDL2HIP_OK) ov += st.overflow_feeds;
+	}
+	if(ov != G.overflow_seen) { fprintf(stderr, "vdl2hip: device output buffers overflowed in %llu block(s): frames were dropped\n", (unsigned long long)(ov - G.overflow_seen)); G.overflow_seen = ov; }
 }
 
 void process_buf_uchar(unsigned char *buf, uint32_t len, void *ctx) {   /* src/demod.c:339-347 */

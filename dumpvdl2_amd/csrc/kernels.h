@@ -94,40 +94,6 @@ __device__ __forceinline__ void load_sample(const K1Args &a, int64_t s, float &r
 	}
 }
 
-// ---- NCO look-up (sincosf_lut(), demod.c:58-72): 256 entries {sin, cos, dsin, dcos} of 16 bytes in LDS ----
-// Build-time variants (tests/gpu_k1_variants.sh):
-//   VDL2_K1_SDWA      entry address in one SDWA instruction (byte 2 of the phase, shifted) instead of bfe + shift
-//   VDL2_K1_SWZ       entries stored at index i ^ (i >> 4): the lanes of a wavefront walk the table with a constant stride
-//                     (run * dphi), and a stride with a power-of-two factor lands them all on a few of the 16 bank groups
-//                     ds_read_b128 serves per cycle; the XOR spreads every stride over all of them
-//   VDL2_K1_PREFETCH  the gathers of sample j+1 are issued before the arithmetic of sample j
-#ifndef VDL2_K1_SDWA
-#define VDL2_K1_SDWA 0
-#endif
-#ifndef VDL2_K1_SWZ
-#define VDL2_K1_SWZ 0
-#endif
-#ifndef VDL2_K1_PREFETCH
-#define VDL2_K1_PREFETCH 0
-#endif
-__device__ __forceinline__ uint32_t lut_slot(uint32_t i) { return VDL2_K1_SWZ ? (i ^ (i >> 4)) & 0xffu : i; }   // where entry i lives
-
-__device__ __forceinline__ float4 lut_gather(const float4 *lut, uint32_t p) {
-#if VDL2_K1_SDWA
-	uint32_t off;
-	asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off) : "v"(p));
-#if VDL2_K1_SWZ
-	uint32_t hi;
-	asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(hi) : "s"(0xf0u), "v"(p));
-	off ^= hi;
-#endif
-	return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(lut) + off);
-#else
-	const uint32_t i = (p >> 16) & 0xffu;
-	return lut[VDL2_K1_SWZ ? (i ^ ((i >> 4) & 0xfu)) : i];
-#endif
-}
-
 // One workgroup = 4 waves that walk `a.tiles` consecutive time tiles (64*R blocks of OS samples each, staged in LDS
 // and shared by the waves); each wave owns CR channels; each lane owns R consecutive decimated outputs per tile.
 // Within a workgroup's segment the filter state is carried from tile to tile in registers, so the outputs it
@@ -149,11 +115,10 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	__shared__ __align__(16) float4 lut[256];     // NCO look-up
 	__shared__ __align__(16) float4 qpow[64];     // Q^(l+1), l = 0..63: what a carry contributes to lane l's end state
 	__shared__ __align__(16) float park[4 * 4 * 4 * 4];   // per wave: carried state and the end-of-feed state, [wave][4][CR][4]
-	__shared__ __align__(8) float2 taps[kMaxOversample + 1];   // (g0[j], g1[j]), entry os = entry 0 again
 	extern __shared__ __align__(16) unsigned char smem[];
 	const int os = OS ? OS : a.os;
 	const int run = R * os;                       // input samples per lane and tile
-	float2 *tile = (float2 *)smem;                // [run + 1][65]: one spare row, read (never used) by the last prefetch of a tile
+	float2 *tile = (float2 *)smem;                // [run][65]
 	const int tid = threadIdx.x;
 
 	// XCD-aware decode of the 1-D block id: workgroups that share a time tile land on one XCD (same L2)
@@ -163,9 +128,8 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	const int seg = (q / a.gy) * 8 + xcd;         // workgroup segment = a.tiles tiles
 	if(seg >= a.nseg) return;
 
-	lut[lut_slot((uint32_t)tid)] = ((const float4 *)a.lut)[tid];
+	lut[tid] = ((const float4 *)a.lut)[tid];
 	if(tid < 64) qpow[tid] = a.qpow[tid];
-	if(tid <= os) taps[tid] = make_float2(a.bf.g0[tid < os ? tid : 0], a.bf.g1[tid < os ? tid : 0]);
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform, so per-channel values stay in SGPRs
 	const int cbase = (gy * 4 + wave) * CR;
 	const bool wave_active = cbase < a.nchan;
@@ -234,14 +198,6 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 		}
 
 		// The block loop stays rolled: one iteration = OS samples x CR channels of straight-line code.
-#if VDL2_K1_PREFETCH
-		float4 enx[CR];                               // LUT entries of the next sample, in flight while the current one is computed
-		#pragma unroll
-		for(int c = 0; c < CR; c++) enx[c] = lut_gather(lut, ph[c]);
-#if VDL2_K1_PREFETCH >= 2
-		float2 xnx = tile[lane], gnx = taps[0];       // ... and its input sample and filter taps: LDS only, so the waits are counted
-#endif
-#endif
 		#pragma unroll 1
 		for(int i = 0; i < R; i++) {
 			// (re, im) pairs throughout, so that the mix and the two tap sums are packed FP32 operations
@@ -253,37 +209,14 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			// gather (4 VGPRs each) to the top and spill.  Taps come from scalar loads (uniform index).
 			#pragma unroll kK1Unroll
 			for(int j = 0; j < os; j++) {
-#if VDL2_K1_PREFETCH >= 2
-				const float2 x = xnx, gg = gnx;
-				const float g0 = gg.x, g1 = gg.y;
-				xnx = trow[(j + 1) * 65]; gnx = taps[j + 1];     // row run of the last block is the spare one, taps[os] = taps[0]
-#else
 				const float2 x = trow[j * 65];
-				const float g0 = bf.g0[j], g1 = bf.g1[j];
-#endif
 				const v2f X = v2f{x.x, x.y}, Xr = v2f{-x.y, x.x};          // x and i*x, shared by the channels
-#if VDL2_K1_PREFETCH
-				float4 ecur[CR]; float Fc[CR];
-				#pragma unroll
-				for(int c = 0; c < CR; c++) { ecur[c] = enx[c]; Fc[c] = (float)(ph[c] & 0xffffu); ph[c] += dph[c]; }
-				#pragma unroll
-				for(int c = 0; c < CR; c++) enx[c] = lut_gather(lut, ph[c]);   // the run's last one fetches an entry nobody uses
-				__builtin_amdgcn_sched_barrier(0);
-				#pragma unroll
-				for(int c = 0; c < CR; c++) {
-					const float4 e = ecur[c]; const float F = Fc[c];
-					const v2f sc = __builtin_elementwise_fma(v2f{e.z, e.w}, v2f{F, F}, v2f{e.x, e.y});
-					const v2f m = __builtin_elementwise_fma(v2f{sc.y, sc.y}, X, v2f{sc.x, sc.x} * Xr);
-					A0[c] = __builtin_elementwise_fma(v2f{g0, g0}, m, A0[c]);
-					A1[c] = __builtin_elementwise_fma(v2f{g1, g1}, m, A1[c]);
-					M[c] = m;
-				}
-#else
+				const float g0 = bf.g0[j], g1 = bf.g1[j];
 				#pragma unroll
 				for(int c = 0; c < CR; c++) {
 					const uint32_t p = ph[c];
 					const float F = (float)(p & 0xffffu);                 // sincosf_lut(): fract * 65536
-					const float4 e = lut_gather(lut, p);
+					const float4 e = lut[(p >> 16) & 0xffu];
 					const v2f sc = __builtin_elementwise_fma(v2f{e.z, e.w}, v2f{F, F}, v2f{e.x, e.y});   // (sin, cos)
 					// multiply(): (re*cos - im*sin, im*cos + re*sin) = cos * x + sin * (i x), the product rounded as before
 					const v2f m = __builtin_elementwise_fma(v2f{sc.y, sc.y}, X, v2f{sc.x, sc.x} * Xr);
@@ -292,7 +225,6 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 					M[c] = m;
 					ph[c] = p + dph[c];
 				}
-#endif
 			}
 			float a0r[CR], a0i[CR], a1r[CR], a1i[CR], lr[CR], li[CR];
 			#pragma unroll
@@ -547,8 +479,8 @@ __device__ __forceinline__ void k3_exact(const cf32 *y, uint32_t mask, int64_t n
 		yv[i] = (t < 0 || t >= k1) ? cf32{0.f, 0.f} : y[(uint32_t)t & mask];
 	}
 	float ph[kPreamble];
-	#pragma unroll 1
-	for(int i = 0; i < kPreamble; i++) ph[i] = phase_of(yv[i]);
+	#pragma unroll
+	for(int i = 0; i < kPreamble; i++) ph[i] = phase_of(yv[i]);   // unrolled: a rolled loop would index yv/ph dynamically, i.e. through scratch
 	sync_metric(ph, T, p, f);
 }
 

@@ -235,19 +235,29 @@ VDL2_HD void walk_state_init(WalkState &s) {
 VDL2_HD double atan2_f64(double y, double x) {
 	const double ax = fabs(x), ay = fabs(y);
 	const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+#if VDL2_DEVICE_PASS
+	// the device only ever sees float samples widened to double: finite, and 0 or >= 1.4e-45 in magnitude.  atan2(+-0, x):
+	// +-0 for x > 0 or x = +0, +-pi for x < 0 or x = -0 - no library routine in the kernels
+	if(!(mx > 0.0)) return copysign(signbit(x) ? 3.141592653589793 : 0.0, y);
+	const float r = (float)mn / (float)mx;
+#else
 	if(!(mx > 0.0) || !(mx < 1.0e300)) return atan2(y, x);         // zeros, infinities, NaN: leave to the library
 	const float r = (float)mn / (float)mx;
 	if(!(r >= 0.f && r <= 1.f)) return atan2(y, x);                // operands outside the float range (never for float inputs)
+#endif
 	const int k = (int)(r * 8.0f + 0.5f);
-	static const double A[9] = { 0.0, 0.12435499454676144, 0.24497866312686414, 0.35877067027057225, 0.4636476090008061,
-	                             0.5585993153435624, 0.6435011087932844, 0.7188299996216245, 0.7853981633974483 };
+	// atan(k/8), k = 0..8, picked with selects: an indexed table would be a per-lane memory load in the middle of what is, in
+	// the walker and the exact tier of the sync kernel, a latency-bound dependent chain
+	const double Ak = k < 4 ? (k < 2 ? (k == 0 ? 0.0 : 0.12435499454676144) : (k == 2 ? 0.24497866312686414 : 0.35877067027057225))
+	                        : (k < 6 ? (k == 4 ? 0.4636476090008061 : 0.5585993153435624)
+	                                 : (k == 6 ? 0.6435011087932844 : (k == 7 ? 0.7188299996216245 : 0.7853981633974483)));
 	const double c = 0.125 * (double)k;
 	const double u = fma(-c, mx, mn) / fma(c, mn, mx);
 	const double z = u * u;
 	double p = -1.0 / 15.0;
 	p = fma(p, z, 1.0 / 13.0); p = fma(p, z, -1.0 / 11.0); p = fma(p, z, 1.0 / 9.0); p = fma(p, z, -1.0 / 7.0);
 	p = fma(p, z, 1.0 / 5.0); p = fma(p, z, -1.0 / 3.0);
-	double a = A[k] + fma(p * z, u, u);
+	double a = Ak + fma(p * z, u, u);
 	if(ay > ax) a = 1.5707963267948966 - a;
 	if(x < 0.0) a = 3.141592653589793 - a;
 	return copysign(a, y);
@@ -335,7 +345,16 @@ VDL2_HD void screen_taps(const float *ph, const Tables &T, int i0, int i1, Scree
 		const float cur = ph[i] - T.pr_phase[i];
 		const float diff = cur - a.prev;
 		a.prev = cur;
-		a.unwrap += diff > kPiBelow ? -(float)(2.0 * M_PI) : (diff < -kPiBelow ? (float)(2.0 * M_PI) : 0.f);
+		// the reference's rule - one step of -+2 pi when the difference is beyond +-pi (demod.c:137-141) - as arithmetic:
+		// round(diff / 2 pi) clamped to +-1 (|diff| < 4 pi).  The two can only disagree within a few ulps of +-pi, deep inside
+		// the guard zone, where the window goes to the exact tier anyway.
+		float q = rintf(diff * (float)(0.5 / M_PI));
+#if VDL2_DEVICE_PASS
+		q = __builtin_amdgcn_fmed3f(q, -1.f, 1.f);
+#else
+		q = q < -1.f ? -1.f : (q > 1.f ? 1.f : q);
+#endif
+		a.unwrap = fmaf(q, -(float)(2.0 * M_PI), a.unwrap);
 		a.guard = fminf(a.guard, fabsf(fabsf(diff) - kPiBelow));
 		const float e = cur + a.unwrap;
 		a.m0 += e; a.m1 = fmaf((float)i, e, a.m1); a.m2 = fmaf(e, e, a.m2);

@@ -38,6 +38,9 @@ EXPORTS = [
     "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
     "vdl2hip_drain_packed", "vdl2hip_pack_raw_frame", "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_set_drain_lag", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
     "vdl2hip_avlc_counters", "vdl2hip_set_avlc_filter", "vdl2hip_statsd_lines", "vdl2hip_feed_pinned",
+    "vdl2hip_group_create", "vdl2hip_group_destroy", "vdl2hip_group_feed", "vdl2hip_group_sync", "vdl2hip_group_drain",
+    "vdl2hip_group_set_drain_lag", "vdl2hip_group_counters", "vdl2hip_group_avlc_counters", "vdl2hip_group_size", "vdl2hip_group_ctx",
+    "vdl2hip_group_uses_rccl",
 ]
 
 
@@ -106,6 +109,19 @@ def load_library(path: str = None):
     L.vdl2hip_get_lpf.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.vdl2hip_get_nco_step.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.vdl2hip_read_decimated.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_void_p, C.c_size_t]
+    L.vdl2hip_group_create.argtypes = [C.POINTER(Cfg), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
+    L.vdl2hip_group_destroy.argtypes = [C.c_void_p]
+    L.vdl2hip_group_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.vdl2hip_group_sync.argtypes = [C.c_void_p]
+    L.vdl2hip_group_drain.argtypes = [C.c_void_p, FRAME_CB, C.c_void_p]
+    L.vdl2hip_group_set_drain_lag.argtypes = [C.c_void_p, C.c_int]
+    L.vdl2hip_group_counters.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.vdl2hip_group_avlc_counters.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.vdl2hip_group_size.restype = C.c_uint32
+    L.vdl2hip_group_size.argtypes = [C.c_void_p]
+    L.vdl2hip_group_ctx.restype = C.c_void_p
+    L.vdl2hip_group_ctx.argtypes = [C.c_void_p, C.c_uint32]
+    L.vdl2hip_group_uses_rccl.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -274,3 +290,68 @@ class Receiver:
         buf = np.zeros((count, 2), dtype=np.float32)
         n = self._chk(self.L.vdl2hip_read_decimated(self.h, chan, first, buf.ctypes.data, count), "vdl2hip_read_decimated")
         return buf[:n]
+
+
+def _frame_dict(f):
+    return dict(chan=f.chan, freq=f.freq, idx=f.idx, octets=bytes(C.string_at(f.octets, f.len)) if f.len else b"",
+                synd_weight=f.synd_weight, datalen_octets=f.datalen_octets, num_fec_corrections=f.num_fec_corrections,
+                frame_pwr_dbfs=f.frame_pwr_dbfs, nf_pwr_dbfs=f.nf_pwr_dbfs, ppm_error=f.ppm_error, burst_ord=f.burst_ord,
+                sync_sample=f.sync_sample, end_sample=f.end_sample, avlc_status=f.avlc_status, dst_addr=f.dst_addr, src_addr=f.src_addr)
+
+
+class ReceiverGroup:
+    """vdl2hip_group: one receiver spread over several GPUs of this process (the C-level multi-GPU path; the per-process form
+    used by bench.py is Receiver + dist.ShardedFeeder).  `devices` may name a device more than once (virtual shards)."""
+
+    def __init__(self, centerfreq: int, freqs: Sequence[int], devices: Sequence[int], oversample: int = 20,
+                 sample_fmt: int = FMT_S16LE, max_ppm: float = 0.0, max_block_bytes: int = 320000):
+        self.L = load_library()
+        self.freqs = list(freqs)
+        self._freq_arr = (C.c_uint32 * len(self.freqs))(*self.freqs)
+        cfg = Cfg(C.sizeof(Cfg), centerfreq, oversample, sample_fmt, len(self.freqs), self._freq_arr, max_ppm, 0, max_block_bytes, 0, 0)
+        dev = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        r = self.L.vdl2hip_group_create(C.byref(cfg), dev, len(devices), C.byref(h))
+        if r < 0:
+            raise Vdl2HipError(f"vdl2hip_group_create: {self.L.vdl2hip_strerror(r).decode()} ({r})")
+        self.h = h
+
+    def _chk(self, r, what):
+        if r < 0:
+            raise Vdl2HipError(f"{what}: {self.L.vdl2hip_strerror(r).decode()} ({r})")
+        return r
+
+    def feed(self, raw) -> None:
+        a = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        self._chk(self.L.vdl2hip_group_feed(self.h, a.ctypes.data, a.size), "vdl2hip_group_feed")
+
+    def set_drain_lag(self, lag: int) -> None:
+        self._chk(self.L.vdl2hip_group_set_drain_lag(self.h, lag), "vdl2hip_group_set_drain_lag")
+
+    def drain(self) -> List[dict]:
+        out: List[dict] = []
+        self._cb = FRAME_CB(lambda fp, _u: out.append(_frame_dict(fp.contents)))
+        self._chk(self.L.vdl2hip_group_drain(self.h, self._cb, None), "vdl2hip_group_drain")
+        return out
+
+    def counters(self, chan: int) -> dict:
+        a = (C.c_uint64 * NUM_COUNTERS)()
+        self._chk(self.L.vdl2hip_group_counters(self.h, chan, a), "vdl2hip_group_counters")
+        return dict(zip(COUNTER_NAMES, list(a)))
+
+    def size(self) -> int:
+        return self.L.vdl2hip_group_size(self.h)
+
+    def uses_rccl(self) -> bool:
+        return bool(self.L.vdl2hip_group_uses_rccl(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vdl2hip_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

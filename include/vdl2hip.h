@@ -25,7 +25,8 @@ extern "C" {
 #endif
 
 #define VDL2HIP_ABI_VERSION 3   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added
-                                 * 3: vdl2hip_feed_pinned(); vdl2hip_stats.overflow_feeds; a look-back timeout is VDL2HIP_E_DEVICE */
+                                 * 3: vdl2hip_feed_pinned(); vdl2hip_stats.overflow_feeds; a look-back timeout is VDL2HIP_E_DEVICE;
+                                 *    vdl2hip_group_*: one receiver over several GPUs from C */
 
 /* enum sample_formats, src/dumpvdl2.h:319 */
 #define VDL2HIP_FMT_U8     0
@@ -202,6 +203,25 @@ int  vdl2hip_set_profiling(vdl2hip_ctx *ctx, int level); /* 0 off; 1 time the ch
                                                           * its launch); 2 time every stage the same way (costs ~5 % throughput) */
 int  vdl2hip_get_stats(vdl2hip_ctx *ctx, vdl2hip_stats *out);
 void *vdl2hip_stream(vdl2hip_ctx *ctx);                 /* the hipStream_t all work is queued on */
+
+/* ---- One receiver over several GPUs of this process (src/dumpvdl2.c:117-135: one worker per channel over a shared block;
+ * here the workers are grouped by device).  Member k of n decodes channels [k*nchan/n, (k+1)*nchan/n) of cfg->freqs on
+ * devices[k]; cfg->device, chan_first and chan_count are ignored/must be 0.  A block handed to vdl2hip_group_feed() crosses
+ * PCIe once, into devices[0], and reaches the other devices over xGMI: RCCL ncclBroadcast when librccl.so can be loaded and
+ * the devices are distinct, hipMemcpyPeerAsync fan-out otherwise (a device may be listed more than once: "virtual shards",
+ * which is how the path is tested on one GPU).  Frames are delivered merged, in vdl2hip_drain()'s order. ---- */
+typedef struct vdl2hip_group vdl2hip_group;
+int  vdl2hip_group_create(const vdl2hip_cfg *cfg, const int32_t *devices, uint32_t ndev, vdl2hip_group **out);
+void vdl2hip_group_destroy(vdl2hip_group *g);
+int  vdl2hip_group_feed(vdl2hip_group *g, const void *buf, size_t nbytes);      /* = process_buf_*(), blocking like vdl2hip_feed() */
+int  vdl2hip_group_sync(vdl2hip_group *g);
+int  vdl2hip_group_drain(vdl2hip_group *g, vdl2hip_frame_cb cb, void *user);
+int  vdl2hip_group_set_drain_lag(vdl2hip_group *g, int lag);
+int  vdl2hip_group_counters(vdl2hip_group *g, uint32_t chan, uint64_t out[VDL2HIP_NUM_COUNTERS]);
+int  vdl2hip_group_avlc_counters(vdl2hip_group *g, uint32_t chan, uint64_t out[VDL2HIP_NUM_AVLC_COUNTERS]);
+uint32_t vdl2hip_group_size(vdl2hip_group *g);
+vdl2hip_ctx *vdl2hip_group_ctx(vdl2hip_group *g, uint32_t member);            /* for the per-context calls above (stats, statsd, ...) */
+int  vdl2hip_group_uses_rccl(vdl2hip_group *g);                                /* 1: ncclBroadcast, 0: peer copies */
 
 /* Introspection used by the parity tests (host copies of what the kernels use) */
 int  vdl2hip_get_lpf(vdl2hip_ctx *ctx, float A[3], float B[3]);      /* = static A/B of src/demod.c:55 */

@@ -1,13 +1,14 @@
 #!/bin/bash
-# HBM traffic per kernel of the default bench (8 channels): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (never
-# combined with other trace domains), summarised per kernel.  Output: the text kept under profiles/ as rNN_pmc_hbm_traffic_*.txt
+# HBM traffic per kernel of the default bench (config4, 256 channels): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
+# (never combined with other trace domains), summarised per kernel.  Output: the text kept under profiles/ as rNN_pmc_hbm_traffic_*.txt
 R="$(cd "$(dirname "$0")/.." && pwd)"
+W=${1:-config4}
 cd /tmp && export TMPDIR=/tmp
-echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on \`bench.py --steps 3 --warmup 1\` (8 channels, 16 s = 33.6 M samples per launch)"
+echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on \`bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary\` (16 s = 33.6 M samples per launch)"
 echo "# units: KB per dispatch, averaged over dispatches.  FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)"
 for CN in FETCH_SIZE WRITE_SIZE; do
 	rm -rf /tmp/pmc_$CN
-	rocprofv3 --kernel-trace --pmc $CN -d /tmp/pmc_$CN -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > /tmp/pmc_$CN.log 2>&1
+	rocprofv3 --kernel-trace --pmc $CN -d /tmp/pmc_$CN -o p -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary > /tmp/pmc_$CN.log 2>&1
 	python - "$CN" <<'PY'
 import sqlite3, sys, glob
 cn = sys.argv[1]

@@ -538,3 +538,46 @@ def test_handoff_under_uneven_load(vh):
         rx2.close()
     torch.cuda.synchronize()
     rx.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0]])
+def test_group_of_virtual_shards_from_c(vh, devices):
+    """vdl2hip_group_* (multi-GPU from plain C): the channels spread over n members - here all on device 0, "virtual shards",
+    SURVEY 8.6 - fed with host blocks (one H2D, then the fan-out to the other members), frames merged in drain order."""
+    cfg, iq, _, gold = cases.load("config2_1s")
+    raw = iq.view(np.uint8)
+    g = vh.ReceiverGroup(cfg.centerfreq, list(cfg.freqs), devices, cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=1 << 20)
+    assert g.size() == len(devices) and not g.uses_rccl()          # one physical device: peer-copy fan-out
+    g.set_drain_lag(1)
+    got = []
+    for k in range(0, raw.size, 1 << 20):
+        g.feed(raw[k:k + (1 << 20)])
+        got += g.drain()
+    g.set_drain_lag(0)
+    got += g.drain()
+    cases.check_against_golden(got, [list(g.counters(c).values()) for c in range(len(cfg.freqs))], gold, label=f"group of {len(devices)}",
+                               exact_diagnostics=False)
+    ends = [(f["end_sample"], f["chan"], f["idx"]) for f in got]
+    assert ends == sorted(ends)
+    g.close()
+
+
+def test_dropin_adapter_over_several_devices(vh, tmp_path):
+    """The reference-named adapter with VDL2HIP_DEVICES=0,0,0: an unmodified dumpvdl2 main() linking it spreads its channels over
+    the listed GPUs (here three virtual shards of device 0); 8 channels of the golden 1 s capture."""
+    import os, subprocess, hashlib
+    from dumpvdl2_amd import build
+    cfg, iq, _, gold = cases.load("config2_1s")
+    exe = build.build_harness(str(tmp_path / "dropin_harness"))
+    path = tmp_path / "cap.cs16"
+    iq.tofile(path)
+    env = dict(os.environ, VDL2HIP_DEVICES="0,0,0")
+    out = subprocess.run([exe, str(path), str(cfg.oversample), str(cfg.centerfreq)] + [str(f) for f in cfg.freqs], check=True,
+                         capture_output=True, text=True, timeout=180, env=env).stdout
+    got = []
+    for l in out.splitlines():
+        if l.startswith("FRAME"):
+            kv = dict(t.split("=", 1) for t in l.split()[1:])
+            got.append((int(kv["freq"]), int(kv["idx"]), hashlib.sha1(bytes.fromhex(kv["octets"])).hexdigest(), int(kv["S"]), int(kv["L"]), int(kv["F"])))
+    want = [(cfg.freqs[f["chan"]], f["idx"], f["sha1"], f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"]) for f in gold["frames"]]
+    assert sorted(got) == sorted(want) and len(got) > 20
