@@ -209,12 +209,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # development only (tests/gpu_r02_run_e.sh): rehearse the N > 1 control flow on a one-GPU box - every rank on device 0, gloo
+    # instead of RCCL as the transport.  Never set by the driver; the numbers of such a run mean nothing.
+    rehearsal = os.environ.get("VDL2_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU path)"
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     case = Case(args.workload, args.duration, world, rank, local, torch, channels=args.channels)
     cfg = case.cfg
@@ -274,7 +282,7 @@ def main():
             ndiff += co[nref:] != cg[nref:]
         o.close()
         verified.update({"oracle_window_s": cfg.duration_s, "oracle_frames": len(ofr), "oracle_identical": True,
-                         "burst_timing_ties": cmp["timing_ties"], "max_abs_diff": cmp["max_abs_diff"],
+                         "burst_timing_ties": cmp["timing_ties"], "nf_update_ties": cmp["nf_update_ties"], "max_abs_diff": cmp["max_abs_diff"],
                          "channels_with_reference_counters_identical": case.count, "channels_with_diagnostic_counter_diff": int(ndiff)})
         if world == 1 and not args.no_cpu_baseline:
             ci = cpu_info()
@@ -358,6 +366,7 @@ def main():
                        "realtime_channels_at_2.1MSps": round(value * case.C / 2.1, 1),
                        "frames_per_step": t_host["frames"] / args.steps,
                        "parallelism": (f"channels sharded x{world} ({case.count} per GPU), RCCL {mode} of every IQ block inside the timed steps"
+                                       + (" [REHEARSAL: all ranks on one GPU over gloo - not a measurement]" if rehearsal else "")
                                        if world > 1 else "single GPU, all channels"),
                        "exchange": exchange_info,
                        "stage_ms_per_step": stage_ms,

@@ -39,7 +39,7 @@ def compare_at_full_size(ref, got, label="", max_tie_frac=1e-3):
     ref = sorted(ref, key=frame_key)
     got = sorted(got, key=frame_key)
     assert len(ref) == len(got), f"{label}: frame count {len(got)} != reference {len(ref)}"
-    ties = 0
+    ties = nf_ties = 0
     worst = {"frame_pwr_db": 0.0, "nf_pwr_db": 0.0, "ppm": 0.0}
     for a, b in zip(ref, got):
         for k in EXACT_KEYS:
@@ -50,14 +50,22 @@ def compare_at_full_size(ref, got, label="", max_tie_frac=1e-3):
             assert abs(a["sync_sample"] - b["sync_sample"]) <= 1 and abs(a["end_sample"] - b["end_sample"]) <= 1, \
                 f"{label}: frame {frame_key(a)} timing {b['sync_sample']},{b['end_sample']} != {a['sync_sample']},{a['end_sample']}"
         assert abs(a["frame_pwr_dbfs"] - b["frame_pwr_dbfs"]) <= TOL_DB, f"{label}: frame_pwr {a['frame_pwr_dbfs']} vs {b['frame_pwr_dbfs']}"
-        assert abs(a["nf_pwr_dbfs"] - b["nf_pwr_dbfs"]) <= TOL_DB, f"{label}: nf_pwr {a['nf_pwr_dbfs']} vs {b['nf_pwr_dbfs']}"
+        # the noise floor a frame reports is mag_nf after (evaluations so far) / 1000 updates (demod.c:240-243, decode.c:181): a tie
+        # anywhere earlier on the channel (also at a preamble the --max-ppm gate dropped) shifts the evaluation grid, hence the
+        # evaluation count, by one - a burst that synchronises right at an update then sees the value before / after it
+        dnf = abs(a["nf_pwr_dbfs"] - b["nf_pwr_dbfs"])
+        if dnf > TOL_DB:
+            nf_ties += 1
+            assert dnf <= 1.5, f"{label}: nf_pwr {a['nf_pwr_dbfs']} vs {b['nf_pwr_dbfs']}"
+        else:
+            worst["nf_pwr_db"] = max(worst["nf_pwr_db"], dnf)
         assert abs(a["ppm_error"] - b["ppm_error"]) <= (0.5 if tie else TOL_PPM), f"{label}: ppm {a['ppm_error']} vs {b['ppm_error']} (tie={tie})"
         if not tie:
             worst["ppm"] = max(worst["ppm"], abs(a["ppm_error"] - b["ppm_error"]))
         worst["frame_pwr_db"] = max(worst["frame_pwr_db"], abs(a["frame_pwr_dbfs"] - b["frame_pwr_dbfs"]))
-        worst["nf_pwr_db"] = max(worst["nf_pwr_db"], abs(a["nf_pwr_dbfs"] - b["nf_pwr_dbfs"]))
-    assert ties <= max(1, int(max_tie_frac * len(ref))), f"{label}: {ties} of {len(ref)} frames differ in burst timing"
-    return {"frames": len(ref), "timing_ties": ties, "max_abs_diff": {k: round(v, 6) for k, v in worst.items()}}
+    lim = max(1, int(max_tie_frac * len(ref)))
+    assert ties <= lim and nf_ties <= lim, f"{label}: {ties} / {nf_ties} of {len(ref)} frames differ in burst timing / noise-floor update"
+    return {"frames": len(ref), "timing_ties": ties, "nf_update_ties": nf_ties, "max_abs_diff": {k: round(v, 6) for k, v in worst.items()}}
 
 
 def frames_multiset(frames):
