@@ -471,6 +471,11 @@ __global__ __launch_bounds__(256) void k_sync_screen(K3Args a) {
 	}
 }
 
+__device__ __forceinline__ unsigned long long b4_clear(unsigned long long b) {   // drop the four lowest set bits
+	for(int k = 0; k < 4 && b; k++) b &= b - 1;
+	return b;
+}
+
 __device__ __forceinline__ void k3_exact(const cf32 *y, uint32_t mask, int64_t n, int64_t k1, const Tables &T, float &p, float &f) {
 	cf32 yv[kPreamble];
 	#pragma unroll
@@ -484,9 +489,16 @@ __device__ __forceinline__ void k3_exact(const cf32 *y, uint32_t mask, int64_t n
 	sync_metric(ph, T, p, f);
 }
 
-// one lane per 64-sample word; a wavefront then gathers on each of its words that holds work, one lane per sample
-__global__ __launch_bounds__(256) void k_sync_exact(K3Args a) {
-	const int c = blockIdx.y, lane = threadIdx.x & 63;
+// One lane per 64-sample word for the scan; the words that hold work are then taken four at a time, 16 lanes each: a word
+// with work has a cluster of ~5-10 flagged samples plus three either side, so a quarter wavefront per word keeps most lanes busy
+// (one word per pass left three quarters of them idle; 0.63 -> 0.2 ms at 256 channels with 160 000 preamble-like events per
+// 16 s block).  Metric values go through LDS - exact where computed, "big" elsewhere - and the 16 lanes of a quarter then form
+// the word's 64 candidate bits, four per lane.
+// (launch bound 256 threads with 4 waves per SIMD = the 128-register budget: a wave of this kernel then fits into the slot a
+// channeliser wave leaves behind; see k_walk_stitch)
+__global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
+	__shared__ float psh[4][4][64 + 3];                  // [wave][quarter][3 + bit]: metric of sample word*64 + bit, entries 0..2 = the three samples before the word
+	const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const cf32 *y = a.y + (size_t)c * a.cap;
 	const uint64_t *flag = a.flag + (size_t)c * (a.cap >> 6);
 	uint64_t *cand = a.cand + (size_t)c * (a.cap >> 6);
@@ -509,24 +521,48 @@ __global__ __launch_bounds__(256) void k_sync_exact(K3Args a) {
 		if(need == 0) cand[(uint32_t)w & wmask] = 0;
 	}
 	unsigned long long busy = __ballot(need != 0);
+	const int q = lane >> 4, r = lane & 15;
+	float *ps = psh[wave][q];
 	while(busy) {
-		const int j = __builtin_ctzll(busy); busy &= busy - 1;
-		const uint64_t needj = __shfl(need, j), fprevj = __shfl(fprev, j);
-		const int64_t wj = w - lane + j;                                   // every lane of the wavefront turns to lane j's word
-		const int64_t n = (wj << 6) + lane;
-		float p = kPherrBig, f = 0.f;
-		if((needj >> lane) & 1ull) {
-			k3_exact(y, a.mask, n, a.k1, T, p, f);
-			a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = cf32{p, f};
+		// quarter q takes the q-th word with work that is left (wave-uniform bookkeeping; j < 0: this quarter idles)
+		unsigned long long b = busy; int j = -1;
+		for(int k = 0; k <= q && b; k++) { j = __builtin_ctzll(b); b &= b - 1; if(k < q) j = -1; }
+		busy = b4_clear(busy);
+		const uint64_t needj = j >= 0 ? __shfl(need, j) : 0ull, fprevj = j >= 0 ? __shfl(fprev, j) : 0ull;
+		const int64_t wj = w - lane + (j >= 0 ? j : 0);
+		for(int k = r; k < 67; k += 16) ps[k] = kPherrBig;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+		// the r-th, (r+16)-th, ... set bit of the word's work mask is this lane's
+		uint64_t left = needj;
+		for(int skip = 0; skip < r && left; skip++) left &= left - 1;
+		while(__any(left != 0)) {
+			if(left) {
+				const int bit = __builtin_ctzll(left);
+				const int64_t n = (wj << 6) + bit;
+				float p, f;
+				k3_exact(y, a.mask, n, a.k1, T, p, f);
+				a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = cf32{p, f};
+				ps[3 + bit] = p;
+				for(int skip = 0; skip < 16 && left; skip++) left &= left - 1;
+			}
 		}
-		float pm3 = __shfl_up(p, 3);
-		if(lane < 3) {                                                      // n-3 lies in the previous word
-			pm3 = kPherrBig;
-			float fm;
-			if(n >= 3 && ((fprevj >> (61 + lane)) & 1ull)) k3_exact(y, a.mask, n - 3, a.k1, T, pm3, fm);
+		if(j >= 0 && r < 3) {                                               // the three samples before the word
+			const int64_t m = (wj << 6) - 3 + r;
+			float pm = kPherrBig, fm;
+			if(m >= 0 && ((fprevj >> (61 + r)) & 1ull)) k3_exact(y, a.mask, m, a.k1, T, pm, fm);
+			ps[r] = pm;
 		}
-		const unsigned long long bits = __ballot(n >= 3 && n < a.k1 && is_candidate(pm3, p));
-		if(lane == 0) cand[(uint32_t)wj & wmask] = bits;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+		uint64_t bits = 0;
+		for(int k = 0; k < 4; k++) {
+			const int bit = r + 16 * k;
+			const int64_t n = (wj << 6) + bit;
+			if(j >= 0 && n >= 3 && n < a.k1 && is_candidate(ps[bit], ps[3 + bit])) bits |= 1ull << bit;
+		}
+		#pragma unroll
+		for(int d = 1; d < 16; d <<= 1) bits |= __shfl_xor(bits, d);         // OR over the quarter's 16 lanes
+		if(j >= 0 && r == 0) cand[(uint32_t)wj & wmask] = bits;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
 	}
 }
 
@@ -537,7 +573,7 @@ struct K4Args {
 	int64_t k_end; float max_ppm; uint32_t cap, mask; int32_t chan_first;
 };
 
-__global__ __launch_bounds__(64) void k_walk(K4Args a) {
+__global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
 	__shared__ WalkShared sh;
 	const int c = blockIdx.x;
 	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
@@ -551,7 +587,7 @@ struct K4sArgs {
 	K4Args k; SpecOut *spec; uint32_t spec_stride; int32_t nseg; int64_t k0, seglen; uint32_t *seg_stats;
 };
 
-__global__ __launch_bounds__(64) void k_walk_spec(K4sArgs s) {
+__global__ __launch_bounds__(64, 4) void k_walk_spec(K4sArgs s) {
 	__shared__ WalkShared sh;
 	const K4Args &a = s.k;
 	const int c = blockIdx.y, x = blockIdx.x;
@@ -567,7 +603,11 @@ __global__ __launch_bounds__(64) void k_walk_spec(K4sArgs s) {
 	}
 }
 
-__global__ __launch_bounds__(64) void k_walk_stitch(K4sArgs s) {
+// (64 threads are launched; the declared bound of 256 threads x 4 waves per SIMD is what gives the kernel the 128-register
+// budget: with the true bound the compiler sizes the budget by the LDS-limited occupancy and takes 166, and a wave that needs
+// more registers than one channeliser wave frees (128) waits for two of them to retire at once - measured 25 us alone, 1.6 ms
+// beside the channeliser.  The same for k_burst.)
+__global__ __launch_bounds__(256, 4) void k_walk_stitch(K4sArgs s) {
 	__shared__ WalkShared sh;
 	__shared__ StitchShared ss;
 	const K4Args &a = s.k;
@@ -636,7 +676,7 @@ struct K5Args {
 	uint32_t cap, mask;
 };
 
-__global__ __launch_bounds__(64) void k_burst(K5Args a) {
+__global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
 	__shared__ BurstShared sh;
 	const uint32_t total = a.bbase[a.nchan];
 	for(uint32_t g = blockIdx.x; g < total; g += gridDim.x) {

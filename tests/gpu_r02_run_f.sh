@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 2, GPU call F: packed exact tier, 128-register back end
+R="$(cd "$(dirname "$0")/.." && pwd)"
+cd "$R"; mkdir -p gpurun_out
+O=gpurun_out/r02f
+timeout 900 python -m pytest tests -m gpu -x -q > $O.pytest.txt 2>&1; echo "pytest rc=$?" >> $O.pytest.txt
+tail -3 $O.pytest.txt
+timeout 300 python tests/gpu_stage_times.py config4 16 3 2>&1 | grep -v amdgpu.ids > $O.stage.txt; cat $O.stage.txt
+timeout 900 python bench.py --no-secondary > $O.bench.json 2> $O.bench.err; echo "bench rc=$?"; tail -c 600 $O.bench.err
+timeout 600 python bench.py --workload config5 --no-secondary --no-cpu-baseline > $O.bench_config5.json 2> $O.bench_config5.err; echo "config5 rc=$?"; tail -c 600 $O.bench_config5.err
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_iso; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_iso -o r -- python $R/tests/gpu_stage_times.py config4 16 3 > /dev/null 2>&1
+DB=$(find /tmp/prof_iso -name "*.db" | head -1); [ -n "$DB" ] && python $R/profiles/summarize_rocpd.py $DB > $R/$O.kernel_trace_isolated_config4.txt
+rm -rf /tmp/prof_c4; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_c4 -o r -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-secondary > /dev/null 2>&1
+DB=$(find /tmp/prof_c4 -name "*.db" | head -1); [ -n "$DB" ] && python $R/profiles/summarize_rocpd.py $DB > $R/$O.kernel_trace_bench_config4.txt

@@ -33,9 +33,9 @@ def compare_at_full_size(ref, got, label="", max_tie_frac=1e-3):
     metadata identical, floats within tolerance.  Burst timing (sync_sample / end_sample - diagnostics of this repo, not
     reference metadata) is required identical too, except for "ties": the time-parallel filter differs from the reference's
     sequential one by ~1e-5 relative, and where calc_para_vertex lands within that of a rounding boundary the sync
-    point moves by one decimated sample (1/10 symbol - the same symbols are sliced, the same octets come out).  Such frames
-    are counted, must stay under max_tie_frac of all frames, may differ by at most 1 sample and get the looser ppm bound of a
-    slope estimated one sample later.  Returns the statistics."""
+    point moves by one or two decimated samples (the evaluation grid has a stride of three; <= 2/10 of a symbol - the same
+    symbols are sliced, the same octets come out).  Such frames are counted, must stay under max_tie_frac of all frames, may
+    differ by at most 2 samples and get the looser ppm bound of a slope estimated a sample or two later.  Returns the statistics."""
     ref = sorted(ref, key=frame_key)
     got = sorted(got, key=frame_key)
     assert len(ref) == len(got), f"{label}: frame count {len(got)} != reference {len(ref)}"
@@ -47,7 +47,7 @@ def compare_at_full_size(ref, got, label="", max_tie_frac=1e-3):
         tie = a["sync_sample"] != b["sync_sample"] or a["end_sample"] != b["end_sample"]
         if tie:
             ties += 1
-            assert abs(a["sync_sample"] - b["sync_sample"]) <= 1 and abs(a["end_sample"] - b["end_sample"]) <= 1, \
+            assert abs(a["sync_sample"] - b["sync_sample"]) <= 2 and abs(a["end_sample"] - b["end_sample"]) <= 2, \
                 f"{label}: frame {frame_key(a)} timing {b['sync_sample']},{b['end_sample']} != {a['sync_sample']},{a['end_sample']}"
         assert abs(a["frame_pwr_dbfs"] - b["frame_pwr_dbfs"]) <= TOL_DB, f"{label}: frame_pwr {a['frame_pwr_dbfs']} vs {b['frame_pwr_dbfs']}"
         # the noise floor a frame reports is mag_nf after (evaluations so far) / 1000 updates (demod.c:240-243, decode.c:181): a tie
