@@ -528,8 +528,11 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
 		unsigned long long b = busy; int j = -1;
 		for(int k = 0; k <= q && b; k++) { j = __builtin_ctzll(b); b &= b - 1; if(k < q) j = -1; }
 		busy = b4_clear(busy);
-		const uint64_t needj = j >= 0 ? __shfl(need, j) : 0ull, fprevj = j >= 0 ? __shfl(fprev, j) : 0ull;
-		const int64_t wj = w - lane + (j >= 0 ? j : 0);
+		// (every lane takes part in the shuffles: a lane that sat one out would read as zero to the quarter whose word it holds)
+		const int jj = j >= 0 ? j : 0;
+		uint64_t needj = __shfl(need, jj), fprevj = __shfl(fprev, jj);
+		if(j < 0) { needj = 0; fprevj = 0; }
+		const int64_t wj = w - lane + jj;
 		for(int k = r; k < 67; k += 16) ps[k] = kPherrBig;
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
 		// the r-th, (r+16)-th, ... set bit of the word's work mask is this lane's
