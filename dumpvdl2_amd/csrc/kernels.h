@@ -440,40 +440,65 @@ constexpr int kK3Tile = 1024;
 
 __global__ __launch_bounds__(256) void k_sync_screen(K3Args a) {
 	__shared__ float tile[kK3Tile + 150];           // screening phases of samples nblk-150 .. nblk+kK3Tile-1
+	__shared__ uint16_t list[kK3Tile];              // samples (tile-local) still under the bound after the first pass
+	__shared__ uint8_t fl[kK3Tile];
+	__shared__ int nlist;
 	const int c = blockIdx.y, tid = threadIdx.x;
 	const int64_t nblk = a.nbase + (int64_t)blockIdx.x * kK3Tile;
 	const cf32 *y = a.y + (size_t)c * a.cap;
 	const Tables &T = *a.tab;
+	if(tid == 0) nlist = 0;
 	for(int j = tid; j < kK3Tile + 150; j += 256) {
 		const int64_t t = nblk - 150 + j;
 		tile[j] = (t < 0 || t >= a.k1) ? 0.f : phase_fast(y[(uint32_t)t & a.mask]);
 	}
 	__syncthreads();
 	float ph[kPreamble];
+	// first pass, every sample: the residual over the first kScreenFirst taps bounds the 16-tap value from below; 13 % of noise or
+	// data windows stay under the bound and are compacted into a list, so that the second pass runs on full wavefronts (an early
+	// exit inside a wavefront only pays when all 64 lanes agree: after 8 taps they never do, after 12 in 4 of 5 wavefronts)
 	#pragma unroll
 	for(int q = 0; q < kK3Tile / 256; q++) {
 		const int i0 = tid + 256 * q;               // sample nblk + i0: phases tile[i0 + 10 i]
-		const int64_t n = nblk + i0;
+		#pragma unroll
+		for(int i = 0; i < kScreenFirst; i++) ph[i] = tile[i0 + 10 * i];
+		ScreenAcc acc;
+		screen_taps(ph, T, 0, kScreenFirst, acc);
+		const bool more = nblk + i0 < a.k1 && screen_value(acc, kScreenFirst) < kScreenEarlyThr;
+		fl[i0] = 0;
+		const unsigned long long m = __ballot(more);
+		int base = 0;
+		if((tid & 63) == 0 && m) base = atomicAdd(&nlist, __builtin_popcountll(m));
+		base = __shfl(base, 0);
+		if(more) list[base + __builtin_popcountll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i0;
+	}
+	__syncthreads();
+	// second pass, the listed samples: all 16 taps (stopping after kScreenEarly where a whole wavefront is over the bound)
+	const int nl = nlist;
+	for(int k0 = 0; k0 < nl; k0 += 256) {
+		const int k = k0 + tid;
+		const int i0 = k < nl ? (int)list[k] : 0;
 		#pragma unroll
 		for(int i = 0; i < kScreenEarly; i++) ph[i] = tile[i0 + 10 * i];
-		// the first kScreenEarly taps bound the value from below: most wavefronts stop here
 		ScreenAcc acc;
 		screen_taps(ph, T, 0, kScreenEarly, acc);
 		float ps = screen_value(acc, kScreenEarly);
-		if(__any(ps < kScreenEarlyThr)) {
+		if(__any(k < nl && ps < kScreenEarlyThr)) {
 			#pragma unroll
 			for(int i = kScreenEarly; i < kPreamble; i++) ph[i] = tile[i0 + 10 * i];
 			screen_taps(ph, T, kScreenEarly, kPreamble, acc);
 			ps = screen_value(acc, kPreamble);
 		}
-		const unsigned long long bits = __ballot(n < a.k1 && ps < kScreenThr);
+		if(k < nl && ps < kScreenThr) fl[i0] = 1;
+	}
+	__syncthreads();
+	#pragma unroll
+	for(int q = 0; q < kK3Tile / 256; q++) {
+		const int i0 = tid + 256 * q;
+		const int64_t n = nblk + i0;
+		const unsigned long long bits = __ballot(fl[i0] != 0);
 		if((tid & 63) == 0 && n < a.k1) a.flag[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
 	}
-}
-
-__device__ __forceinline__ unsigned long long b4_clear(unsigned long long b) {   // drop the four lowest set bits
-	for(int k = 0; k < 4 && b; k++) b &= b - 1;
-	return b;
 }
 
 __device__ __forceinline__ void k3_exact(const cf32 *y, uint32_t mask, int64_t n, int64_t k1, const Tables &T, float &p, float &f) {
@@ -489,15 +514,20 @@ __device__ __forceinline__ void k3_exact(const cf32 *y, uint32_t mask, int64_t n
 	sync_metric(ph, T, p, f);
 }
 
-// One lane per 64-sample word for the scan; the words that hold work are then taken four at a time, 16 lanes each: a word
-// with work has a cluster of ~5-10 flagged samples plus three either side, so a quarter wavefront per word keeps most lanes busy
-// (one word per pass left three quarters of them idle; 0.63 -> 0.2 ms at 256 channels with 160 000 preamble-like events per
-// 16 s block).  Metric values go through LDS - exact where computed, "big" elsewhere - and the 16 lanes of a quarter then form
-// the word's 64 candidate bits, four per lane.
+// A wavefront scans 256 consecutive 64-sample words (four per lane) and lists the ones that hold work; those are then taken
+// four at a time, 16 lanes each: a word with work has a cluster of ~5-10 flagged samples plus three either side, so a quarter
+// wavefront per word keeps most lanes busy, and 256 words (16 384 samples) hold enough such words to fill the quarters (one
+// word per pass with all 64 lanes: 0.63 ms at 256 channels with 160 000 preamble-like events per 16 s block; four per pass
+// out of 64 words: 0.43; out of 256: see DESIGN 6).  Metric values go through LDS - exact where computed, "big" elsewhere -
+// and the 16 lanes of a quarter then form the word's 64 candidate bits, four per lane.
 // (launch bound 256 threads with 4 waves per SIMD = the 128-register budget: a wave of this kernel then fits into the slot a
 // channeliser wave leaves behind; see k_walk_stitch)
+constexpr int kK3bWordsPerLane = 4;
 __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
 	__shared__ float psh[4][4][64 + 3];                  // [wave][quarter][3 + bit]: metric of sample word*64 + bit, entries 0..2 = the three samples before the word
+	__shared__ uint64_t s_need[4][64 * kK3bWordsPerLane];
+	__shared__ uint8_t s_fprev[4][64 * kK3bWordsPerLane];
+	__shared__ uint16_t s_list[4][64 * kK3bWordsPerLane];
 	const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const cf32 *y = a.y + (size_t)c * a.cap;
 	const uint64_t *flag = a.flag + (size_t)c * (a.cap >> 6);
@@ -505,34 +535,39 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
 	const uint32_t wmask = a.mask >> 6;
 	const Tables &T = *a.tab;
 	const int64_t w0 = a.nbase >> 6, w1 = (a.k1 + 63) >> 6;
-	const int64_t w = w0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
-	uint64_t need = 0, fprev = 0;
-	if(w < w1) {
-		const uint64_t f0 = flag[(uint32_t)w & wmask];
-		fprev = w > 0 ? flag[(uint32_t)(w - 1) & wmask] : 0ull;          // words before nbase hold the previous feed's flags
-		const uint64_t fnext = w + 1 < w1 ? flag[(uint32_t)(w + 1) & wmask] : 0ull;
-		need = f0 | (f0 << 3) | (f0 >> 3) | (fprev >> 61) | (fnext << 61);
-		const int64_t base = w << 6;
-		if(a.k1 - 3 < base + 64) {                                          // right neighbour n+3 not there yet
-			const int64_t lo = a.k1 - 3 - base;
-			need |= lo <= 0 ? ~0ull : (~0ull << lo);
+	const int64_t wb = w0 + ((int64_t)blockIdx.x * 4 + wave) * (64 * kK3bWordsPerLane);   // first word of this wavefront
+	int nwork = 0;
+	#pragma unroll
+	for(int g = 0; g < kK3bWordsPerLane; g++) {
+		const int64_t w = wb + 64 * g + lane;
+		uint64_t need = 0, fprev = 0;
+		if(w < w1) {
+			const uint64_t f0 = flag[(uint32_t)w & wmask];
+			fprev = w > 0 ? flag[(uint32_t)(w - 1) & wmask] : 0ull;      // words before nbase hold the previous feed's flags
+			const uint64_t fnext = w + 1 < w1 ? flag[(uint32_t)(w + 1) & wmask] : 0ull;
+			need = f0 | (f0 << 3) | (f0 >> 3) | (fprev >> 61) | (fnext << 61);
+			const int64_t base = w << 6;
+			if(a.k1 - 3 < base + 64) {                                      // right neighbour n+3 not there yet
+				const int64_t lo = a.k1 - 3 - base;
+				need |= lo <= 0 ? ~0ull : (~0ull << lo);
+			}
+			if(a.k1 < base + 64) need &= (a.k1 - base <= 0) ? 0ull : (~0ull >> (64 - (a.k1 - base)));   // samples that exist
+			if(need == 0) cand[(uint32_t)w & wmask] = 0;
 		}
-		if(a.k1 < base + 64) need &= (a.k1 - base <= 0) ? 0ull : (~0ull >> (64 - (a.k1 - base)));   // samples that exist
-		if(need == 0) cand[(uint32_t)w & wmask] = 0;
+		s_need[wave][64 * g + lane] = need; s_fprev[wave][64 * g + lane] = (uint8_t)(fprev >> 61);
+		const unsigned long long busy = __ballot(need != 0);
+		if(need != 0) s_list[wave][nwork + __builtin_popcountll(busy & ((1ull << lane) - 1ull))] = (uint16_t)(64 * g + lane);
+		nwork += __builtin_popcountll(busy);
 	}
-	unsigned long long busy = __ballot(need != 0);
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
 	const int q = lane >> 4, r = lane & 15;
 	float *ps = psh[wave][q];
-	while(busy) {
-		// quarter q takes the q-th word with work that is left (wave-uniform bookkeeping; j < 0: this quarter idles)
-		unsigned long long b = busy; int j = -1;
-		for(int k = 0; k <= q && b; k++) { j = __builtin_ctzll(b); b &= b - 1; if(k < q) j = -1; }
-		busy = b4_clear(busy);
-		// (every lane takes part in the shuffles: a lane that sat one out would read as zero to the quarter whose word it holds)
-		const int jj = j >= 0 ? j : 0;
-		uint64_t needj = __shfl(need, jj), fprevj = __shfl(fprev, jj);
-		if(j < 0) { needj = 0; fprevj = 0; }
-		const int64_t wj = w - lane + jj;
+	for(int it = 0; it < nwork; it += 4) {
+		// quarter q takes entry it + q of the list (idx < 0: this quarter idles)
+		const int idx = it + q < nwork ? (int)s_list[wave][it + q] : -1;
+		const uint64_t needj = idx >= 0 ? s_need[wave][idx] : 0ull;
+		const uint32_t fprevj = idx >= 0 ? s_fprev[wave][idx] : 0u;       // flags of the three samples before the word
+		const int64_t wj = wb + (idx >= 0 ? idx : 0);
 		for(int k = r; k < 67; k += 16) ps[k] = kPherrBig;
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
 		// the r-th, (r+16)-th, ... set bit of the word's work mask is this lane's
@@ -549,10 +584,10 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
 				for(int skip = 0; skip < 16 && left; skip++) left &= left - 1;
 			}
 		}
-		if(j >= 0 && r < 3) {                                               // the three samples before the word
+		if(idx >= 0 && r < 3) {                                             // the three samples before the word
 			const int64_t m = (wj << 6) - 3 + r;
 			float pm = kPherrBig, fm;
-			if(m >= 0 && ((fprevj >> (61 + r)) & 1ull)) k3_exact(y, a.mask, m, a.k1, T, pm, fm);
+			if(m >= 0 && ((fprevj >> r) & 1u)) k3_exact(y, a.mask, m, a.k1, T, pm, fm);
 			ps[r] = pm;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
@@ -560,11 +595,11 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
 		for(int k = 0; k < 4; k++) {
 			const int bit = r + 16 * k;
 			const int64_t n = (wj << 6) + bit;
-			if(j >= 0 && n >= 3 && n < a.k1 && is_candidate(ps[bit], ps[3 + bit])) bits |= 1ull << bit;
+			if(idx >= 0 && n >= 3 && n < a.k1 && is_candidate(ps[bit], ps[3 + bit])) bits |= 1ull << bit;
 		}
 		#pragma unroll
-		for(int d = 1; d < 16; d <<= 1) bits |= __shfl_xor(bits, d);         // OR over the quarter's 16 lanes
-		if(j >= 0 && r == 0) cand[(uint32_t)wj & wmask] = bits;
+		for(int d = 1; d < 16; d <<= 1) bits |= __shfl_xor(bits, d);         // OR over the quarter's 16 lanes (every lane takes part)
+		if(idx >= 0 && r == 0) cand[(uint32_t)wj & wmask] = bits;
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
 	}
 }

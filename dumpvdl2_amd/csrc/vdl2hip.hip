@@ -262,7 +262,8 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		// the exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry
 		// less on the front stream than a separate hipEventRecord
 		const int64_t nwords = ((k1 + 63) >> 6) - (nbase >> 6);
-		LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + 255) / 256), (unsigned)c->C), dim3(256), st, (hipEvent_t) nullptr, sl.ev_front, k3);
+		const int64_t wpb = 256 * kK3bWordsPerLane;                            // words per block
+		LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), st, (hipEvent_t) nullptr, sl.ev_front, k3);
 	}
 	// The burst-rate back end runs on three more streams, so that consecutive feeds overlap stage by stage:
 	//   stream_back   K4   walk(i) -> walk(i+1) -> ...             (each needs the previous one's FSM state)

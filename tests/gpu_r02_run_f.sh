@@ -2,7 +2,7 @@
 # round 2, GPU call F: packed exact tier, 128-register back end
 R="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$R"; mkdir -p gpurun_out
-O=gpurun_out/r02f
+O=gpurun_out/r02g
 timeout 900 python -m pytest tests -m gpu -x -q > $O.pytest.txt 2>&1; echo "pytest rc=$?" >> $O.pytest.txt
 tail -3 $O.pytest.txt
 timeout 300 python tests/gpu_stage_times.py config4 16 3 2>&1 | grep -v amdgpu.ids > $O.stage.txt; cat $O.stage.txt

@@ -28,7 +28,7 @@ def assert_frames_equal(ref, got, exact_samples=True, label=""):
         assert abs(a["ppm_error"] - b["ppm_error"]) <= TOL_PPM, f"{label}: ppm {a['ppm_error']} vs {b['ppm_error']}"
 
 
-def compare_at_full_size(ref, got, label="", max_tie_frac=1e-3):
+def compare_at_full_size(ref, got, label="", max_tie_frac=5e-3):
     """The parity gate of SURVEY 8.5 for runs with thousands of bursts: (channel, burst ordinal, idx, octets) and the integer
     metadata identical, floats within tolerance.  Burst timing (sync_sample / end_sample - diagnostics of this repo, not
     reference metadata) is required identical too, except for "ties": the time-parallel filter differs from the reference's

@@ -117,6 +117,11 @@ int main(int argc, char **argv) {
 					freqs[c], cnt[VDL2HIP_CNT_SYNC_GOOD], cnt[VDL2HIP_CNT_CRC_GOOD], cnt[VDL2HIP_CNT_BLOCKS_FEC_OK],
 					cnt[VDL2HIP_CNT_BLOCKS_PROCESSED], cnt[VDL2HIP_CNT_MSG_GOOD], cnt[VDL2HIP_CNT_ERR_FEC_BAD]);
 	fprintf(stderr, "%lu frames\n", nframes);
+	{
+		vdl2hip_stats st;                                                       /* the drain calls only count buffer overflows: say so */
+		if(vdl2hip_get_stats(rx, &st) == VDL2HIP_OK && st.overflow_feeds)
+			fprintf(stderr, "warning: device output buffers overflowed in %llu block(s): frames were dropped\n", (unsigned long long)st.overflow_feeds);
+	}
 	if(statsd_path) {
 		static char lines[1 << 20];
 		char ns[300];
