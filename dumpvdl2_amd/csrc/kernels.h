@@ -440,63 +440,33 @@ constexpr int kK3Tile = 1024;
 
 __global__ __launch_bounds__(256) void k_sync_screen(K3Args a) {
 	__shared__ float tile[kK3Tile + 150];           // screening phases of samples nblk-150 .. nblk+kK3Tile-1
-	__shared__ uint16_t list[kK3Tile];              // samples (tile-local) still under the bound after the first pass
-	__shared__ uint8_t fl[kK3Tile];
-	__shared__ int nlist;
 	const int c = blockIdx.y, tid = threadIdx.x;
 	const int64_t nblk = a.nbase + (int64_t)blockIdx.x * kK3Tile;
 	const cf32 *y = a.y + (size_t)c * a.cap;
 	const Tables &T = *a.tab;
-	if(tid == 0) nlist = 0;
 	for(int j = tid; j < kK3Tile + 150; j += 256) {
 		const int64_t t = nblk - 150 + j;
 		tile[j] = (t < 0 || t >= a.k1) ? 0.f : phase_fast(y[(uint32_t)t & a.mask]);
 	}
 	__syncthreads();
 	float ph[kPreamble];
-	// first pass, every sample: the residual over the first kScreenFirst taps bounds the 16-tap value from below; 13 % of noise or
-	// data windows stay under the bound and are compacted into a list, so that the second pass runs on full wavefronts (an early
-	// exit inside a wavefront only pays when all 64 lanes agree: after 8 taps they never do, after 12 in 4 of 5 wavefronts)
 	#pragma unroll
 	for(int q = 0; q < kK3Tile / 256; q++) {
 		const int i0 = tid + 256 * q;               // sample nblk + i0: phases tile[i0 + 10 i]
-		#pragma unroll
-		for(int i = 0; i < kScreenFirst; i++) ph[i] = tile[i0 + 10 * i];
-		ScreenAcc acc;
-		screen_taps(ph, T, 0, kScreenFirst, acc);
-		const bool more = nblk + i0 < a.k1 && screen_value(acc, kScreenFirst) < kScreenEarlyThr;
-		fl[i0] = 0;
-		const unsigned long long m = __ballot(more);
-		int base = 0;
-		if((tid & 63) == 0 && m) base = atomicAdd(&nlist, __builtin_popcountll(m));
-		base = __shfl(base, 0);
-		if(more) list[base + __builtin_popcountll(m & ((1ull << (tid & 63)) - 1ull))] = (uint16_t)i0;
-	}
-	__syncthreads();
-	// second pass, the listed samples: all 16 taps (stopping after kScreenEarly where a whole wavefront is over the bound)
-	const int nl = nlist;
-	for(int k0 = 0; k0 < nl; k0 += 256) {
-		const int k = k0 + tid;
-		const int i0 = k < nl ? (int)list[k] : 0;
+		const int64_t n = nblk + i0;
 		#pragma unroll
 		for(int i = 0; i < kScreenEarly; i++) ph[i] = tile[i0 + 10 * i];
+		// the first kScreenEarly taps bound the value from below: most wavefronts stop here
 		ScreenAcc acc;
 		screen_taps(ph, T, 0, kScreenEarly, acc);
 		float ps = screen_value(acc, kScreenEarly);
-		if(__any(k < nl && ps < kScreenEarlyThr)) {
+		if(__any(ps < kScreenEarlyThr)) {
 			#pragma unroll
 			for(int i = kScreenEarly; i < kPreamble; i++) ph[i] = tile[i0 + 10 * i];
 			screen_taps(ph, T, kScreenEarly, kPreamble, acc);
 			ps = screen_value(acc, kPreamble);
 		}
-		if(k < nl && ps < kScreenThr) fl[i0] = 1;
-	}
-	__syncthreads();
-	#pragma unroll
-	for(int q = 0; q < kK3Tile / 256; q++) {
-		const int i0 = tid + 256 * q;
-		const int64_t n = nblk + i0;
-		const unsigned long long bits = __ballot(fl[i0] != 0);
+		const unsigned long long bits = __ballot(n < a.k1 && ps < kScreenThr);
 		if((tid & 63) == 0 && n < a.k1) a.flag[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
 	}
 }

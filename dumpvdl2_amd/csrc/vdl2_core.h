@@ -328,7 +328,6 @@ constexpr float kScreenThr = 5.5f;
 // line through those n points, a lower bound of the residual over all 16 - is available along the way: the sync kernel stops
 // after kScreenEarly taps when no lane of the wavefront is still under the threshold (97 % of them on noise or data).
 constexpr int kScreenEarly = 12;
-constexpr int kScreenFirst = 8;           // the sync kernel's first pass: 87 % of noise / data windows are over the bound after 8 taps
 constexpr float kScreenEarlyThr = 5.8f;   // early bound + its rounding slack must stay above kScreenThr
 // The screening tier runs on phase_fast() phases (error < 5e-7 rad each), so an unwrap decision - "is the difference of two
 // taps beyond +-pi" - could differ from the one the exact phases give when the difference is within ~2e-6 of +-pi.  `guard`

@@ -84,12 +84,8 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 				if(n < 0 || n >= k1) return kPherrBig;
 				float ph[kPreamble];
 				for(int i = 0; i < kPreamble; i++) { int64_t t = n - 150 + 10 * i; ph[i] = t < 0 ? 0.f : phase_fast(y[(uint32_t)t & s->mask]); }
-				// the kernel's two stopping places: after kScreenFirst taps (first pass) and after kScreenEarly (second pass)
-				ScreenAcc a0; screen_taps(ph, s->T, 0, kScreenFirst, a0);
-				float v = screen_value(a0, kScreenFirst);
-				if(!(v < kScreenEarlyThr)) return v;
 				ScreenAcc a; screen_taps(ph, s->T, 0, kScreenEarly, a);
-				v = screen_value(a, kScreenEarly);
+				float v = screen_value(a, kScreenEarly);
 				if(v < kScreenEarlyThr) { screen_taps(ph, s->T, kScreenEarly, kPreamble, a); v = screen_value(a, kPreamble); }
 				return v;
 			};
@@ -207,13 +203,6 @@ void hostsim_metric_early(const float *ph, int64_t n, float *early) {
 	for(int64_t i = 0; i < n; i++) { ScreenAcc a; screen_taps(ph + 16 * i, T, 0, kScreenEarly, a); early[i] = screen_value(a, kScreenEarly); }
 }
 int hostsim_screen_early_taps() { return kScreenEarly; }
-// ... and after kScreenFirst taps (the first pass)
-void hostsim_metric_first(const float *ph, int64_t n, float *first) {
-	static Tables T; static bool init = false;
-	if(!init) { build_tables(T); init = true; }
-	for(int64_t i = 0; i < n; i++) { ScreenAcc a; screen_taps(ph + 16 * i, T, 0, kScreenFirst, a); first[i] = screen_value(a, kScreenFirst); }
-}
-int hostsim_screen_first_taps() { return kScreenFirst; }
 
 // more of tables.h: preamble phases (units of pi/4 are checked by the caller), Gray map, FCS table, first PRBS bits, RS field
 void hostsim_misc_tables(float *pr_phase16, uint8_t *gray8, uint16_t *crc256, uint8_t *prbs64, uint8_t *gf_exp8) {
