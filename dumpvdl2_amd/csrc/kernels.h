@@ -422,6 +422,7 @@ struct K3Args {
 	const cf32 *y; cf32 *pf; uint64_t *cand; uint64_t *flag; const Tables *tab;
 	int64_t nbase, k1;        // first sample to (re)compute (multiple of 64); one past the last valid sample
 	uint32_t cap, mask;
+	int32_t wpl;              // k_sync_exact: flag words scanned per lane (1..kK3bWordsPerLane)
 };
 
 // K3: got_sync() metric (contiguous ring) + the candidate bitmap, in two tiers and two kernels.
@@ -492,7 +493,7 @@ __device__ __forceinline__ void k3_exact(const cf32 *y, uint32_t mask, int64_t n
 // and the 16 lanes of a quarter then form the word's 64 candidate bits, four per lane.
 // (launch bound 256 threads with 4 waves per SIMD = the 128-register budget: a wave of this kernel then fits into the slot a
 // channeliser wave leaves behind; see k_walk_stitch)
-constexpr int kK3bWordsPerLane = 4;
+constexpr int kK3bWordsPerLane = 4;      // at most; fewer when that leaves the chip short of wavefronts (few channels)
 __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
 	__shared__ float psh[4][4][64 + 3];                  // [wave][quarter][3 + bit]: metric of sample word*64 + bit, entries 0..2 = the three samples before the word
 	__shared__ uint64_t s_need[4][64 * kK3bWordsPerLane];
@@ -505,10 +506,9 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
 	const uint32_t wmask = a.mask >> 6;
 	const Tables &T = *a.tab;
 	const int64_t w0 = a.nbase >> 6, w1 = (a.k1 + 63) >> 6;
-	const int64_t wb = w0 + ((int64_t)blockIdx.x * 4 + wave) * (64 * kK3bWordsPerLane);   // first word of this wavefront
+	const int64_t wb = w0 + ((int64_t)blockIdx.x * 4 + wave) * (64 * a.wpl);   // first word of this wavefront
 	int nwork = 0;
-	#pragma unroll
-	for(int g = 0; g < kK3bWordsPerLane; g++) {
+	for(int g = 0; g < a.wpl; g++) {
 		const int64_t w = wb + 64 * g + lane;
 		uint64_t need = 0, fprev = 0;
 		if(w < w1) {

@@ -257,12 +257,15 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	c->carry_sel ^= 1; c->ncarry = nrem;
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
-		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1 };
+		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1 };
 		LAUNCH_EV(k_sync_screen, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(256), st, EV(4), (hipEvent_t) nullptr, k3);
 		// the exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry
 		// less on the front stream than a separate hipEventRecord
 		const int64_t nwords = ((k1 + 63) >> 6) - (nbase >> 6);
-		const int64_t wpb = 256 * kK3bWordsPerLane;                            // words per block
+		// words per lane of the exact tier: as many as keep >= 2 workgroups per CU (a wavefront with more words finds more of
+		// them with work, but a grid that does not fill the chip is latency-bound)
+		for(int wpl = kK3bWordsPerLane; wpl >= 1; wpl >>= 1) { k3.wpl = wpl; if(((nwords + 256 * wpl - 1) / (256 * wpl)) * c->C >= 512 || wpl == 1) break; }
+		const int64_t wpb = 256 * k3.wpl;                                      // words per block
 		LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), st, (hipEvent_t) nullptr, sl.ev_front, k3);
 	}
 	// The burst-rate back end runs on three more streams, so that consecutive feeds overlap stage by stage:
