@@ -437,71 +437,8 @@ struct K3Args {
 // y1/y3 of calc_para_vertex and the right-hand side of the candidate test), stored in pf, and the candidate bit
 // pherr(n-3) < 4 && pherr(n) > pherr(n-3) of every sample.  The walker reads the metric nowhere else.  A sample whose right
 // neighbour has not arrived yet is computed exactly; the next feed redoes the last partial bitmap word anyway.
-#ifndef VDL2_K3_WAVE_COMPACT
-#define VDL2_K3_WAVE_COMPACT 1
-#endif
-#if VDL2_K3_WAVE_COMPACT
-// Every wavefront screens kK3Wave consecutive samples of its own: a first pass of kK3First taps for all of them (the residual
-// over the first taps bounds the 16-tap value from below; 87 % of noise or data windows are over the bound by then), the rest
-// compacted into a wave-private list - ballots and a wave-uniform counter, no atomics, no workgroup barrier - and a second pass
-// over the list on (nearly) full wavefronts.  An early exit inside a wavefront only pays when all 64 lanes agree: after 8 taps
-// they never do, which is why the single-pass form ran 12.7 taps per sample.
-constexpr int kK3Wave = 1024, kK3First = 8;
-__global__ __launch_bounds__(256) void k_sync_screen(K3Args a) {
-	__shared__ float tiles[4][kK3Wave + 150];       // per wave: screening phases of samples nw-150 .. nw+kK3Wave-1
-	__shared__ uint16_t lists[4][kK3Wave];          // per wave: samples still under the bound after the first pass
-	__shared__ uint32_t bms[4][kK3Wave / 32];       // per wave: the flag bits
-	const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int64_t nw = a.nbase + ((int64_t)blockIdx.x * 4 + wave) * kK3Wave;
-	if(nw >= a.k1) return;                          // wave-uniform; no workgroup barrier below
-	const cf32 *y = a.y + (size_t)c * a.cap;
-	const Tables &T = *a.tab;
-	float *tile = tiles[wave]; uint16_t *list = lists[wave]; uint32_t *bm = bms[wave];
-	if(lane < kK3Wave / 32) bm[lane] = 0;
-	for(int j = lane; j < kK3Wave + 150; j += 64) {
-		const int64_t t = nw - 150 + j;
-		tile[j] = (t < 0 || t >= a.k1) ? 0.f : phase_fast(y[(uint32_t)t & a.mask]);
-	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-	float ph[kPreamble];
-	int nl = 0;
-	for(int q = 0; q < kK3Wave / 64; q++) {
-		const int i0 = lane + 64 * q;               // sample nw + i0: phases tile[i0 + 10 i]
-		#pragma unroll
-		for(int i = 0; i < kK3First; i++) ph[i] = tile[i0 + 10 * i];
-		ScreenAcc acc;
-		screen_taps(ph, T, 0, kK3First, acc);
-		const bool more = nw + i0 < a.k1 && screen_value(acc, kK3First) < kScreenEarlyThr;
-		const unsigned long long m = __ballot(more);
-		if(more) list[nl + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)i0;
-		nl += __builtin_popcountll(m);
-	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-	for(int k0 = 0; k0 < nl; k0 += 64) {
-		const int k = k0 + lane;
-		const int i0 = k < nl ? (int)list[k] : 0;
-		#pragma unroll
-		for(int i = 0; i < kScreenEarly; i++) ph[i] = tile[i0 + 10 * i];
-		ScreenAcc acc;
-		screen_taps(ph, T, 0, kScreenEarly, acc);
-		float ps = screen_value(acc, kScreenEarly);
-		if(__any(k < nl && ps < kScreenEarlyThr)) {
-			#pragma unroll
-			for(int i = kScreenEarly; i < kPreamble; i++) ph[i] = tile[i0 + 10 * i];
-			screen_taps(ph, T, kScreenEarly, kPreamble, acc);
-			ps = screen_value(acc, kPreamble);
-		}
-		if(k < nl && ps < kScreenThr) atomicOr(&bm[i0 >> 5], 1u << (i0 & 31));
-	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-	if(lane < kK3Wave / 64) {                       // one 64-sample flag word per lane
-		const int64_t n = nw + 64 * lane;
-		if(n < a.k1) a.flag[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = (uint64_t)bm[2 * lane] | ((uint64_t)bm[2 * lane + 1] << 32);
-	}
-}
-constexpr int kK3Tile = 4 * kK3Wave;             // samples per workgroup
-#else
 constexpr int kK3Tile = 1024;
+
 __global__ __launch_bounds__(256) void k_sync_screen(K3Args a) {
 	__shared__ float tile[kK3Tile + 150];           // screening phases of samples nblk-150 .. nblk+kK3Tile-1
 	const int c = blockIdx.y, tid = threadIdx.x;
@@ -534,8 +471,6 @@ __global__ __launch_bounds__(256) void k_sync_screen(K3Args a) {
 		if((tid & 63) == 0 && n < a.k1) a.flag[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
 	}
 }
-
-#endif
 
 __device__ __forceinline__ void k3_exact(const cf32 *y, uint32_t mask, int64_t n, int64_t k1, const Tables &T, float &p, float &f) {
 	cf32 yv[kPreamble];

@@ -1037,13 +1037,8 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, int64_t k0, 
 // kLpTerms of them (0.9^256 ~ 2e-12, below fp32 resolution).  One lane per update.
 // ======================================================================
 constexpr int kNfGroup = 16;               // updates replayed per wavefront pass (4 lanes gather for each)
-constexpr int kNfSlice = 448;              // chunks of the evaluation list a group of updates may stage in LDS
 struct NfShared {
 	alignas(16) float mags[kNfGroup][kLpTerms + 1];    // +1: row padding keeps the per-lane replay off one LDS bank
-	// the slice of the combined chunk list this group's gathers walk through (global memory beyond it)
-	int64_t c_cum[kNfSlice + 1], c_first[kNfSlice];
-	int32_t c_lo, c_n;
-	int32_t s_ci[64];
 };
 
 struct NfScratch { int64_t *first; int64_t *cum; };   // combined (tail + feed) chunk list: first sample, ordinal of first evaluation
@@ -1092,49 +1087,18 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 	const int64_t ubase = fd.u0 + 1 + (int64_t)kNfGroup * group;      // first (1-based, global) update of this group
 	if(ubase > fd.u1) return;
 	const int ncomb = (int)fd.ncomb;
-	// where each lane's first (newest) evaluation lies in the chunk list, and - lane 63 - the group's oldest one
 	WAVE_FOR(l)
 		const int u = l >> 2, part = l & 3;
 		const int64_t U = ubase + u;
-		int ci = -1;
-		if(U <= fd.u1) {
-			const int64_t o = 1000 * U - 1 - 64 * part;
-			if(o >= fd.begin_ord) {
-				int lo = 0, hi = ncomb;
-				while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sc.cum[mid] <= o) lo = mid; else hi = mid; }
-				ci = lo;
-			}
-		}
-		sh.s_ci[l] = ci;
-	WAVE_END
-	LANE0
-		int64_t omin = 1000 * ubase - 1 - (kLpTerms - 1);
-		if(omin < fd.begin_ord) omin = fd.begin_ord;
-		int lo = 0, hi = ncomb;
-		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sc.cum[mid] <= omin) lo = mid; else hi = mid; }
-		int top = -1;
-		for(int q = 0; q < 64; q++) if(sh.s_ci[q] > top) top = sh.s_ci[q];
-		const int n = top - lo + 1;
-		sh.c_lo = lo; sh.c_n = (top >= 0 && n >= 1 && n <= kNfSlice) ? n : 0;
-	LANE0_END
-	WAVE_FOR(l)
-		const int n = sh.c_n, lo = sh.c_lo;
-		for(int i = l; i < n; i += 64) { sh.c_cum[i] = sc.cum[lo + i]; sh.c_first[i] = sc.first[lo + i]; }
-		if(l == 0 && n > 0) sh.c_cum[n] = sc.cum[lo + n];
-	WAVE_END
-	WAVE_FOR(l)
-		const int u = l >> 2, part = l & 3;
-		const int64_t U = ubase + u;
-		const int slo = sh.c_lo, sn = sh.c_n;
 		if(U <= fd.u1) {
 			const int64_t o_last = 1000 * U - 1;                     // ordinal of the evaluation that triggers the update
 			// this lane gathers evaluations o_last - j, j = 64*part .. 64*part+63 (newest first)
 			int64_t o = o_last - 64 * part;
 			int ci = 0; int64_t pos = 0, off = 0;
 			if(o >= fd.begin_ord) {
-				ci = sh.s_ci[l];
-				const bool in = ci - slo >= 0 && ci - slo < sn;
-				off = o - (in ? sh.c_cum[ci - slo] : sc.cum[ci]); pos = (in ? sh.c_first[ci - slo] : sc.first[ci]) + 3 * off;
+				int lo = 0, hi = ncomb;
+				while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sc.cum[mid] <= o) lo = mid; else hi = mid; }
+				ci = lo; off = o - sc.cum[ci]; pos = sc.first[ci] + 3 * off;
 			}
 			for(int j0 = 0; j0 < 64; j0 += 8) {
 				int64_t ps[8]; cf32 yv[8];
@@ -1144,12 +1108,7 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 						ps[q] = pos;
 						o--;
 						if(off > 0) { off--; pos -= 3; }
-						else if(ci > 0 && o >= fd.begin_ord) {
-							ci--;
-							const bool in = ci - slo >= 0 && ci - slo < sn;       // then ci + 1 - slo <= sn is staged too
-							const int64_t c1 = in ? sh.c_cum[ci + 1 - slo] : sc.cum[ci + 1], c0 = in ? sh.c_cum[ci - slo] : sc.cum[ci];
-							off = c1 - c0 - 1; pos = (in ? sh.c_first[ci - slo] : sc.first[ci]) + 3 * off;
-						}
+						else if(ci > 0 && o >= fd.begin_ord) { ci--; off = sc.cum[ci + 1] - sc.cum[ci] - 1; pos = sc.first[ci] + 3 * off; }
 					} else o--;
 				}
 				for(int q = 0; q < 8; q++) yv[q] = ps[q] >= 0 ? v.Y(ps[q]) : cf32{0.f, 0.f};
