@@ -422,15 +422,22 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	#define DEV_ALLOC(ptr, bytes) do { if(hipMalloc((void **)&(ptr), (bytes)) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_NOMEM; } } while(0)
 	#define DEV_CHK(expr) do { if((expr) != hipSuccess) { vdl2hip_destroy(c); return VDL2HIP_E_DEVICE; } } while(0)
 	{
-		// the back end is a chain of small latency-bound kernels: it goes first whenever it competes with the
-		// channeliser of a later feed for compute units
 		int prio_low = 0, prio_high = 0;
 		DEV_CHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
 		if(getenv("VDL2HIP_NO_PRIO")) prio_low = prio_high = 0;   // experiments only
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_low));
-		DEV_CHK(hipStreamCreateWithPriority(&c->stream_back, hipStreamNonBlocking, prio_high));
-		DEV_CHK(hipStreamCreateWithPriority(&c->stream_nf, hipStreamNonBlocking, prio_high));
-		DEV_CHK(hipStreamCreateWithPriority(&c->stream_burst, hipStreamNonBlocking, prio_high));
+		// The walk goes first whenever it competes with the channeliser of a later feed (every later stage waits for it).  The
+		// noise-floor and burst streams do not: their many single-wave workgroups, dispatched with priority, each take the
+		// register slot of one of the four waves a channeliser workgroup needs on a CU and so keep whole workgroups out; at
+		// the front's priority they fill in while the sync kernels (few registers) run.  Measured at 256 channels
+		// (profiles/r02_stream_priorities.txt): all three high 7.10 ms/step, walk only 6.91, none 6.93; no difference at 8.
+		// VDL2HIP_LOW_PRIO=<list of nf,burst,walk> overrides (experiments).
+		const char *lowp = getenv("VDL2HIP_LOW_PRIO");
+		if(!lowp) lowp = "nf,burst";
+		auto prio_of = [&](const char *name) { return strstr(lowp, name) ? prio_low : prio_high; };
+		DEV_CHK(hipStreamCreateWithPriority(&c->stream_back, hipStreamNonBlocking, prio_of("walk")));
+		DEV_CHK(hipStreamCreateWithPriority(&c->stream_nf, hipStreamNonBlocking, prio_of("nf")));
+		DEV_CHK(hipStreamCreateWithPriority(&c->stream_burst, hipStreamNonBlocking, prio_of("burst")));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
 	}
