@@ -12,6 +12,8 @@
 //
 // K1 is the only kernel that touches every input sample; everything after it runs at
 // 1/oversample of that rate.  See DESIGN.md for the block-form derivation and the roofline.
+// There is no stored phase stream: atan2 in double (demod.c:232,256) is evaluated where a decision reads a phase - the exact tier
+// of K3, the walker, K5 - and K3's screening tier uses a single-precision phase of its own (vdl2_core.h: ChanView::Phi, phase_fast).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vdl2_core.h"
