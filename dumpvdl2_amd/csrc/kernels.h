@@ -96,6 +96,37 @@ __device__ __forceinline__ void load_sample(const K1Args &a, int64_t s, float &r
 	}
 }
 
+// Cross-lane moves on the VALU's data-parallel-primitive path (GFX9 DPP controls; checked on the device by
+// tests/test_gpu_parity.py::test_dpp_primitives_behave_as_the_scan_assumes).
+__device__ __forceinline__ float dpp_row_shr(float v, int d) {     // value of lane - 2^d inside the same row of 16 lanes, else 0
+	const int x = __builtin_bit_cast(int, v);
+	int r;
+	switch(d) {
+		case 0: r = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); break;
+		case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); break;
+		case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); break;
+		default: r = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); break;
+	}
+	return __builtin_bit_cast(float, r);
+}
+template<int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_bcast(float v) {               // row_bcast:15 (0x142) / row_bcast:31 (0x143) into the rows of ROWS, 0 elsewhere
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ float dpp_wave_shr1(float v) {           // value of lane - 1 across the whole wavefront (lane 0: 0)
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+
+// debug kernel for the test above: out[0..3][lane] = row_shr:4, row_bcast:15 (rows 1,3), row_bcast:31 (rows 2,3), wave_shr:1 of in[lane]
+__global__ void k_dpp_probe(const float *in, float *out) {
+	const int l = threadIdx.x & 63;
+	const float v = in[l];
+	out[l] = dpp_row_shr(v, 2);
+	out[64 + l] = dpp_bcast<0x142, 0xa>(v);
+	out[128 + l] = dpp_bcast<0x143, 0xc>(v);
+	out[192 + l] = dpp_wave_shr1(v);
+}
+
 // One workgroup = 4 waves that walk `a.tiles` consecutive time tiles (64*R blocks of OS samples each, staged in LDS
 // and shared by the waves); each wave owns CR channels; each lane owns R consecutive decimated outputs per tile.
 // Within a workgroup's segment the filter state is carried from tile to tile in registers, so the outputs it
@@ -246,18 +277,39 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			}
 		}
 
-		// wave-level scan of the lane end states: X_l = Q X_{l-1} + E_l, Q = P^R (Kogge-Stone, 6 steps), X_-1 = carry
+		// wave-level scan of the lane end states: X_l = Q X_{l-1} + E_l, Q = P^R, X_-1 = carry - on the cross-lane data paths
+		// of the VALU (DPP), no LDS traffic (ds_bpermute) and no lane-range selects:
+		//   4 Kogge-Stone steps inside each row of 16 lanes (row_shr:2^d; a lane whose source lies outside its row reads 0),
+		//   rows 1 and 3 take the end state of rows 0 and 2 (row_bcast:15) times Q^(p+1), p = lane & 15,
+		//   rows 2 and 3 take the end state of lane 31 (row_bcast:31) times Q^(lane-31),
+		// then every lane adds what the carried state of the previous tile contributes, Q^(lane+1) carry.
 		#pragma unroll
-		for(int d = 0; d < 6; d++) {
+		for(int d = 0; d < 4; d++) {
 			const float q0 = bf.Q[d][0], q1 = bf.Q[d][1], q2 = bf.Q[d][2], q3 = bf.Q[d][3];
 			#pragma unroll
 			for(int c = 0; c < CR; c++) {
-				const float o0r = __shfl_up(t0r[c], 1u << d), o0i = __shfl_up(t0i[c], 1u << d);
-				const float o1r = __shfl_up(t1r[c], 1u << d), o1i = __shfl_up(t1i[c], 1u << d);
-				if(lane >= (1 << d)) {
-					t0r[c] = __builtin_fmaf(q0, o0r, __builtin_fmaf(q1, o1r, t0r[c])); t0i[c] = __builtin_fmaf(q0, o0i, __builtin_fmaf(q1, o1i, t0i[c]));
-					t1r[c] = __builtin_fmaf(q2, o0r, __builtin_fmaf(q3, o1r, t1r[c])); t1i[c] = __builtin_fmaf(q2, o0i, __builtin_fmaf(q3, o1i, t1i[c]));
-				}
+				const float o0r = dpp_row_shr(t0r[c], d), o0i = dpp_row_shr(t0i[c], d);
+				const float o1r = dpp_row_shr(t1r[c], d), o1i = dpp_row_shr(t1i[c], d);
+				t0r[c] = __builtin_fmaf(q0, o0r, __builtin_fmaf(q1, o1r, t0r[c])); t0i[c] = __builtin_fmaf(q0, o0i, __builtin_fmaf(q1, o1i, t0i[c]));
+				t1r[c] = __builtin_fmaf(q2, o0r, __builtin_fmaf(q3, o1r, t1r[c])); t1i[c] = __builtin_fmaf(q2, o0i, __builtin_fmaf(q3, o1i, t1i[c]));
+			}
+		}
+		{
+			const float4 qa = qpow[lane & 15];                  // Q^(p+1): only rows 1 and 3 receive a non-zero operand
+			#pragma unroll
+			for(int c = 0; c < CR; c++) {
+				const float o0r = dpp_bcast<0x142, 0xa>(t0r[c]), o0i = dpp_bcast<0x142, 0xa>(t0i[c]);
+				const float o1r = dpp_bcast<0x142, 0xa>(t1r[c]), o1i = dpp_bcast<0x142, 0xa>(t1i[c]);
+				t0r[c] = __builtin_fmaf(qa.x, o0r, __builtin_fmaf(qa.y, o1r, t0r[c])); t0i[c] = __builtin_fmaf(qa.x, o0i, __builtin_fmaf(qa.y, o1i, t0i[c]));
+				t1r[c] = __builtin_fmaf(qa.z, o0r, __builtin_fmaf(qa.w, o1r, t1r[c])); t1i[c] = __builtin_fmaf(qa.z, o0i, __builtin_fmaf(qa.w, o1i, t1i[c]));
+			}
+			const float4 qb = qpow[(lane - 32) & 63];           // Q^(lane-31) for lanes 32..63 (rows 2 and 3)
+			#pragma unroll
+			for(int c = 0; c < CR; c++) {
+				const float o0r = dpp_bcast<0x143, 0xc>(t0r[c]), o0i = dpp_bcast<0x143, 0xc>(t0i[c]);
+				const float o1r = dpp_bcast<0x143, 0xc>(t1r[c]), o1i = dpp_bcast<0x143, 0xc>(t1i[c]);
+				t0r[c] = __builtin_fmaf(qb.x, o0r, __builtin_fmaf(qb.y, o1r, t0r[c])); t0i[c] = __builtin_fmaf(qb.x, o0i, __builtin_fmaf(qb.y, o1i, t0i[c]));
+				t1r[c] = __builtin_fmaf(qb.z, o0r, __builtin_fmaf(qb.w, o1r, t1r[c])); t1i[c] = __builtin_fmaf(qb.z, o0i, __builtin_fmaf(qb.w, o1i, t1i[c]));
 			}
 		}
 		const float4 qp = qpow[lane];
@@ -267,7 +319,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			const float4 cy = carry[c];
 			t0r[c] = __builtin_fmaf(qp.x, cy.x, __builtin_fmaf(qp.y, cy.z, t0r[c])); t0i[c] = __builtin_fmaf(qp.x, cy.y, __builtin_fmaf(qp.y, cy.w, t0i[c]));
 			t1r[c] = __builtin_fmaf(qp.z, cy.x, __builtin_fmaf(qp.w, cy.z, t1r[c])); t1i[c] = __builtin_fmaf(qp.z, cy.y, __builtin_fmaf(qp.w, cy.w, t1i[c]));
-			float T0r = __shfl_up(t0r[c], 1), T0i = __shfl_up(t0i[c], 1), T1r = __shfl_up(t1r[c], 1), T1i = __shfl_up(t1i[c], 1);
+			float T0r = dpp_wave_shr1(t0r[c]), T0i = dpp_wave_shr1(t0i[c]), T1r = dpp_wave_shr1(t1r[c]), T1i = dpp_wave_shr1(t1i[c]);
 			if(lane == 0) { T0r = cy.x; T0i = cy.y; T1r = cy.z; T1i = cy.w; }
 			const bool cvalid = cbase + c < a.nchan;
 			const int64_t kloc = kbase + (int64_t)lane * R;

@@ -752,6 +752,20 @@ int vdl2hip_set_drain_lag(vdl2hip_ctx *c, int lag) {
 	return VDL2HIP_OK;
 }
 
+// test hook (not declared in vdl2hip.h): what the DPP controls the channeliser's scan relies on do on this device
+int vdl2hip_debug_dpp_probe(const float in[64], float out[256]) {
+	float *d_in = nullptr, *d_out = nullptr;
+	if(hipMalloc((void **)&d_in, 64 * 4) != hipSuccess || hipMalloc((void **)&d_out, 256 * 4) != hipSuccess) return VDL2HIP_E_NOMEM;
+	int rc = VDL2HIP_OK;
+	if(hipMemcpy(d_in, in, 64 * 4, hipMemcpyHostToDevice) != hipSuccess) rc = VDL2HIP_E_DEVICE;
+	if(rc == VDL2HIP_OK) {
+		hipLaunchKernelGGL(k_dpp_probe, dim3(1), dim3(64), 0, 0, (const float *)d_in, d_out);
+		if(hipMemcpy(out, d_out, 256 * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = VDL2HIP_E_DEVICE;
+	}
+	(void)hipFree(d_in); (void)hipFree(d_out);
+	return rc;
+}
+
 #ifdef VDL2_K5_PROF
 int vdl2hip_debug_k5_prof(unsigned long long out[16]) {
 	return hipMemcpyFromSymbol(out, HIP_SYMBOL(vdl2_k5_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;

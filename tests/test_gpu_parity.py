@@ -581,3 +581,20 @@ def test_dropin_adapter_over_several_devices(vh, tmp_path):
             got.append((int(kv["freq"]), int(kv["idx"]), hashlib.sha1(bytes.fromhex(kv["octets"])).hexdigest(), int(kv["S"]), int(kv["L"]), int(kv["F"])))
     want = [(cfg.freqs[f["chan"]], f["idx"], f["sha1"], f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"]) for f in gold["frames"]]
     assert sorted(got) == sorted(want) and len(got) > 20
+
+
+def test_dpp_primitives_behave_as_the_scan_assumes(vh):
+    """The channeliser's wave scan (kernels.h) moves filter states between lanes with DPP controls: row_shr inside rows of 16 lanes
+    (out-of-row sources read 0), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3, wave_shr:1 across the wavefront."""
+    import ctypes as C
+    L = vh.load_library()
+    L.vdl2hip_debug_dpp_probe.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    a = (C.c_float * 64)(*[float(l + 1) for l in range(64)])
+    out = (C.c_float * 256)()
+    assert L.vdl2hip_debug_dpp_probe(a, out) == 0
+    o = np.array(out[:]).reshape(4, 64)
+    lanes = np.arange(64)
+    assert np.array_equal(o[0], np.where((lanes & 15) >= 4, lanes - 4 + 1, 0))
+    assert np.array_equal(o[1], np.where((lanes // 16) % 2 == 1, (lanes // 16) * 16 - 1 + 1, 0))
+    assert np.array_equal(o[2], np.where(lanes >= 32, 32, 0))
+    assert np.array_equal(o[3], np.where(lanes >= 1, lanes, 0))
