@@ -23,6 +23,7 @@
 #ifndef VDL2_K1_UNROLL
 #define VDL2_K1_UNROLL 5
 #endif
+
 #ifndef VDL2_K1_WAVES_PER_EU
 #define VDL2_K1_WAVES_PER_EU 3
 #endif
