@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvdl2hip.so")
-SOURCES = ["vdl2hip.hip", "kernels.h", "vdl2_core.h", "design.h", "tables.h"]
+SOURCES = ["vdl2hip.hip", "group.inc", "kernels.h", "vdl2_core.h", "design.h", "tables.h"]
 # -ffp-contract=off: the walker/burst code must keep the reference's mul/add sequence;
 # the channeliser asks for FMAs explicitly where it wants them.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]

@@ -806,225 +806,4 @@ int vdl2hip_read_decimated(vdl2hip_ctx *c, uint32_t chan, int64_t first, float *
 
 }  // extern "C"
 
-// ======================================================================================================================
-// vdl2hip_group: one receiver spread over several GPUs of THIS process, from plain C (include/vdl2hip.h).  The reference
-// runs one worker per channel over a shared sample block (src/dumpvdl2.c:117-135, src/demod.c:300-301); here the workers
-// are grouped by device: device k of n decodes the contiguous channel range k (the same rule as dist.shard_channels), the
-// block crosses PCIe once (into the first device) and is then put on the other devices over xGMI - with RCCL's
-// ncclBroadcast when librccl.so loads and the devices are distinct, else with hipMemcpyPeerAsync fan-out from the first
-// device (also what "virtual shards" on one device use: the path is testable with one GPU).
-// ======================================================================================================================
-#include <dlfcn.h>
-#include <rccl/rccl.h>
-
-struct vdl2hip_group {
-	int n = 0; size_t in_cap = 0; int fmt = 0; uint64_t feed_no = 0;
-	std::vector<int> dev; std::vector<vdl2hip_ctx *> ctx;
-	std::vector<uint8_t *> blk[kSlots];                 // [slot][device index] input block on that device
-	std::vector<hipStream_t> xs;                         // exchange stream per device (index 0: the H2D stream)
-	std::vector<hipEvent_t> ready[kSlots];               // block of slot k complete on device i
-	// RCCL, loaded at run time (no link-time dependency)
-	void *rccl = nullptr; std::vector<ncclComm_t> comms; bool use_rccl = false;
-	ncclResult_t (*p_init_all)(ncclComm_t *, int, const int *) = nullptr;
-	ncclResult_t (*p_bcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-	ncclResult_t (*p_gstart)() = nullptr; ncclResult_t (*p_gend)() = nullptr; ncclResult_t (*p_destroy)(ncclComm_t) = nullptr;
-	struct QF { HostFrame h; int who; };
-	std::vector<QF> merged;
-};
-
-namespace {
-struct DeviceGuard {                                      // the calling thread's current device is left as it was found
-	int prev = 0; DeviceGuard() { (void)hipGetDevice(&prev); } ~DeviceGuard() { (void)hipSetDevice(prev); }
-};
-void group_try_rccl(vdl2hip_group *g) {
-	if(getenv("VDL2HIP_NO_RCCL")) return;
-	for(int i = 0; i < g->n; i++) for(int j = 0; j < i; j++) if(g->dev[i] == g->dev[j]) return;    // one communicator rank per GPU
-	if(g->n < 2) return;
-	g->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-	if(!g->rccl) g->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-	if(!g->rccl) return;
-	g->p_init_all = (decltype(g->p_init_all))dlsym(g->rccl, "ncclCommInitAll");
-	g->p_bcast = (decltype(g->p_bcast))dlsym(g->rccl, "ncclBroadcast");
-	g->p_gstart = (decltype(g->p_gstart))dlsym(g->rccl, "ncclGroupStart");
-	g->p_gend = (decltype(g->p_gend))dlsym(g->rccl, "ncclGroupEnd");
-	g->p_destroy = (decltype(g->p_destroy))dlsym(g->rccl, "ncclCommDestroy");
-	if(!g->p_init_all || !g->p_bcast || !g->p_gstart || !g->p_gend || !g->p_destroy) return;
-	g->comms.assign((size_t)g->n, nullptr);
-	if(g->p_init_all(g->comms.data(), g->n, g->dev.data()) != ncclSuccess) { g->comms.clear(); return; }
-	g->use_rccl = true;
-}
-}  // namespace
-
-extern "C" {
-
-void vdl2hip_group_destroy(vdl2hip_group *g) {
-	if(!g) return;
-	DeviceGuard guard;
-	for(int i = 0; i < g->n; i++) {
-		(void)hipSetDevice(g->dev[i]);
-		if(i < (int)g->ctx.size() && g->ctx[i]) vdl2hip_destroy(g->ctx[i]);
-		if(i < (int)g->xs.size() && g->xs[i]) { (void)hipStreamSynchronize(g->xs[i]); (void)hipStreamDestroy(g->xs[i]); }
-		for(int k = 0; k < kSlots; k++) {
-			if(i < (int)g->blk[k].size() && g->blk[k][i]) (void)hipFree(g->blk[k][i]);
-			if(i < (int)g->ready[k].size() && g->ready[k][i]) (void)hipEventDestroy(g->ready[k][i]);
-		}
-		if(g->use_rccl && i < (int)g->comms.size() && g->comms[i]) (void)g->p_destroy(g->comms[i]);
-	}
-	if(g->rccl) dlclose(g->rccl);
-	delete g;
-}
-
-int vdl2hip_group_create(const vdl2hip_cfg *cfg, const int32_t *devices, uint32_t ndev, vdl2hip_group **out) {
-	if(!cfg || !out || !devices || ndev == 0 || ndev > 64 || cfg->struct_size < sizeof(vdl2hip_cfg) || !cfg->freqs || cfg->nchan < ndev) return VDL2HIP_E_INVAL;
-	if(cfg->chan_first != 0 || cfg->chan_count != 0) return VDL2HIP_E_INVAL;      // the group does the sharding
-	*out = nullptr;
-	DeviceGuard guard;
-	vdl2hip_group *g = new(std::nothrow) vdl2hip_group();
-	if(!g) return VDL2HIP_E_NOMEM;
-	g->n = (int)ndev; g->dev.assign(devices, devices + ndev);
-	g->in_cap = cfg->max_block_bytes ? cfg->max_block_bytes : 320000u; g->fmt = (int)cfg->sample_fmt;
-	g->ctx.assign(ndev, nullptr); g->xs.assign(ndev, nullptr);
-	for(int k = 0; k < kSlots; k++) { g->blk[k].assign(ndev, nullptr); g->ready[k].assign(ndev, nullptr); }
-	const uint32_t base = cfg->nchan / ndev, extra = cfg->nchan % ndev;
-	for(uint32_t i = 0; i < ndev; i++) {
-		vdl2hip_cfg c = *cfg;
-		c.device = devices[i];
-		c.chan_first = i * base + std::min(i, extra);                           // dist.shard_channels()
-		c.chan_count = base + (i < extra ? 1u : 0u);
-		int r = vdl2hip_create(&c, &g->ctx[i]);
-		if(r != VDL2HIP_OK) { vdl2hip_group_destroy(g); return r; }
-		bool ok = hipSetDevice(devices[i]) == hipSuccess && hipStreamCreateWithFlags(&g->xs[i], hipStreamNonBlocking) == hipSuccess;
-		for(int k = 0; k < kSlots && ok; k++)
-			ok = hipMalloc((void **)&g->blk[k][i], g->in_cap + 16) == hipSuccess && hipEventCreateWithFlags(&g->ready[k][i], hipEventDisableTiming) == hipSuccess;
-		if(!ok) { vdl2hip_group_destroy(g); return VDL2HIP_E_NOMEM; }
-		if(i > 0 && devices[i] != devices[0]) { int can = 0; (void)hipDeviceCanAccessPeer(&can, devices[i], devices[0]); if(can) (void)hipDeviceEnablePeerAccess(devices[0], 0); }
-	}
-	group_try_rccl(g);
-	*out = g;
-	return VDL2HIP_OK;
-}
-
-uint32_t vdl2hip_group_size(vdl2hip_group *g) { return g ? (uint32_t)g->n : 0u; }
-vdl2hip_ctx *vdl2hip_group_ctx(vdl2hip_group *g, uint32_t i) { return g && i < (uint32_t)g->n ? g->ctx[i] : nullptr; }
-int vdl2hip_group_uses_rccl(vdl2hip_group *g) { return g && g->use_rccl ? 1 : 0; }
-
-int vdl2hip_group_feed(vdl2hip_group *g, const void *buf, size_t nbytes) {
-	if(!g || (!buf && nbytes)) return VDL2HIP_E_INVAL;
-	if(nbytes == 0) return VDL2HIP_OK;
-	if(nbytes > g->in_cap) return VDL2HIP_E_TOOBIG;
-	nbytes -= nbytes % sample_bytes(g->fmt);
-	DeviceGuard guard;
-	const int k = (int)(g->feed_no % kSlots);
-	// the buffers of this slot were last read by the channelisers of feed i - kSlots: every member has to be past that
-	for(int i = 0; i < g->n; i++) {
-		HIPCHK(hipSetDevice(g->dev[i]));
-		vdl2hip_ctx *c = g->ctx[i];
-		if(c->failed) return VDL2HIP_E_DEVICE;
-		int r = collect_slot(c, c->slot[c->feed_no % kSlots]);
-		if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
-	}
-	HIPCHK(hipSetDevice(g->dev[0]));
-	HIPCHK(hipMemcpyAsync(g->blk[k][0], buf, nbytes, hipMemcpyHostToDevice, g->xs[0]));   // the block crosses PCIe once
-	HIPCHK(hipEventRecord(g->ready[k][0], g->xs[0]));
-	bool sent = false;
-	if(g->use_rccl) {
-		// ncclBroadcast over xGMI, one rank per device, all enqueued from this thread as one group
-		bool ok = true;
-		for(int i = 1; i < g->n && ok; i++) { ok = hipSetDevice(g->dev[i]) == hipSuccess && hipStreamWaitEvent(g->xs[i], g->ready[k][0], 0) == hipSuccess; }
-		ok = ok && g->p_gstart() == ncclSuccess;
-		for(int i = 0; i < g->n && ok; i++)
-			ok = g->p_bcast(g->blk[k][0], g->blk[k][i], nbytes, ncclChar, 0, g->comms[i], g->xs[i]) == ncclSuccess;
-		ok = g->p_gend() == ncclSuccess && ok;
-		if(ok) {
-			sent = true;
-			for(int i = 0; i < g->n; i++) { HIPCHK(hipSetDevice(g->dev[i])); HIPCHK(hipEventRecord(g->ready[k][i], g->xs[i])); }
-		} else {
-			fprintf(stderr, "vdl2hip: RCCL broadcast failed - falling back to peer copies\n");
-			g->use_rccl = false;
-		}
-	}
-	if(!sent) {
-		for(int i = 1; i < g->n; i++) {
-			HIPCHK(hipSetDevice(g->dev[i]));
-			HIPCHK(hipStreamWaitEvent(g->xs[i], g->ready[k][0], 0));
-			HIPCHK(hipMemcpyPeerAsync(g->blk[k][i], g->dev[i], g->blk[k][0], g->dev[0], nbytes, g->xs[i]));
-			HIPCHK(hipEventRecord(g->ready[k][i], g->xs[i]));
-		}
-	}
-	HIPCHK(hipEventSynchronize(g->ready[k][0]));          // `buf` is only ours during the call
-	int rc = VDL2HIP_OK;
-	for(int i = 0; i < g->n; i++) {
-		HIPCHK(hipSetDevice(g->dev[i]));
-		HIPCHK(hipStreamWaitEvent(g->ctx[i]->stream, g->ready[k][i], 0));
-		int r = feed_common(g->ctx[i], g->blk[k][i], nbytes);
-		if(r != VDL2HIP_OK) rc = r;
-	}
-	g->feed_no++;
-	return rc;
-}
-
-int vdl2hip_group_sync(vdl2hip_group *g) {
-	if(!g) return VDL2HIP_E_INVAL;
-	DeviceGuard guard;
-	int rc = VDL2HIP_OK;
-	for(int i = 0; i < g->n; i++) { HIPCHK(hipSetDevice(g->dev[i])); int r = vdl2hip_sync(g->ctx[i]); if(r != VDL2HIP_OK) rc = r; }
-	return rc;
-}
-
-// deliver every finished frame of every member, merged into the order vdl2hip_drain() uses: (end_sample, chan, idx)
-int vdl2hip_group_drain(vdl2hip_group *g, vdl2hip_frame_cb cb, void *user) {
-	if(!g) return VDL2HIP_E_INVAL;
-	DeviceGuard guard;
-	for(int i = 0; i < g->n; i++) {
-		HIPCHK(hipSetDevice(g->dev[i]));
-		vdl2hip_ctx *c = g->ctx[i];
-		if(c->failed) return VDL2HIP_E_DEVICE;
-		int r = collect_pending(c, c->drain_lag);
-		if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
-		for(auto &h : c->queue) g->merged.push_back(vdl2hip_group::QF{ std::move(h), i });
-		c->queue.clear();
-	}
-	std::stable_sort(g->merged.begin(), g->merged.end(), [g](const vdl2hip_group::QF &a, const vdl2hip_group::QF &b) {
-		if(a.h.f.end_sample != b.h.f.end_sample) return a.h.f.end_sample < b.h.f.end_sample;
-		const int ca = a.h.f.chan + g->ctx[a.who]->chan_first, cb_ = b.h.f.chan + g->ctx[b.who]->chan_first;
-		if(ca != cb_) return ca < cb_;
-		return a.h.f.idx < b.h.f.idx;
-	});
-	int n = 0;
-	for(const auto &q : g->merged) {
-		if(cb) { vdl2hip_frame f{}; fill_frame(g->ctx[q.who], q.h, f); cb(&f, user); }
-		n++;
-	}
-	g->merged.clear();
-	return n;
-}
-
-int vdl2hip_group_set_drain_lag(vdl2hip_group *g, int lag) {
-	if(!g) return VDL2HIP_E_INVAL;
-	for(int i = 0; i < g->n; i++) { int r = vdl2hip_set_drain_lag(g->ctx[i], lag); if(r != VDL2HIP_OK) return r; }
-	return VDL2HIP_OK;
-}
-
-static vdl2hip_ctx *group_owner(vdl2hip_group *g, uint32_t chan) {
-	if(!g) return nullptr;
-	for(int i = 0; i < g->n; i++) if(chan >= (uint32_t)g->ctx[i]->chan_first && chan < (uint32_t)(g->ctx[i]->chan_first + g->ctx[i]->C)) return g->ctx[i];
-	return nullptr;
-}
-
-int vdl2hip_group_counters(vdl2hip_group *g, uint32_t chan, uint64_t out[VDL2HIP_NUM_COUNTERS]) {
-	vdl2hip_ctx *c = group_owner(g, chan);
-	if(!c) return VDL2HIP_E_INVAL;
-	DeviceGuard guard;
-	HIPCHK(hipSetDevice(c->cfg.device));
-	return vdl2hip_counters(c, chan, out);
-}
-
-int vdl2hip_group_avlc_counters(vdl2hip_group *g, uint32_t chan, uint64_t out[VDL2HIP_NUM_AVLC_COUNTERS]) {
-	vdl2hip_ctx *c = group_owner(g, chan);
-	if(!c) return VDL2HIP_E_INVAL;
-	DeviceGuard guard;
-	HIPCHK(hipSetDevice(c->cfg.device));
-	return vdl2hip_avlc_counters(c, chan, out);
-}
-
-}  // extern "C"
+#include "group.inc"   // vdl2hip_group_*: one receiver over several GPUs of this process (needs the statics above)
