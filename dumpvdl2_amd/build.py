@@ -9,7 +9,10 @@ LIB = os.path.join(HERE, "libvdl2hip.so")
 SOURCES = ["vdl2hip.hip", "group.inc", "kernels.h", "vdl2_core.h", "design.h", "tables.h"]
 # -ffp-contract=off: the walker/burst code must keep the reference's mul/add sequence;
 # the channeliser asks for FMAs explicitly where it wants them.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+# -fno-slp-vectorize: packed FP32 issues at half rate on CDNA4, so a v_pk_add the SLP vectoriser glues together from two scalar
+# adds gains nothing and costs the moves that line its operands up (sync screening kernel 2.05 -> 1.71 ms at 256 channels, the
+# channeliser 1 % faster; gpurun_out r02q).  Where the channeliser wants packed operations it writes float2 arithmetic itself.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall"]
 
 
 def hipcc_path():

@@ -483,46 +483,76 @@ struct K3Args {
 // K3: got_sync() metric (contiguous ring) + the candidate bitmap, in two tiers and two kernels.
 //
 // k_sync_screen - every decimated sample.  A block turns kK3Tile consecutive outputs (+150 back) into screening-precision
-// phases (phase_fast) in LDS, so the 16 taps are plain ds_reads at constant offsets, and gives every sample the cheap
-// screening value of the metric (vdl2_core.h: same unwrap decisions, running sums, float only).  Output: one flag bit per
-// sample - "the exact value may be under the threshold".
+// phases (phase_fast, in turns) in LDS and gives every sample the cheap screening value of the metric (vdl2_core.h: same unwrap
+// decisions, running sums, float only).  The windows of samples n, n+10, n+20, n+30 read the same taps one place apart, so one
+// lane takes those four: it reads 15 phases for what would be 48, forms the 14 tap-to-tap differences once, and walks the four
+// windows one after the other (each with the wavefront-wide early exit).  Ten consecutive lanes cover 40 consecutive samples;
+// 320 threads cover the tile.  Verdicts go through LDS to be regrouped into words of 64 consecutive samples.  Output: one flag
+// bit per sample - "the exact value may be under the threshold".
 //
 // k_sync_exact - only where a flag is set (on noise 3e-5 of the samples): the reference's arithmetic - atan2 in double on the
 // 16 taps, the double-precision unwrap, the centred regression - for the flagged samples and 3 samples either side (those are
 // y1/y3 of calc_para_vertex and the right-hand side of the candidate test), stored in pf, and the candidate bit
 // pherr(n-3) < 4 && pherr(n) > pherr(n-3) of every sample.  The walker reads the metric nowhere else.  A sample whose right
 // neighbour has not arrived yet is computed exactly; the next feed redoes the last partial bitmap word anyway.
-constexpr int kK3Tile = 1024;
+constexpr int kK3Tile = 1280, kK3Threads = 320, kK3Share = 4;
+static_assert(kK3Tile == kK3Threads * kK3Share && kK3Tile % 64 == 0 && kK3Threads % 10 == 0 && (kK3Tile / 64) % (kK3Threads / 64) == 0, "screen tile");
 
-__global__ __launch_bounds__(256) void k_sync_screen(K3Args a) {
+__global__ __launch_bounds__(kK3Threads) void k_sync_screen(K3Args a) {
 	__shared__ float tile[kK3Tile + 150];           // screening phases of samples nblk-150 .. nblk+kK3Tile-1
+	__shared__ uint8_t verdict[kK3Tile];
 	const int c = blockIdx.y, tid = threadIdx.x;
 	const int64_t nblk = a.nbase + (int64_t)blockIdx.x * kK3Tile;
 	const cf32 *y = a.y + (size_t)c * a.cap;
-	const Tables &T = *a.tab;
-	for(int j = tid; j < kK3Tile + 150; j += 256) {
-		const int64_t t = nblk - 150 + j;
-		tile[j] = (t < 0 || t >= a.k1) ? 0.f : phase_fast(y[(uint32_t)t & a.mask]);
+	constexpr int kFull = (kK3Tile + 150) / kK3Threads, kRest = (kK3Tile + 150) % kK3Threads;
+	if(nblk >= 150 && nblk + kK3Tile <= a.k1) {
+		// the whole tile and its history exist (all but the first and last block of a channel): no per-sample range tests, ring
+		// offsets in 32 bits, all loads in flight before the first phase is worked out
+		const uint32_t r0 = (uint32_t)(nblk - 150) + tid;
+		cf32 v[kFull + 1];
+		#pragma unroll
+		for(int k = 0; k <= kFull; k++) if(k < kFull || tid < kRest) v[k] = y[(r0 + kK3Threads * k) & a.mask];
+		#pragma unroll
+		for(int k = 0; k <= kFull; k++) if(k < kFull || tid < kRest) tile[tid + kK3Threads * k] = phase_fast(v[k]);
+	} else {
+		for(int j = tid; j < kK3Tile + 150; j += kK3Threads) {
+			const int64_t t = nblk - 150 + j;
+			tile[j] = (t < 0 || t >= a.k1) ? 0.f : phase_fast(y[(uint32_t)t & a.mask]);
+		}
 	}
 	__syncthreads();
-	float ph[kPreamble];
+	// this lane's windows: samples nblk + s0 + 10 q, q = 0..3; tap i of window q is tile[s0 + 10 (q + i)]
+	const int s0 = 10 * kK3Share * (tid / 10) + tid % 10;
+	constexpr int kEarlyPh = kScreenEarly + kK3Share - 1;             // phases the first kScreenEarly taps of the four windows touch
+	float ph[kEarlyPh], d[kEarlyPh];
 	#pragma unroll
-	for(int q = 0; q < kK3Tile / 256; q++) {
-		const int i0 = tid + 256 * q;               // sample nblk + i0: phases tile[i0 + 10 i]
-		const int64_t n = nblk + i0;
-		#pragma unroll
-		for(int i = 0; i < kScreenEarly; i++) ph[i] = tile[i0 + 10 * i];
+	for(int k = 0; k < kEarlyPh; k++) ph[k] = tile[s0 + 10 * k];
+	#pragma unroll
+	for(int k = 1; k < kEarlyPh; k++) d[k] = ph[k] - ph[k - 1];
+	#pragma unroll
+	for(int q = 0; q < kK3Share; q++) {
 		// the first kScreenEarly taps bound the value from below: most wavefronts stop here
 		ScreenAcc acc;
-		screen_taps(ph, T, 0, kScreenEarly, acc);
+		screen_begin(acc, ph[q]);
+		screen_taps(&d[q], 1, kScreenEarly, acc);
 		float ps = screen_value(acc, kScreenEarly);
 		if(__any(ps < kScreenEarlyThr)) {
+			float pl[kPreamble - kScreenEarly + 1], dl[kPreamble];
 			#pragma unroll
-			for(int i = kScreenEarly; i < kPreamble; i++) ph[i] = tile[i0 + 10 * i];
-			screen_taps(ph, T, kScreenEarly, kPreamble, acc);
+			for(int j = 0; j <= kPreamble - kScreenEarly; j++) pl[j] = tile[s0 + 10 * (q + kScreenEarly - 1 + j)];
+			#pragma unroll
+			for(int j = 0; j < kPreamble - kScreenEarly; j++) dl[kScreenEarly + j] = pl[j + 1] - pl[j];
+			screen_taps(dl, kScreenEarly, kPreamble, acc);
 			ps = screen_value(acc, kPreamble);
 		}
-		const unsigned long long bits = __ballot(n < a.k1 && ps < kScreenThr);
+		verdict[s0 + 10 * q] = !(ps >= kScreenThr);      // a NaN (sample too small for phase_fast) goes to the exact tier
+	}
+	__syncthreads();
+	#pragma unroll
+	for(int j = 0; j < (kK3Tile / 64) / (kK3Threads / 64); j++) {
+		const int word = (tid >> 6) * ((kK3Tile / 64) / (kK3Threads / 64)) + j;
+		const int64_t n = nblk + 64 * word + (tid & 63);
+		const unsigned long long bits = __ballot(n < a.k1 && verdict[64 * word + (tid & 63)] != 0);
 		if((tid & 63) == 0 && n < a.k1) a.flag[(size_t)c * (a.cap >> 6) + ((uint32_t)(n >> 6) & (a.mask >> 6))] = bits;
 	}
 }

@@ -264,25 +264,34 @@ VDL2_HD double atan2_f64(double y, double x) {
 }
 VDL2_HD float phase_of(cf32 y) { return (float)atan2_f64((double)y.im, (double)y.re); }
 
-// Single-precision phase for the sync kernel's screening tier only: odd minimax polynomial of degree 13 on min/max, error
-// < 5e-7 rad (tests/test_phase.py).  No decision is taken on it: a window whose screening value is near the threshold, or
-// in which one of its unwrap decisions could go the other way with the exact phases, is redone exactly (kScreenGuard).
+// Single-precision phase for the sync kernel's screening tier only, in TURNS (-0.5, 0.5]: odd minimax polynomial of degree 13
+// on min/max with the 1/2pi folded into its coefficients, error < 1e-7 turn = 6e-7 rad (tests/test_phase.py).  No decision is
+// taken on it: a window whose screening value is near the threshold, or in which one of its unwrap decisions could go the other
+// way with the exact phases, is redone exactly (kScreenGuard).  Turns, because the unique word's phases are exact eighths then
+// and the unwrap "subtract the nearest whole turn" is a v_rndne and a subtraction.
 VDL2_HD float phase_fast(cf32 y) {
 	const float ax = fabsf(y.re), ay = fabsf(y.im);
-	const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
-	if(!(mx > 0.f)) return 0.f;
+	const bool steep = ay > ax;
 #if VDL2_DEVICE_PASS
-	const float t = mn * __builtin_amdgcn_rcpf(mx);
+	// branch-free, 19 instructions.  A zero sample gives 0 (v_mul_legacy: 0 * inf = 0); a sample so small that v_rcp overflows
+	// gives a NaN, which the screening kernel reads as "flag it"
+	const float mx = steep ? ay : ax, mn = __builtin_amdgcn_fmed3f(ax, ay, 0.f);
+	float t;
+	// (the s_nop is the wait state a VALU read of a transcendental result needs on gfx940+; the compiler does not look inside)
+	asm("s_nop 0\n\tv_mul_legacy_f32 %0, %1, %2" : "=v"(t) : "v"(mn), "v"(__builtin_amdgcn_rcpf(mx)));
 #else
+	const float mx = steep ? ay : ax, mn = steep ? ax : ay;
+	if(!(mx > 0.f)) return 0.f;
 	const float t = mn / mx;
 #endif
 	const float z = t * t;
-	float p = 0.006811664905399084f;
-	p = fmaf(p, z, -0.03360380604863167f); p = fmaf(p, z, 0.07962316274642944f); p = fmaf(p, z, -0.13233311474323273f);
-	p = fmaf(p, z, 0.19807806611061096f); p = fmaf(p, z, -0.3331736624240875f); p = fmaf(p, z, 0.9999961256980896f);
+	constexpr double k = 0.15915494309189535;     // 1 / 2 pi
+	float p = (float)(0.006811664905399084 * k);
+	p = fmaf(p, z, (float)(-0.03360380604863167 * k)); p = fmaf(p, z, (float)(0.07962316274642944 * k)); p = fmaf(p, z, (float)(-0.13233311474323273 * k));
+	p = fmaf(p, z, (float)(0.19807806611061096 * k)); p = fmaf(p, z, (float)(-0.3331736624240875 * k)); p = fmaf(p, z, (float)(0.9999961256980896 * k));
 	float a = p * t;
-	if(ay > ax) a = 1.5707963267948966f - a;
-	if(y.re < 0.f) a = 3.141592653589793f - a;
+	a = steep ? 0.25f - a : a;
+	a = y.re < 0.f ? 0.5f - a : a;
 	return copysignf(a, y.im);
 }
 
@@ -319,61 +328,82 @@ VDL2_HD void sync_metric(const float *ph, const Tables &T, float &pherr, float &
 	pherr = acc; slope_out = slope;
 }
 
-// Screening form of sync_metric(): the same unwrap decisions (they depend only on float differences), but the
-// unwrap offset accumulated in float and the residual taken from running sums, p = S2 - S0^2/16 - S1^2/den.  It differs
-// from the exact value by rounding only (< 0.1 for any phase sequence: |e| <= 16*pi, S2 <= 4e4), which is all the sync
-// kernel needs to know that a sample is nowhere near the threshold kSyncThr.
+// Screening form of sync_metric(): the same unwrap decisions, taken on single-precision phases in turns, and the residual from
+// running sums, p = S2 - S0^2/16 - S1^2/den.  It works on the raw differences d[i] = phase(tap i) - phase(tap i-1) - which the
+// windows n, n+10, n+20, ... share, so a lane that screens several of those forms them once - and the unique word's own phase
+// steps, which are exact eighths of a turn:
+//   u = d[i] - dq[i]/8                    the reference's cur[i] - cur[i-1]                              (demod.c:133-136)
+//   w = u - clamp(rint(u), -1, 1)         one step of -+2 pi when the difference is beyond +-pi          (demod.c:137-141)
+//   e[i] = e[i-1] + w                     = cur[i] + unwrap
+// It differs from the exact value by rounding only (< 0.2 rad^2 for any phase sequence), which is all the sync kernel needs to
+// know that a sample is nowhere near the threshold kSyncThr.  screen_value() is in rad^2 like the exact metric.
 constexpr float kScreenThr = 5.5f;
 // The running sums are raw moments (sum e, sum i*e, sum e^2), so the value over the first n taps - the residual of the best
 // line through those n points, a lower bound of the residual over all 16 - is available along the way: the sync kernel stops
 // after kScreenEarly taps when no lane of the wavefront is still under the threshold (97 % of them on noise or data).
 constexpr int kScreenEarly = 12;
 constexpr float kScreenEarlyThr = 5.8f;   // early bound + its rounding slack must stay above kScreenThr
-// The screening tier runs on phase_fast() phases (error < 5e-7 rad each), so an unwrap decision - "is the difference of two
-// taps beyond +-pi" - could differ from the one the exact phases give when the difference is within ~2e-6 of +-pi.  `guard`
-// is the smallest distance of any difference from +-pi: a window where it is under kScreenGuard is treated as flagged.
-constexpr float kScreenGuard = 2e-5f;
-struct ScreenAcc { float prev, unwrap, m0, m1, m2, guard; };
+// An unwrap decision - "is the difference of two taps beyond half a turn" - could differ from the one the reference takes on
+// its own phases when |u| is within the combined error of 0.5: two phase_fast() errors (2e-7 turn), the roundings of d and u
+// (1.8e-7 turn) and the reference's own three roundings in radians (1e-6 rad = 1.6e-7 turn).  A window where some |u| comes
+// within kScreenGuard of 0.5 is treated as flagged.  (|u| = 1.5, where the clamp starts to matter, is not a decision of the
+// reference - it never takes a second step - and needs no guard: rint() and the clamp give the same w on both sides of it.)
+constexpr float kScreenGuard = 3.2e-6f;   // turns (2e-5 rad)
+// cumulative unique-word phases in eighths of a turn (tables.h: q[]) differenced: dq[i] = q[i] - q[i-1]
+VDL2_HD constexpr int screen_dq(int i) {
+	constexpr int dq[kPreamble] = { 0, 3, -6, 4, 0, 1, -2, 4, -7, 7, -6, 5, -2, -3, -1, 3 };
+	return dq[i];
+}
+// gmax: largest |w| over the taps whose |u| cannot reach 1.5 (|d| <= 1, |dq| < 4), where 0.5 - |w| is the distance from the
+// decision; gmin: smallest ||u| - 0.5| over the others
+struct ScreenAcc { float e, m0, m1, m2, gmax, gmin; };
 
-VDL2_HD void screen_taps(const float *ph, const Tables &T, int i0, int i1, ScreenAcc &a) {
-	if(i0 == 0) {
-		a.prev = ph[0] - T.pr_phase[0]; a.unwrap = 0.f;
-		a.m0 = a.prev; a.m1 = 0.f; a.m2 = a.prev * a.prev; a.guard = 1.f;
-		i0 = 1;
-	}
+VDL2_HD void screen_begin(ScreenAcc &a, float ph0) {   // tap 0: e[0] = phase - 0
+	a.e = ph0; a.m0 = ph0; a.m1 = 0.f; a.m2 = ph0 * ph0; a.gmax = 0.f; a.gmin = 1.f;
+}
+
+// taps i0 <= i < i1 (i0 >= 1), d[i] as above
+VDL2_HD void screen_taps(const float *d, int i0, int i1, ScreenAcc &a) {
 	for(int i = i0; i < i1; i++) {
-		const float cur = ph[i] - T.pr_phase[i];
-		const float diff = cur - a.prev;
-		a.prev = cur;
-		// the reference's rule - one step of -+2 pi when the difference is beyond +-pi (demod.c:137-141) - as arithmetic:
-		// round(diff / 2 pi) clamped to +-1 (|diff| < 4 pi).  The two can only disagree within a few ulps of +-pi, deep inside
-		// the guard zone, where the window goes to the exact tier anyway.
-		float q = rintf(diff * (float)(0.5 / M_PI));
+		const int dq = screen_dq(i);
+		const float u = dq == 0 ? d[i] : d[i] - 0.125f * (float)dq;
+		float q = rintf(u);
+		float w;
+		if(dq > -4 && dq < 4) {
+			w = u - q;                                // |u| < 1.5: rint() is already within +-1
+			a.gmax = fmaxf(a.gmax, fabsf(w));
+		} else {
 #if VDL2_DEVICE_PASS
-		q = __builtin_amdgcn_fmed3f(q, -1.f, 1.f);
+			q = __builtin_amdgcn_fmed3f(q, -1.f, 1.f);
 #else
-		q = q < -1.f ? -1.f : (q > 1.f ? 1.f : q);
+			q = q < -1.f ? -1.f : (q > 1.f ? 1.f : q);
 #endif
-		a.unwrap = fmaf(q, -(float)(2.0 * M_PI), a.unwrap);
-		a.guard = fminf(a.guard, fabsf(fabsf(diff) - kPiBelow));
-		const float e = cur + a.unwrap;
-		a.m0 += e; a.m1 = fmaf((float)i, e, a.m1); a.m2 = fmaf(e, e, a.m2);
+			w = u - q;
+			a.gmin = fminf(a.gmin, fabsf(fabsf(u) - 0.5f));
+		}
+		a.e += w;
+		a.m0 += a.e; a.m1 = fmaf((float)i, a.e, a.m1); a.m2 = fmaf(a.e, a.e, a.m2);
 	}
 }
 
 // residual of the least-squares line through the first n points: m2 - m0^2/n - (m1 - xbar m0)^2 / Sxx, Sxx = n(n^2-1)/12
-// (n is a constant at every call site: the reciprocals fold, no division is executed - it is a screening value)
+// (n is a constant at every call site: the reciprocals fold, no division is executed - it is a screening value), in rad^2
 VDL2_HD float screen_value(const ScreenAcc &a, int n) {
 	const float xbar = 0.5f * (float)(n - 1), inv_n = 1.0f / (float)n, inv_sxx = 12.0f / (float)(n * (n * n - 1));
 	const float c = a.m1 - xbar * a.m0;
-	const float v = a.m2 - a.m0 * a.m0 * inv_n - c * c * inv_sxx;
-	return a.guard < kScreenGuard ? 0.f : v;        // an unwrap decision too close to call: let the exact tier look
+	const float v = (a.m2 - a.m0 * a.m0 * inv_n - c * c * inv_sxx) * (float)(4.0 * M_PI * M_PI);
+	// an unwrap decision too close to call: let the exact tier look
+	return (a.gmax > 0.5f - kScreenGuard || a.gmin < kScreenGuard) ? 0.f : v;
 }
 
-VDL2_HD float sync_metric_screen(const float *ph, const Tables &T) {
+// ph[i]: phase_fast() of tap i (turns)
+VDL2_HD float sync_metric_screen(const float *ph, int ntaps = kPreamble) {
+	float d[kPreamble];
+	for(int i = 1; i < ntaps; i++) d[i] = ph[i] - ph[i - 1];
 	ScreenAcc a;
-	screen_taps(ph, T, 0, kPreamble, a);
-	return screen_value(a, kPreamble);
+	screen_begin(a, ph[0]);
+	screen_taps(d, 1, ntaps, a);
+	return screen_value(a, ntaps);
 }
 
 // calc_para_vertex(v->sclk = 0, SYNC_SKIP, y1, y2, y3): demod.c:98-103,178

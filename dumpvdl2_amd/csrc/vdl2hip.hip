@@ -258,7 +258,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
 		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1 };
-		LAUNCH_EV(k_sync_screen, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(256), st, EV(4), (hipEvent_t) nullptr, k3);
+		LAUNCH_EV(k_sync_screen, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(kK3Threads), st, EV(4), (hipEvent_t) nullptr, k3);
 		// the exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry
 		// less on the front stream than a separate hipEventRecord
 		const int64_t nwords = ((k1 + 63) >> 6) - (nbase >> 6);

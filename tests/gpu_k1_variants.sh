@@ -2,7 +2,7 @@
 # Development aid: build K1 variants on the GPU box and time them (python tests/gpu_k1_bench.py).
 # usage: tests/gpu_k1_variants.sh "<name>:<flags>" ...   (default set below); channel counts from $CHANS (default "8 64 256")
 cd "$(dirname "$0")/.."
-F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared"
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared"
 if [ $# -eq 0 ]; then set -- "base:" "mb5:-DVDL2_K1_MIN_BLOCKS=5" "cr4mb5:-DVDL2_K1_MIN_BLOCKS_CR4=5" "cr4mb3:-DVDL2_K1_MIN_BLOCKS_CR4=3" "unr4:-DVDL2_K1_UNROLL=4" "unr10:-DVDL2_K1_UNROLL=10"; fi
 for v in "$@"; do ( hipcc $F ${v#*:} -o /tmp/k1_${v%%:*}.so dumpvdl2_amd/csrc/vdl2hip.hip 2>/dev/null || echo "build of $v failed" ) & done
 wait

@@ -84,9 +84,11 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 				if(n < 0 || n >= k1) return kPherrBig;
 				float ph[kPreamble];
 				for(int i = 0; i < kPreamble; i++) { int64_t t = n - 150 + 10 * i; ph[i] = t < 0 ? 0.f : phase_fast(y[(uint32_t)t & s->mask]); }
-				ScreenAcc a; screen_taps(ph, s->T, 0, kScreenEarly, a);
+				float d[kPreamble];
+				for(int i = 1; i < kPreamble; i++) d[i] = ph[i] - ph[i - 1];
+				ScreenAcc a; screen_begin(a, ph[0]); screen_taps(d, 1, kScreenEarly, a);
 				float v = screen_value(a, kScreenEarly);
-				if(v < kScreenEarlyThr) { screen_taps(ph, s->T, kScreenEarly, kPreamble, a); v = screen_value(a, kPreamble); }
+				if(v < kScreenEarlyThr) { screen_taps(d, kScreenEarly, kPreamble, a); v = screen_value(a, kPreamble); }
 				return v;
 			};
 			for(int64_t n = nb; n < ne + 3; n++) scr[(size_t)(n - nb)] = screen_at(n);
@@ -180,7 +182,7 @@ void hostsim_avlc_counters(Sim *s, int chan, unsigned long long *out) { memcpy(o
 void hostsim_counters(Sim *s, int chan, unsigned long long *out) { memcpy(out, &s->cnt[(size_t)chan * kNumCounters], sizeof(unsigned long long) * kNumCounters); }
 // phase_of() of the device code on n (re, im) pairs, for comparison with libm
 void hostsim_phase(const float *reim, float *out, int64_t n) { for(int64_t i = 0; i < n; i++) out[i] = phase_of(cf32{reim[2 * i], reim[2 * i + 1]}); }
-// the screening-tier phase of the sync kernel
+// the screening-tier phase of the sync kernel (turns)
 void hostsim_phase_fast(const float *reim, float *out, int64_t n) { for(int64_t i = 0; i < n; i++) out[i] = phase_fast(cf32{reim[2 * i], reim[2 * i + 1]}); }
 float hostsim_screen_guard() { return kScreenGuard; }
 double hostsim_atan2(double y, double x) { return atan2_f64(y, x); }
@@ -193,14 +195,18 @@ void hostsim_metric_pairs(const float *ph, int64_t n, float *exact, float *slope
 	if(!init) { build_tables(T); init = true; }
 	for(int64_t i = 0; i < n; i++) {
 		sync_metric(ph + 16 * i, T, exact[i], slope[i]);
-		screen[i] = sync_metric_screen(ph + 16 * i, T);
+		float pt[16];
+		for(int j = 0; j < 16; j++) pt[j] = ph[16 * i + j] * (float)(0.5 / M_PI);     // the screening tier works in turns
+		screen[i] = sync_metric_screen(pt);
 	}
 }
 // the early bound the sync kernel tests after kScreenEarly taps
 void hostsim_metric_early(const float *ph, int64_t n, float *early) {
-	static Tables T; static bool init = false;
-	if(!init) { build_tables(T); init = true; }
-	for(int64_t i = 0; i < n; i++) { ScreenAcc a; screen_taps(ph + 16 * i, T, 0, kScreenEarly, a); early[i] = screen_value(a, kScreenEarly); }
+	for(int64_t i = 0; i < n; i++) {
+		float pt[16];
+		for(int j = 0; j < 16; j++) pt[j] = ph[16 * i + j] * (float)(0.5 / M_PI);
+		early[i] = sync_metric_screen(pt, kScreenEarly);
+	}
 }
 int hostsim_screen_early_taps() { return kScreenEarly; }
 

@@ -37,8 +37,9 @@ def test_atan2_matches_libm_after_narrowing():
 
 
 def test_screening_phase_is_within_its_guard():
-    """phase_fast() (the sync kernel's screening tier) against the exact phase: the error of a difference of two such phases
-    must stay far inside kScreenGuard, the margin within which an unwrap decision is handed to the exact tier."""
+    """phase_fast() (the sync kernel's screening tier; it works in turns) against the exact phase: the error of a difference of
+    two such phases, plus the roundings on the way to the unwrap decision on both sides, must stay far inside kScreenGuard, the
+    margin within which an unwrap decision is handed to the exact tier."""
     H = C.CDLL(pyhostsim.build())
     H.hostsim_phase.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     H.hostsim_phase_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -55,7 +56,16 @@ def test_screening_phase_is_within_its_guard():
     a = np.empty(len(xy), dtype=np.float32); b = np.empty(len(xy), dtype=np.float32)
     H.hostsim_phase(xy.ctypes.data, a.ctypes.data, len(xy))
     H.hostsim_phase_fast(xy.ctypes.data, b.ctypes.data, len(xy))
-    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
-    d = np.minimum(d, 2 * np.pi - d)                       # +pi and -pi are the same direction
-    assert d.max() < 1e-6, d.max()
-    assert 2 * d.max() + 4 * np.spacing(np.float32(2 * np.pi)) < 0.25 * H.hostsim_screen_guard()
+    assert np.abs(b).max() <= 0.5
+    d = np.abs(a.astype(np.float64) / (2 * np.pi) - b.astype(np.float64))
+    d = np.minimum(d, 1.0 - d)                             # +half a turn and -half a turn are the same direction
+    assert d.max() < 1.2e-7, d.max()                       # turns (7.5e-7 rad)
+    guard = H.hostsim_screen_guard()                       # turns
+    assert abs(guard * 2 * np.pi - 2e-5) < 1e-6
+    # two phase errors + rounding of their difference (|d| <= 1) and of d - k/8 (|u| < 2) + the reference's own three roundings
+    # (two values under 8 rad, one difference under 16 rad) expressed in turns
+    ref_side = (2 * 0.5 * np.spacing(np.float32(4.0)) + 0.5 * np.spacing(np.float32(8.0))) / (2 * np.pi)
+    ours = 2 * d.max() + 0.5 * np.spacing(np.float32(0.5)) + 0.5 * np.spacing(np.float32(1.0))
+    assert ours + ref_side < 0.25 * guard, (ours, ref_side, guard)
+    # a zero sample has phase 0, whichever zero it is
+    assert (b[len(xy) - 3] == 0) and abs(b[len(xy) - 2]) == 0.5
