@@ -680,10 +680,16 @@ struct K4sArgs {
 	K4Args k; SpecOut *spec; uint32_t spec_stride; int32_t nseg; int64_t k0, seglen; uint32_t *seg_stats;
 };
 
-__global__ __launch_bounds__(64, 4) void k_walk_spec(K4sArgs s) {
-	__shared__ WalkShared sh;
+// Four walks per workgroup, one per wavefront (they share nothing): see k_nf_replay for why the back-end kernels that run
+// beside the channeliser come in workgroups of four waves.
+constexpr int kWalkWaves = 4;
+__global__ __launch_bounds__(64 * kWalkWaves, 4) void k_walk_spec(K4sArgs s) {
+	__shared__ WalkShared shw[kWalkWaves];
 	const K4Args &a = s.k;
-	const int c = blockIdx.y, x = blockIdx.x;
+	const int wave = threadIdx.x >> 6;
+	const int c = blockIdx.y, x = blockIdx.x * kWalkWaves + wave;
+	if(x >= 1 + 3 * (s.nseg - 1)) return;
+	WalkShared &sh = shw[wave];
 	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
 	if(x == 0) {
 		EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
@@ -726,15 +732,20 @@ __global__ __launch_bounds__(64) void k_nf_prepare(K4bArgs a) {
 	nf_prepare(&a.nf[c], lg, sc, a.cap_comb, &a.feed[c], sh);
 }
 
-__global__ __launch_bounds__(64) void k_nf_replay(K4bArgs a) {
-	__shared__ NfShared sh;
-	const int c = blockIdx.y;
+// Four wavefronts per workgroup, each with a group of updates of its own: a workgroup then takes exactly the room one
+// channeliser workgroup leaves on a CU (a wave per SIMD inside its 120 registers, 37 KB of LDS), where single-wave workgroups
+// each kept a whole channeliser workgroup out for as long as they lived (measured: the replay beside the channeliser cost the
+// front 0.29 ms per 256-channel step).
+constexpr int kNfWaves = 4;
+__global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_replay(K4bArgs a) {
+	__shared__ NfShared shw[kNfWaves];
+	const int c = blockIdx.y, wave = threadIdx.x >> 6;
 	ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask };
 	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
 	const NfFeed fd = a.feed[c];
-	for(int64_t g = blockIdx.x; fd.u0 + 1 + kNfGroup * g <= fd.u1; g += gridDim.x) {
-		nf_replay_group(v, sc, fd, g, a.lpbuf + (size_t)c * a.cap_hist, a.cap_hist, sh);
-		__syncthreads();
+	for(int64_t g = (int64_t)blockIdx.x * kNfWaves + wave; fd.u0 + 1 + kNfGroup * g <= fd.u1; g += (int64_t)gridDim.x * kNfWaves) {
+		nf_replay_group(v, sc, fd, g, a.lpbuf + (size_t)c * a.cap_hist, a.cap_hist, shw[wave]);
+		WAVE_SYNC();
 	}
 }
 
@@ -769,17 +780,26 @@ struct K5Args {
 	uint32_t cap, mask;
 };
 
+// Two bursts per workgroup, one per wavefront (they share nothing; four would need more LDS than a channeliser workgroup
+// leaves on a CU): see k_nf_replay.
+#ifndef VDL2_K5_WAVES
+#define VDL2_K5_WAVES 2
+#endif
+constexpr int kBurstWaves = VDL2_K5_WAVES;
+// (the LDS is dynamic so that the compiler does not see its size: it would size the register budget by the LDS-limited occupancy
+// and take 169, more than a channeliser wave leaves)
 __global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
-	__shared__ BurstShared sh;
+	extern __shared__ __align__(16) unsigned char k5_lds[];       // BurstShared[kBurstWaves]
+	BurstShared &sh = reinterpret_cast<BurstShared *>(k5_lds)[threadIdx.x >> 6];
 	const uint32_t total = a.bbase[a.nchan];
-	for(uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
+	for(uint32_t g = blockIdx.x * kBurstWaves + (threadIdx.x >> 6); g < total; g += gridDim.x * kBurstWaves) {
 		int lo = 0, hi = a.nchan;                       // channel c with bbase[c] <= g < bbase[c+1]
 		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(a.bbase[mid] <= g) lo = mid; else hi = mid; }
 		const int c = lo;
 		const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - a.bbase[c])];
 		ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask };
 		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
-		__syncthreads();
+		WAVE_SYNC();
 	}
 }
 

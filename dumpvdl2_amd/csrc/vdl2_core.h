@@ -1064,11 +1064,16 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, int64_t k0, 
 // Noise floor: v->mag_lp / v->mag_nf of demod.c:238-243, replayed per feed from the walker's
 // evaluation log.  Update U happens at the (1000*U)-th evaluation; v->mag_lp there is the
 // recurrence mag_lp = mag_lp*0.9 + mag*0.1 over the preceding evaluations, replayed over the last
-// kLpTerms of them (0.9^256 ~ 2e-12, below fp32 resolution).  One lane per update.
+// kLpTerms of them (0.9^256 ~ 2e-12, below fp32 resolution) in the reference's order.
 // ======================================================================
-constexpr int kNfGroup = 16;               // updates replayed per wavefront pass (4 lanes gather for each)
+constexpr int kNfGroup = 32;               // updates a wavefront replays per pass: one lane per update in the recurrence (the cheap part)
+constexpr int kNfSeg = 64;                 // evaluations gathered between two stretches of the recurrence (one per lane)
+static_assert(kLpTerms % kNfSeg == 0, "the replay window is a whole number of gather segments");
 struct NfShared {
-	alignas(16) float mags[kNfGroup][kLpTerms + 1];    // +1: row padding keeps the per-lane replay off one LDS bank
+	alignas(16) float mags[kNfGroup][kNfSeg + 1];      // [update][evaluation of the segment, newest first]; +1: row padding keeps the per-lane replay off one LDS bank
+	float   lp[kNfGroup];                               // the recurrence between segments
+	int64_t pos[kNfGroup], avail[kNfGroup];             // sample of the evaluation that triggers the update; evaluations before it in the same chunk
+	int32_t ci[kNfGroup];                               // its chunk (-1: nothing to replay)
 };
 
 struct NfScratch { int64_t *first; int64_t *cum; };   // combined (tail + feed) chunk list: first sample, ordinal of first evaluation
@@ -1078,7 +1083,7 @@ struct NfFeed { int64_t ev0, ev1, u0, u1, begin_ord; uint32_t ncomb, pad_; };
 
 // pass 1: combined chunk list = remembered tail + this feed's log, with evaluation ordinals (a prefix sum, 64 chunks at a time)
 VDL2_HD void nf_prepare(const NfState *g, const EvalLog &lg, const NfScratch &sc, uint32_t cap_comb, NfFeed *fd, NfShared &sh) {
-	int64_t *cnt64 = reinterpret_cast<int64_t *>(&sh.mags[0][0]);   // 64 counts, then 64 running ordinals
+	int64_t *cnt64 = reinterpret_cast<int64_t *>(&sh.mags[0][0]);   // 64 counts, then 64 running ordinals, then one total
 	const uint32_t nlog = *lg.n;
 	const uint32_t ntail = (uint32_t)g->ntail;
 	uint32_t ntot = ntail + nlog; if(ntot > cap_comb) ntot = cap_comb;
@@ -1112,51 +1117,68 @@ VDL2_HD void nf_prepare(const NfState *g, const EvalLog &lg, const NfScratch &sc
 	LANE0_END
 }
 
-// pass 2 (one wavefront per group of kNfGroup updates): v->mag_lp at each update of the group
+// pass 2 (one wavefront per group of kNfGroup updates): v->mag_lp at each update of the group.
+// The 256 evaluations before an update are gathered 64 at a time, oldest segment first, by the whole wavefront - lane l takes
+// the l-th newest evaluation of the segment, so a load instruction reads 64 evaluations 3 samples apart of one update (1.5 KiB
+// of one channel's ring), 16 updates' worth in flight - then one lane per update runs 64 steps of its recurrence out of LDS.
+// An evaluation's sample follows from the update's own chunk by arithmetic (the stretches of search between bursts are
+// thousands of evaluations long); only a lane whose evaluation lies before the chunk's first walks the chunk list.
 VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFeed &fd, int64_t group, float *lpbuf, uint32_t cap_hist, NfShared &sh) {
 	const int64_t ubase = fd.u0 + 1 + (int64_t)kNfGroup * group;      // first (1-based, global) update of this group
 	if(ubase > fd.u1) return;
 	const int ncomb = (int)fd.ncomb;
+	const int nupd = fd.u1 - ubase + 1 < kNfGroup ? (int)(fd.u1 - ubase + 1) : kNfGroup;
 	WAVE_FOR(l)
-		const int u = l >> 2, part = l & 3;
-		const int64_t U = ubase + u;
-		if(U <= fd.u1) {
-			const int64_t o_last = 1000 * U - 1;                     // ordinal of the evaluation that triggers the update
-			// this lane gathers evaluations o_last - j, j = 64*part .. 64*part+63 (newest first)
-			int64_t o = o_last - 64 * part;
-			int ci = 0; int64_t pos = 0, off = 0;
-			if(o >= fd.begin_ord) {
+		if(l < nupd) {
+			const int64_t o_last = 1000 * (ubase + l) - 1;               // ordinal of the evaluation that triggers the update
+			int ci = -1; int64_t pos = 0, avail = 0;
+			if(o_last >= fd.begin_ord && ncomb > 0) {
 				int lo = 0, hi = ncomb;
-				while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sc.cum[mid] <= o) lo = mid; else hi = mid; }
-				ci = lo; off = o - sc.cum[ci]; pos = sc.first[ci] + 3 * off;
+				while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sc.cum[mid] <= o_last) lo = mid; else hi = mid; }
+				ci = lo; avail = o_last - sc.cum[ci]; pos = sc.first[ci] + 3 * avail;
 			}
-			for(int j0 = 0; j0 < 64; j0 += 8) {
-				int64_t ps[8]; cf32 yv[8];
-				for(int q = 0; q < 8; q++) {
-					ps[q] = -1;
-					if(o >= fd.begin_ord) {
-						ps[q] = pos;
-						o--;
-						if(off > 0) { off--; pos -= 3; }
-						else if(ci > 0 && o >= fd.begin_ord) { ci--; off = sc.cum[ci + 1] - sc.cum[ci] - 1; pos = sc.first[ci] + 3 * off; }
-					} else o--;
-				}
-				for(int q = 0; q < 8; q++) yv[q] = ps[q] >= 0 ? v.Y(ps[q]) : cf32{0.f, 0.f};
-				for(int q = 0; q < 8; q++) sh.mags[u][64 * part + j0 + q] = ps[q] >= 0 ? mag_of(yv[q]) : -1.f;
-			}
+			sh.ci[l] = ci; sh.pos[l] = pos; sh.avail[l] = avail; sh.lp[l] = 0.f;
 		}
 	WAVE_END
-	WAVE_FOR(l)
-		const int64_t U = ubase + l;
-		if(l < kNfGroup && U <= fd.u1) {
-			float lp = 0.f;
-			for(int j = kLpTerms - 1; j >= 0; j--) {
-				const float mg = sh.mags[l][j];
-				if(mg >= 0.f) lp = lp * 0.9f + mg * (1.0f - 0.9f);
+	for(int seg = kLpTerms / kNfSeg - 1; seg >= 0; seg--) {
+		WAVE_FOR(l)
+			const int64_t t = (int64_t)kNfSeg * seg + l;                  // this lane's evaluation: the t-th before the triggering one
+			constexpr int kBatch = 16;
+			for(int u0 = 0; u0 < nupd; u0 += kBatch) {
+				int64_t ps[kBatch]; cf32 yv[kBatch];
+				for(int q = 0; q < kBatch; q++) {
+					const int u = u0 + q;
+					ps[q] = -1;
+					if(u < nupd && sh.ci[u] >= 0) {
+						if(t <= sh.avail[u]) ps[q] = sh.pos[u] - 3 * t;
+						else {                                                  // in an earlier chunk, if anywhere
+							int64_t rem = t - sh.avail[u] - 1;                    // evaluations to skip, counted back from the end of chunk ci-1
+							for(int cj = sh.ci[u] - 1; cj >= 0; cj--) {
+								const int64_t len = sc.cum[cj + 1] - sc.cum[cj];
+								if(rem < len) { ps[q] = sc.first[cj] + 3 * (len - 1 - rem); break; }
+								rem -= len;
+							}
+						}
+					}
+				}
+				for(int q = 0; q < kBatch; q++) yv[q] = ps[q] >= 0 ? v.Y(ps[q]) : cf32{0.f, 0.f};
+				for(int q = 0; q < kBatch; q++) if(u0 + q < nupd) sh.mags[u0 + q][l] = ps[q] >= 0 ? mag_of(yv[q]) : -1.f;
 			}
-			const int64_t i = U - fd.u0;
-			if(i < (int64_t)cap_hist) lpbuf[i] = lp;
-		}
+		WAVE_END
+		WAVE_FOR(l)
+			if(l < nupd) {
+				float lp = sh.lp[l];
+				for(int j = kNfSeg - 1; j >= 0; j--) {
+					const float mg = sh.mags[l][j];
+					if(mg >= 0.f) lp = lp * 0.9f + mg * (1.0f - 0.9f);
+				}
+				sh.lp[l] = lp;
+			}
+		WAVE_END
+	}
+	WAVE_FOR(l)
+		const int64_t i = ubase + l - fd.u0;
+		if(l < nupd && i < (int64_t)cap_hist) lpbuf[i] = sh.lp[l];
 	WAVE_END
 }
 

@@ -45,7 +45,7 @@ struct OutSlot {
 	OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
 	OutCtl *h_ctl = nullptr;               // pinned
-	hipEvent_t done = nullptr, ev_front = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
+	hipEvent_t done = nullptr, ev_front = nullptr, ev_chan = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
 	bool pending = false, ev_valid = false, fused = false; int ev_level = 0;
 	uint64_t seq = 0;
 };
@@ -82,6 +82,7 @@ struct vdl2hip_ctx {
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
 	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr;
+	hipStream_t stream_sync = nullptr;   // K3 of feed i beside the channeliser of feed i+1 (null: K3 stays on the front stream)
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
 	std::vector<uint64_t> statsd_prev;
@@ -257,6 +258,11 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	c->carry_sel ^= 1; c->ncarry = nrem;
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
+		// The sync kernels of this feed need the channeliser of this feed, the channeliser of the next feed does not need them:
+		// on a stream of their own they run beside it (few registers, no LDS to speak of - they fit in beside its waves and
+		// issue while those wait), instead of holding it up.
+		hipStream_t st = c->stream_sync ? c->stream_sync : c->stream;
+		if(c->stream_sync) { HIPCHK(hipEventRecord(sl.ev_chan, c->stream)); HIPCHK(hipStreamWaitEvent(st, sl.ev_chan, 0)); }
 		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1 };
 		LAUNCH_EV(k_sync_screen, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(kK3Threads), st, EV(4), (hipEvent_t) nullptr, k3);
 		// the exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry
@@ -273,7 +279,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	//   stream_nf     K4b  noise floor of feed i, after walk(i)    (each needs the previous one's NfState)
 	//   stream_burst  K5   bursts of feed i, after walk(i); the frames get their noise-floor figure when K4b(i) is done
 	hipStream_t sn_ = c->stream_nf, s5_ = c->stream_burst;
-	if(D <= 0) HIPCHK(hipEventRecord(sl.ev_front, st));
+	if(D <= 0) HIPCHK(hipEventRecord(sl.ev_front, c->stream_sync ? c->stream_sync : st));
 	HIPCHK(hipStreamWaitEvent(sb_, sl.ev_front, 0));
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D;
@@ -285,7 +291,10 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 			const int64_t seglen = (D + nseg - 1) / nseg;
 			nseg = (int)((D + seglen - 1) / seglen);
 			K4sArgs k4s{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, c->k_total, seglen, c->d_segstats };
-			LAUNCH_EV(k_walk_spec, dim3((unsigned)(1 + 3 * (nseg - 1)), (unsigned)c->C), dim3(64), sb_, EV(6), (hipEvent_t) nullptr, k4s);
+#ifdef VDL2_ABLATE
+			if(!(getenv("VDL2HIP_ABLATE") && strstr(getenv("VDL2HIP_ABLATE"), "walk")))
+#endif
+			LAUNCH_EV(k_walk_spec, dim3((unsigned)((1 + 3 * (nseg - 1) + kWalkWaves - 1) / kWalkWaves), (unsigned)c->C), dim3(64 * kWalkWaves), sb_, EV(6), (hipEvent_t) nullptr, k4s);
 			LAUNCH_EV(k_walk_stitch, dim3((unsigned)c->C), dim3(64), sb_, (hipEvent_t) nullptr, EV(7), k4s);
 		} else {
 			LAUNCH_EV(k_walk, dim3((unsigned)c->C), dim3(64), sb_, EV(6), EV(7), k4);
@@ -298,14 +307,20 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		K4bArgs k4b{ c->d_y, c->d_nf, sl.d_log, sl.d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfring, c->nf_ring - 1,
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist };
 		LAUNCH_EV(k_nf_prepare, dim3((unsigned)c->C), dim3(64), sn_, EV(8), (hipEvent_t) nullptr, k4b);
-		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup - 1) / kNfGroup);
-		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64), 0, sn_, k4b);
+		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup * kNfWaves - 1) / (kNfGroup * kNfWaves));   // workgroups per channel
+#ifdef VDL2_ABLATE     // development builds only (tests/gpu_r02_run_s.sh): what does a stage cost the front by running beside it?
+		if(!(getenv("VDL2HIP_ABLATE") && strstr(getenv("VDL2HIP_ABLATE"), "nf")))
+#endif
+		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64 * kNfWaves), 0, sn_, k4b);
 		LAUNCH_EV(k_nf_finish, dim3((unsigned)c->C), dim3(64), sn_, (hipEvent_t) nullptr, EV(9), k4b);
 		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
 		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl, (const uint32_t *)c->d_synctmo);
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
-		LAUNCH_EV(k_burst, dim3(2048), dim3(64), s5_, EV(10), EV(11), k5);
+#ifdef VDL2_ABLATE
+		if(!(getenv("VDL2HIP_ABLATE") && strstr(getenv("VDL2HIP_ABLATE"), "burst")))
+#endif
+		hipExtLaunchKernelGGL(k_burst, dim3(2048 / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)(sizeof(BurstShared) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
 		sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0;
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
 		hipLaunchKernelGGL(k_frame_finish, dim3(1024), dim3(64), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, (const OutCtl *)sl.d_ctl, (const Tables *)c->d_tab,
@@ -366,6 +381,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 		if(sl.done) (void)hipEventDestroy(sl.done);
 		if(sl.ev_walk) (void)hipEventDestroy(sl.ev_walk);
 		if(sl.ev_front) (void)hipEventDestroy(sl.ev_front);
+		if(sl.ev_chan) (void)hipEventDestroy(sl.ev_chan);
 		if(sl.ev_nf) (void)hipEventDestroy(sl.ev_nf);
 		for(int i = 0; i < kNumEv; i++) if(sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
 	}
@@ -374,6 +390,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
 	if(c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
 	if(c->stream_out) { (void)hipStreamSynchronize(c->stream_out); (void)hipStreamDestroy(c->stream_out); }
+	if(c->stream_sync) { (void)hipStreamSynchronize(c->stream_sync); (void)hipStreamDestroy(c->stream_sync); }
 	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
 	if(c->stream_nf) { (void)hipStreamSynchronize(c->stream_nf); (void)hipStreamDestroy(c->stream_nf); }
 	if(c->stream_burst) { (void)hipStreamSynchronize(c->stream_burst); (void)hipStreamDestroy(c->stream_burst); }
@@ -440,11 +457,15 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_burst, hipStreamNonBlocking, prio_of("burst")));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
+		// VDL2HIP_SYNC_STREAM=0|low|high (experiments): K3 on the front stream / on its own stream at the front's or the walk's priority
+		const char *ss = getenv("VDL2HIP_SYNC_STREAM");
+		if(!ss) ss = "0";
+		if(strcmp(ss, "0") != 0) DEV_CHK(hipStreamCreateWithPriority(&c->stream_sync, hipStreamNonBlocking, strcmp(ss, "high") == 0 ? prio_high : prio_low));
 	}
 	for(auto &sl : c->slot) {
 		DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i]));
 		DEV_CHK(hipEventCreateWithFlags(&sl.ev_walk, hipEventDisableTiming)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_nf, hipEventDisableTiming));
-		DEV_CHK(hipEventCreate(&sl.ev_front));
+		DEV_CHK(hipEventCreate(&sl.ev_front)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_chan, hipEventDisableTiming));
 	}
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
 	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count);
