@@ -663,7 +663,7 @@ struct K4Args {
 	const cf32 *y; const cf32 *pf; const uint64_t *cand; const Tables *tab;
 	WalkState *ws; unsigned long long *cnt; Burst *bursts; uint32_t *nb_chan; uint32_t cap_bursts_chan; OutCtl *ctl; const uint32_t *freq;
 	EvalChunk *log; uint32_t *nlog; uint32_t cap_log;
-	int64_t k_end; float max_ppm; uint32_t cap, mask; int32_t chan_first;
+	int64_t k_end; float max_ppm; uint32_t cap, mask; int32_t chan_first, nchan;
 };
 
 __global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
@@ -706,37 +706,42 @@ __global__ __launch_bounds__(64 * kWalkWaves, 4) void k_walk_spec(K4sArgs s) {
 // budget: with the true bound the compiler sizes the budget by the LDS-limited occupancy and takes 166, and a wave that needs
 // more registers than one channeliser wave frees (128) waits for two of them to retire at once - measured 25 us alone, 1.6 ms
 // beside the channeliser.  The same for k_burst.)
+// Two channels per workgroup (dynamic LDS, as in k_burst: four would be 67 KB).
+constexpr int kStitchWaves = 2;
+struct StitchLds { WalkShared sh; StitchShared ss; };
 __global__ __launch_bounds__(256, 4) void k_walk_stitch(K4sArgs s) {
-	__shared__ WalkShared sh;
-	__shared__ StitchShared ss;
+	extern __shared__ __align__(16) unsigned char k4_lds[];       // StitchLds[kStitchWaves]
 	const K4Args &a = s.k;
-	const int c = blockIdx.x;
+	const int wave = threadIdx.x >> 6, c = blockIdx.x * kStitchWaves + wave;      // a channel per wavefront
+	if(c >= a.nchan) return;
+	StitchLds &lds = reinterpret_cast<StitchLds *>(k4_lds)[wave];
 	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	stitch_channel(c, a.freq[c], a.max_ppm, s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	               a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg,
-	               s.spec + (size_t)c * s.spec_stride, sh, ss, s.seg_stats + 2 * c);
+	               s.spec + (size_t)c * s.spec_stride, lds.sh, lds.ss, s.seg_stats + 2 * c);
 }
 
 struct K4bArgs {
 	const cf32 *y; NfState *nf; EvalChunk *log; uint32_t *nlog; int64_t *sc_first; int64_t *sc_cum;
-	NfFeed *feed; float *lpbuf; float *ring; uint32_t ring_mask; uint32_t cap, mask, cap_log, cap_comb, cap_hist;
+	NfFeed *feed; float *lpbuf; float *ring; uint32_t ring_mask; uint32_t cap, mask, cap_log, cap_comb, cap_hist; int32_t nchan;
 };
 
 // K4b: noise-floor replay from the walker's evaluation log, in three small passes
-__global__ __launch_bounds__(64) void k_nf_prepare(K4bArgs a) {
-	const int c = blockIdx.x;
+constexpr int kNfWaves = 4;                // wavefronts per workgroup in the three passes: a channel (passes 1, 3) or a group of updates (pass 2) each
+__global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_prepare(K4bArgs a) {
+	__shared__ NfShared shw[kNfWaves];
+	const int wave = threadIdx.x >> 6, c = blockIdx.x * kNfWaves + wave;
+	if(c >= a.nchan) return;
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
-	__shared__ NfShared sh;
-	nf_prepare(&a.nf[c], lg, sc, a.cap_comb, &a.feed[c], sh);
+	nf_prepare(&a.nf[c], lg, sc, a.cap_comb, &a.feed[c], shw[wave]);
 }
 
 // Four wavefronts per workgroup, each with a group of updates of its own: a workgroup then takes exactly the room one
 // channeliser workgroup leaves on a CU (a wave per SIMD inside its 120 registers, 37 KB of LDS), where single-wave workgroups
 // each kept a whole channeliser workgroup out for as long as they lived (measured: the replay beside the channeliser cost the
 // front 0.29 ms per 256-channel step).
-constexpr int kNfWaves = 4;
 __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_replay(K4bArgs a) {
 	__shared__ NfShared shw[kNfWaves];
 	const int c = blockIdx.y, wave = threadIdx.x >> 6;
@@ -749,11 +754,12 @@ __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_replay(K4bArgs a) {
 	}
 }
 
-__global__ __launch_bounds__(64) void k_nf_finish(K4bArgs a) {
-	const int c = blockIdx.x;
+__global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_finish(K4bArgs a) {
+	__shared__ NfShared shw[kNfWaves];
+	const int wave = threadIdx.x >> 6, c = blockIdx.x * kNfWaves + wave;
+	if(c >= a.nchan) return;
 	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
-	__shared__ NfShared sh;
-	nf_finish(&a.nf[c], sc, a.feed[c], a.lpbuf + (size_t)c * a.cap_hist, a.ring + (size_t)c * (a.ring_mask + 1), a.ring_mask, a.cap_hist, sh);
+	nf_finish(&a.nf[c], sc, a.feed[c], a.lpbuf + (size_t)c * a.cap_hist, a.ring + (size_t)c * (a.ring_mask + 1), a.ring_mask, a.cap_hist, shw[wave]);
 }
 
 // Each channel's walker fills its own burst list (no atomics on its critical path); this one-wave kernel turns the
@@ -804,17 +810,20 @@ __global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
 }
 
 // after K4b and K5 have both finished, one wavefront per frame: the noise-floor figure and the AVLC front-door checks
-__global__ __launch_bounds__(64) void k_frame_finish(OutFrame *frames, const uint8_t *pool, const OutCtl *ctl, const Tables *tab,
+constexpr int kFrameWaves = 4;
+__global__ __launch_bounds__(64 * kFrameWaves) void k_frame_finish(OutFrame *frames, const uint8_t *pool, const OutCtl *ctl, const Tables *tab,
 		unsigned long long *acnt, const float *ring, uint32_t ring_mask) {
-	__shared__ FrameShared sh;
+	__shared__ FrameShared shw[kFrameWaves];
 	const uint32_t n = ctl->nframes < ctl->cap_frames ? ctl->nframes : ctl->cap_frames;
-	if(blockIdx.x >= n) return;
+	const uint32_t first = blockIdx.x * kFrameWaves + (threadIdx.x >> 6);
+	if(first >= n) return;
+	FrameShared &sh = shw[threadIdx.x >> 6];
 	frame_shared_init(*tab, sh);
-	for(uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+	for(uint32_t i = first; i < n; i += gridDim.x * kFrameWaves) {
 		const int c = frames[i].chan;
 		if(c < 0) continue;                              // tombstone (octet pool overflow): wave-uniform
 		finish_frame(frames[i], pool, *tab, acnt + (size_t)c * kNumAvlcCounters, ring + (size_t)c * (ring_mask + 1), ring_mask, sh);
-		__syncthreads();
+		WAVE_SYNC();
 	}
 }
 

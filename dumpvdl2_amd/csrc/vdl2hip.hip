@@ -82,7 +82,7 @@ struct vdl2hip_ctx {
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
 	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr;
-	hipStream_t stream_sync = nullptr;   // K3 of feed i beside the channeliser of feed i+1 (null: K3 stays on the front stream)
+	bool exact_on_walk = false;          // experiments: K3b of feed i on the walk stream (beside the channeliser of feed i+1) instead of the front stream
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
 	std::vector<uint64_t> statsd_prev;
@@ -258,33 +258,33 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	c->carry_sel ^= 1; c->ncarry = nrem;
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
-		// The sync kernels of this feed need the channeliser of this feed, the channeliser of the next feed does not need them:
-		// on a stream of their own they run beside it (few registers, no LDS to speak of - they fit in beside its waves and
-		// issue while those wait), instead of holding it up.
-		hipStream_t st = c->stream_sync ? c->stream_sync : c->stream;
-		if(c->stream_sync) { HIPCHK(hipEventRecord(sl.ev_chan, c->stream)); HIPCHK(hipStreamWaitEvent(st, sl.ev_chan, 0)); }
 		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1 };
-		LAUNCH_EV(k_sync_screen, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(kK3Threads), st, EV(4), (hipEvent_t) nullptr, k3);
-		// the exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry
-		// less on the front stream than a separate hipEventRecord
+		LAUNCH_EV(k_sync_screen, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(kK3Threads), st, EV(4), c->exact_on_walk ? sl.ev_chan : (hipEvent_t) nullptr, k3);
+		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
+		// on the front stream than a separate hipEventRecord.  (VDL2HIP_EXACT_STREAM=walk puts the exact tier in front of the
+		// walk on the walk stream, so that the front stream goes on with the next feed: measured slower, 6.11 vs 6.04 ms per
+		// 256-channel step - it then competes with the channeliser instead of preceding it - as was moving both sync kernels
+		// to a stream of their own, 6.36 vs 6.29; profiles/r02_sync_kernel_streams.txt.)
+		hipStream_t sx = c->exact_on_walk ? sb_ : st;
+		if(c->exact_on_walk) HIPCHK(hipStreamWaitEvent(sb_, sl.ev_chan, 0));
 		const int64_t nwords = ((k1 + 63) >> 6) - (nbase >> 6);
 		// words per lane of the exact tier: as many as keep >= 2 workgroups per CU (a wavefront with more words finds more of
 		// them with work, but a grid that does not fill the chip is latency-bound)
 		for(int wpl = kK3bWordsPerLane; wpl >= 1; wpl >>= 1) { k3.wpl = wpl; if(((nwords + 256 * wpl - 1) / (256 * wpl)) * c->C >= 512 || wpl == 1) break; }
 		const int64_t wpb = 256 * k3.wpl;                                      // words per block
-		LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), st, (hipEvent_t) nullptr, sl.ev_front, k3);
+		LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
 	}
 	// The burst-rate back end runs on three more streams, so that consecutive feeds overlap stage by stage:
 	//   stream_back   K4   walk(i) -> walk(i+1) -> ...             (each needs the previous one's FSM state)
 	//   stream_nf     K4b  noise floor of feed i, after walk(i)    (each needs the previous one's NfState)
 	//   stream_burst  K5   bursts of feed i, after walk(i); the frames get their noise-floor figure when K4b(i) is done
 	hipStream_t sn_ = c->stream_nf, s5_ = c->stream_burst;
-	if(D <= 0) HIPCHK(hipEventRecord(sl.ev_front, c->stream_sync ? c->stream_sync : st));
+	if(D <= 0) HIPCHK(hipEventRecord(sl.ev_front, st));
 	HIPCHK(hipStreamWaitEvent(sb_, sl.ev_front, 0));
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D;
 		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
-		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first };
+		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C };
 		// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
 		int nseg = (int)std::min<int64_t>(c->seg_max, D / c->seg_min);
 		if(nseg >= 2) {
@@ -295,7 +295,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 			if(!(getenv("VDL2HIP_ABLATE") && strstr(getenv("VDL2HIP_ABLATE"), "walk")))
 #endif
 			LAUNCH_EV(k_walk_spec, dim3((unsigned)((1 + 3 * (nseg - 1) + kWalkWaves - 1) / kWalkWaves), (unsigned)c->C), dim3(64 * kWalkWaves), sb_, EV(6), (hipEvent_t) nullptr, k4s);
-			LAUNCH_EV(k_walk_stitch, dim3((unsigned)c->C), dim3(64), sb_, (hipEvent_t) nullptr, EV(7), k4s);
+			hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, EV(7), 0, k4s);
 		} else {
 			LAUNCH_EV(k_walk, dim3((unsigned)c->C), dim3(64), sb_, EV(6), EV(7), k4);
 		}
@@ -305,14 +305,14 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	HIPCHK(hipStreamWaitEvent(s5_, sl.ev_walk, 0));
 	if(D > 0) {
 		K4bArgs k4b{ c->d_y, c->d_nf, sl.d_log, sl.d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfring, c->nf_ring - 1,
-		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist };
-		LAUNCH_EV(k_nf_prepare, dim3((unsigned)c->C), dim3(64), sn_, EV(8), (hipEvent_t) nullptr, k4b);
+		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist, c->C };
+		LAUNCH_EV(k_nf_prepare, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), sn_, EV(8), (hipEvent_t) nullptr, k4b);
 		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup * kNfWaves - 1) / (kNfGroup * kNfWaves));   // workgroups per channel
 #ifdef VDL2_ABLATE     // development builds only (tests/gpu_r02_run_s.sh): what does a stage cost the front by running beside it?
 		if(!(getenv("VDL2HIP_ABLATE") && strstr(getenv("VDL2HIP_ABLATE"), "nf")))
 #endif
 		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64 * kNfWaves), 0, sn_, k4b);
-		LAUNCH_EV(k_nf_finish, dim3((unsigned)c->C), dim3(64), sn_, (hipEvent_t) nullptr, EV(9), k4b);
+		LAUNCH_EV(k_nf_finish, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), sn_, (hipEvent_t) nullptr, EV(9), k4b);
 		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
 		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl, (const uint32_t *)c->d_synctmo);
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
@@ -323,7 +323,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		hipExtLaunchKernelGGL(k_burst, dim3(2048 / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)(sizeof(BurstShared) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
 		sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0;
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
-		hipLaunchKernelGGL(k_frame_finish, dim3(1024), dim3(64), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, (const OutCtl *)sl.d_ctl, (const Tables *)c->d_tab,
+		hipLaunchKernelGGL(k_frame_finish, dim3(1024 / kFrameWaves), dim3(64 * kFrameWaves), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, (const OutCtl *)sl.d_ctl, (const Tables *)c->d_tab,
 		                   c->d_acnt, (const float *)c->d_nfring, c->nf_ring - 1);
 		c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C;
 	}
@@ -390,7 +390,6 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
 	if(c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
 	if(c->stream_out) { (void)hipStreamSynchronize(c->stream_out); (void)hipStreamDestroy(c->stream_out); }
-	if(c->stream_sync) { (void)hipStreamSynchronize(c->stream_sync); (void)hipStreamDestroy(c->stream_sync); }
 	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
 	if(c->stream_nf) { (void)hipStreamSynchronize(c->stream_nf); (void)hipStreamDestroy(c->stream_nf); }
 	if(c->stream_burst) { (void)hipStreamSynchronize(c->stream_burst); (void)hipStreamDestroy(c->stream_burst); }
@@ -457,15 +456,12 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_burst, hipStreamNonBlocking, prio_of("burst")));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
-		// VDL2HIP_SYNC_STREAM=0|low|high (experiments): K3 on the front stream / on its own stream at the front's or the walk's priority
-		const char *ss = getenv("VDL2HIP_SYNC_STREAM");
-		if(!ss) ss = "0";
-		if(strcmp(ss, "0") != 0) DEV_CHK(hipStreamCreateWithPriority(&c->stream_sync, hipStreamNonBlocking, strcmp(ss, "high") == 0 ? prio_high : prio_low));
+		if(const char *e = getenv("VDL2HIP_EXACT_STREAM")) c->exact_on_walk = strcmp(e, "front") != 0;   // experiments: front | walk
 	}
 	for(auto &sl : c->slot) {
 		DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i]));
 		DEV_CHK(hipEventCreateWithFlags(&sl.ev_walk, hipEventDisableTiming)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_nf, hipEventDisableTiming));
-		DEV_CHK(hipEventCreate(&sl.ev_front)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_chan, hipEventDisableTiming));
+		DEV_CHK(hipEventCreate(&sl.ev_front)); DEV_CHK(hipEventCreate(&sl.ev_chan));
 	}
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
 	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count);
