@@ -82,6 +82,7 @@ struct vdl2hip_ctx {
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
 	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr;
+	int k1_force = 0;                    // VDL2HIP_K1=seq (+1) | tile (-1): force one of the two channelisers (tests, experiments)
 	bool exact_on_walk = false;          // experiments: K3b of feed i on the walk stream (beside the channeliser of feed i+1) instead of the front stream
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
@@ -117,6 +118,13 @@ static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds, 
 		case 2: hipExtLaunchKernelGGL((k_chanfir<OS, R, 2>), grid, block, (uint32_t)lds, c->stream, e0, e1, 0, b); break;
 		default: hipExtLaunchKernelGGL((k_chanfir<OS, R, 1>), grid, block, (uint32_t)lds, c->stream, e0, e1, 0, b); break;
 	}
+}
+
+// the many-channel channeliser (a lane = a channel): `waves` wavefronts per workgroup, `gy` workgroups per time segment
+template<int OS>
+static void launch_chanseq(vdl2hip_ctx *c, const K1Args &a, int waves, hipEvent_t e0, hipEvent_t e1) {
+	const int nseg8 = (a.nseg + 7) / 8 * 8;
+	hipExtLaunchKernelGGL((k_chanseq<OS>), dim3((unsigned)(nseg8 * a.gy)), dim3((unsigned)(64 * waves)), 0u, c->stream, e0, e1, 0, a);
 }
 
 static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
@@ -235,7 +243,31 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 
 	HIPCHK(hipMemcpyAsync(sl.d_ctl, c->h_ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, sb_));
 	sl.ev_valid = false;
-	if(D > 0) {
+	// Which channeliser: the time-per-lane kernel k_chanfir.  VDL2HIP_K1=seq selects the channel-per-lane kernel k_chanseq
+	// instead (kernels.h: no scan, no tile, 27 % fewer instructions - and, measured, 4.59 against 4.13 ms at 256 channels,
+	// because both kernels are held back by the LDS pipe's random NCO look-ups and k_chanseq adds its input broadcasts and
+	// output transposes to that pipe).  It is kept as a tested alternative, not used by default.
+	bool use_seq = false;
+	if(D > 0 && a.fuse) {
+		const int ngw = (c->C + 63) / 64;                                  // wavefronts that hold all channels
+		int64_t Ls = (D * ngw + 8191) / 8192; if(Ls < 512) Ls = 512; Ls = (Ls + 1) & ~1ll;   // about one full round of the chip
+		const int64_t nseg = (D + Ls - 1) / Ls;
+		use_seq = c->k1_force > 0;
+		if(nseg > (int64_t)c->nseg_cap) use_seq = false;
+		if(use_seq) {
+			const int waves = ngw < 4 ? ngw : 4;
+			a.tiles = (int)Ls; a.nseg = (int)nseg; a.gy = (ngw + waves - 1) / waves;
+			hipEvent_t e0 = prof ? ev[0] : nullptr, e1 = prof ? ev[1] : nullptr;
+			switch(c->specialised ? c->os : 0) {
+				case 20: launch_chanseq<20>(c, a, waves, e0, e1); break;
+				case 13: launch_chanseq<13>(c, a, waves, e0, e1); break;
+				case 10: launch_chanseq<10>(c, a, waves, e0, e1); break;
+				default: launch_chanseq<0>(c, a, waves, e0, e1); break;
+			}
+			c->tcarry_sel ^= 1;
+		}
+	}
+	if(D > 0 && !use_seq) {
 		const size_t lds = (size_t)c->run * c->os * 65 * sizeof(float2);   // the tile; the tables are static LDS
 		hipEvent_t e0 = prof ? ev[0] : nullptr, e1 = prof ? ev[1] : nullptr;
 		if(c->specialised) {
@@ -457,6 +489,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
 		if(const char *e = getenv("VDL2HIP_EXACT_STREAM")) c->exact_on_walk = strcmp(e, "front") != 0;   // experiments: front | walk
+		if(const char *e = getenv("VDL2HIP_K1")) c->k1_force = strcmp(e, "seq") == 0 ? 1 : strcmp(e, "tile") == 0 ? -1 : 0;
 	}
 	for(auto &sl : c->slot) {
 		DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i]));

@@ -459,6 +459,27 @@ def test_separate_phase_kernel_gives_the_same_answer(vh, monkeypatch, name):
     rx.close(); rx2.close()
 
 
+@pytest.mark.parametrize("name,chunks", [("config4_0p4s", None), ("config3_0p6s", (70000, 300000)), ("os10_noisy_1s", None), ("config2_1s", (50000, 400000))])
+def test_channel_per_lane_channeliser_gives_the_golden_answers(vh, monkeypatch, name, chunks):
+    """VDL2HIP_K1=seq: the alternative channeliser k_chanseq (a lane is a channel, time runs inside the lane; not the default
+    - DESIGN 6) - 256, 64, 1 and 8 channels, whole and chunked feeds, segments of 512 outputs with the one-step look-back
+    between them: golden frames, counters and timing, a decimated stream within float rounding of the default kernel's, and
+    no look-back time-out."""
+    cfg, iq, bursts, gold = cases.load(name)
+    kw = dict(chunks=chunks, max_block=1600000) if chunks else {}
+    rx, fr, cnt = gpu_decode(vh, cfg, iq, **kw)
+    D = iq.size // 2 // cfg.oversample
+    y_tile = [rx.read_decimated(c, 0, min(D, 40000)) for c in range(min(len(cfg.freqs), 70))]
+    monkeypatch.setenv("VDL2HIP_K1", "seq")
+    rx2, fr2, cnt2 = gpu_decode(vh, cfg, iq, **kw)
+    assert rx2.stats()["front_sync_timeouts"] == 0
+    y_seq = [rx2.read_decimated(c, 0, min(D, 40000)) for c in range(min(len(cfg.freqs), 70))]
+    for a, b in zip(y_tile, y_seq):
+        assert np.abs(a - b).max() <= 3e-6 * max(1e-9, np.abs(a).max())     # same arithmetic per block, different association of the carried state
+    cases.check_against_golden(fr2, cnt2, gold, label=f"{name} channel-per-lane K1", exact_diagnostics=False)
+    rx.close(); rx2.close()
+
+
 def test_pinned_feed_overlaps_and_matches(vh):
     """vdl2hip_feed_pinned(): blocks queued from two alternating page-locked buffers without waiting for the copies give
     the golden answers; so does the blocking vdl2hip_feed() from pageable memory with three blocks in flight (the copy of
