@@ -61,3 +61,22 @@ def assert_counters_equal(got, want, label="", exact_diagnostics=True):
         for k in (18, 19):
             a = sum(c[k] for c in got); b = sum(c[k] for c in want)
             assert abs(a - b) <= max(3, 0.01 * b), f"{label}: diagnostic counter {k}: {a} vs {b}"
+
+
+def with_silence(cfg, iq, bursts):
+    """The capture with exact silence (zero samples) in front of it, behind it and - where no burst of any channel is on the
+    air - cut into it: the filter output then decays through the denormal range to exact (signed) zeros.  A burst is never cut:
+    what a receiver makes of the ringing after a cut is implementation noise, in the reference too."""
+    x = np.array(iq, dtype=np.int16).reshape(-1, 2).copy()
+    n = x.shape[0]
+    sps = 10 * cfg.oversample
+    busy = np.zeros(n, dtype=bool)
+    for b in bursts:
+        a = max(0, int(b.start_sample) - 20 * sps)
+        e = min(n, int(b.start_sample) + (120 + (int(b.tl_bits) + 8 * 60) // 3) * sps)
+        busy[a:e] = True
+    free = np.flatnonzero(np.diff(np.concatenate(([True], busy, [True])).astype(np.int8)))   # edges of the free stretches
+    for a, e in zip(free[0::2], free[1::2]):
+        if e - a >= 40000: x[a + 5000:e - 5000] = 0
+    pad = np.zeros((150000, 2), dtype=np.int16)
+    return np.concatenate([pad, x, pad[:120000]]).reshape(-1)

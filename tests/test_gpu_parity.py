@@ -315,6 +315,23 @@ def test_degenerate_feeds_and_errors(vh, golden_wav):
     rx.close(); ref.close()
 
 
+def test_silence_and_decaying_tails(vh, oracle_mod):
+    """Exact zeros in the input: the filter output decays through the denormal range to exact zero, where the screening
+    tier's phase (v_rcp of a denormal, 0 * inf) has to stay harmless - a zero sample has phase 0, a sample too small for
+    v_rcp flags its windows for the exact tier.  A capture with stretches of silence cut into it, one that ends in silence,
+    and pure silence: same frames, counters and timing as the oracle."""
+    cfg, iq, bursts, _ = cases.load("config2_1s")
+    x = cases.with_silence(cfg, iq, bursts)
+    for raw, label in ((x.reshape(-1), "silence cut in"), (np.zeros(600000, dtype=np.int16), "pure silence")):
+        o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+        o.process(raw.view(np.uint8), block_bytes=1 << 22, nthreads=4)
+        rx, fr, cnt = gpu_decode(vh, cfg, raw, chunks=(30000, 400000), max_block=1600000)
+        assert_frames_equal(o.frames(), fr, label=label)
+        assert cnt == [list(o.counters(c).values()) for c in range(len(cfg.freqs))]
+        rx.close()
+    assert len(fr) == 0                                    # pure silence decodes to nothing
+
+
 def test_two_receivers_in_one_process(vh, oracle_mod, golden_wav):
     """Contexts are independent (different oversampling, formats, channel counts) and can interleave their feeds."""
     cfg, iq, _, gold = cases.load("config2_1s")

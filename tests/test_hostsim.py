@@ -125,6 +125,20 @@ def test_two_tier_sync_metric_changes_nothing(oracle_mod, name, chunks, segments
     print(name, st, st["exact"] / st["total"])
 
 
+def test_silence_cut_into_a_capture(oracle_mod):
+    """Stretches of exact zeros in the input (the filter output decays through the denormal range to exact zero) and a
+    capture that ends in silence: the two-tier sync rule, the segmented walk and the noise-floor replay still reproduce the
+    oracle bit for bit."""
+    cfg, iq, bursts, _ = cases.load("config2_1s")
+    x = cases.with_silence(cfg, iq, bursts)
+    fo, fh, co, ch = run_both(oracle_mod, cfg, x.reshape(-1), chunks=(500, 40000), segments=(1500, 16), two_tier=True)
+    assert len(fo) >= 4
+    assert_frames_equal(fo, fh, label="silence cut in")
+    assert co == ch
+    key = lambda f: (f["chan"], f["burst_ord"], f["idx"])
+    assert [f["nf_pwr_dbfs"] for f in sorted(fo, key=key)] == [f["nf_pwr_dbfs"] for f in sorted(fh, key=key)]
+
+
 @pytest.mark.parametrize("seed", [5019, 5029, 5041, 1002, 1018])
 def test_fuzz_regressions(oracle_mod, seed):
     """Seeds of tests/fuzz_hostsim.py kept as regressions.  5019/5029/5041: a sync fired just before a segment end while the
