@@ -83,7 +83,9 @@ struct vdl2hip_ctx {
 	uint64_t feed_no = 0; int drain_lag = 0;
 	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr;
 	int k1_force = 0;                    // VDL2HIP_K1=seq (+1) | tile (-1): force one of the two channelisers (tests, experiments)
-	bool exact_on_walk = false;          // experiments: K3b of feed i on the walk stream (beside the channeliser of feed i+1) instead of the front stream
+	// experiments (VDL2HIP_SYNC_ON): 0 = both sync kernels on the front stream; 1 = the exact tier in front of the walk on the walk
+	// stream; 2 = both on a stream of their own (stream_sync), beside the channeliser of the next feed
+	int sync_on = 0; hipStream_t stream_sync = nullptr;
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
 	std::vector<uint64_t> statsd_prev;
@@ -291,14 +293,15 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
 		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1 };
-		LAUNCH_EV(k_sync_screen, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(kK3Threads), st, EV(4), c->exact_on_walk ? sl.ev_chan : (hipEvent_t) nullptr, k3);
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
-		// on the front stream than a separate hipEventRecord.  (VDL2HIP_EXACT_STREAM=walk puts the exact tier in front of the
-		// walk on the walk stream, so that the front stream goes on with the next feed: measured slower, 6.11 vs 6.04 ms per
-		// 256-channel step - it then competes with the channeliser instead of preceding it - as was moving both sync kernels
-		// to a stream of their own, 6.36 vs 6.29; profiles/r02_sync_kernel_streams.txt.)
-		hipStream_t sx = c->exact_on_walk ? sb_ : st;
-		if(c->exact_on_walk) HIPCHK(hipStreamWaitEvent(sb_, sl.ev_chan, 0));
+		// on the front stream than a separate hipEventRecord.  (VDL2HIP_SYNC_ON=walk puts the exact tier in front of the walk on
+		// the walk stream, VDL2HIP_SYNC_ON=own both sync kernels on a stream of their own, so that the front stream goes on
+		// with the next feed's channeliser: measured, profiles/r02_sync_kernel_streams.txt.)
+		hipStream_t s3 = c->sync_on == 2 ? c->stream_sync : st;
+		if(c->sync_on == 2) { HIPCHK(hipEventRecord(sl.ev_chan, st)); HIPCHK(hipStreamWaitEvent(s3, sl.ev_chan, 0)); }
+		LAUNCH_EV(k_sync_screen, dim3((unsigned)((k1 - nbase + kK3Tile - 1) / kK3Tile), (unsigned)c->C), dim3(kK3Threads), s3, EV(4), c->sync_on == 1 ? sl.ev_chan : (hipEvent_t) nullptr, k3);
+		hipStream_t sx = c->sync_on == 1 ? sb_ : s3;
+		if(c->sync_on == 1) HIPCHK(hipStreamWaitEvent(sb_, sl.ev_chan, 0));
 		const int64_t nwords = ((k1 + 63) >> 6) - (nbase >> 6);
 		// words per lane of the exact tier: as many as keep >= 2 workgroups per CU (a wavefront with more words finds more of
 		// them with work, but a grid that does not fill the chip is latency-bound)
@@ -422,6 +425,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
 	if(c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
 	if(c->stream_out) { (void)hipStreamSynchronize(c->stream_out); (void)hipStreamDestroy(c->stream_out); }
+	if(c->stream_sync) { (void)hipStreamSynchronize(c->stream_sync); (void)hipStreamDestroy(c->stream_sync); }
 	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
 	if(c->stream_nf) { (void)hipStreamSynchronize(c->stream_nf); (void)hipStreamDestroy(c->stream_nf); }
 	if(c->stream_burst) { (void)hipStreamSynchronize(c->stream_burst); (void)hipStreamDestroy(c->stream_burst); }
@@ -488,7 +492,8 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_burst, hipStreamNonBlocking, prio_of("burst")));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
-		if(const char *e = getenv("VDL2HIP_EXACT_STREAM")) c->exact_on_walk = strcmp(e, "front") != 0;   // experiments: front | walk
+		if(const char *e = getenv("VDL2HIP_SYNC_ON")) c->sync_on = strcmp(e, "walk") == 0 ? 1 : strncmp(e, "own", 3) == 0 ? 2 : 0;   // experiments: front | walk | own | own-high
+		if(c->sync_on == 2) DEV_CHK(hipStreamCreateWithPriority(&c->stream_sync, hipStreamNonBlocking, strcmp(getenv("VDL2HIP_SYNC_ON"), "own-high") == 0 ? prio_high : prio_low));
 		if(const char *e = getenv("VDL2HIP_K1")) c->k1_force = strcmp(e, "seq") == 0 ? 1 : strcmp(e, "tile") == 0 ? -1 : 0;
 	}
 	for(auto &sl : c->slot) {
