@@ -4,9 +4,9 @@ R="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$R"; mkdir -p gpurun_out
 O=gpurun_out/r02r
 : > $O.txt
-for ss in 0 low high 0 low high; do
+for ss in front own own-high front own own-high; do
   for wl in config4 config3; do
-    VDL2HIP_SYNC_STREAM=$ss timeout 600 python bench.py --no-secondary --no-cpu-baseline --no-verify --workload $wl > $O.tmp.json 2> $O.err
+    VDL2HIP_SYNC_ON=$ss timeout 600 python bench.py --no-secondary --no-cpu-baseline --no-verify --workload $wl > $O.tmp.json 2> $O.err
     python - "$ss" "$wl" >> $O.txt <<'P'
 import json,sys
 j=json.loads(open('gpurun_out/r02r.tmp.json').read().strip().splitlines()[-1])
@@ -16,4 +16,4 @@ P
   done
 done
 cat $O.txt
-VDL2HIP_SYNC_STREAM=low timeout 900 python -m pytest tests -x -q -m gpu > $O.pytest_low.txt 2>&1; tail -3 $O.pytest_low.txt
+VDL2HIP_SYNC_ON=own timeout 900 python -m pytest tests -x -q -m gpu > $O.pytest_low.txt 2>&1; tail -3 $O.pytest_low.txt
