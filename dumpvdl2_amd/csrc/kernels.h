@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 // The arithmetic per block is k_chanfir's, statement for statement; only the order in which the carried state reaches a
 // block differs (sequentially here, through the scan there), i.e. the result differs in rounding only.
 #ifndef VDL2_K1S_MIN_BLOCKS
-#define VDL2_K1S_MIN_BLOCKS 6
+#define VDL2_K1S_MIN_BLOCKS 4      // what its LDS (input and output staging) allows per CU
 #endif
 #ifndef VDL2_K1S_UNROLL
 #define VDL2_K1S_UNROLL 4
@@ -570,8 +570,7 @@ __global__ __launch_bounds__(256, VDL2_K1S_MIN_BLOCKS) void k_chanseq(K1Args a) 
 					step(v2f{xx.z, xx.w}, j + 1);
 				}
 			} else {
-				#pragma unroll kK1SeqUnroll
-				for(int j = 0; j < os; j++) {
+				auto one = [&](const int j) {
 					v2f X;
 					if constexpr(kFast) {
 						const float2 x = xb[j];
@@ -582,6 +581,13 @@ __global__ __launch_bounds__(256, VDL2_K1S_MIN_BLOCKS) void k_chanseq(K1Args a) 
 						X = v2f{re, im};
 					}
 					step(X, j);
+				};
+				if constexpr(OS != 0) {
+					#pragma unroll kK1SeqUnroll
+					for(int j = 0; j < OS; j++) one(j);
+				} else {
+					#pragma unroll 1
+					for(int j = 0; j < os; j++) one(j);      // run-time block length: rolled
 				}
 			}
 			// state update t <- P t + acc, then y = c0*v[n] + c1*v[n-1] + c2*xm[n]

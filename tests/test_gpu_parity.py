@@ -170,17 +170,26 @@ def test_uint8_input(vh, oracle_mod):
 
 
 @pytest.mark.parametrize("os_", [13, 16, 7])
-def test_other_oversampling_factors(vh, oracle_mod, os_):
+def test_other_oversampling_factors(vh, oracle_mod, monkeypatch, os_):
     """13 = Mirics rate (specialised build), 16 and 7 go through the generic-oversample build."""
     from dumpvdl2_amd import synth
     cfg = synth.SynthConfig(centerfreq=CF, freqs=[CF + 30000, CF - 60000], oversample=os_, duration_s=0.7, seed=40 + os_)
     iq, bursts = synth.synthesize(cfg)
     o = oracle_mod.Oracle(CF, list(cfg.freqs), oversample=os_)
     o.process(iq.view(np.uint8))
+    want = o.frames()
     rx, fr, cnt = gpu_decode(vh, cfg, iq, chunks=(1000, 100000), max_block=400000)
     assert len(fr) > 0
-    assert_frames_equal(o.frames(), fr, label=f"os{os_}")
+    assert_frames_equal(want, fr, label=f"os{os_}")
     assert cnt == [list(o.counters(c).values()) for c in range(2)]
+    rx.close()
+    # and through the alternative channeliser (k_chanseq; specialised for 13, generic for 16 and 7; odd block lengths take its
+    # one-sample-at-a-time input path)
+    monkeypatch.setenv("VDL2HIP_K1", "seq")
+    rx, fr, cnt = gpu_decode(vh, cfg, iq, chunks=(50000, 300000), max_block=1200000)
+    assert_frames_equal(want, fr, label=f"os{os_} channel-per-lane K1")
+    assert cnt == [list(o.counters(c).values()) for c in range(2)]
+    rx.close()
 
 
 def test_full_size_config2_properties(vh, oracle_mod):
