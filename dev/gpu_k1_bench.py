@@ -1,5 +1,5 @@
 """Development micro-benchmark of the channeliser (K1) alone-ish: feeds noise for C channels and reports the
-HIP-event time of k_chanfir per launch.  usage: python tests/gpu_k1_bench.py [C] [seconds] [reps]"""
+HIP-event time of k_chanfir per launch.  usage: python dev/gpu_k1_bench.py [C] [seconds] [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

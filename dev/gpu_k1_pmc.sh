@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for G in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE"; do
 	i=$((i+1))
-	rocprofv3 --kernel-trace --pmc $G -d /tmp/pmc$i -o p -- python $R/tests/gpu_k1_bench.py ${1:-8} 16 2 > /tmp/pmc$i.log 2>&1
+	rocprofv3 --kernel-trace --pmc $G -d /tmp/pmc$i -o p -- python $R/dev/gpu_k1_bench.py ${1:-8} 16 2 > /tmp/pmc$i.log 2>&1
 	python - "$i" "${KFILTER:-chanfir}" <<'PY'
 import sqlite3, sys, glob
 i = sys.argv[1]; kf = sys.argv[2]

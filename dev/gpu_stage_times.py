@@ -1,5 +1,5 @@
 """Development aid: isolated per-stage kernel times of one workload (drain lag 0: nothing overlaps), and with VDL2_K5_PROF builds
-the walker's per-phase cycle counters.  usage: python tests/gpu_stage_times.py [config4] [seconds] [reps]"""
+the walker's per-phase cycle counters.  usage: python dev/gpu_stage_times.py [config4] [seconds] [reps]"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,7 +1,7 @@
 // Development micro-benchmark (not part of the product): issue rates that K1's design rests on.
 //   v_fma_f32 vs v_pk_fma_f32 throughput per wave, 4 and 8 waves per SIMD
 //   ds_read_b128 gather: same address / conflict-free / random 256-entry LUT (16 B entries)
-// build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -o /tmp/ub tests/gpu_ubench_valu.hip && /tmp/ub
+// build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -o /tmp/ub dev/gpu_ubench_valu.hip && /tmp/ub
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

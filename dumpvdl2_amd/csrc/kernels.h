@@ -20,7 +20,7 @@
 #include "vdl2_core.h"
 #include "design.h"
 
-// tuning knobs of K1 (overridable at build time for experiments: tests/gpu_k1_variants.sh)
+// tuning knobs of K1 (overridable at build time for experiments: dev/gpu_k1_variants.sh)
 #ifndef VDL2_K1_UNROLL
 #define VDL2_K1_UNROLL 5
 #endif
@@ -134,7 +134,7 @@ __global__ void k_dpp_probe(const float *in, float *out) {
 // Within a workgroup's segment the filter state is carried from tile to tile in registers, so the outputs it
 // stores are final except for the (decayed) state at the segment start, which K2 adds to the first kFixW of them.
 // OS == 0 selects the generic (run-time oversample) build of the same code.
-// resident workgroups per CU the channeliser is compiled for (LDS allows 6; tests/gpu_k1_variants.sh sweeps the choices)
+// resident workgroups per CU the channeliser is compiled for (LDS allows 6; dev/gpu_k1_variants.sh sweeps the choices)
 #ifndef VDL2_K1_MIN_BLOCKS
 #define VDL2_K1_MIN_BLOCKS 6
 #endif

@@ -32,7 +32,7 @@ struct HostFrame {
 #ifndef VDL2_K1_RUN
 #define VDL2_K1_RUN 2
 #endif
-constexpr int kRun = VDL2_K1_RUN;        // decimated outputs per lane in K1 (specialised builds); 2 measured best: tests/gpu_k1_variants.sh
+constexpr int kRun = VDL2_K1_RUN;        // decimated outputs per lane in K1 (specialised builds); 2 measured best: dev/gpu_k1_variants.sh
 constexpr int kRunGeneric = 2;
 constexpr int kHistory = 65536;          // decimated samples kept behind the newest block (> longest burst, 56 090)
 constexpr int kNumEv = 12;            // profiling: {start, stop} of K1, K2, K3, K4, K4b, K5
@@ -85,7 +85,7 @@ struct vdl2hip_ctx {
 	int k1_force = 0;                    // VDL2HIP_K1=seq (+1) | tile (-1): force one of the two channelisers (tests, experiments)
 	// experiments (VDL2HIP_SYNC_ON): 0 = both sync kernels on the front stream; 1 = the exact tier in front of the walk on the walk
 	// stream; 2 = both on a stream of their own (stream_sync), beside the channeliser of the next feed
-	int sync_on = 0; hipStream_t stream_sync = nullptr;
+	int sync_on = 0; hipStream_t stream_sync = nullptr; int k3b_wpl = 0;
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
 	std::vector<uint64_t> statsd_prev;
@@ -234,7 +234,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	if(c->debug_force_timeout) { a.pub_epoch = a.epoch ^ 0x40000000u; a.spin_limit = 16; }   // tests only: the look-back must fail loudly
 	{
 		// tiles per workgroup segment: long segments save K2 work, but the grid should still offer several thousand
-		// workgroups (measured: tests/gpu_k1_tiles.sh - 2 is best at 8 channels, 8 at 256)
+		// workgroups (measured: dev/gpu_k1_tiles.sh - 2 is best at 8 channels, 8 at 256)
 		const int64_t ntile = (D + seglen - 1) / seglen;
 		const int groups = (c->C + c->cr - 1) / c->cr, gy = (groups + 3) / 4;
 		int64_t tiles = ntile * gy / 6144; if(tiles < 1) tiles = 1; if(tiles > 8) tiles = 8;
@@ -306,6 +306,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		// words per lane of the exact tier: as many as keep >= 2 workgroups per CU (a wavefront with more words finds more of
 		// them with work, but a grid that does not fill the chip is latency-bound)
 		for(int wpl = kK3bWordsPerLane; wpl >= 1; wpl >>= 1) { k3.wpl = wpl; if(((nwords + 256 * wpl - 1) / (256 * wpl)) * c->C >= 512 || wpl == 1) break; }
+		if(c->k3b_wpl) k3.wpl = c->k3b_wpl;                                   // experiments only (VDL2HIP_K3B_WPL)
 		const int64_t wpb = 256 * k3.wpl;                                      // words per block
 		LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
 	}
@@ -343,7 +344,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist, c->C };
 		LAUNCH_EV(k_nf_prepare, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), sn_, EV(8), (hipEvent_t) nullptr, k4b);
 		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup * kNfWaves - 1) / (kNfGroup * kNfWaves));   // workgroups per channel
-#ifdef VDL2_ABLATE     // development builds only (tests/gpu_r02_run_s.sh): what does a stage cost the front by running beside it?
+#ifdef VDL2_ABLATE     // development builds only (dev/gpu_r02_run_s.sh): what does a stage cost the front by running beside it?
 		if(!(getenv("VDL2HIP_ABLATE") && strstr(getenv("VDL2HIP_ABLATE"), "nf")))
 #endif
 		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64 * kNfWaves), 0, sn_, k4b);
@@ -494,6 +495,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
 		if(const char *e = getenv("VDL2HIP_SYNC_ON")) c->sync_on = strcmp(e, "walk") == 0 ? 1 : strncmp(e, "own", 3) == 0 ? 2 : 0;   // experiments: front | walk | own | own-high
 		if(c->sync_on == 2) DEV_CHK(hipStreamCreateWithPriority(&c->stream_sync, hipStreamNonBlocking, strcmp(getenv("VDL2HIP_SYNC_ON"), "own-high") == 0 ? prio_high : prio_low));
+		if(const char *e = getenv("VDL2HIP_K3B_WPL")) { int v = atoi(e); if(v == 1 || v == 2 || v == 4) c->k3b_wpl = v; }
 		if(const char *e = getenv("VDL2HIP_K1")) c->k1_force = strcmp(e, "seq") == 0 ? 1 : strcmp(e, "tile") == 0 ? -1 : 0;
 	}
 	for(auto &sl : c->slot) {

@@ -61,40 +61,44 @@ def lib(variant="strict"):
     return _lib
 
 
+RUN_THREAD_PER_CHANNEL, RUN_WORKQUEUE = 1, 2
+
+
 def _bind(L):
-    if True:
-        L.vdl2o_create.restype = C.c_void_p
-        L.vdl2o_create.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.c_int, C.c_uint32, C.c_int, C.c_float]
-        L.vdl2o_destroy.argtypes = [C.c_void_p]
-        L.vdl2o_process.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
-        L.vdl2o_num_frames.restype = C.c_size_t
-        L.vdl2o_num_frames.argtypes = [C.c_void_p]
-        L.vdl2o_frames.restype = C.POINTER(Frame)
-        L.vdl2o_frames.argtypes = [C.c_void_p]
-        L.vdl2o_octets.restype = C.POINTER(C.c_uint8)
-        L.vdl2o_octets.argtypes = [C.c_void_p]
-        L.vdl2o_clear_frames.argtypes = [C.c_void_p]
-        L.vdl2o_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
-        L.vdl2o_get_lpf.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        L.vdl2o_get_dphi.restype = C.c_uint32
-        L.vdl2o_get_dphi.argtypes = [C.c_void_p, C.c_int]
-        L.vdl2o_get_sincos_lut.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        L.vdl2o_trace_decimated.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
-        L.vdl2o_trace_count.restype = C.c_size_t
-        L.vdl2o_trace_count.argtypes = [C.c_void_p]
-        L.vdl2o_trace_all.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-        L.vdl2o_decimated_count.restype = C.c_int64
-        L.vdl2o_decimated_count.argtypes = [C.c_void_p, C.c_int]
-        L.vdl2o_rs_decode.restype = C.c_int
-        L.vdl2o_rs_decode.argtypes = [C.c_void_p, C.c_int]
-        L.vdl2o_rs_encode.argtypes = [C.c_void_p, C.c_void_p]
-        L.vdl2o_header_decode.restype = C.c_uint32
-        L.vdl2o_header_decode.argtypes = [C.POINTER(C.c_uint32)]
-        L.vdl2o_header_parity.restype = C.c_uint32
-        L.vdl2o_header_parity.argtypes = [C.c_uint32]
-        L.vdl2o_crc16.restype = C.c_uint16
-        L.vdl2o_crc16.argtypes = [C.c_void_p, C.c_uint32, C.c_uint16]
-        L.vdl2o_chebyshev.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.vdl2o_run.restype = C.c_int
+    L.vdl2o_run.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int]
+    L.vdl2o_create.restype = C.c_void_p
+    L.vdl2o_create.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.c_int, C.c_uint32, C.c_int, C.c_float]
+    L.vdl2o_destroy.argtypes = [C.c_void_p]
+    L.vdl2o_process.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    L.vdl2o_num_frames.restype = C.c_size_t
+    L.vdl2o_num_frames.argtypes = [C.c_void_p]
+    L.vdl2o_frames.restype = C.POINTER(Frame)
+    L.vdl2o_frames.argtypes = [C.c_void_p]
+    L.vdl2o_octets.restype = C.POINTER(C.c_uint8)
+    L.vdl2o_octets.argtypes = [C.c_void_p]
+    L.vdl2o_clear_frames.argtypes = [C.c_void_p]
+    L.vdl2o_counters.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.vdl2o_get_lpf.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.vdl2o_get_dphi.restype = C.c_uint32
+    L.vdl2o_get_dphi.argtypes = [C.c_void_p, C.c_int]
+    L.vdl2o_get_sincos_lut.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.vdl2o_trace_decimated.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.vdl2o_trace_count.restype = C.c_size_t
+    L.vdl2o_trace_count.argtypes = [C.c_void_p]
+    L.vdl2o_trace_all.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.vdl2o_decimated_count.restype = C.c_int64
+    L.vdl2o_decimated_count.argtypes = [C.c_void_p, C.c_int]
+    L.vdl2o_rs_decode.restype = C.c_int
+    L.vdl2o_rs_decode.argtypes = [C.c_void_p, C.c_int]
+    L.vdl2o_rs_encode.argtypes = [C.c_void_p, C.c_void_p]
+    L.vdl2o_header_decode.restype = C.c_uint32
+    L.vdl2o_header_decode.argtypes = [C.POINTER(C.c_uint32)]
+    L.vdl2o_header_parity.restype = C.c_uint32
+    L.vdl2o_header_parity.argtypes = [C.c_uint32]
+    L.vdl2o_crc16.restype = C.c_uint16
+    L.vdl2o_crc16.argtypes = [C.c_void_p, C.c_uint32, C.c_uint16]
+    L.vdl2o_chebyshev.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     return L
 
 
@@ -126,6 +130,15 @@ class Oracle:
             m = min(block_bytes, n - off)
             self.L.vdl2o_process(self.h, base + off, m, nthreads)
             off += m
+
+    def run(self, raw, block_bytes=320000, mode=RUN_THREAD_PER_CHANNEL, nthreads=0):
+        """The whole capture with persistent threads (vdl2_oracle.h: vdl2o_run): mode RUN_THREAD_PER_CHANNEL is the reference's
+        own threading (one thread per channel + producer, two barriers per block, serial conversion), RUN_WORKQUEUE a pool of
+        `nthreads` workers with parallel conversion.  Same frames, in the same order, as process()."""
+        raw = np.ascontiguousarray(np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw.view(np.uint8).reshape(-1))
+        r = self.L.vdl2o_run(self.h, raw.ctypes.data, raw.size, block_bytes, mode, nthreads or (os.cpu_count() or 1))
+        if r != 0:
+            raise RuntimeError(f"vdl2o_run failed ({r})")
 
     def trace(self, chan, cap):
         self._trace = np.zeros((cap, 2), dtype=np.float32)

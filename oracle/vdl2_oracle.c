@@ -808,6 +808,7 @@ static void chan_scan_block(vdl2o_ctx *c, int k) {
 	}
 }
 
+static void gather_block_frames(vdl2o_ctx *c);
 typedef struct { vdl2o_ctx *c; int first, step; } scan_job;
 static void *scan_thread(void *arg) {
 	scan_job *j = arg;
@@ -835,7 +836,38 @@ void vdl2o_process(vdl2o_ctx *c, const uint8_t *buf, uint32_t len, int nthreads)
 		for(int t = 0; t < nthreads; t++) { jobs[t] = (scan_job){ c, t, nthreads }; pthread_create(&th[t], NULL, scan_thread, &jobs[t]); }
 		for(int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
 	}
-	/* gather this block's frames in channel order */
+	gather_block_frames(c);
+}
+
+/* ======================================================================
+ * whole-capture runs with persistent threads (the CPU baseline of bench.py)
+ *
+ * VDL2O_RUN_THREAD_PER_CHANNEL is the reference's own threading (dumpvdl2.c:117-135, demod.c:300-301,342-346,356-365):
+ * one persistent thread per channel plus the producer, two pthread barriers of count N+1 per block - the producer waits on
+ * `demods_ready` until every channel has finished the previous block, converts the new block serially while the channel
+ * threads are parked on `samples_ready`, then releases them; after the last block one more wait on `demods_ready`
+ * (dumpvdl2.c:1170).  VDL2O_RUN_WORKQUEUE is what a CPU implementation free to restructure would do with the same
+ * per-channel scan: `nthreads` persistent workers, the conversion spread over them, channels handed out from a counter.
+ * ==================================================================== */
+typedef struct {
+	vdl2o_ctx *c; int mode, nworkers;
+	pthread_barrier_t demods_ready, samples_ready;
+	volatile int done;
+	const uint8_t *blk; uint32_t blk_len;     /* work-queue mode: raw block being converted */
+	volatile int next_chan;
+} run_shared;
+typedef struct { run_shared *r; int id; } run_worker;
+
+static void convert_range(vdl2o_ctx *c, const uint8_t *buf, uint32_t f0, uint32_t f1) {
+	if(c->fmt == VDL2O_FMT_S16LE) {
+		const int16_t *p = (const int16_t *)buf;
+		for(uint32_t i = f0; i < f1; i++) c->sbuf[i] = (float)p[i] / 32768.0f;      /* demod.c:362-363 */
+	} else {
+		for(uint32_t i = f0; i < f1; i++) c->sbuf[i] = c->u8_levels[buf[i]];        /* demod.c:344-345 */
+	}
+}
+
+static void gather_block_frames(vdl2o_ctx *c) {
 	for(int k = 0; k < c->nchan; k++) {
 		chan_t *v = &c->ch[k];
 		for(size_t i = 0; i < v->nfr; i++) {
@@ -849,6 +881,90 @@ void vdl2o_process(vdl2o_ctx *c, const uint8_t *buf, uint32_t len, int nthreads)
 		}
 		v->nfr = 0; v->noct = 0;
 	}
+}
+
+static void *run_channel_thread(void *arg) {      /* process_samples(), demod.c:288-337: one channel, forever */
+	run_worker *w = arg; run_shared *r = w->r;
+	for(;;) {
+		pthread_barrier_wait(&r->demods_ready);
+		pthread_barrier_wait(&r->samples_ready);
+		if(r->done) break;
+		chan_scan_block(r->c, w->id);
+	}
+	return NULL;
+}
+
+static void *run_queue_thread(void *arg) {
+	run_worker *w = arg; run_shared *r = w->r; vdl2o_ctx *c = r->c;
+	for(;;) {
+		pthread_barrier_wait(&r->demods_ready);         /* block handed over (or done) */
+		if(r->done) break;
+		const uint32_t nfl = (c->fmt == VDL2O_FMT_S16LE) ? r->blk_len / 2 : r->blk_len;
+		const uint32_t per = (nfl + (uint32_t)r->nworkers - 1) / (uint32_t)r->nworkers;
+		const uint32_t f0 = per * (uint32_t)w->id < nfl ? per * (uint32_t)w->id : nfl, f1 = f0 + per < nfl ? f0 + per : nfl;
+		convert_range(c, r->blk, f0, f1);
+		pthread_barrier_wait(&r->samples_ready);        /* every slice converted */
+		for(;;) {
+			const int k = __atomic_fetch_add(&r->next_chan, 1, __ATOMIC_RELAXED);
+			if(k >= c->nchan) break;
+			chan_scan_block(c, k);
+		}
+		pthread_barrier_wait(&r->samples_ready);        /* block done */
+	}
+	return NULL;
+}
+
+int vdl2o_run(vdl2o_ctx *c, const uint8_t *buf, uint64_t total_len, uint32_t block_bytes, int mode, int nthreads) {
+	if(block_bytes == 0 || (mode != VDL2O_RUN_THREAD_PER_CHANNEL && mode != VDL2O_RUN_WORKQUEUE)) return -1;
+	run_shared r; memset(&r, 0, sizeof r);
+	r.c = c; r.mode = mode;
+	const int nw = mode == VDL2O_RUN_THREAD_PER_CHANNEL ? c->nchan : (nthreads < 1 ? 1 : nthreads);
+	r.nworkers = nw;
+	const uint32_t maxfl = (c->fmt == VDL2O_FMT_S16LE) ? block_bytes / 2 : block_bytes;
+	if(maxfl + 1 > c->sbuf_cap) { c->sbuf_cap = maxfl + 1; c->sbuf = realloc(c->sbuf, (size_t)c->sbuf_cap * sizeof(float)); }
+	if(pthread_barrier_init(&r.demods_ready, NULL, (unsigned)nw + 1) || pthread_barrier_init(&r.samples_ready, NULL, (unsigned)nw + 1)) return -2;
+	pthread_t *th = calloc((size_t)nw, sizeof *th); run_worker *ws = calloc((size_t)nw, sizeof *ws);
+	pthread_attr_t at; pthread_attr_init(&at); pthread_attr_setstacksize(&at, 1 << 20);
+	int started = 0;
+	for(; started < nw; started++) {
+		ws[started] = (run_worker){ &r, started };
+		if(pthread_create(&th[started], &at, mode == VDL2O_RUN_THREAD_PER_CHANNEL ? run_channel_thread : run_queue_thread, &ws[started])) break;
+	}
+	pthread_attr_destroy(&at);
+	if(started < nw) { fprintf(stderr, "vdl2o_run: could only start %d of %d threads\n", started, nw); abort(); }
+	for(uint64_t off = 0; off < total_len; off += block_bytes) {
+		const uint32_t len = (uint32_t)(total_len - off < block_bytes ? total_len - off : block_bytes);
+		const uint32_t nfl = (c->fmt == VDL2O_FMT_S16LE) ? len / 2 : len;
+		if(mode == VDL2O_RUN_THREAD_PER_CHANNEL) {
+			pthread_barrier_wait(&r.demods_ready);            /* demod.c:360: every channel finished the previous block */
+			gather_block_frames(c);
+			convert_range(c, buf + off, 0, nfl);              /* serial, as in the reference */
+			c->sbuf[nfl] = 0.f;
+			c->sbuf_len = nfl & ~1u;
+			pthread_barrier_wait(&r.samples_ready);           /* demod.c:364 */
+		} else {
+			r.blk = buf + off; r.blk_len = len; r.next_chan = 0;
+			c->sbuf[nfl] = 0.f;
+			c->sbuf_len = nfl & ~1u;
+			pthread_barrier_wait(&r.demods_ready);
+			pthread_barrier_wait(&r.samples_ready);
+			pthread_barrier_wait(&r.samples_ready);
+			gather_block_frames(c);
+		}
+	}
+	if(mode == VDL2O_RUN_THREAD_PER_CHANNEL) {
+		pthread_barrier_wait(&r.demods_ready);                /* dumpvdl2.c:1170: let the channels finish the last block */
+		gather_block_frames(c);
+		r.done = 1;
+		pthread_barrier_wait(&r.samples_ready);
+	} else {
+		r.done = 1;
+		pthread_barrier_wait(&r.demods_ready);
+	}
+	for(int t = 0; t < nw; t++) pthread_join(th[t], NULL);
+	pthread_barrier_destroy(&r.demods_ready); pthread_barrier_destroy(&r.samples_ready);
+	free(th); free(ws);
+	return 0;
 }
 
 size_t vdl2o_num_frames(const vdl2o_ctx *c) { return c->nfr; }

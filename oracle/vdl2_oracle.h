@@ -76,6 +76,14 @@ void vdl2o_destroy(vdl2o_ctx *c);
  * runs one thread per channel; conversion stays serial as in the reference). */
 void vdl2o_process(vdl2o_ctx *c, const uint8_t *buf, uint32_t len, int nthreads);
 
+/* A whole capture with persistent threads, fed in block_bytes pieces like process_iq_file() (dumpvdl2.c:323-358).
+ * VDL2O_RUN_THREAD_PER_CHANNEL: the reference's threading - one thread per channel + the producer, two barriers of count N+1
+ * per block, serial sample conversion on the producer (dumpvdl2.c:117-135, demod.c:300-301,342-346,356-365); nthreads ignored.
+ * VDL2O_RUN_WORKQUEUE: nthreads persistent workers, conversion spread over them, channels handed out dynamically.
+ * Frames are gathered per block in channel order, exactly as by repeated vdl2o_process() calls.  Returns 0 or < 0. */
+enum { VDL2O_RUN_THREAD_PER_CHANNEL = 1, VDL2O_RUN_WORKQUEUE = 2 };
+int vdl2o_run(vdl2o_ctx *c, const uint8_t *buf, uint64_t total_len, uint32_t block_bytes, int mode, int nthreads);
+
 size_t vdl2o_num_frames(const vdl2o_ctx *c);
 const vdl2o_frame *vdl2o_frames(const vdl2o_ctx *c);
 const uint8_t *vdl2o_octets(const vdl2o_ctx *c);

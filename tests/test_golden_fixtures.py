@@ -38,3 +38,16 @@ def test_fast_math_build_on_the_reference_wav(oracle_mod, golden_wav):
         o.process(golden_wav)
         out.append([(f["octets"], f["sync_sample"], f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"]) for f in o.frames()])
     assert out[0] == out[1] and len(out[0]) == 2
+
+
+@pytest.mark.parametrize("name", ["config2_1s", "config5_0p4s"])
+def test_persistent_thread_runs_reproduce_golden(oracle_mod, name):
+    """bench.py's cpu_baseline leg times vdl2o_run(): the reference's own threading (a persistent thread per channel + the
+    producer, two barriers per block: dumpvdl2.c:117-135, demod.c:300-301,356-365) and a work-queue variant.  Both must give
+    what the block-by-block oracle gives - the golden answers."""
+    cfg, iq, bursts, gold = cases.load(name)
+    for mode, nth, blk in ((oracle_mod.RUN_THREAD_PER_CHANNEL, 0, 320000), (oracle_mod.RUN_WORKQUEUE, 3, 320000), (oracle_mod.RUN_WORKQUEUE, 2, 1 << 22)):
+        o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+        o.run(iq.view(np.uint8), block_bytes=blk, mode=mode, nthreads=nth)
+        cases.check_against_golden(o.frames(), [list(o.counters(c).values()) for c in range(len(cfg.freqs))], gold, 1e-3, 1e-4, f"{name} mode {mode}")
+        o.close()

@@ -57,6 +57,29 @@ def test_reference_wav_is_a_drop_in(vh, oracle_mod, golden_wav):
     assert A.tobytes() == Ao.tobytes() and B.tobytes() == Bo.tobytes()
 
 
+@pytest.mark.parametrize("delta", [25000, -250000, 100008, -412500])
+def test_reference_wav_offset_tuned(vh, oracle_mod, delta):
+    """The NCO / mix branch of K1 (demod.c:58-72,200-203,312-317,385) against reference-held data: the reference's capture moved
+    off-centre (tests/golden/shift_wav.py), the same expectations as tests/test_oracle_golden.py::test_reference_wav_offset_tuned,
+    and the oracle beside it."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import shift_wav as sw
+    from test_oracle_golden import _expect_offset_tuned
+    raw = sw.shifted(delta)
+    cf = sw.CHANNEL - delta
+    rx = vh.Receiver(cf, [sw.CHANNEL], 10, vh.FMT_S16LE)
+    for k in range(0, raw.size, 320000):
+        rx.feed(raw[k:k + 320000])
+    fr = rx.drain()
+    step = _expect_offset_tuned(fr, delta, oracle_mod.crc16_x25)
+    assert rx.nco_step(0) & 0xFFFFFFFF == step & 0xFFFFFFFF
+    o = oracle_mod.Oracle(cf, [sw.CHANNEL], oversample=10)
+    o.process(raw)
+    assert_frames_equal(o.frames(), fr, label=f"wav shifted by {delta} Hz")
+    assert list(o.counters(0).values()) == list(rx.counters(0).values())
+
+
 @pytest.mark.parametrize("name", sorted(cases.CASES))
 def test_golden_cases_single_feed(vh, name):
     cfg, iq, bursts, gold = cases.load(name)
