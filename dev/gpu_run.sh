@@ -11,6 +11,9 @@
 #   iso           per-stage kernel times of config4, nothing overlapped
 #   k1:<C>        dev/gpu_k1_bench.py on C channels
 #   env:<A=B>     export A=B for the jobs that follow;  unenv:<A>  unset it
+#   exp           build the library with -DVDL2_EXPERIMENTS (the VDL2HIP_CR / K1_TILES / K3B_WPL / SYNC_ON / LOW_PRIO / ABLATE / GAPS
+#                 switches exist only there) into /tmp/vdl2hip_exp.so and point VDL2HIP_LIB at it for the jobs that follow
+#   exp:<flags>   the same with extra compiler flags (-D...)
 R="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$R"; mkdir -p gpurun_out
 TAG=$1; shift
@@ -25,6 +28,7 @@ trace() {  # name, command...
 for job in "$@"; do
 	echo "=== $job [$(sfx)]"
 	case $job in
+	exp|exp:*) X="${job#exp}"; X="${X#:}"; hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DVDL2_EXPERIMENTS $X -o /tmp/vdl2hip_exp.so dumpvdl2_amd/csrc/vdl2hip.hip 2>/dev/null && export VDL2HIP_LIB=/tmp/vdl2hip_exp.so || echo "experiment build failed" ;;
 	env:*) export "${job#env:}" ;;
 	unenv:*) unset "${job#unenv:}" ;;
 	pytest) timeout 1200 python -m pytest tests -m gpu -x -q > $O.pytest.txt 2>&1; echo "pytest rc=$?" >> $O.pytest.txt; tail -3 $O.pytest.txt ;;

@@ -15,7 +15,6 @@
 // There is no stored phase stream: atan2 in double (demod.c:232,256) is evaluated where a decision reads a phase - the exact tier
 // of K3, the walker, K5 - and K3's screening tier uses a single-precision phase of its own (vdl2_core.h: ChanView::Phi, phase_fast).
 #pragma once
-#include <type_traits>
 #include <hip/hip_runtime.h>
 #include "vdl2_core.h"
 #include "design.h"
@@ -422,278 +421,6 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 				e.z += Pp[2] * ts.x + Pp[3] * ts.z; e.w += Pp[2] * ts.y + Pp[3] * ts.w;
 			}
 			a.carry_out[cbase + c] = e;
-		}
-	}
-}
-
-// ----------------------------------------------------------------------------------------------------------------------
-// K1 for many channels and long feeds: **a lane is a channel, time runs inside the lane**.
-//
-// k_chanfir above makes a lane own a short run of time (R blocks) and stitches the 64 runs of a tile together with a wave
-// scan; with R*os = 40 samples per lane and tile, the scan, the epilogue and the tile staging are 4-5 of its 13.5 instructions
-// per channel-sample.  With >= 64 channels to fill a wavefront none of that is needed: the 64 lanes of a wave are 64 channels
-// walking the SAME stretch of time, so the input sample is wave-uniform (read once per wave, converted once per wave, no LDS
-// tile, no barrier), the filter state simply stays in the lane's registers from block to block, and what is left per
-// channel-sample is the NCO look-up, the mix and the two tap sums (8 instructions) plus 14 per block for the state update.
-// Parallelism over time comes from cutting the feed into segments of a.tiles outputs, one workgroup (up to four waves = 256
-// channels) per segment and channel group; a segment starts from zero state and, exactly as in k_chanfir, the decayed
-// contribution of the true state at its start - the previous segment's zero-start end state, one-step look-back through
-// seg_pub, epoch-tagged words, no fences - is added to its first kFixW outputs, here by the lane that wrote them (its own
-// earlier stores, so no ordering question arises) once the segment is done.  Outputs leave in pairs (16 bytes per lane and
-// two blocks; the partial lines merge in L2: every lane walks its own row of y).
-// The arithmetic per block is k_chanfir's, statement for statement; only the order in which the carried state reaches a
-// block differs (sequentially here, through the scan there), i.e. the result differs in rounding only.
-#ifndef VDL2_K1S_MIN_BLOCKS
-#define VDL2_K1S_MIN_BLOCKS 4      // what its LDS (input and output staging) allows per CU
-#endif
-#ifndef VDL2_K1S_UNROLL
-#define VDL2_K1S_UNROLL 4
-#endif
-constexpr int kK1SeqUnroll = VDL2_K1S_UNROLL;
-template<int OS>
-__global__ __launch_bounds__(256, VDL2_K1S_MIN_BLOCKS) void k_chanseq(K1Args a) {
-	__shared__ __align__(16) float4 lut[256];     // NCO look-up
-	constexpr int kSeqChunk = 8;                  // blocks per input chunk
-	constexpr int kSeqBuf = kSeqChunk * (OS ? OS : kMaxOversample);      // samples per chunk buffer
-	__shared__ __align__(16) float2 xstage[4][2 * kSeqBuf];              // per wave: two chunks of converted input samples
-	constexpr int kOutW = 8, kOutStride = kOutW + 2;                      // outputs collected per channel before they are written (64 bytes); padded rows: 16-byte aligned, 4-way instead of 16-way conflicts on the per-block write
-	__shared__ __align__(16) float2 ostage[4][64 * kOutStride];          // per wave: [lane][slot & 7]
-	const int os = OS ? OS : a.os;
-	const int tid = threadIdx.x;
-	const int bid = blockIdx.x;
-	const int xcd = bid & 7, q = bid >> 3;          // the workgroups of one segment (several only above 256 channels) share an XCD
-	const int g = q % a.gy;
-	const int seg = (q / a.gy) * 8 + xcd;
-	if(seg >= a.nseg) return;
-	for(int i = tid; i < 256; i += (int)blockDim.x) lut[i] = ((const float4 *)a.lut)[i];
-	__syncthreads();
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-	float2 *xs = xstage[wave];
-	float2 *os_row = ostage[wave] + lane * kOutStride;
-	const int c0w = (g * ((int)blockDim.x >> 6) + wave) * 64;      // first channel of this wave
-	if(c0w >= a.nchan) return;
-	const int ch = c0w + lane;
-	const bool cvalid = ch < a.nchan;
-	const int chc = cvalid ? ch : a.nchan - 1;
-	const K1Consts &bf = a.bf;
-	const float P0 = bf.P[0], P1 = bf.P[1], P2 = bf.P[2], P3 = bf.P[3];
-	const float c0 = bf.c0, c1 = bf.c1, c2 = bf.c2;
-
-	const int64_t Ls = a.tiles;                                    // outputs per segment (even)
-	const int64_t kbase = (int64_t)seg * Ls;                        // feed-local index of the segment's first output
-	const int nblk = (int)(a.D - kbase < Ls ? a.D - kbase : Ls);
-	const int64_t sbase = kbase * os;                               // logical sample (carry + block) of the segment's first input
-	const uint32_t dph = a.dphi[chc];
-	uint32_t ph = (uint32_t)((a.n0 + (uint64_t)sbase) & 0xffffffu) * dph;
-	// the usual case - a cs16 segment that lies entirely inside this feed's block: wave-uniform loads, no per-sample range tests
-	const bool fast = a.fmt == 1 && sbase >= (int64_t)a.ncarry && sbase + (int64_t)nblk * os <= (int64_t)a.nlogical;
-	const uint32_t *srcg = (const uint32_t *)a.in + (sbase - (int64_t)a.ncarry);   // fast path: the segment's first sample
-	const int64_t navail = (int64_t)a.nlogical - sbase;                               // samples from there to the end of the block
-	cf32 *yout = a.y + (size_t)chc * a.cap;
-	const uint32_t kabs0 = (uint32_t)(a.k0 + kbase);                // ring position of the segment's first output, before the mask
-	const bool paired = (kabs0 & 1u) == 0;                          // wave-uniform: outputs 2i, 2i+1 share a 16-byte slot
-
-	float t0r = 0.f, t0i = 0.f, t1r = 0.f, t1i = 0.f;              // zero-start state
-	auto run = [&](auto fast_tag) {
-		constexpr bool kFast = decltype(fast_tag)::value;
-		// Fast path: the wave stages its input itself, kSeqChunk blocks at a time, double-buffered in LDS: one coalesced 16-byte
-		// load per lane (four samples), issued a whole chunk - thousands of cycles of the wave's own work - before the samples
-		// are needed; the lane converts its four samples on the way into LDS (so the conversion costs 1/64 of what it would cost
-		// in the loop below, where every lane needs every sample), and the loop reads them back as wave-uniform (broadcast)
-		// LDS reads.  No workgroup barrier: every wave has its own buffers (the four waves of a workgroup read the same bytes;
-		// L2 serves three of them).
-		uint4 pend = make_uint4(0u, 0u, 0u, 0u);
-		const int npiece = (kSeqChunk * os) >> 2;                      // 16-byte pieces per chunk (<= 64: kSeqChunk * kMaxOversample / 4)
-		auto fetch = [&](int c) {                                      // issue the load of chunk c
-			const int64_t idx = (int64_t)c * kSeqChunk * os + 4 * lane;
-			uint4 r = make_uint4(0u, 0u, 0u, 0u);
-			if(lane < npiece) {
-				if(idx + 4 <= navail) r = *reinterpret_cast<const uint4 *>(srcg + idx);   // (dword-aligned; fine for global loads)
-				else {
-					if(idx + 0 < navail) r.x = srcg[idx + 0];
-					if(idx + 1 < navail) r.y = srcg[idx + 1];
-					if(idx + 2 < navail) r.z = srcg[idx + 2];
-				}
-			}
-			pend = r;
-		};
-		auto conv = [](uint32_t w) { return make_float2((float)(int16_t)(w & 0xffff) / 32768.0f, (float)(int16_t)(w >> 16) / 32768.0f); };   // demod.c:362-363
-		auto commit = [&](int c) {                                     // pending registers -> the chunk's LDS buffer, converted
-			if(lane < npiece) {
-				float4 *dst = reinterpret_cast<float4 *>(xs + (c & 1) * kSeqBuf + 4 * lane);
-				const float2 s0 = conv(pend.x), s1 = conv(pend.y), s2 = conv(pend.z), s3 = conv(pend.w);
-				dst[0] = make_float4(s0.x, s0.y, s1.x, s1.y);
-				dst[1] = make_float4(s2.x, s2.y, s3.x, s3.y);
-			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // LDS traffic inside one wave: in order anyway
-		};
-		if constexpr(kFast) {
-			fetch(0); commit(0);
-			if(kSeqChunk < nblk) fetch(1);
-		}
-		#pragma unroll 1
-		for(int b = 0; b < nblk; b++) {
-			const float2 *xb = nullptr;
-			if constexpr(kFast) {
-				const int cb = b / kSeqChunk, bi = b - cb * kSeqChunk;
-				if(bi == 0 && b > 0) {                                    // wave-uniform
-					commit(cb);
-					if((int64_t)(cb + 1) * kSeqChunk < nblk) fetch(cb + 1);
-				}
-				xb = xs + (cb & 1) * kSeqBuf + bi * os;
-			}
-			v2f A0 = v2f{0.f, 0.f}, A1 = v2f{0.f, 0.f}, M = v2f{0.f, 0.f};
-			auto step = [&](const v2f X, const int j) {
-				const float g0 = bf.g0[j], g1 = bf.g1[j];
-				const float F = (float)(ph & 0xffffu);                    // sincosf_lut(): fract * 65536
-				const float4 e = lut[(ph >> 16) & 0xffu];
-				const v2f sc = __builtin_elementwise_fma(v2f{e.z, e.w}, v2f{F, F}, v2f{e.x, e.y});   // (sin, cos)
-				// multiply(), as in k_chanfir: cos * x + sin * (i x), the product rounded as before.  sin * (i x) = (-im sin, re sin)
-				// is one packed multiply with operand-select and negate modifiers; written out because here, where i x is used
-				// once, the compiler builds (-im, re) with two more instructions instead
-				v2f sx;
-				asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(sx) : "v"(X), "v"(sc));
-				const v2f m = __builtin_elementwise_fma(v2f{sc.y, sc.y}, X, sx);
-				A0 = __builtin_elementwise_fma(v2f{g0, g0}, m, A0);
-				A1 = __builtin_elementwise_fma(v2f{g1, g1}, m, A1);
-				M = m;
-				ph += dph;
-			};
-			// partially unrolled on purpose, as in k_chanfir: fully unrolled, the scheduler hoists every LUT gather and spills
-			if constexpr(kFast && OS != 0 && OS % 2 == 0) {
-				// the same address in every lane: a broadcast read, two samples at a time (the chunk buffer and an even block length
-				// keep every pair 16-byte aligned)
-				#pragma unroll kK1SeqUnroll / 2
-				for(int j = 0; j < os; j += 2) {
-					const float4 xx = *reinterpret_cast<const float4 *>(xb + j);
-					step(v2f{xx.x, xx.y}, j);
-					step(v2f{xx.z, xx.w}, j + 1);
-				}
-			} else {
-				auto one = [&](const int j) {
-					v2f X;
-					if constexpr(kFast) {
-						const float2 x = xb[j];
-						X = v2f{x.x, x.y};
-					} else {
-						float re, im;
-						load_sample(a, sbase + (int64_t)b * os + j, re, im);
-						X = v2f{re, im};
-					}
-					step(X, j);
-				};
-				if constexpr(OS != 0) {
-					#pragma unroll kK1SeqUnroll
-					for(int j = 0; j < OS; j++) one(j);
-				} else {
-					#pragma unroll 1
-					for(int j = 0; j < os; j++) one(j);      // run-time block length: rolled
-				}
-			}
-			// state update t <- P t + acc, then y = c0*v[n] + c1*v[n-1] + c2*xm[n]
-			const float n0r = __builtin_fmaf(P0, t0r, __builtin_fmaf(P1, t1r, A0.x));
-			const float n0i = __builtin_fmaf(P0, t0i, __builtin_fmaf(P1, t1i, A0.y));
-			const float n1r = __builtin_fmaf(P2, t0r, __builtin_fmaf(P3, t1r, A1.x));
-			const float n1i = __builtin_fmaf(P2, t0i, __builtin_fmaf(P3, t1i, A1.y));
-			t0r = n0r; t0i = n0i; t1r = n1r; t1i = n1i;
-			const float yr = __builtin_fmaf(c0, n0r, __builtin_fmaf(c1, n1r, c2 * M.x));
-			const float yi = __builtin_fmaf(c0, n0i, __builtin_fmaf(c1, n1i, c2 * M.y));
-			// An output waits in LDS until its group of kOutW ring slots (64 bytes of the channel's row of y, a whole DRAM burst) is
-			// complete; then the wave writes the 64 groups TRANSPOSED - four adjacent lanes write the four 16-byte quarters of
-			// one channel's group, so that the store unit sees whole 64-byte requests.  (A lane writing its own channel's group,
-			// 16 or 32 or even 64 bytes in consecutive instructions, reaches L2 as 16-byte requests that are not merged again:
-			// 6.8 GB written per 256-channel block instead of 3.4, and 7.2 ms.)
-			const uint32_t kab = kabs0 + (uint32_t)b, col = kab & (uint32_t)(kOutW - 1);
-			os_row[col] = make_float2(yr, yi);
-			if(col == (uint32_t)(kOutW - 1) || b == nblk - 1) {             // wave-uniform
-				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // LDS traffic inside one wave: in order anyway
-				const int first = (int)col - b > 0 ? (int)col - b : 0;        // first column of the group that belongs to this segment
-				const int part = lane & 3;                                     // this lane's quarter of a group: columns 2 part, 2 part + 1
-				#pragma unroll
-				for(int i = 0; i < 4; i++) {
-					const int row = (lane >> 2) + 16 * i;                        // channel c0w + row
-					if(c0w + row < a.nchan) {
-						const float4 v = *reinterpret_cast<const float4 *>(ostage[wave] + row * kOutStride + 2 * part);
-						cf32 *yrow = a.y + (size_t)(c0w + row) * a.cap;
-						const uint32_t s0 = (kab - col + 2u * (uint32_t)part) & a.mask;
-						if(first == 0 && col == (uint32_t)(kOutW - 1)) *reinterpret_cast<float4 *>(yrow + s0) = v;
-						else {
-							if(2 * part >= first && 2 * part <= (int)col) yrow[s0] = cf32{v.x, v.y};
-							if(2 * part + 1 >= first && 2 * part + 1 <= (int)col) yrow[(s0 + 1u) & a.mask] = cf32{v.z, v.w};
-						}
-					}
-				}
-				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();   // LDS traffic inside one wave: in order anyway
-			}
-		}
-	};
-	if(fast) run(std::true_type{}); else run(std::false_type{});
-
-	// publish the zero-start end state for the next segment's workgroup (each word carries the feed's epoch: no flag, no fence)
-	if(cvalid) {
-		unsigned long long *pub = a.seg_pub + ((size_t)ch * a.nseg_cap + seg) * 4;
-		const unsigned long long ep = (unsigned long long)a.pub_epoch << 32;
-		__hip_atomic_store(pub + 0, ep | __float_as_uint(t0r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__hip_atomic_store(pub + 1, ep | __float_as_uint(t0i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__hip_atomic_store(pub + 2, ep | __float_as_uint(t1r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__hip_atomic_store(pub + 3, ep | __float_as_uint(t1i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-	// the true state at the segment start: the previous feed's end state, or the previous segment's zero-start end state (a
-	// segment is >= kFixW blocks long, older history has decayed below fp32 resolution).  Its producer has the smaller block id
-	// and publishes before it waits for anything itself.
-	float ts[4];
-	if(seg == 0) {
-		const float4 ci = a.carry_in[chc];
-		ts[0] = ci.x; ts[1] = ci.y; ts[2] = ci.z; ts[3] = ci.w;
-	} else {
-		const unsigned long long *srcw = a.seg_pub + ((size_t)chc * a.nseg_cap + seg - 1) * 4;
-		bool timed_out = false;
-		#pragma unroll
-		for(int k = 0; k < 4; k++) {
-			unsigned long long w = __hip_atomic_load(srcw + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			for(int spins = 0; (uint32_t)(w >> 32) != a.epoch; spins++) {
-				if((uint32_t)spins > a.spin_limit) { timed_out = true; break; }
-				__builtin_amdgcn_s_sleep(8);
-				w = __hip_atomic_load(srcw + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			ts[k] = __uint_as_float((uint32_t)w);
-		}
-		if(timed_out) atomicAdd(a.sync_timeouts, 1u);
-	}
-	// its decayed contribution on the first kFixW outputs: v += cP[i][0] * ts.(x|y) + cP[i][1] * ts.(z|w)  (K2's arithmetic).
-	// The lane of a channel corrects what other lanes of this wave stored (the transposed groups above), long ago: one
-	// workgroup-scope fence orders those stores before the loads below.
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-	const int nfix = nblk < kFixW ? nblk : kFixW;
-	if(cvalid) {
-		int i = 0;
-		if(paired) {
-			#pragma unroll 4
-			for(; i + 1 < nfix; i += 2) {
-				float4 *pp = reinterpret_cast<float4 *>(yout + ((kabs0 + (uint32_t)i) & a.mask));
-				float4 v = *pp;
-				const float ca0 = a.bfd->cP[i][0], ca1 = a.bfd->cP[i][1], cb0 = a.bfd->cP[i + 1][0], cb1 = a.bfd->cP[i + 1][1];
-				v.x += ca0 * ts[0] + ca1 * ts[2]; v.y += ca0 * ts[1] + ca1 * ts[3];
-				v.z += cb0 * ts[0] + cb1 * ts[2]; v.w += cb0 * ts[1] + cb1 * ts[3];
-				*pp = v;
-			}
-		}
-		for(; i < nfix; i++) {
-			cf32 *pp = yout + ((kabs0 + (uint32_t)i) & a.mask);
-			cf32 v = *pp;
-			const float ca0 = a.bfd->cP[i][0], ca1 = a.bfd->cP[i][1];
-			v.re += ca0 * ts[0] + ca1 * ts[2]; v.im += ca0 * ts[1] + ca1 * ts[3];
-			*pp = v;
-		}
-		// the filter state handed to the next feed
-		if(kbase + Ls >= a.D) {
-			float4 e = make_float4(t0r, t0i, t1r, t1i);
-			if(nblk <= kFixW) {
-				const float *Pp = a.bfd->Ppow[nblk];
-				e.x += Pp[0] * ts[0] + Pp[1] * ts[2]; e.y += Pp[0] * ts[1] + Pp[1] * ts[3];
-				e.z += Pp[2] * ts[0] + Pp[3] * ts[2]; e.w += Pp[2] * ts[1] + Pp[3] * ts[3];
-			}
-			a.carry_out[ch] = e;
 		}
 	}
 }

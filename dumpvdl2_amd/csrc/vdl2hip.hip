@@ -82,10 +82,11 @@ struct vdl2hip_ctx {
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
 	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr;
-	int k1_force = 0;                    // VDL2HIP_K1=seq (+1) | tile (-1): force one of the two channelisers (tests, experiments)
-	// experiments (VDL2HIP_SYNC_ON): 0 = both sync kernels on the front stream; 1 = the exact tier in front of the walk on the walk
-	// stream; 2 = both on a stream of their own (stream_sync), beside the channeliser of the next feed
-	int sync_on = 0; hipStream_t stream_sync = nullptr; int k3b_wpl = 0;
+	// Experiment switches (only read in builds with -DVDL2_EXPERIMENTS, dev/gpu_run.sh; the measured outcomes are in DESIGN 6).
+	// sync_on: 0 = both sync kernels on the front stream (the product); 1 = the exact tier in front of the walk on the walk stream;
+	// 2 = both on a stream of their own (stream_sync), beside the channeliser of the next feed.  tiles_force / k3b_wpl: K1 tiles per
+	// workgroup segment / K3b words per lane instead of the values chosen from the channel count.
+	int sync_on = 0; hipStream_t stream_sync = nullptr; int k3b_wpl = 0, tiles_force = 0; bool show_gaps = false; int ablate = 0;
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
 	std::vector<uint64_t> statsd_prev;
@@ -122,13 +123,6 @@ static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds, 
 	}
 }
 
-// the many-channel channeliser (a lane = a channel): `waves` wavefronts per workgroup, `gy` workgroups per time segment
-template<int OS>
-static void launch_chanseq(vdl2hip_ctx *c, const K1Args &a, int waves, hipEvent_t e0, hipEvent_t e1) {
-	const int nseg8 = (a.nseg + 7) / 8 * 8;
-	hipExtLaunchKernelGGL((k_chanseq<OS>), dim3((unsigned)(nseg8 * a.gy)), dim3((unsigned)(64 * waves)), 0u, c->stream, e0, e1, 0, a);
-}
-
 static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 	if(!sl.pending) return VDL2HIP_OK;
 	HIPCHK(hipEventSynchronize(sl.done));
@@ -143,7 +137,7 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 		if(hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) c->stats.walk_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) c->stats.nf_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[10], ev[11]) == hipSuccess) c->stats.burst_ms += ms;
-		if(getenv("VDL2HIP_GAPS")) {   // development: idle time of the front stream between its kernels
+		if(c->show_gaps) {   // development: idle time of the front stream between its kernels
 			float g12 = 0, g23 = 0, g31 = -1;
 			if(!sl.fused) { (void)hipEventElapsedTime(&g12, ev[1], ev[2]); (void)hipEventElapsedTime(&g23, ev[3], ev[4]); } else (void)hipEventElapsedTime(&g23, ev[1], ev[4]);
 			OutSlot &pv = c->slot[(sl.seq + kSlots - 1) % kSlots];
@@ -186,9 +180,9 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 		c->queue.reserve(c->queue.size() + nf);
 		for(uint32_t i = 0; i < nf; i++) {
 			if(fr[i].chan < 0 || fr[i].chan >= c->C) continue;           // a slot reserved past the octet pool's end (overflow): decode_burst() left a tombstone
+			c->stats.frames++;                                           // frames the decoder produced (before the optional AVLC filter), tombstones not counted
 			if(!c->avlc_filter || fr[i].avlc_status == AVLC_OK) c->queue.push_back(HostFrame{ fr[i], pool });
 		}
-		c->stats.frames += nf;
 	}
 	return ctl.overflow ? VDL2HIP_E_OVERFLOW : VDL2HIP_OK;
 }
@@ -238,38 +232,14 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		const int64_t ntile = (D + seglen - 1) / seglen;
 		const int groups = (c->C + c->cr - 1) / c->cr, gy = (groups + 3) / 4;
 		int64_t tiles = ntile * gy / 6144; if(tiles < 1) tiles = 1; if(tiles > 8) tiles = 8;
-		if(const char *e = getenv("VDL2HIP_K1_TILES")) { long v = atol(e); if(v >= 1 && v <= 64) tiles = v; }   // experiments only
+		if(c->tiles_force) tiles = c->tiles_force;
 		a.tiles = (int)tiles;
 		a.nseg = (int)((ntile + tiles - 1) / tiles);
 	}
 
 	HIPCHK(hipMemcpyAsync(sl.d_ctl, c->h_ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, sb_));
 	sl.ev_valid = false;
-	// Which channeliser: the time-per-lane kernel k_chanfir.  VDL2HIP_K1=seq selects the channel-per-lane kernel k_chanseq
-	// instead (kernels.h: no scan, no tile, 27 % fewer instructions - and, measured, 4.59 against 4.13 ms at 256 channels,
-	// because both kernels are held back by the LDS pipe's random NCO look-ups and k_chanseq adds its input broadcasts and
-	// output transposes to that pipe).  It is kept as a tested alternative, not used by default.
-	bool use_seq = false;
-	if(D > 0 && a.fuse) {
-		const int ngw = (c->C + 63) / 64;                                  // wavefronts that hold all channels
-		int64_t Ls = (D * ngw + 8191) / 8192; if(Ls < 512) Ls = 512; Ls = (Ls + 1) & ~1ll;   // about one full round of the chip
-		const int64_t nseg = (D + Ls - 1) / Ls;
-		use_seq = c->k1_force > 0;
-		if(nseg > (int64_t)c->nseg_cap) use_seq = false;
-		if(use_seq) {
-			const int waves = ngw < 4 ? ngw : 4;
-			a.tiles = (int)Ls; a.nseg = (int)nseg; a.gy = (ngw + waves - 1) / waves;
-			hipEvent_t e0 = prof ? ev[0] : nullptr, e1 = prof ? ev[1] : nullptr;
-			switch(c->specialised ? c->os : 0) {
-				case 20: launch_chanseq<20>(c, a, waves, e0, e1); break;
-				case 13: launch_chanseq<13>(c, a, waves, e0, e1); break;
-				case 10: launch_chanseq<10>(c, a, waves, e0, e1); break;
-				default: launch_chanseq<0>(c, a, waves, e0, e1); break;
-			}
-			c->tcarry_sel ^= 1;
-		}
-	}
-	if(D > 0 && !use_seq) {
+	if(D > 0) {
 		const size_t lds = (size_t)c->run * c->os * 65 * sizeof(float2);   // the tile; the tables are static LDS
 		hipEvent_t e0 = prof ? ev[0] : nullptr, e1 = prof ? ev[1] : nullptr;
 		if(c->specialised) {
@@ -327,9 +297,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 			const int64_t seglen = (D + nseg - 1) / nseg;
 			nseg = (int)((D + seglen - 1) / seglen);
 			K4sArgs k4s{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, c->k_total, seglen, c->d_segstats };
-#ifdef VDL2_ABLATE
-			if(!(getenv("VDL2HIP_ABLATE") && strstr(getenv("VDL2HIP_ABLATE"), "walk")))
-#endif
+			if(!(c->ablate & 1))
 			LAUNCH_EV(k_walk_spec, dim3((unsigned)((1 + 3 * (nseg - 1) + kWalkWaves - 1) / kWalkWaves), (unsigned)c->C), dim3(64 * kWalkWaves), sb_, EV(6), (hipEvent_t) nullptr, k4s);
 			hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, EV(7), 0, k4s);
 		} else {
@@ -344,18 +312,14 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist, c->C };
 		LAUNCH_EV(k_nf_prepare, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), sn_, EV(8), (hipEvent_t) nullptr, k4b);
 		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup * kNfWaves - 1) / (kNfGroup * kNfWaves));   // workgroups per channel
-#ifdef VDL2_ABLATE     // development builds only (dev/gpu_r02_run_s.sh): what does a stage cost the front by running beside it?
-		if(!(getenv("VDL2HIP_ABLATE") && strstr(getenv("VDL2HIP_ABLATE"), "nf")))
-#endif
+		if(!(c->ablate & 2))      // (experiment builds: what does a stage cost the front by running beside it?)
 		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64 * kNfWaves), 0, sn_, k4b);
 		LAUNCH_EV(k_nf_finish, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), sn_, (hipEvent_t) nullptr, EV(9), k4b);
 		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
 		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl, (const uint32_t *)c->d_synctmo);
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
-#ifdef VDL2_ABLATE
-		if(!(getenv("VDL2HIP_ABLATE") && strstr(getenv("VDL2HIP_ABLATE"), "burst")))
-#endif
+		if(!(c->ablate & 4))
 		hipExtLaunchKernelGGL(k_burst, dim3(2048 / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)(sizeof(BurstShared) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
 		sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0;
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
@@ -458,7 +422,9 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	c->specialised = (c->os == 10 || c->os == 13 || c->os == 20);
 	c->run = c->specialised ? kRun : kRunGeneric;
 	c->cr = c->C >= 16 ? 4 : c->C >= 8 ? 2 : 1;                   // channels per wave: keep >= 4 channel groups where possible
-	if(const char *e = getenv("VDL2HIP_CR")) { int v = atoi(e); if(v == 1 || v == 2 || v == 4) c->cr = v; }   // experiments only
+#ifdef VDL2_EXPERIMENTS
+	if(const char *e = getenv("VDL2HIP_CR")) { int v = atoi(e); if(v == 1 || v == 2 || v == 4) c->cr = v; }
+#endif
 	c->bf = derive_block_form(c->lpf, c->os, c->run);
 	c->dphi.resize(count);
 	for(uint32_t i = 0; i < count; i++) c->dphi[i] = nco_step(cfg->centerfreq, c->freqs[i], fs) & 0xffffffu;
@@ -477,26 +443,31 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	{
 		int prio_low = 0, prio_high = 0;
 		DEV_CHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-		if(getenv("VDL2HIP_NO_PRIO")) prio_low = prio_high = 0;   // experiments only
+		const char *lowp = "nf,burst";
+#ifdef VDL2_EXPERIMENTS
+		if(getenv("VDL2HIP_NO_PRIO")) prio_low = prio_high = 0;
+		if(getenv("VDL2HIP_LOW_PRIO")) lowp = getenv("VDL2HIP_LOW_PRIO");          // list of nf,burst,walk
+		if(const char *e = getenv("VDL2HIP_SYNC_ON")) c->sync_on = strcmp(e, "walk") == 0 ? 1 : strncmp(e, "own", 3) == 0 ? 2 : 0;   // front | walk | own | own-high
+		if(const char *e = getenv("VDL2HIP_K3B_WPL")) { int v = atoi(e); if(v == 1 || v == 2 || v == 4) c->k3b_wpl = v; }
+		if(const char *e = getenv("VDL2HIP_K1_TILES")) { long v = atol(e); if(v >= 1 && v <= 64) c->tiles_force = (int)v; }
+		if(const char *e = getenv("VDL2HIP_ABLATE")) c->ablate = (strstr(e, "walk") ? 1 : 0) | (strstr(e, "nf") ? 2 : 0) | (strstr(e, "burst") ? 4 : 0);
+		c->show_gaps = getenv("VDL2HIP_GAPS") != nullptr;
+#endif
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_low));
 		// The walk goes first whenever it competes with the channeliser of a later feed (every later stage waits for it).  The
 		// noise-floor and burst streams do not: their many single-wave workgroups, dispatched with priority, each take the
 		// register slot of one of the four waves a channeliser workgroup needs on a CU and so keep whole workgroups out; at
 		// the front's priority they fill in while the sync kernels (few registers) run.  Measured at 256 channels
 		// (profiles/r02_stream_priorities.txt): all three high 7.10 ms/step, walk only 6.91, none 6.93; no difference at 8.
-		// VDL2HIP_LOW_PRIO=<list of nf,burst,walk> overrides (experiments).
-		const char *lowp = getenv("VDL2HIP_LOW_PRIO");
-		if(!lowp) lowp = "nf,burst";
 		auto prio_of = [&](const char *name) { return strstr(lowp, name) ? prio_low : prio_high; };
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_back, hipStreamNonBlocking, prio_of("walk")));
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_nf, hipStreamNonBlocking, prio_of("nf")));
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_burst, hipStreamNonBlocking, prio_of("burst")));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
-		if(const char *e = getenv("VDL2HIP_SYNC_ON")) c->sync_on = strcmp(e, "walk") == 0 ? 1 : strncmp(e, "own", 3) == 0 ? 2 : 0;   // experiments: front | walk | own | own-high
+#ifdef VDL2_EXPERIMENTS
 		if(c->sync_on == 2) DEV_CHK(hipStreamCreateWithPriority(&c->stream_sync, hipStreamNonBlocking, strcmp(getenv("VDL2HIP_SYNC_ON"), "own-high") == 0 ? prio_high : prio_low));
-		if(const char *e = getenv("VDL2HIP_K3B_WPL")) { int v = atoi(e); if(v == 1 || v == 2 || v == 4) c->k3b_wpl = v; }
-		if(const char *e = getenv("VDL2HIP_K1")) c->k1_force = strcmp(e, "seq") == 0 ? 1 : strcmp(e, "tile") == 0 ? -1 : 0;
+#endif
 	}
 	for(auto &sl : c->slot) {
 		DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i]));
@@ -515,8 +486,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_tcarry[0], count * sizeof(float4)); DEV_ALLOC(c->d_tcarry[1], count * sizeof(float4));
 	DEV_ALLOC(c->d_segpub, (size_t)count * c->nseg_cap * 4 * 8); DEV_ALLOC(c->d_synctmo, 4);
 	DEV_CHK(hipMemset(c->d_segpub, 0, (size_t)count * c->nseg_cap * 4 * 8)); DEV_CHK(hipMemset(c->d_synctmo, 0, 4));
-	c->fuse_k2 = getenv("VDL2HIP_NO_FUSE") == nullptr;
-	c->debug_force_timeout = getenv("VDL2HIP_DEBUG_FORCE_TIMEOUT") != nullptr;   // tests only (tests/test_gpu_parity.py::test_lookback_timeout_fails_loudly)
+	c->fuse_k2 = true;
 	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, (size_t)count * kNumCounters * 8);
 	DEV_ALLOC(c->d_acnt, (size_t)count * kNumAvlcCounters * 8);
 	// a decodable burst occupies >= 22 symbols = 220 decimated samples (header + 3 data + 2 FEC octets)
@@ -807,6 +777,18 @@ int vdl2hip_set_drain_lag(vdl2hip_ctx *c, int lag) {
 	if(!c || lag < 0 || lag > kSlots - 1) return VDL2HIP_E_INVAL;
 	c->drain_lag = lag;
 	return VDL2HIP_OK;
+}
+
+// test hook (not declared in vdl2hip.h; tests/test_gpu_parity.py): "no_fuse" = run the segment-start fix-up as the separate kernel
+// k_fixup instead of inside K1 (bit-identical results); "force_timeout" = make the look-back hand-off fail (producers publish under
+// a wrong epoch), so that the loud-failure path can be tested
+int vdl2hip_debug_option(vdl2hip_ctx *c, const char *name, long value) {
+	if(!c || !name) return VDL2HIP_E_INVAL;
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	if(strcmp(name, "no_fuse") == 0) { c->fuse_k2 = value == 0; return VDL2HIP_OK; }
+	if(strcmp(name, "force_timeout") == 0) { c->debug_force_timeout = value != 0; return VDL2HIP_OK; }
+	return VDL2HIP_E_INVAL;
 }
 
 // test hook (not declared in vdl2hip.h): what the DPP controls the channeliser's scan relies on do on this device

@@ -195,6 +195,7 @@ def time_exchange(block_host, world: int, rank: int, mode: str, source: str, dev
 
     class _Null:
         def feed_tensor(self, t): pass
+        def feed_pinned_tensor(self, t): pass
         def drain_packed(self): return None
 
     front = torch.cuda.current_stream(device) if device.type == "cuda" else None

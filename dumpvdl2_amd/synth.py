@@ -290,6 +290,7 @@ class SynthConfig:
     rx_max_ppm: float = 0.0              # receiver --max-ppm gate to use with this workload (demod.c:192); 0 = off
     tdm_slots: int = 0                   # >0: channel k transmits only in slot k % tdm_slots
     tdm_slot_s: float = 0.2
+    tdm_pack: bool = False               # several bursts may follow each other inside the channel's slot (default: one per slot)
     error_injection: bool = False        # config 5: RS byte errors + header bit flips
     invalid_frame_rate: float = 0.0      # fraction of frames that are not valid AVLC (bad FCS or < 11 octets)
     first_burst_s: float = 0.02
@@ -348,12 +349,20 @@ def synthesize(cfg: SynthConfig, dtype=np.int16):
                 u = rng.random()
                 hflips = 2 if u < 0.02 else 1 if u < 0.12 else 0
             bb = build_burst(frames, rng, errs, hflips)
+            wave = None
             if cfg.tdm_slots > 0:
                 period = cfg.tdm_slots * cfg.tdm_slot_s
                 slot0 = (k % cfg.tdm_slots) * cfg.tdm_slot_s
-                m = np.ceil((t - slot0) / period)
-                t = slot0 + max(m, 0) * period + 0.002
-            wave = modulate(bb.symbols, sps, start_phase=float(rng.uniform(0, 2 * np.pi)))
+                stay = False
+                if cfg.tdm_pack:
+                    wave = modulate(bb.symbols, sps, start_phase=float(rng.uniform(0, 2 * np.pi)))
+                    into = (t - slot0) % period              # position inside the channel's own period
+                    stay = t >= slot0 and 0.002 <= into and into + wave.size / fs + 0.002 <= cfg.tdm_slot_s
+                if not stay:
+                    m = np.ceil((t - slot0) / period)
+                    t = slot0 + max(m, 0) * period + 0.002
+            if wave is None:
+                wave = modulate(bb.symbols, sps, start_phase=float(rng.uniform(0, 2 * np.pi)))
             start = int(round(t * fs))
             if start + wave.size >= n:
                 break

@@ -38,7 +38,7 @@ EXPORTS = [
     "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
     "vdl2hip_drain_packed", "vdl2hip_pack_raw_frame", "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_set_drain_lag", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
     "vdl2hip_avlc_counters", "vdl2hip_set_avlc_filter", "vdl2hip_statsd_lines", "vdl2hip_feed_pinned",
-    "vdl2hip_group_create", "vdl2hip_group_destroy", "vdl2hip_group_feed", "vdl2hip_group_sync", "vdl2hip_group_drain",
+    "vdl2hip_group_create", "vdl2hip_group_destroy", "vdl2hip_group_feed", "vdl2hip_group_feed_pinned", "vdl2hip_group_sync", "vdl2hip_group_drain",
     "vdl2hip_group_set_drain_lag", "vdl2hip_group_counters", "vdl2hip_group_avlc_counters", "vdl2hip_group_size", "vdl2hip_group_ctx",
     "vdl2hip_group_uses_rccl",
 ]
@@ -112,6 +112,7 @@ def load_library(path: str = None):
     L.vdl2hip_group_create.argtypes = [C.POINTER(Cfg), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(C.c_void_p)]
     L.vdl2hip_group_destroy.argtypes = [C.c_void_p]
     L.vdl2hip_group_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.vdl2hip_group_feed_pinned.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.vdl2hip_group_sync.argtypes = [C.c_void_p]
     L.vdl2hip_group_drain.argtypes = [C.c_void_p, FRAME_CB, C.c_void_p]
     L.vdl2hip_group_set_drain_lag.argtypes = [C.c_void_p, C.c_int]
@@ -264,6 +265,12 @@ class Receiver:
         self._chk(self.L.vdl2hip_counters(self.h, chan, a), "vdl2hip_counters")
         return dict(zip(COUNTER_NAMES, list(a)))
 
+    def debug_option(self, name: str, value: int) -> None:
+        """test hook of the library (not part of include/vdl2hip.h): "no_fuse", "force_timeout" """
+        f = self.L.vdl2hip_debug_option
+        f.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+        self._chk(f(self.h, name.encode(), value), "vdl2hip_debug_option")
+
     def set_profiling(self, level) -> None:
         """0/False off, 1/True: time the channeliser kernel only, 2: every stage (a few percent slower)"""
         self._chk(self.L.vdl2hip_set_profiling(self.h, int(level)), "vdl2hip_set_profiling")
@@ -324,6 +331,13 @@ class ReceiverGroup:
     def feed(self, raw) -> None:
         a = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
         self._chk(self.L.vdl2hip_group_feed(self.h, a.ctypes.data, a.size), "vdl2hip_group_feed")
+
+    def feed_pinned(self, host_ptr: int, nbytes: int) -> None:
+        """one block from page-locked host memory, queued without waiting for the copy"""
+        self._chk(self.L.vdl2hip_group_feed_pinned(self.h, C.c_void_p(host_ptr), nbytes), "vdl2hip_group_feed_pinned")
+
+    def sync(self) -> None:
+        self._chk(self.L.vdl2hip_group_sync(self.h), "vdl2hip_group_sync")
 
     def set_drain_lag(self, lag: int) -> None:
         self._chk(self.L.vdl2hip_group_set_drain_lag(self.h, lag), "vdl2hip_group_set_drain_lag")

@@ -38,3 +38,13 @@ def config4(duration_s=16.0, seed=20260926 + 4, error_injection=False):
 def config5(duration_s=16.0, seed=20260926 + 5):
     """config4 with injected RS byte errors and header bit flips (FEC-heavy path)."""
     return config4(duration_s, seed, error_injection=True)
+
+
+def config4_bursty(duration_s=16.0, seed=20260926 + 14):
+    """Back-end stress: config4's channel plan and air time, but cut into four times as many, four times shorter bursts
+    (payloads <= 60 octets, 4 ms mean gap): ~4x the synchronisations, headers, burst descriptors and frames per second that
+    the walker (K4), the noise-floor replay (K4b) and the burst decoder (K5) have to get through per block."""
+    return SynthConfig(centerfreq=CENTER, freqs=channel_plan(256, CENTER, 8000), oversample=20,
+                       duration_s=duration_s, seed=seed, amplitude=0.01, noise_sigma=0.0005,
+                       tdm_slots=16, tdm_slot_s=0.1, tdm_pack=True, min_payload=12, max_payload=60, max_frames=2, mean_gap_s=0.004,
+                       max_ppm=0.5, rx_max_ppm=2.5)

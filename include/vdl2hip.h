@@ -209,11 +209,18 @@ void *vdl2hip_stream(vdl2hip_ctx *ctx);                 /* the hipStream_t all w
  * devices[k]; cfg->device, chan_first and chan_count are ignored/must be 0.  A block handed to vdl2hip_group_feed() crosses
  * PCIe once, into devices[0], and reaches the other devices over xGMI: RCCL ncclBroadcast when librccl.so can be loaded and
  * the devices are distinct, hipMemcpyPeerAsync fan-out otherwise (a device may be listed more than once: "virtual shards",
- * which is how the path is tested on one GPU).  Frames are delivered merged, in vdl2hip_drain()'s order. ---- */
+ * which is how the path is tested on one GPU).  Frames are delivered merged, in vdl2hip_drain()'s order.
+ * EXPERIMENTAL where it uses RCCL: the ncclBroadcast branch has been built and reviewed but has not yet run on hardware (the
+ * development boxes have one GPU; tests/test_gpu_parity.py::test_group_over_two_real_gpus covers it where two are visible);
+ * VDL2HIP_NO_RCCL=1 selects the peer-copy fan-out, which has.  A failure part-way through a group feed disables the group
+ * (every later call returns VDL2HIP_E_DEVICE). ---- */
 typedef struct vdl2hip_group vdl2hip_group;
 int  vdl2hip_group_create(const vdl2hip_cfg *cfg, const int32_t *devices, uint32_t ndev, vdl2hip_group **out);
 void vdl2hip_group_destroy(vdl2hip_group *g);
 int  vdl2hip_group_feed(vdl2hip_group *g, const void *buf, size_t nbytes);      /* = process_buf_*(), blocking like vdl2hip_feed() */
+/* the same from page-locked memory without waiting for the copy (the rule of vdl2hip_feed_pinned(): `buf` stays untouched until the
+ * next vdl2hip_group_feed*() or vdl2hip_group_sync() has returned) */
+int  vdl2hip_group_feed_pinned(vdl2hip_group *g, const void *buf, size_t nbytes);
 int  vdl2hip_group_sync(vdl2hip_group *g);
 int  vdl2hip_group_drain(vdl2hip_group *g, vdl2hip_frame_cb cb, void *user);
 int  vdl2hip_group_set_drain_lag(vdl2hip_group *g, int lag);

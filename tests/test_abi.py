@@ -80,3 +80,15 @@ def test_product_never_touches_the_oracle():
                         continue
                     bad.append((os.path.relpath(os.path.join(dp, f), root), m.group(0).strip()[:100]))
     assert not bad, bad
+
+
+def test_library_source_builds_without_rccl_headers():
+    """RCCL is optional at build time as well as at run time: the host side of vdl2hip.hip must compile with the fallback
+    declarations of group.inc (an installation without rccl/rccl.h still gets the single-GPU library and the peer-copy group)."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "--cuda-host-only", "-DVDL2HIP_NO_RCCL_HEADER",
+                        os.path.join(ROOT, "dumpvdl2_amd", "csrc", "vdl2hip.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

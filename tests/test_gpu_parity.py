@@ -21,10 +21,12 @@ def vh():
     return vdl2hip
 
 
-def gpu_decode(vh, cfg, raw, fmt=1, chunks=None, max_block=None, seed=3, **kw):
+def gpu_decode(vh, cfg, raw, fmt=1, chunks=None, max_block=None, seed=3, debug=None, **kw):
     raw = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
     rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, fmt, cfg.rx_max_ppm,
                      max_block_bytes=max_block or raw.size, **kw)
+    for k, v in (debug or {}).items():
+        rx.debug_option(k, v)
     sb = 4 if fmt == 1 else 2
     if chunks is None:
         rx.feed(raw)
@@ -193,7 +195,7 @@ def test_uint8_input(vh, oracle_mod):
 
 
 @pytest.mark.parametrize("os_", [13, 16, 7])
-def test_other_oversampling_factors(vh, oracle_mod, monkeypatch, os_):
+def test_other_oversampling_factors(vh, oracle_mod, os_):
     """13 = Mirics rate (specialised build), 16 and 7 go through the generic-oversample build."""
     from dumpvdl2_amd import synth
     cfg = synth.SynthConfig(centerfreq=CF, freqs=[CF + 30000, CF - 60000], oversample=os_, duration_s=0.7, seed=40 + os_)
@@ -204,13 +206,6 @@ def test_other_oversampling_factors(vh, oracle_mod, monkeypatch, os_):
     rx, fr, cnt = gpu_decode(vh, cfg, iq, chunks=(1000, 100000), max_block=400000)
     assert len(fr) > 0
     assert_frames_equal(want, fr, label=f"os{os_}")
-    assert cnt == [list(o.counters(c).values()) for c in range(2)]
-    rx.close()
-    # and through the alternative channeliser (k_chanseq; specialised for 13, generic for 16 and 7; odd block lengths take its
-    # one-sample-at-a-time input path)
-    monkeypatch.setenv("VDL2HIP_K1", "seq")
-    rx, fr, cnt = gpu_decode(vh, cfg, iq, chunks=(50000, 300000), max_block=1200000)
-    assert_frames_equal(want, fr, label=f"os{os_} channel-per-lane K1")
     assert cnt == [list(o.counters(c).values()) for c in range(2)]
     rx.close()
 
@@ -486,17 +481,16 @@ def test_ring_wraps_many_times(vh, oracle_mod):
 
 
 @pytest.mark.parametrize("name", ["config2_1s", "os10_noisy_1s", "config4_0p4s"])
-def test_separate_phase_kernel_gives_the_same_answer(vh, monkeypatch, name):
-    """By default K1 applies the segment-start fix-up and writes the phases itself (one-step look-back between workgroup
-    segments); VDL2HIP_NO_FUSE=1 runs the separate K2 instead.  Same arithmetic, so the decimated samples are bit-identical
+def test_separate_fixup_kernel_gives_the_same_answer(vh, name):
+    """By default K1 applies the segment-start fix-up itself (one-step look-back between workgroup segments); the test hook
+    "no_fuse" runs the separate kernel k_fixup instead.  Same arithmetic, so the decimated samples are bit-identical
     and so is everything after them; and no look-back wait ever times out."""
     cfg, iq, bursts, gold = cases.load(name)
     rx, fr, cnt = gpu_decode(vh, cfg, iq, chunks=(50000, 400000), max_block=1600000)
     assert rx.stats()["front_sync_timeouts"] == 0
     D = iq.size // 2 // cfg.oversample
     y_fused = [rx.read_decimated(c, max(0, D - 60000), 60000) for c in range(len(cfg.freqs))]
-    monkeypatch.setenv("VDL2HIP_NO_FUSE", "1")
-    rx2, fr2, cnt2 = gpu_decode(vh, cfg, iq, chunks=(50000, 400000), max_block=1600000)
+    rx2, fr2, cnt2 = gpu_decode(vh, cfg, iq, chunks=(50000, 400000), max_block=1600000, debug={"no_fuse": 1})
     y_sep = [rx2.read_decimated(c, max(0, D - 60000), 60000) for c in range(len(cfg.freqs))]
     for a, b in zip(y_fused, y_sep):
         assert a.tobytes() == b.tobytes()
@@ -505,30 +499,6 @@ def test_separate_phase_kernel_gives_the_same_answer(vh, monkeypatch, name):
            [(key(f), f["octets"], f["sync_sample"], f["ppm_error"], f["frame_pwr_dbfs"], f["nf_pwr_dbfs"]) for f in sorted(fr2, key=key)]
     assert cnt == cnt2
     cases.check_against_golden(fr2, cnt2, gold, label=f"{name} separate K2", exact_diagnostics=False)
-    rx.close(); rx2.close()
-
-
-@pytest.mark.parametrize("name,chunks", [("config4_0p4s", None), ("config3_0p6s", (70000, 300000)), ("os10_noisy_1s", None), ("config2_1s", (50000, 400000))])
-def test_channel_per_lane_channeliser_gives_the_golden_answers(vh, monkeypatch, name, chunks):
-    """VDL2HIP_K1=seq: the alternative channeliser k_chanseq (a lane is a channel, time runs inside the lane; not the default
-    - DESIGN 6) - 256, 64, 1 and 8 channels, whole and chunked feeds, segments of 512 outputs with the one-step look-back
-    between them: golden frames, counters and timing, a decimated stream as close to the default kernel's as both are to the
-    reference's, and no look-back time-out."""
-    cfg, iq, bursts, gold = cases.load(name)
-    kw = dict(chunks=chunks, max_block=1600000) if chunks else {}
-    rx, fr, cnt = gpu_decode(vh, cfg, iq, **kw)
-    D = iq.size // 2 // cfg.oversample
-    y_tile = [rx.read_decimated(c, 0, min(D, 40000)) for c in range(min(len(cfg.freqs), 70))]
-    monkeypatch.setenv("VDL2HIP_K1", "seq")
-    rx2, fr2, cnt2 = gpu_decode(vh, cfg, iq, **kw)
-    assert rx2.stats()["front_sync_timeouts"] == 0
-    y_seq = [rx2.read_decimated(c, 0, min(D, 40000)) for c in range(min(len(cfg.freqs), 70))]
-    # same arithmetic per block, different association of the carried state: the two differ by the filter's own rounding noise,
-    # which scales with the wide-band input, not with the (possibly quiet) channel
-    peak = float(np.abs(np.asarray(iq).astype(np.float32)).max()) / 32768.0
-    for a, b in zip(y_tile, y_seq):
-        assert np.abs(a - b).max() <= 1e-4 * peak
-    cases.check_against_golden(fr2, cnt2, gold, label=f"{name} channel-per-lane K1", exact_diagnostics=False)
     rx.close(); rx2.close()
 
 
@@ -558,14 +528,13 @@ def test_pinned_feed_overlaps_and_matches(vh):
     rx.close()
 
 
-def test_lookback_timeout_fails_loudly(vh, monkeypatch):
+def test_lookback_timeout_fails_loudly(vh):
     """A channeliser workgroup that gives up waiting for its predecessor's filter state must not go on silently: with the
     hand-off forced to fail (the producers publish under a wrong epoch) the feed's results are refused with
     VDL2HIP_E_DEVICE and the context stays disabled."""
     cfg, iq, _, gold = cases.load("config2_1s")
-    monkeypatch.setenv("VDL2HIP_DEBUG_FORCE_TIMEOUT", "1")
     rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=iq.nbytes)
-    monkeypatch.delenv("VDL2HIP_DEBUG_FORCE_TIMEOUT")
+    rx.debug_option("force_timeout", 1)
     rx.feed(iq)                                            # queues; the failure is detected when the feed is collected
     with pytest.raises(vh.Vdl2HipError, match="-3"):
         rx.drain()
@@ -632,6 +601,50 @@ def test_group_of_virtual_shards_from_c(vh, devices):
                                exact_diagnostics=False)
     ends = [(f["end_sample"], f["chan"], f["idx"]) for f in got]
     assert ends == sorted(ends)
+    g.close()
+
+
+def test_group_feed_pinned(vh):
+    """vdl2hip_group_feed_pinned(): blocks from two alternating page-locked buffers, queued without waiting for the copy."""
+    import torch
+    cfg, iq, _, gold = cases.load("config2_1s")
+    raw = torch.from_numpy(iq.view(np.uint8).copy())
+    blk = 1 << 20
+    pins = [torch.empty(blk, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    g = vh.ReceiverGroup(cfg.centerfreq, list(cfg.freqs), [0, 0], cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=blk)
+    g.set_drain_lag(2)
+    got = []
+    for j, k in enumerate(range(0, raw.numel(), blk)):
+        n = min(blk, raw.numel() - k)
+        if j >= 2:
+            pass            # buffer j % 2 was handed over two feeds ago: the feed in between has returned, so it is ours again
+        pins[j % 2][:n].copy_(raw[k:k + n])
+        g.feed_pinned(pins[j % 2].data_ptr(), n)
+        got += g.drain()
+    g.sync()
+    g.set_drain_lag(0)
+    got += g.drain()
+    cases.check_against_golden(got, [list(g.counters(c).values()) for c in range(len(cfg.freqs))], gold, label="group, pinned feeds",
+                               exact_diagnostics=False)
+    g.close()
+
+
+def test_group_over_two_real_gpus(vh):
+    """The RCCL branch of vdl2hip_group_feed (ncclCommInitAll + grouped ncclBroadcast from one thread): only where two GPUs are
+    visible - the development boxes have one, so this is the test that exercises it first on a multi-GPU node."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    cfg, iq, _, gold = cases.load("config2_1s")
+    raw = iq.view(np.uint8)
+    g = vh.ReceiverGroup(cfg.centerfreq, list(cfg.freqs), [0, 1], cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=1 << 20)
+    assert g.uses_rccl(), "librccl.so did not load or ncclCommInitAll failed"
+    got = []
+    for k in range(0, raw.size, 1 << 20):
+        g.feed(raw[k:k + (1 << 20)])
+        got += g.drain()
+    assert g.uses_rccl(), "the broadcast fell back to peer copies"
+    cases.check_against_golden(got, [list(g.counters(c).values()) for c in range(len(cfg.freqs))], gold, label="two GPUs, RCCL", exact_diagnostics=False)
     g.close()
 
 
