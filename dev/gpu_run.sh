@@ -3,6 +3,7 @@
 #   pytest        python -m pytest tests -m gpu
 #   bench         the driver's line: python bench.py --gpus 1 --steps 20 --warmup 5
 #   bench5        config5 (injected errors), no secondary / cpu baseline
+#   benchw:<w>    bench.py --workload <w> without gate / baseline / secondary: value, ms/step, stage times
 #   shard32       dev/gpu_shard32.py: the rank-sized workload (32 of 256 channels), ranks 0,3,7
 #   trace32       rocprofv3 --kernel-trace --stats of the rank-sized workload (rank 3)
 #   trace256      rocprofv3 --kernel-trace --stats of bench.py config4
@@ -10,6 +11,7 @@
 #   sq_k1:<C>     SQ counters of the channeliser on C channels of noise;  sq_k3a:<C> the same for k_sync_screen
 #   iso           per-stage kernel times of config4, nothing overlapped
 #   k1:<C>        dev/gpu_k1_bench.py on C channels
+#   ubench        dev/gpu_ubench_valu.hip: issue rates, LDS gathers, and K1's inner loop with its tap sums on the VALU / on the matrix pipe
 #   env:<A=B>     export A=B for the jobs that follow;  unenv:<A>  unset it
 #   exp           build the library with -DVDL2_EXPERIMENTS (the VDL2HIP_CR / K1_TILES / K3B_WPL / SYNC_ON / LOW_PRIO / ABLATE / GAPS
 #                 switches exist only there) into /tmp/vdl2hip_exp.so and point VDL2HIP_LIB at it for the jobs that follow
@@ -35,6 +37,7 @@ for job in "$@"; do
 	bench) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O.bench_default.json 2> $O.bench_default.err; echo "bench rc=$?"; tail -c 400 $O.bench_default.err; cut -c1-600 $O.bench_default.json ;;
 	bench5) timeout 600 python bench.py --workload config5 --no-secondary --no-cpu-baseline > $O.bench_config5.json 2> $O.bench_config5.err; echo "config5 rc=$?"; cut -c1-400 $O.bench_config5.json ;;
 	benchq) timeout 600 python bench.py --no-secondary --no-cpu-baseline --no-verify >> $O.benchq.jsonl 2>> $O.benchq.err; echo "rc=$?"; tail -1 $O.benchq.jsonl | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['ms_per_step_hbm_resident'], j['config']['stage_ms_per_step'])" ;;
+	benchw:*) timeout 600 python bench.py --workload ${job#benchw:} --no-secondary --no-cpu-baseline --no-verify --repeats 2 2>> $O.benchw.err | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('$job [$(sfx)]', j['value'], j['ms_per_step'], j['ms_per_step_hbm_resident'], j['config']['stage_ms_per_step'])" | tee -a $O.benchw.txt ;;
 	shard32) timeout 900 python dev/gpu_shard32.py --json $O.shard32.json 2> $O.shard32.err | python -c "
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
@@ -53,6 +56,7 @@ for r in j['ranks']: print(j['env'], 'rank', r['rank'], r['ms_per_step'], 'K1', 
 	sq_k3a:*) KFILTER=sync_screen timeout 500 bash dev/gpu_k1_pmc.sh ${job#sq_k3a:} > $O.sq_k3a_${job#sq_k3a:}ch.txt 2>&1; cut -c1-140 $O.sq_k3a_${job#sq_k3a:}ch.txt ;;
 	iso) timeout 300 python dev/gpu_stage_times.py config4 16 3 2>&1 | grep -v amdgpu.ids | tee $O.stage_times_alone.txt | cut -c1-400 ;;
 	k1:*) timeout 300 python dev/gpu_k1_bench.py ${job#k1:} 16 3 2>&1 | grep -v amdgpu.ids | cut -c1-260 | tee -a $O.k1.txt ;;
+	ubench) hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o /tmp/ub dev/gpu_ubench_valu.hip 2>/dev/null && timeout 300 /tmp/ub 2>&1 | tee $O.ubench.txt | head -12 ;;
 	*) echo "unknown job $job" ;;
 	esac
 done

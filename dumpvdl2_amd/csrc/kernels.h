@@ -484,10 +484,10 @@ struct K3Args {
 //
 // k_sync_screen - every decimated sample.  A block turns kK3Tile consecutive outputs (+150 back) into screening-precision
 // phases (phase_fast, in turns) in LDS and gives every sample the cheap screening value of the metric (vdl2_core.h: same unwrap
-// decisions, running sums, float only).  The windows of samples n, n+10, n+20, n+30 read the same taps one place apart, so one
-// lane takes those four: it reads 15 phases for what would be 48, forms the 14 tap-to-tap differences once, and walks the four
-// windows one after the other (each with the wavefront-wide early exit).  Ten consecutive lanes cover 40 consecutive samples;
-// 320 threads cover the tile.  Verdicts go through LDS to be regrouped into words of 64 consecutive samples.  Output: one flag
+// decisions, running sums, float only).  The windows of samples n, n+10, ..., n+10(S-1) (S = kK3Share = 8) read the same taps
+// one place apart, so one lane takes those S: for the 12 taps before the early exit it reads 11+S phases for what would be 12 S,
+// forms the tap-to-tap differences once, and walks the S windows one after the other (each with the wavefront-wide early exit).
+// Ten consecutive lanes cover 10 S consecutive samples; 320 threads cover the tile.  Verdicts go through LDS to be regrouped into words of 64 consecutive samples.  Output: one flag
 // bit per sample - "the exact value may be under the threshold".
 //
 // k_sync_exact - only where a flag is set (on noise 3e-5 of the samples): the reference's arithmetic - atan2 in double on the
@@ -495,7 +495,11 @@ struct K3Args {
 // y1/y3 of calc_para_vertex and the right-hand side of the candidate test), stored in pf, and the candidate bit
 // pherr(n-3) < 4 && pherr(n) > pherr(n-3) of every sample.  The walker reads the metric nowhere else.  A sample whose right
 // neighbour has not arrived yet is computed exactly; the next feed redoes the last partial bitmap word anyway.
-constexpr int kK3Tile = 1280, kK3Threads = 320, kK3Share = 4;
+#ifndef VDL2_K3_SHARE
+#define VDL2_K3_SHARE 8              // windows (10 samples apart) per lane; tile = 320 threads x share.  8 against 4 (round 2): 27 phases read
+                                     // for what would be 8 x 16, a halo of 150 on 2 560 samples instead of on 1 280: K3a 5 % faster (profiles/r03_k3_share8.txt)
+#endif
+constexpr int kK3Share = VDL2_K3_SHARE, kK3Threads = 320, kK3Tile = kK3Threads * kK3Share;
 static_assert(kK3Tile == kK3Threads * kK3Share && kK3Tile % 64 == 0 && kK3Threads % 10 == 0 && (kK3Tile / 64) % (kK3Threads / 64) == 0, "screen tile");
 
 __global__ __launch_bounds__(kK3Threads) void k_sync_screen(K3Args a) {
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(kK3Threads) void k_sync_screen(K3Args a) {
 	__syncthreads();
 	// this lane's windows: samples nblk + s0 + 10 q, q = 0..3; tap i of window q is tile[s0 + 10 (q + i)]
 	const int s0 = 10 * kK3Share * (tid / 10) + tid % 10;
-	constexpr int kEarlyPh = kScreenEarly + kK3Share - 1;             // phases the first kScreenEarly taps of the four windows touch
+	constexpr int kEarlyPh = kScreenEarly + kK3Share - 1;             // phases the first kScreenEarly taps of the lane's windows touch
 	float ph[kEarlyPh], d[kEarlyPh];
 	#pragma unroll
 	for(int k = 0; k < kEarlyPh; k++) ph[k] = tile[s0 + 10 * k];
