@@ -438,6 +438,9 @@ def main():
     rehearsal = os.environ.get("VDL2_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
+        # several PROCESSES time-slicing one GPU: the channeliser's fused look-back assumes in-order resident workgroups (one process
+        # per GPU) and is switched off for this case (vdl2hip.hip: VDL2HIP_NO_FUSE)
+        os.environ["VDL2HIP_NO_FUSE"] = "1"
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU path)"
     torch.cuda.set_device(local)

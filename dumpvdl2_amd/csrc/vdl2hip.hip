@@ -486,7 +486,13 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_ALLOC(c->d_tcarry[0], count * sizeof(float4)); DEV_ALLOC(c->d_tcarry[1], count * sizeof(float4));
 	DEV_ALLOC(c->d_segpub, (size_t)count * c->nseg_cap * 4 * 8); DEV_ALLOC(c->d_synctmo, 4);
 	DEV_CHK(hipMemset(c->d_segpub, 0, (size_t)count * c->nseg_cap * 4 * 8)); DEV_CHK(hipMemset(c->d_synctmo, 0, 4));
-	c->fuse_k2 = true;
+	// The fused fix-up makes a workgroup wait for the workgroup of the previous segment (one-step look-back, kernels.h).  That is
+	// safe while the workgroups of a launch are dispatched in order and stay resident - one process per GPU, the deployment this
+	// library is built for.  On a GPU time-sliced between PROCESSES the driver saves and restores waves in no particular order, waiting
+	// consumers can then hold the CUs their producers need, the wait times out and the feed is refused (loudly: VDL2HIP_E_DEVICE).
+	// VDL2HIP_NO_FUSE=1 selects the separate fix-up kernel k_fixup instead (no inter-workgroup wait, bit-identical results, ~3 % slower):
+	// the setting for a GPU shared with other processes (bench.py's one-GPU rehearsal of the multi-rank run uses it).
+	c->fuse_k2 = getenv("VDL2HIP_NO_FUSE") == nullptr;
 	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, (size_t)count * kNumCounters * 8);
 	DEV_ALLOC(c->d_acnt, (size_t)count * kNumAvlcCounters * 8);
 	// a decodable burst occupies >= 22 symbols = 220 decimated samples (header + 3 data + 2 FEC octets)
