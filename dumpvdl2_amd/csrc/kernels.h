@@ -663,6 +663,99 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
 	}
 }
 
+// The exact tier with FOUR lanes per sample: a word with work is taken by the whole wavefront, 16 of its samples at a time - lane
+// 4 s + part works out the phases of taps 4 part .. 4 part + 3 of sample s (4 loads, 4 atan2 in double instead of 16 per lane), the
+// phases meet in LDS and the lane with part 0 runs the reference's metric on them.  Same loads, same atan2, same metric, same
+// operation order as k3_exact(): bit-identical values; what changes is the length of the dependent chain a wavefront sits on (the
+// kernel is latency-bound: its arithmetic is a quarter of its run time) and how many lanes have work (a cluster around a preamble
+// is ~13 samples: 13 of 64 lanes busy in the 16-lanes-per-word form, 52 of 64 here).
+__global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
+	__shared__ float psh[4][64 + 3];                     // [wave][3 + bit]: metric of sample word*64 + bit, entries 0..2 = the three samples before the word
+	__shared__ float phs[4][16][kPreamble + 1];          // [wave][sample slot][tap]: exact phases (floats, as the reference keeps them)
+	__shared__ uint8_t items[4][64 + 3];                 // [wave][e]: bit number of the e-th sample to work out (64..66: the three before the word)
+	__shared__ uint64_t s_need[4][64 * kK3bWordsPerLane];
+	__shared__ uint8_t s_fprev[4][64 * kK3bWordsPerLane];
+	__shared__ uint16_t s_list[4][64 * kK3bWordsPerLane];
+	const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const cf32 *y = a.y + (size_t)c * a.cap;
+	const uint64_t *flag = a.flag + (size_t)c * (a.cap >> 6);
+	uint64_t *cand = a.cand + (size_t)c * (a.cap >> 6);
+	const uint32_t wmask = a.mask >> 6;
+	const Tables &T = *a.tab;
+	const int64_t w0 = a.nbase >> 6, w1 = (a.k1 + 63) >> 6;
+	const int64_t wb = w0 + ((int64_t)blockIdx.x * 4 + wave) * (64 * a.wpl);   // first word of this wavefront
+	int nwork = 0;
+	for(int g = 0; g < a.wpl; g++) {
+		const int64_t w = wb + 64 * g + lane;
+		uint64_t need = 0, fprev = 0;
+		if(w < w1) {
+			const uint64_t f0 = flag[(uint32_t)w & wmask];
+			fprev = w > 0 ? flag[(uint32_t)(w - 1) & wmask] : 0ull;      // words before nbase hold the previous feed's flags
+			const uint64_t fnext = w + 1 < w1 ? flag[(uint32_t)(w + 1) & wmask] : 0ull;
+			need = f0 | (f0 << 3) | (f0 >> 3) | (fprev >> 61) | (fnext << 61);
+			const int64_t base = w << 6;
+			if(a.k1 - 3 < base + 64) {                                      // right neighbour n+3 not there yet
+				const int64_t lo = a.k1 - 3 - base;
+				need |= lo <= 0 ? ~0ull : (~0ull << lo);
+			}
+			if(a.k1 < base + 64) need &= (a.k1 - base <= 0) ? 0ull : (~0ull >> (64 - (a.k1 - base)));   // samples that exist
+			if(need == 0) cand[(uint32_t)w & wmask] = 0;
+		}
+		s_need[wave][64 * g + lane] = need; s_fprev[wave][64 * g + lane] = (uint8_t)(fprev >> 61);
+		const unsigned long long busy = __ballot(need != 0);
+		if(need != 0) s_list[wave][nwork + __builtin_popcountll(busy & ((1ull << lane) - 1ull))] = (uint16_t)(64 * g + lane);
+		nwork += __builtin_popcountll(busy);
+	}
+	WAVE_SYNC();
+	const int slot = lane >> 2, part = lane & 3;
+	float *ps = psh[wave];
+	#pragma unroll 1
+	for(int it = 0; it < nwork; it++) {
+		const int idx = (int)s_list[wave][it];
+		const uint64_t needj = s_need[wave][idx];
+		const uint32_t fprevj = s_fprev[wave][idx] & 7u;                  // flags of the three samples before the word
+		const int64_t wj = wb + idx;
+		ps[lane] = kPherrBig; if(lane < 3) ps[64 + lane] = kPherrBig;
+		const int cnt = __builtin_popcountll(needj);
+		if((needj >> lane) & 1ull) items[wave][__builtin_popcountll(needj & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+		if(lane < 3 && ((fprevj >> lane) & 1u)) items[wave][cnt + __builtin_popcount(fprevj & ((1u << lane) - 1u))] = (uint8_t)(64 + lane);
+		const int total = cnt + __builtin_popcount(fprevj);
+		WAVE_SYNC();
+		#pragma unroll 1
+		for(int r0 = 0; r0 < total; r0 += 16) {
+			const bool active = r0 + slot < total;
+			const int item = active ? (int)items[wave][r0 + slot] : 0;
+			const int bit = item < 64 ? item : item - 67;                 // 64..66 -> -3..-1
+			const int64_t n = (wj << 6) + bit;
+			if(active) {
+				cf32 yv[4];
+				#pragma unroll
+				for(int k = 0; k < 4; k++) {                                 // all four loads first
+					const int64_t t = n - 150 + 10 * (4 * part + k);
+					yv[k] = (t < 0 || t >= a.k1) ? cf32{0.f, 0.f} : y[(uint32_t)t & a.mask];
+				}
+				#pragma unroll
+				for(int k = 0; k < 4; k++) phs[wave][slot][4 * part + k] = phase_of(yv[k]);
+			}
+			WAVE_SYNC();
+			if(active && part == 0) {
+				float ph[kPreamble];
+				#pragma unroll
+				for(int i = 0; i < kPreamble; i++) ph[i] = phs[wave][slot][i];
+				float p, f;
+				sync_metric(ph, T, p, f);
+				if(bit >= 0) a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = cf32{p, f};
+				ps[3 + bit] = p;
+			}
+			WAVE_SYNC();
+		}
+		const int64_t n = (wj << 6) + lane;
+		const unsigned long long bits = __ballot(n >= 3 && n < a.k1 && is_candidate(ps[lane], ps[3 + lane]));
+		if(lane == 0) cand[(uint32_t)wj & wmask] = bits;
+		WAVE_SYNC();
+	}
+}
+
 struct K4Args {
 	const cf32 *y; const cf32 *pf; const uint64_t *cand; const Tables *tab;
 	WalkState *ws; unsigned long long *cnt; Burst *bursts; uint32_t *nb_chan; uint32_t cap_bursts_chan; OutCtl *ctl; const uint32_t *freq;

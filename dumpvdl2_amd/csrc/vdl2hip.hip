@@ -86,6 +86,7 @@ struct vdl2hip_ctx {
 	// sync_on: 0 = both sync kernels on the front stream (the product); 1 = the exact tier in front of the walk on the walk stream;
 	// 2 = both on a stream of their own (stream_sync), beside the channeliser of the next feed.  tiles_force / k3b_wpl: K1 tiles per
 	// workgroup segment / K3b words per lane instead of the values chosen from the channel count.
+	int k3b_form = 4;                      // lanes per sample in the exact tier of the sync metric: 4 = k_sync_exact4, 16 = k_sync_exact (test hook "k3b_form")
 	int sync_on = 0; hipStream_t stream_sync = nullptr; int k3b_wpl = 0, tiles_force = 0; bool show_gaps = false; int ablate = 0;
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
@@ -278,7 +279,8 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		for(int wpl = kK3bWordsPerLane; wpl >= 1; wpl >>= 1) { k3.wpl = wpl; if(((nwords + 256 * wpl - 1) / (256 * wpl)) * c->C >= 512 || wpl == 1) break; }
 		if(c->k3b_wpl) k3.wpl = c->k3b_wpl;                                   // experiments only (VDL2HIP_K3B_WPL)
 		const int64_t wpb = 256 * k3.wpl;                                      // words per block
-		LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
+		if(c->k3b_form == 16) LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
+		else LAUNCH_EV(k_sync_exact4, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
 	}
 	// The burst-rate back end runs on three more streams, so that consecutive feeds overlap stage by stage:
 	//   stream_back   K4   walk(i) -> walk(i+1) -> ...             (each needs the previous one's FSM state)
@@ -448,6 +450,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		if(getenv("VDL2HIP_NO_PRIO")) prio_low = prio_high = 0;
 		if(getenv("VDL2HIP_LOW_PRIO")) lowp = getenv("VDL2HIP_LOW_PRIO");          // list of nf,burst,walk
 		if(const char *e = getenv("VDL2HIP_SYNC_ON")) c->sync_on = strcmp(e, "walk") == 0 ? 1 : strncmp(e, "own", 3) == 0 ? 2 : 0;   // front | walk | own | own-high
+		if(const char *e = getenv("VDL2HIP_K3B")) c->k3b_form = atoi(e) == 16 ? 16 : 4;
 		if(const char *e = getenv("VDL2HIP_K3B_WPL")) { int v = atoi(e); if(v == 1 || v == 2 || v == 4) c->k3b_wpl = v; }
 		if(const char *e = getenv("VDL2HIP_K1_TILES")) { long v = atol(e); if(v >= 1 && v <= 64) c->tiles_force = (int)v; }
 		if(const char *e = getenv("VDL2HIP_ABLATE")) c->ablate = (strstr(e, "walk") ? 1 : 0) | (strstr(e, "nf") ? 2 : 0) | (strstr(e, "burst") ? 4 : 0);
@@ -794,6 +797,7 @@ int vdl2hip_debug_option(vdl2hip_ctx *c, const char *name, long value) {
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	if(strcmp(name, "no_fuse") == 0) { c->fuse_k2 = value == 0; return VDL2HIP_OK; }
 	if(strcmp(name, "force_timeout") == 0) { c->debug_force_timeout = value != 0; return VDL2HIP_OK; }
+	if(strcmp(name, "k3b_form") == 0) { c->k3b_form = value == 16 ? 16 : 4; return VDL2HIP_OK; }
 	return VDL2HIP_E_INVAL;
 }
 

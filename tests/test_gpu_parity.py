@@ -502,6 +502,23 @@ def test_separate_fixup_kernel_gives_the_same_answer(vh, name):
     rx.close(); rx2.close()
 
 
+@pytest.mark.parametrize("name", ["config2_1s", "os10_noisy_1s", "config4_0p4s", "config5_0p4s"])
+def test_both_forms_of_the_exact_sync_tier_agree(vh, name):
+    """The exact tier of the sync metric runs with four lanes per sample (k_sync_exact4: 4 taps' phases per lane, the metric on the
+    lane that collects them); the test hook "k3b_form" = 16 selects the older one-lane-per-sample form (k_sync_exact).  Same loads,
+    same atan2 in double, same metric in the reference's operation order: everything downstream - frames, timing, every float of the
+    metadata, the counters - is bit-identical, for whole and for chunked feeds."""
+    cfg, iq, bursts, gold = cases.load(name)
+    key = lambda f: (f["chan"], f["burst_ord"], f["idx"])
+    out = []
+    for dbg in (None, {"k3b_form": 16}):
+        for kw in ({}, dict(chunks=(3000, 200000), max_block=800000)):
+            rx, fr, cnt = gpu_decode(vh, cfg, iq, debug=dbg, **kw)
+            out.append(([(key(f), f["octets"], f["sync_sample"], f["end_sample"], f["ppm_error"], f["frame_pwr_dbfs"], f["nf_pwr_dbfs"]) for f in sorted(fr, key=key)], cnt))
+            rx.close()
+    assert out[0] == out[2] and out[1] == out[3]          # (whole and chunked feeds differ from each other in float rounding)
+
+
 def test_pinned_feed_overlaps_and_matches(vh):
     """vdl2hip_feed_pinned(): blocks queued from two alternating page-locked buffers without waiting for the copies give
     the golden answers; so does the blocking vdl2hip_feed() from pageable memory with three blocks in flight (the copy of
