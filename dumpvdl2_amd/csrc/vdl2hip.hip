@@ -274,9 +274,10 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		hipStream_t sx = c->sync_on == 1 ? sb_ : s3;
 		if(c->sync_on == 1) HIPCHK(hipStreamWaitEvent(sb_, sl.ev_chan, 0));
 		const int64_t nwords = ((k1 + 63) >> 6) - (nbase >> 6);
-		// words per lane of the exact tier: as many as keep >= 2 workgroups per CU (a wavefront with more words finds more of
-		// them with work, but a grid that does not fill the chip is latency-bound)
-		for(int wpl = kK3bWordsPerLane; wpl >= 1; wpl >>= 1) { k3.wpl = wpl; if(((nwords + 256 * wpl - 1) / (256 * wpl)) * c->C >= 512 || wpl == 1) break; }
+		// words per lane of the exact tier: as many as keep >= 8 workgroups per CU (a wavefront with more words amortises its scan,
+		// but the kernel is latency-bound: at 32 channels 1 word per lane - 3 296 workgroups - beat 4 - 832 - by 0.02 ms of a 0.85 ms step,
+		// at 256 channels 4 is as good as any; profiles/r03_k3b_forms.txt)
+		for(int wpl = kK3bWordsPerLane; wpl >= 1; wpl >>= 1) { k3.wpl = wpl; if(((nwords + 256 * wpl - 1) / (256 * wpl)) * c->C >= 2048 || wpl == 1) break; }
 		if(c->k3b_wpl) k3.wpl = c->k3b_wpl;                                   // experiments only (VDL2HIP_K3B_WPL)
 		const int64_t wpb = 256 * k3.wpl;                                      // words per block
 		if(c->k3b_form == 16) LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
