@@ -457,7 +457,12 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		if(const char *e = getenv("VDL2HIP_ABLATE")) c->ablate = (strstr(e, "walk") ? 1 : 0) | (strstr(e, "nf") ? 2 : 0) | (strstr(e, "burst") ? 4 : 0);
 		c->show_gaps = getenv("VDL2HIP_GAPS") != nullptr;
 #endif
-		DEV_CHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_low));
+		int prio_front = prio_low;
+#ifdef VDL2_EXPERIMENTS
+		if(const char *e = getenv("VDL2HIP_FRONT_PRIO")) { if(strcmp(e, "mid") == 0) prio_front = (prio_low + prio_high) / 2; else if(strcmp(e, "high") == 0) prio_front = prio_high; }
+		if(getenv("VDL2HIP_GAPS")) fprintf(stderr, "vdl2hip: stream priority range low %d .. high %d, front %d\n", prio_low, prio_high, prio_front);
+#endif
+		DEV_CHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_front));
 		// The walk goes first whenever it competes with the channeliser of a later feed (every later stage waits for it).  The
 		// noise-floor and burst streams do not: their many single-wave workgroups, dispatched with priority, each take the
 		// register slot of one of the four waves a channeliser workgroup needs on a CU and so keep whole workgroups out; at
