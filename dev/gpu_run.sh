@@ -54,6 +54,7 @@ for r in j['ranks']: print(j['env'], 'rank', r['rank'], r['ms_per_step'], 'K1', 
 	pmc256) timeout 500 bash dev/gpu_pmc_traffic.sh config4 > $O.pmc_hbm_traffic_config4.txt 2>&1; cat $O.pmc_hbm_traffic_config4.txt | cut -c1-160 ;;
 	sq_k1:*) timeout 500 bash dev/gpu_k1_pmc.sh ${job#sq_k1:} > $O.sq_k1_${job#sq_k1:}ch.txt 2>&1; cut -c1-140 $O.sq_k1_${job#sq_k1:}ch.txt ;;
 	sq_k3a:*) KFILTER=sync_screen timeout 500 bash dev/gpu_k1_pmc.sh ${job#sq_k3a:} > $O.sq_k3a_${job#sq_k3a:}ch.txt 2>&1; cut -c1-140 $O.sq_k3a_${job#sq_k3a:}ch.txt ;;
+	k5prof:*) hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DVDL2_K5_PROF -o /tmp/vdl2hip_prof.so dumpvdl2_amd/csrc/vdl2hip.hip 2>/dev/null && VDL2HIP_LIB=/tmp/vdl2hip_prof.so timeout 300 python dev/gpu_stage_times.py ${job#k5prof:} 16 2 2>&1 | grep -v amdgpu.ids | tee $O.k5prof_${job#k5prof:}.txt | cut -c1-200 ;;
 	iso) timeout 300 python dev/gpu_stage_times.py config4 16 3 2>&1 | grep -v amdgpu.ids | tee $O.stage_times_alone.txt | cut -c1-400 ;;
 	k1:*) timeout 300 python dev/gpu_k1_bench.py ${job#k1:} 16 3 2>&1 | grep -v amdgpu.ids | cut -c1-260 | tee -a $O.k1.txt ;;
 	ubench) hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o /tmp/ub dev/gpu_ubench_valu.hip 2>/dev/null && timeout 300 /tmp/ub 2>&1 | tee $O.ubench.txt | head -12 ;;

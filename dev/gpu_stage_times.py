@@ -29,6 +29,12 @@ except AttributeError:
     have = False
 if have:
     a = (C.c_ulonglong * 16)()
+    L.vdl2hip_debug_k5_prof(a)
+    names5 = ["1 slice symbols (atan2)", "2 descramble/pack", "3 de-interleave", "4 Reed-Solomon", "5 un-stuff", "6 frames out"]
+    tot5 = sum(a[8 + i] for i in range(6)) or 1
+    print("K5 phases (lane-0 cycles summed over all bursts; share; longest single):")
+    for i in range(6):
+        print(f"   {names5[i]:26s} {a[8 + i]:14d} {100.0 * a[8 + i] / tot5:5.1f}%  max={a[i]}")
     L.vdl2hip_debug_k4_prof(a)
     names = ["state load/store", "stale batch eval", "account_evals", "bitmap hop", "(fire setup)", "fire handling", "header", "burst emit/tail"]
     tot = sum(a[i] for i in range(8)) or 1
