@@ -646,23 +646,37 @@ def test_group_feed_pinned(vh):
     g.close()
 
 
+_TWO_GPU_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import cases
+from dumpvdl2_amd import vdl2hip as vh
+cfg, iq, _, gold = cases.load("config2_1s")
+raw = iq.view(np.uint8)
+g = vh.ReceiverGroup(cfg.centerfreq, list(cfg.freqs), [0, 1], cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=1 << 20)
+assert g.uses_rccl(), "librccl.so did not load or ncclCommInitAll failed"
+got = []
+for k in range(0, raw.size, 1 << 20):
+    g.feed(raw[k:k + (1 << 20)])
+    got += g.drain()
+assert g.uses_rccl(), "the broadcast fell back to peer copies"
+cases.check_against_golden(got, [list(g.counters(c).values()) for c in range(len(cfg.freqs))], gold, label="two GPUs, RCCL", exact_diagnostics=False)
+g.close()
+print("TWO_GPU_OK")
+"""
+
+
+@pytest.mark.xfail(strict=False, reason="experimental: the RCCL branch of vdl2hip_group_feed has never run on hardware (development boxes have one GPU); "
+                                        "a failure here is the first report from a multi-GPU node, not a regression")
 def test_group_over_two_real_gpus(vh):
     """The RCCL branch of vdl2hip_group_feed (ncclCommInitAll + grouped ncclBroadcast from one thread): only where two GPUs are
-    visible - the development boxes have one, so this is the test that exercises it first on a multi-GPU node."""
-    import torch
+    visible.  Run in a process of its own with a time limit, so that a hang or a crash inside RCCL cannot take the suite with it."""
+    import os, subprocess, sys, torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
-    cfg, iq, _, gold = cases.load("config2_1s")
-    raw = iq.view(np.uint8)
-    g = vh.ReceiverGroup(cfg.centerfreq, list(cfg.freqs), [0, 1], cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=1 << 20)
-    assert g.uses_rccl(), "librccl.so did not load or ncclCommInitAll failed"
-    got = []
-    for k in range(0, raw.size, 1 << 20):
-        g.feed(raw[k:k + (1 << 20)])
-        got += g.drain()
-    assert g.uses_rccl(), "the broadcast fell back to peer copies"
-    cases.check_against_golden(got, [list(g.counters(c).values()) for c in range(len(cfg.freqs))], gold, label="two GPUs, RCCL", exact_diagnostics=False)
-    g.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _TWO_GPU_SNIPPET, root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "TWO_GPU_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
 def test_dropin_adapter_over_several_devices(vh, tmp_path):
