@@ -575,6 +575,11 @@ def main():
                                                                         "note": "north_star's literal form, host-fed: the whole block crosses ONE PCIe link per step"},
                                        "allgather_of_stripes": {"h2d_ms_per_rank": round(h2d / 8, 4), "speedup_ceiling": round(t_host["dt"] / args.steps * 1e3 / t32, 3),
                                                                 "note": "each rank ingests 1/8 over its own link; the xGMI all-gather itself is not measurable on one GPU"}},
+                     # link-rate bounds from the xGMI figures of MI355X_MICROARCH.md (7 links x ~153 GB/s per GPU, i.e. ~77 GB/s per direction
+                     # and link): what an exchange cannot beat, NOT a measurement - one GPU cannot measure them
+                     "xgmi_link_rate_bounds_ms": {"broadcast_one_link_per_hop": round(case.nbytes / 76.5e9 * 1e3, 3),
+                                                  "allgather_into_each_gpu_over_7_links": round(case.nbytes * 7 / 8 / (7 * 76.5e9) * 1e3, 3),
+                                                  "source": "spec link rates, not measured"},
                      "note": "projection from one GPU, not a measurement of 8; the driver's N = 8 run reports by_exchange / rank_ms_per_step"}
 
     if world == 1 and not args.no_secondary and args.workload == "config4":
