@@ -477,7 +477,7 @@ struct K3Args {
 	const cf32 *y; cf32 *pf; uint64_t *cand; uint64_t *flag; const Tables *tab;
 	int64_t nbase, k1;        // first sample to (re)compute (multiple of 64); one past the last valid sample
 	uint32_t cap, mask;
-	int32_t wpl;              // k_sync_exact: flag words scanned per lane (1..kK3bWordsPerLane)
+	int32_t wpl;              // exact tier: flag words scanned per lane (1..kK3bWordsPerLane)
 };
 
 // K3: got_sync() metric (contiguous ring) + the candidate bitmap, in two tiers and two kernels.
@@ -490,7 +490,7 @@ struct K3Args {
 // Ten consecutive lanes cover 10 S consecutive samples; 320 threads cover the tile.  Verdicts go through LDS to be regrouped into words of 64 consecutive samples.  Output: one flag
 // bit per sample - "the exact value may be under the threshold".
 //
-// k_sync_exact - only where a flag is set (on noise 3e-5 of the samples): the reference's arithmetic - atan2 in double on the
+// k_sync_exact4 (and its older form k_sync_exact) - only where a flag is set (on noise 3e-5 of the samples): the reference's arithmetic - atan2 in double on the
 // 16 taps, the double-precision unwrap, the centred regression - for the flagged samples and 3 samples either side (those are
 // y1/y3 of calc_para_vertex and the right-hand side of the candidate test), stored in pf, and the candidate bit
 // pherr(n-3) < 4 && pherr(n) > pherr(n-3) of every sample.  The walker reads the metric nowhere else.  A sample whose right
