@@ -12,6 +12,8 @@ secs = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 cf = 136975000
 freqs = synth.channel_plan(C, cf, max(8000, min(100000, 2000000 // C)))
+if os.environ.get("K1BENCH_SPACING"):      # e.g. 0: every channel on the centre frequency -> all lanes of a gather hit one LUT entry (no bank conflicts)
+    sp = int(os.environ["K1BENCH_SPACING"]); freqs = [cf + (k - C // 2) * sp for k in range(C)]
 n = int(secs * 2100000)
 iq = (torch.randn(2 * n, device="cuda") * 300).to(torch.int16)
 rx = vdl2hip.Receiver(cf, freqs, 20, 1, 3.0, max_block_bytes=iq.numel() * 2)
