@@ -254,7 +254,7 @@ def pmc_traffic(workload, case):
     return None
 
 
-def cpu_baseline_of(case, po, raw, nref_threads, first_pass_s, full=True):
+def cpu_baseline_of(case, po, raw, first_pass_s, full=True):
     """CPU baseline on this box's host cores: the oracle restatement with the REFERENCE'S OWN THREADING (vdl2o_run: a persistent
     thread per channel + the producer, two barriers per 320 000-byte block, serial sample conversion - dumpvdl2.c:117-135,
     demod.c:300-301,356-365), best of 3 passes over the same block (the first pass is the parity gate's).  Beside it: the old
@@ -499,7 +499,7 @@ def main():
         # comparison rank 0's own (the other ranks' counters stay on their GPUs)
         verified, tc = oracle_gate(case, allfr, po, "bench oracle gate" + (" (all ranks)" if world > 1 else ""))
         if world == 1 and not args.no_cpu_baseline:
-            cpu_baseline = cpu_baseline_of(case, po, case.iq.view(np.uint8), case.C, tc)
+            cpu_baseline = cpu_baseline_of(case, po, case.iq.view(np.uint8), tc)
     if world > 1:
         dist.barrier()
     for _ in range(max(0, args.warmup - 1)):
