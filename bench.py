@@ -182,8 +182,10 @@ class Case:
         launches = max(1, s1["chanfir_launches"] - s0["chanfir_launches"])
         k1_ms = (s1["chanfir_ms"] - s0["chanfir_ms"]) / launches
         k1_cs = (s1["chan_samples"] - s0["chan_samples"]) / launches
-        assert s1["front_sync_timeouts"] == 0 and s1["overflow_feeds"] == s0["overflow_feeds"], "device-side overflow or look-back timeout"
+        assert s1["overflow_feeds"] == s0["overflow_feeds"], "device-side buffer overflow"
         out.update({"dt": dt, "frames": nframes, "k1_ms": k1_ms, "k1_chan_samples": k1_cs,
+                    # channeliser workgroups that stopped waiting for their predecessor and recomputed its state (0 with one process per GPU)
+                    "lookback_fallbacks": s1["front_sync_timeouts"] - s0["front_sync_timeouts"],
                     "seg_adopted": (s1["seg_adopted"] - s0["seg_adopted"]) / steps, "seg_walked": (s1["seg_walked"] - s0["seg_walked"]) / steps})
         return out
 
@@ -438,9 +440,8 @@ def main():
     rehearsal = os.environ.get("VDL2_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
-        # several PROCESSES time-slicing one GPU: the channeliser's fused look-back assumes in-order resident workgroups (one process
-        # per GPU) and is switched off for this case (vdl2hip.hip: VDL2HIP_NO_FUSE)
-        os.environ["VDL2HIP_NO_FUSE"] = "1"
+        # (several PROCESSES time-slicing one GPU: here the channeliser's look-back between workgroups does time out now and then and
+        # takes its fall-back - config.lookback_fallbacks_per_step - which the parity gate below then covers)
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the library has no CPU path)"
     torch.cuda.set_device(local)
@@ -624,6 +625,7 @@ def main():
                        "rank_ms_per_step": t_host.get("rank_ms_per_step"),
                        "stage_ms_per_step": stage_ms,
                        "walk_segments_per_step": {"adopted": t_host["seg_adopted"], "walked_sequentially": t_host["seg_walked"]},
+                       "lookback_fallbacks_per_step": t_host["lookback_fallbacks"] / args.steps,
                        "verified": verified,
                        "synth_s": round(case.t_synth, 1),
                        "secondary": secondary},

@@ -56,7 +56,7 @@ def run_rank(cfg, dev_block, nbytes, bursts, first, count, steps, repeats, check
         times.append((time.perf_counter() - t0) / steps * 1e3)
         s1 = rx.stats()
         k1.append((s1["chanfir_ms"] - s0["chanfir_ms"]) / max(1, s1["chanfir_launches"] - s0["chanfir_launches"]))
-        assert s1["front_sync_timeouts"] == 0 and s1["overflow_feeds"] == s0["overflow_feeds"]
+        assert s1["front_sync_timeouts"] == s0["front_sync_timeouts"] and s1["overflow_feeds"] == s0["overflow_feeds"]
     out["ms_per_step"] = {"min": round(min(times), 4), "median": round(statistics.median(times), 4), "all": [round(t, 4) for t in times]}
     out["k_chanfir_ms"] = round(statistics.median(k1), 4)
     # per-stage kernel times, in the pipeline (every launch stamped: a few percent slower)

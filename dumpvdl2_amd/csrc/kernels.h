@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	__shared__ __align__(16) float4 lut[256];     // NCO look-up
 	__shared__ __align__(16) float4 qpow[64];     // Q^(l+1), l = 0..63: what a carry contributes to lane l's end state
 	__shared__ __align__(16) float park[4 * 4 * 4 * 4];   // per wave: carried state and the end-of-feed state, [wave][4][CR][4]
+	__shared__ int fallback;                      // fused fix-up: some wave of this workgroup gave up waiting for the previous segment's state
 	extern __shared__ __align__(16) unsigned char smem[];
 	const int os = OS ? OS : a.os;
 	const int run = R * os;                       // input samples per lane and tile
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 
 	lut[tid] = ((const float4 *)a.lut)[tid];
 	if(tid < 64) qpow[tid] = a.qpow[tid];
+	if(tid == 0) fallback = 0;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave-uniform, so per-channel values stay in SGPRs
 	const int cbase = (gy * 4 + wave) * CR;
 	const bool wave_active = cbase < a.nchan;
@@ -371,26 +373,85 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			if(lane == 63) carry[c] = make_float4(t0r[c], t0i[c], t1r[c], t1i[c]);
 		}
 	}
-	if(!a.fuse || !wave_active) return;
+	if(!a.fuse) return;
 
 	// ---- fused K2: the first tile's outputs get the decayed state of the segment start ----
 	// The state at the start of segment s is the zero-start state at the end of segment s-1 (a segment is >= kFixW blocks
 	// long, older history has decayed below fp32 resolution), which the workgroup of s-1 publishes before it waits for
 	// anything itself (in the epilogue of its last tile): a one-step look-back, no chain.  Workgroups are dispatched in
-	// block-id order and s-1 always has a smaller block id, so the producer is running or done whenever a consumer waits.
-	if(seg == 0) {
-		if(lane < CR) tsp[lane] = a.carry_in[cbase + lane < a.nchan ? cbase + lane : a.nchan - 1];
-	} else if(lane < 4 * CR) {
-		const int c = lane >> 2, ch = cbase + c < a.nchan ? cbase + c : a.nchan - 1;
-		const unsigned long long *src = a.seg_pub + ((size_t)ch * a.nseg_cap + seg - 1) * 4 + (lane & 3);
-		unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		for(int spins = 0; (uint32_t)(w >> 32) != a.epoch; spins++) {
-			if((uint32_t)spins > a.spin_limit) { atomicAdd(a.sync_timeouts, 1u); break; }
-			__builtin_amdgcn_s_sleep(8);
-			w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	// block-id order and s-1 always has a smaller block id, so the producer is running or done whenever a consumer waits -
+	// as long as the launch's workgroups stay resident in that order.  Where they do not (a GPU time-sliced between processes
+	// restores saved waves in any order), a consumer that has waited spin_limit polls stops waiting and WORKS THE STATE OUT ITSELF
+	// (below): nothing fails, the workgroup just does one more tile.
+	bool timed_out = false;
+	if(wave_active) {
+		if(seg == 0) {
+			if(lane < CR) tsp[lane] = a.carry_in[cbase + lane < a.nchan ? cbase + lane : a.nchan - 1];
+		} else if(lane < 4 * CR) {
+			const int c = lane >> 2, ch = cbase + c < a.nchan ? cbase + c : a.nchan - 1;
+			const unsigned long long *src = a.seg_pub + ((size_t)ch * a.nseg_cap + seg - 1) * 4 + (lane & 3);
+			unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			for(int spins = 0; (uint32_t)(w >> 32) != a.epoch; spins++) {
+				if((uint32_t)spins > a.spin_limit) { timed_out = true; break; }
+				__builtin_amdgcn_s_sleep(8);
+				w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			reinterpret_cast<float *>(tsp)[lane] = __uint_as_float((uint32_t)w);
 		}
-		reinterpret_cast<float *>(tsp)[lane] = __uint_as_float((uint32_t)w);
 	}
+	// the whole workgroup has to agree (the fall-back stages a tile together)
+	if(timed_out) fallback = 1;
+	__syncthreads();
+	if(fallback) {
+		// Fall-back: the zero-start state at the end of the previous segment's LAST TILE is, to fp32 resolution, the state the
+		// producer would have published (what lies further back has decayed by P^128 ~ 1e-17).  Stage that tile, let every lane run its
+		// blocks from zero (the arithmetic of the main loop), weigh lane l's end state with Q^(63-l) and sum over the wavefront.
+		// Differs from the published value in rounding only (a sum instead of a scan); rare, so it is written for clarity, not speed.
+		if(tid == 0) atomicAdd(a.sync_timeouts, 1u);
+		const int64_t sbase = ((int64_t)seg * a.tiles - 1) * tile_n;
+		for(int t = tid; t < tile_n; t += 256) {
+			const int64_t sidx = sbase + t;
+			float re = 0.f, im = 0.f;
+			if(sidx >= 0 && sidx < (int64_t)a.nlogical) load_sample(a, sidx, re, im);
+			const int l = t / run, m = t - l * run;
+			tile[m * 65 + l] = make_float2(re, im);
+		}
+		__syncthreads();
+		if(wave_active) {
+			const uint32_t nabs = (uint32_t)((a.n0 + (uint64_t)sbase + (uint64_t)lane * run) & 0xffffffu);
+			const float4 qw = lane < 63 ? qpow[62 - lane] : make_float4(1.f, 0.f, 0.f, 1.f);      // Q^(63 - lane)
+			#pragma unroll 1
+			for(int c = 0; c < CR; c++) {
+				uint32_t p = nabs * dph[c];
+				float u0r = 0.f, u0i = 0.f, u1r = 0.f, u1i = 0.f;
+				#pragma unroll 1
+				for(int i = 0; i < R; i++) {
+					v2f A0 = v2f{0.f, 0.f}, A1 = v2f{0.f, 0.f};
+					const float2 *trow = tile + (size_t)(i * os) * 65 + lane;
+					#pragma unroll 1
+					for(int j = 0; j < os; j++) {
+						const float2 x = trow[j * 65];
+						const v2f X = v2f{x.x, x.y}, Xr = v2f{-x.y, x.x};
+						const float F = (float)(p & 0xffffu);
+						const float4 e = lut[(p >> 16) & 0xffu];
+						const v2f sc = __builtin_elementwise_fma(v2f{e.z, e.w}, v2f{F, F}, v2f{e.x, e.y});
+						const v2f m = __builtin_elementwise_fma(v2f{sc.y, sc.y}, X, v2f{sc.x, sc.x} * Xr);
+						A0 = __builtin_elementwise_fma(v2f{bf.g0[j], bf.g0[j]}, m, A0);
+						A1 = __builtin_elementwise_fma(v2f{bf.g1[j], bf.g1[j]}, m, A1);
+						p += dph[c];
+					}
+					const float n0r = __builtin_fmaf(P0, u0r, __builtin_fmaf(P1, u1r, A0.x)), n0i = __builtin_fmaf(P0, u0i, __builtin_fmaf(P1, u1i, A0.y));
+					const float n1r = __builtin_fmaf(P2, u0r, __builtin_fmaf(P3, u1r, A1.x)), n1i = __builtin_fmaf(P2, u0i, __builtin_fmaf(P3, u1i, A1.y));
+					u0r = n0r; u0i = n0i; u1r = n1r; u1i = n1i;
+				}
+				float s0r = qw.x * u0r + qw.y * u1r, s0i = qw.x * u0i + qw.y * u1i, s1r = qw.z * u0r + qw.w * u1r, s1i = qw.z * u0i + qw.w * u1i;
+				#pragma unroll
+				for(int d = 1; d < 64; d <<= 1) { s0r += __shfl_xor(s0r, d); s0i += __shfl_xor(s0i, d); s1r += __shfl_xor(s1r, d); s1i += __shfl_xor(s1i, d); }
+				if(lane == 0) tsp[c] = make_float4(s0r, s0i, s1r, s1i);
+			}
+		}
+	}
+	if(!wave_active) return;
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	const int64_t seglen = (int64_t)a.tiles * L;

@@ -25,8 +25,8 @@ extern "C" {
 #endif
 
 #define VDL2HIP_ABI_VERSION 3   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added
-                                 * 3: vdl2hip_feed_pinned(); vdl2hip_stats.overflow_feeds; a look-back timeout is VDL2HIP_E_DEVICE;
-                                 *    vdl2hip_group_*: one receiver over several GPUs from C */
+                                 * 3: vdl2hip_feed_pinned(); vdl2hip_stats.overflow_feeds; vdl2hip_group_*: one receiver over several
+                                 *    GPUs from C (a channeliser look-back that gives up is no longer an error: it falls back) */
 
 /* enum sample_formats, src/dumpvdl2.h:319 */
 #define VDL2HIP_FMT_U8     0
@@ -132,8 +132,9 @@ typedef struct {
 	uint64_t frames;            /* frames produced */
 	uint64_t seg_adopted;       /* segmented walk: speculative segments adopted ... */
 	uint64_t seg_walked;        /* ... and segments walked sequentially because a burst straddled their start */
-	uint64_t front_sync_timeouts; /* channeliser workgroups that gave up waiting for their predecessor's state: always 0
-	                               * (non-zero disables the context: every later call returns VDL2HIP_E_DEVICE) */
+	uint64_t front_sync_timeouts; /* channeliser workgroups that stopped waiting for their predecessor's filter state and worked it out
+	                               * themselves (one more tile of work each; results unaffected).  0 with one process per GPU; non-zero
+	                               * where the GPU is time-sliced between processes - consider VDL2HIP_NO_FUSE=1 there */
 	uint64_t overflow_feeds;    /* feeds in which a device-side burst/frame/octet buffer ran out (bursts or frames were dropped);
 	                             * vdl2hip_sync() returns VDL2HIP_E_OVERFLOW for those, the drain calls only count here */
 } vdl2hip_stats;

@@ -545,26 +545,26 @@ def test_pinned_feed_overlaps_and_matches(vh):
     rx.close()
 
 
-def test_lookback_timeout_fails_loudly(vh):
-    """A channeliser workgroup that gives up waiting for its predecessor's filter state must not go on silently: with the
-    hand-off forced to fail (the producers publish under a wrong epoch) the feed's results are refused with
-    VDL2HIP_E_DEVICE and the context stays disabled."""
-    cfg, iq, _, gold = cases.load("config2_1s")
-    rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=iq.nbytes)
-    rx.debug_option("force_timeout", 1)
-    rx.feed(iq)                                            # queues; the failure is detected when the feed is collected
-    with pytest.raises(vh.Vdl2HipError, match="-3"):
-        rx.drain()
-    with pytest.raises(vh.Vdl2HipError, match="-3"):
-        rx.feed(iq)
-    with pytest.raises(vh.Vdl2HipError, match="-3"):
-        rx.sync()
-    assert rx.stats()["front_sync_timeouts"] > 0
-    rx.close()
-    # an undisturbed context next to it is fine
-    rx2, fr, cnt = gpu_decode(vh, cfg, iq)
-    cases.check_against_golden(fr, cnt, gold, label="after a failed context")
-    rx2.close()
+@pytest.mark.parametrize("name,chunks", [("config2_1s", None), ("config4_0p4s", None), ("os10_noisy_1s", (3000, 200000)), ("config5_0p4s", (50000, 400000))])
+def test_lookback_fallback_recovers(vh, name, chunks):
+    """A channeliser workgroup that gives up waiting for its predecessor's filter state works that state out itself from the
+    previous segment's last tile (kernels.h).  With the hand-off forced to fail for EVERY workgroup (the producers publish under
+    a wrong epoch, the consumers poll 16 times) the whole decimated stream goes through the fall-back: golden frames, timing and
+    counters all the same, a stream within rounding of the normal one, nothing refused - and the statistics say it happened."""
+    cfg, iq, _, gold = cases.load(name)
+    kw = dict(chunks=chunks, max_block=1600000) if chunks else {}
+    rx, fr, cnt = gpu_decode(vh, cfg, iq, **kw)
+    rx2, fr2, cnt2 = gpu_decode(vh, cfg, iq, debug={"force_timeout": 1}, **kw)
+    assert rx.stats()["front_sync_timeouts"] == 0 and rx2.stats()["front_sync_timeouts"] > 0
+    cases.check_against_golden(fr2, cnt2, gold, label=f"{name} through the look-back fall-back", exact_diagnostics=False)
+    D = iq.size // 2 // cfg.oversample
+    peak = float(np.abs(np.asarray(iq).astype(np.float32)).max()) / 32768.0
+    for c in range(min(len(cfg.freqs), 16)):
+        a, b = rx.read_decimated(c, max(0, D - 30000), 30000), rx2.read_decimated(c, max(0, D - 30000), 30000)
+        # a sum of the lanes' states instead of a scan: the state differs in its last bit, which this filter form turns into ~1e-5 of
+        # the signal on the first 128 outputs of a segment - the same size as its distance from the reference's own rounding (DESIGN 5)
+        assert np.abs(a - b).max() <= 1e-4 * peak
+    rx.close(); rx2.close()
 
 
 def test_handoff_under_uneven_load(vh):
