@@ -78,8 +78,8 @@ struct K1Args {
 	unsigned long long *seg_pub; // [nchan][nseg_cap][4]: (epoch << 32 | float bits) of the zero-start segment end state
 	uint32_t epoch;
 	uint32_t pub_epoch;        // = epoch (differs only when a test forces the look-back to time out)
-	uint32_t spin_limit;
-	uint32_t *sync_timeouts;   // sticky count of look-back waits that gave up (never expected)
+	uint32_t spin_limit;       // polls (~1 us each) before a consumer stops waiting for the previous segment's state and recomputes it
+	uint32_t *sync_timeouts;   // count of workgroups whose look-back wait gave up and took the fall-back (0 with one process per GPU)
 	uint32_t cap, mask, nseg_cap;
 };
 
