@@ -517,6 +517,7 @@ def main():
         f_hbm.step()
     case.rx.set_drain_lag(0); case.rx.drain_packed()
     t_hbm = case.timed(f_hbm, args.steps, dist, args.repeats)
+    stage_ms_hbm = case.stage_times(f_hbm)
     del f_hbm
 
     # ---- N > 1: the other exchange form, demodulating, beside the chosen one ----
@@ -634,6 +635,7 @@ def main():
                        "by_exchange": by_exchange,
                        "rank_ms_per_step": t_host.get("rank_ms_per_step"),
                        "stage_ms_per_step": stage_ms,
+                       "stage_ms_per_step_hbm_resident": stage_ms_hbm,
                        "walk_segments_per_step": {"adopted": t_host["seg_adopted"], "walked_sequentially": t_host["seg_walked"]},
                        "lookback_fallbacks_per_step": t_host["lookback_fallbacks"] / args.steps,
                        "verified": verified,

@@ -36,7 +36,7 @@ for job in "$@"; do
 	pytest) timeout 1200 python -m pytest tests -m gpu -x -q > $O.pytest.txt 2>&1; echo "pytest rc=$?" >> $O.pytest.txt; tail -3 $O.pytest.txt ;;
 	bench) timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O.bench_default.json 2> $O.bench_default.err; echo "bench rc=$?"; tail -c 400 $O.bench_default.err; cut -c1-600 $O.bench_default.json ;;
 	bench5) timeout 600 python bench.py --workload config5 --no-secondary --no-cpu-baseline > $O.bench_config5.json 2> $O.bench_config5.err; echo "config5 rc=$?"; cut -c1-400 $O.bench_config5.json ;;
-	benchq) timeout 600 python bench.py --no-secondary --no-cpu-baseline --no-verify >> $O.benchq.jsonl 2>> $O.benchq.err; echo "rc=$?"; tail -1 $O.benchq.jsonl | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['ms_per_step_hbm_resident'], j['config']['stage_ms_per_step'])" ;;
+	benchq) timeout 600 python bench.py --no-secondary --no-cpu-baseline --no-verify >> $O.benchq.jsonl 2>> $O.benchq.err; echo "rc=$?"; tail -1 $O.benchq.jsonl | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['ms_per_step_hbm_resident'], j['config']['stage_ms_per_step'], j['config'].get('stage_ms_per_step_hbm_resident'), j['roofline']['avg_launch_ms'], j['roofline']['avg_launch_ms_host_fed'])" ;;
 	benchw:*) timeout 600 python bench.py --workload ${job#benchw:} --no-secondary --no-cpu-baseline --no-verify --repeats 2 2>> $O.benchw.err | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print('$job [$(sfx)]', j['value'], j['ms_per_step'], j['ms_per_step_hbm_resident'], j['config']['stage_ms_per_step'])" | tee -a $O.benchw.txt ;;
 	shard32) timeout 900 python dev/gpu_shard32.py --json $O.shard32.json 2> $O.shard32.err | python -c "
 import json,sys

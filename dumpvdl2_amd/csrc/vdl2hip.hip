@@ -316,7 +316,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl, (const uint32_t *)c->d_synctmo);
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
-		if(!(c->ablate & 4))
+		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: bbase[0] = 0 bursts to decode)
 		hipExtLaunchKernelGGL(k_burst, dim3(2048 / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)(sizeof(BurstShared) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
 		sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0;
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
@@ -587,6 +587,9 @@ static int feed_host(vdl2hip_ctx *c, const void *buf, size_t nbytes, bool wait_c
 		if(hipMalloc((void **)&c->d_in[k], c->in_cap + 16) != hipSuccess) return VDL2HIP_E_NOMEM;
 		HIPCHK(hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming));
 	}
+	// (Where this copy lands relative to the kernels of the blocks before it makes no difference: it costs the kernels that run beside it
+	// about 8 % of its own duration whichever they are - held back on the copy stream or by the host until the channeliser of the
+	// previous block starts, the step is the same or worse; profiles/r03_h2d_placement.txt)
 	HIPCHK(hipMemcpyAsync(c->d_in[k], buf, nbytes, hipMemcpyHostToDevice, c->stream_copy));
 	HIPCHK(hipEventRecord(c->ev_copied[k], c->stream_copy));
 	if(wait_copy) HIPCHK(hipEventSynchronize(c->ev_copied[k]));    // `buf` is only ours during the call
