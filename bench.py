@@ -222,9 +222,15 @@ def roofline_of(t, traffic):
     out = {"bound": "valu", "kernel": "k_chanfir", "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(tf / VALU_PEAK_TFLOPS, 4), "traffic": tr_bytes,
            "flop_per_chan_sample": FLOP_PER_CHAN_SAMPLE, "avg_launch_ms": round(k1_ms, 5), "chan_samples_per_launch": cs,
-           "issue_rate_ceiling": {"v_fma_f32": 100.7, "v_pk_fma_f32": 112.9, "unit": "TFLOP/s",
-                                  "note": "what back-to-back independent FMAs reach on this chip (micro-benchmark dev/gpu_ubench_valu.hip, "
-                                          "profiles/r02_ubench_issue_rates.txt): the practical ceiling of an issue-bound kernel"},
+           "issue_rate_ceiling": {"v_fma_f32": 126.0, "v_pk_fma_f32": 140.0, "unit": "TFLOP/s", "shader_clock_GHz": 2.3,
+                                  "note": "what back-to-back independent FMAs reach with the chip at its working clock (dev/gpu_ubench_clock.hip, "
+                                          "profiles/r03_ubench_clock.txt, r03_clocks_under_load.txt): 2.4 / 4.4 clocks per wave instruction"},
+           "co_bound": {"pipe": "LDS gather", "clocks_per_random_16B_wave_gather_per_CU": 10.7,
+                        "clocks_per_chan_sample_wave_per_SIMD": {"lds_gather_rate": 43, "valu_issue_cost_of_the_sample_loop": 31, "measured_sample_loop": 45},
+                        "share_of_a_tile": {"sample_loop": 0.77, "scan_outputs_carry": 0.16, "staging": 0.05, "barriers": 0.02},
+                        "note": "k_chanfir needs one LUT gather (ds_read_b128 at 64 unrelated entries) per channel-sample; the CU's one LDS pipe serves four "
+                                "SIMDs, so the sample loop runs at the gather rate with the VALU ~70 % busy (profiles/r03_ubench_clock.txt, "
+                                "r03_k1_phase_probe.txt; constants from those files, not measured in this run)"},
            "hbm_algorithmic": {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                "bytes_per_chan_sample": ALGO_BYTES, "bytes_per_launch": cs * ALGO_BYTES,
                                "note": "SURVEY 8.5's accounting: the cs16 block charged once per channel (the reference's access pattern) + one "
@@ -510,6 +516,16 @@ def main():
     # ---- timed region: exactly K steps, host-fed, `repeats` times ----
     t_host = case.timed(f_host, args.steps, dist, args.repeats)
     stage_ms = case.stage_times(f_host)
+    # every timed region above pays the pipeline's fill and drain once (first H2D exposed, the last block's back end after the last
+    # front): a fixed 2-4 ms, i.e. 0.1-0.2 ms per step at K = 20.  One long region (10 K steps, at least 100) shows the streaming rate.
+    steady = None
+    if world == 1 and not args.no_secondary:
+        ks = max(100, 10 * args.steps)
+        ts = case.timed(f_host, ks, dist, 1)
+        steady = {"steps": ks, "value": round(case.nsamples * ks / ts["dt"] / 1e6, 3), "ms_per_step": round(ts["dt"] / ks * 1e3, 4),
+                  "k_chanfir_ms": round(ts["k1_ms"], 5),
+                  "note": "host-fed, one timed region of this many steps: the fill and drain of the three-deep pipeline (paid once per "
+                          "region, whatever its length) weigh a tenth of what they do in the K-step regions `value` comes from"}
     del f_host
     # ---- the same with the block resident in HBM ----
     f_hbm = case.feeder(mode, "hbm")
@@ -617,6 +633,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": args.repeats, "value_is": f"median of {args.repeats} repeats of the K = {args.steps} timed steps",
             "ms_per_step_all_repeats": t_host["all_ms_per_step"], "ms_per_step_min": t_host["min_ms_per_step"],
+            "steady_state": steady,
             "value_hbm_resident": round(value_hbm, 3), "ms_per_step_hbm_resident": round(t_hbm["dt"] / args.steps * 1e3, 4),
             "ms_per_step_hbm_resident_all_repeats": t_hbm["all_ms_per_step"],
             "parity": ("frames, integer metadata and the reference's counters identical to the CPU oracle on the whole block; float metadata within "

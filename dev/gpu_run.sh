@@ -12,6 +12,9 @@
 #   iso           per-stage kernel times of config4, nothing overlapped
 #   k1:<C>        dev/gpu_k1_bench.py on C channels
 #   ubench        dev/gpu_ubench_valu.hip: issue rates, LDS gathers, and K1's inner loop with its tap sums on the VALU / on the matrix pipe
+#   k1phases:<C>  -DVDL2_K1_PROF build: shader clocks per phase of a channeliser tile (dev/gpu_k1_phases.py)
+#   ubclock       dev/gpu_ubench_clock.hip: issue costs in shader clocks (s_memtime), chip at its working clock
+#   clocks        dev/gpu_clocks.sh: rocm-smi clock / power samples while the micro-benchmark and bench.py run
 #   env:<A=B>     export A=B for the jobs that follow;  unenv:<A>  unset it
 #   exp           build the library with -DVDL2_EXPERIMENTS (the VDL2HIP_CR / K1_TILES / K3B_WPL / SYNC_ON / LOW_PRIO / ABLATE / GAPS
 #                 switches exist only there) into /tmp/vdl2hip_exp.so and point VDL2HIP_LIB at it for the jobs that follow
@@ -58,6 +61,9 @@ for r in j['ranks']: print(j['env'], 'rank', r['rank'], r['ms_per_step'], 'K1', 
 	iso) timeout 300 python dev/gpu_stage_times.py config4 16 3 2>&1 | grep -v amdgpu.ids | tee $O.stage_times_alone.txt | cut -c1-400 ;;
 	k1:*) timeout 300 python dev/gpu_k1_bench.py ${job#k1:} 16 3 2>&1 | grep -v amdgpu.ids | cut -c1-260 | tee -a $O.k1.txt ;;
 	ubench) hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o /tmp/ub dev/gpu_ubench_valu.hip 2>/dev/null && timeout 300 /tmp/ub 2>&1 | tee $O.ubench.txt | head -12 ;;
+	k1phases:*) hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DVDL2_K1_PROF -o /tmp/vdl2hip_k1prof.so dumpvdl2_amd/csrc/vdl2hip.hip 2>/dev/null && VDL2HIP_LIB=/tmp/vdl2hip_k1prof.so timeout 300 python dev/gpu_k1_phases.py ${job#k1phases:} 2>&1 | grep -v amdgpu.ids | tee -a $O.k1_phases.txt ;;
+	ubclock) hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -Wno-unused-result -o /tmp/ubc dev/gpu_ubench_clock.hip 2>/dev/null && timeout 300 /tmp/ubc 2>&1 | tee $O.ubench_clock.txt ;;
+	clocks) timeout 400 bash dev/gpu_clocks.sh > $O.clocks.txt 2>&1; tail -5 $O.clocks.txt ;;
 	*) echo "unknown job $job" ;;
 	esac
 done

@@ -140,6 +140,23 @@ __global__ void k_dpp_probe(const float *in, float *out) {
 #ifndef VDL2_K1_MIN_BLOCKS_CR4
 #define VDL2_K1_MIN_BLOCKS_CR4 4
 #endif
+// optional per-phase cycle probe of the channeliser (development aid, -DVDL2_K1_PROF; compiled out by default): wave 0 of every
+// workgroup adds the shader clocks it spends in each phase of a tile to vdl2_k1_prof[phase], the count to [8 + phase]
+#ifdef VDL2_K1_PROF
+__device__ unsigned long long vdl2_k1_prof[64][16];
+// wave-uniform on purpose (every lane of wave 0 does the same scalar arithmetic): the sums live in SGPRs and the kernel's vector
+// registers are left alone; 16 atomics per workgroup at its very end, spread over 64 slots
+#define K1_BEGIN() unsigned k1_t0_ = (unsigned)__builtin_readcyclecounter(), k1_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, k1_tiles_ = 0
+#define K1_MARK(k) do { if(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); \
+	k1_acc_[k] += t_ - k1_t0_; if((k) == 3) k1_tiles_++; k1_t0_ = t_; } } while(0)
+#define K1_END() do { if(threadIdx.x == 0) { for(int k_ = 0; k_ < 8; k_++) atomicAdd(&vdl2_k1_prof[blockIdx.x & 63][k_], (unsigned long long)k1_acc_[k_]); \
+	atomicAdd(&vdl2_k1_prof[blockIdx.x & 63][8], 1ull); atomicAdd(&vdl2_k1_prof[blockIdx.x & 63][9], (unsigned long long)k1_tiles_); } } while(0)
+#else
+#define K1_BEGIN() do {} while(0)
+#define K1_MARK(k) do {} while(0)
+#define K1_END() do {} while(0)
+#endif
+
 template<int OS, int R, int CR>
 __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MIN_BLOCKS)) void k_chanfir(K1Args a) {
 	static_assert(64 * R == kFixW || R == 1, "the fused fix-up assumes the fix window is the segment's first tile");
@@ -155,6 +172,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	const int run = R * os;                       // input samples per lane and tile
 	float2 *tile = (float2 *)smem;                // [run][65]
 	const int tid = threadIdx.x;
+	K1_BEGIN();
 
 	// XCD-aware decode of the 1-D block id: workgroups that share a time tile land on one XCD (same L2)
 	const int bid = blockIdx.x;
@@ -214,7 +232,9 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 		const int64_t kbase = tix * L;                           // feed-local index of the tile's first output
 		if(kbase >= a.D) break;
 		const int64_t sbase = tix * tile_n;
+		K1_MARK(ts ? 4 : 0);                                     // 0: prologue (tables, first prefetch); 4: scan, outputs, carry of the previous tile
 		if(ts) __syncthreads();                                  // everyone is done with the previous tile
+		K1_MARK(5);                                              // 5: waiting for the workgroup's other waves before the tile is overwritten
 		const bool fast_now = a.fmt == 1 && sbase >= (int64_t)a.ncarry && sbase + tile_n <= (int64_t)a.nlogical;
 		if(kPrefetch && fast_now) {
 			// the usual case - a cs16 tile that lies entirely inside this feed's block: no per-sample range or carry checks
@@ -250,7 +270,9 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 				tile[m * 65 + l] = make_float2(re, im);
 			}
 		}
+		K1_MARK(1);                                              // 1: staging (conversion + LDS stores + issue of the next tile's loads)
 		__syncthreads();
+		K1_MARK(2);                                              // 2: waiting for the staging of the other waves
 		if(!wave_active) continue;
 
 		uint32_t ph[CR];
@@ -317,6 +339,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			}
 		}
 
+		K1_MARK(3);                                              // 3: the sample loop and the block updates
 		// wave-level scan of the lane end states: X_l = Q X_{l-1} + E_l, Q = P^R, X_-1 = carry - on the cross-lane data paths
 		// of the VALU (DPP), no LDS traffic (ds_bpermute) and no lane-range selects:
 		//   4 Kogge-Stone steps inside each row of 16 lanes (row_shr:2^d; a lane whose source lies outside its row reads 0),
@@ -410,7 +433,8 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			if(lane == 63) carry[c] = make_float4(t0r[c], t0i[c], t1r[c], t1i[c]);
 		}
 	}
-	if(!a.fuse) return;
+	K1_MARK(4);
+	if(!a.fuse) { K1_END(); return; }
 
 	// ---- fused K2: the first tile's outputs get the decayed state of the segment start ----
 	// The state at the start of segment s is the zero-start state at the end of segment s-1 (a segment is >= kFixW blocks
@@ -439,6 +463,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	// the whole workgroup has to agree (the fall-back stages a tile together)
 	if(timed_out) fallback = 1;
 	__syncthreads();
+	K1_MARK(6);                                                  // 6: look-back wait
 	if(fallback) {
 		// Fall-back: the zero-start state at the end of the previous segment's LAST TILE is, to fp32 resolution, the state the
 		// producer would have published (what lies further back has decayed by P^128 ~ 1e-17).  Stage that tile, let every lane run its
@@ -521,6 +546,8 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			a.carry_out[cbase + c] = e;
 		}
 	}
+	K1_MARK(7);                                                  // 7: fix-up of the first tile's outputs
+	K1_END();
 }
 
 struct K2Args {

@@ -587,9 +587,9 @@ static int feed_host(vdl2hip_ctx *c, const void *buf, size_t nbytes, bool wait_c
 		if(hipMalloc((void **)&c->d_in[k], c->in_cap + 16) != hipSuccess) return VDL2HIP_E_NOMEM;
 		HIPCHK(hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming));
 	}
-	// (Where this copy lands relative to the kernels of the blocks before it makes no difference: it costs the kernels that run beside it
-	// about 8 % of its own duration whichever they are - held back on the copy stream or by the host until the channeliser of the
-	// previous block starts, the step is the same or worse; profiles/r03_h2d_placement.txt)
+	// (In a stream of blocks this copy costs nothing: 200-step regions run at the same 5.51 ms per 256-channel block host-fed and
+	// HBM-resident.  What a short timed region sees is the FIRST copy, which nothing overlaps: 2.6 ms once.  Holding the copy back so that
+	// it lands beside the channeliser rather than the sync kernels changes nothing or makes it worse; profiles/r03_h2d_placement.txt)
 	HIPCHK(hipMemcpyAsync(c->d_in[k], buf, nbytes, hipMemcpyHostToDevice, c->stream_copy));
 	HIPCHK(hipEventRecord(c->ev_copied[k], c->stream_copy));
 	if(wait_copy) HIPCHK(hipEventSynchronize(c->ev_copied[k]));    // `buf` is only ours during the call
@@ -818,6 +818,16 @@ int vdl2hip_debug_dpp_probe(const float in[64], float out[256]) {
 	(void)hipFree(d_in); (void)hipFree(d_out);
 	return rc;
 }
+
+#ifdef VDL2_K1_PROF
+int vdl2hip_debug_k1_prof(unsigned long long out[16], int reset) {
+	static unsigned long long h[64][16];
+	if(hipMemcpyFromSymbol(h, HIP_SYMBOL(vdl2_k1_prof), sizeof h) != hipSuccess) return -3;
+	for(int k = 0; k < 16; k++) { out[k] = 0; for(int s = 0; s < 64; s++) out[k] += h[s][k]; }
+	if(reset) { memset(h, 0, sizeof h); if(hipMemcpyToSymbol(HIP_SYMBOL(vdl2_k1_prof), h, sizeof h) != hipSuccess) return -3; }
+	return 0;
+}
+#endif
 
 #ifdef VDL2_K5_PROF
 int vdl2hip_debug_k5_prof(unsigned long long out[16]) {
