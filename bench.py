@@ -50,6 +50,7 @@ OS = 20
 ALGO_BYTES = 4.0 + 8.0 / OS
 FLOP_PER_CHAN_SAMPLE = 30.0                       # LUT interpolation 6 + mix 6 + 2 x 9 IIR
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s spec
+CLOCK_WARMUP_S = 0.05                             # untimed steps before every set of timed regions (see Case.timed)
 VALU_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: peak FP32 vector
 WORKLOAD_INDEX = {"config2": 1, "config3": 2, "config4": 3, "config5": 4}
 
@@ -136,6 +137,19 @@ class Case:
     def timed(self, feeder, steps, dist, repeats=1):
         """`repeats` times exactly `steps` steps in streaming mode (three blocks in flight); every block fully delivered inside
         each timed region.  Returns the median repeat plus the list."""
+        # the shader clock idles at ~100 MHz and needs some tens of ms of load to come up (profiles/r03_clocks_under_load.txt): after the CPU-side
+        # pauses of this script (oracle gate, set-up of a receiver) a short region would otherwise start on a cold clock.  Untimed steps.
+        t0 = time.perf_counter()
+        while True:
+            for _ in range(8):
+                feeder.step()
+            el = time.perf_counter() - t0
+            if self.world > 1:         # every rank must do the same number of steps (each one is a collective)
+                t = self.torch.tensor([el], dtype=self.torch.float64, device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                el = float(t.item())
+            if el >= CLOCK_WARMUP_S:
+                break
         runs = [self._timed_once(feeder, steps, dist) for _ in range(max(1, repeats))]
         runs_sorted = sorted(runs, key=lambda r: r["dt"])
         med = dict(runs_sorted[len(runs_sorted) // 2])
@@ -546,11 +560,11 @@ def main():
                 continue
             fo = case.feeder(m, "host")
             fo.step(); fo.step(); case.rx.set_drain_lag(0); case.rx.drain_packed()
-            to = case.timed(fo, args.steps, dist, 1)
+            to = case.timed(fo, args.steps, dist, args.repeats)
             del fo
             fo = case.feeder(m, "hbm")
             fo.step(); fo.step(); case.rx.set_drain_lag(0); case.rx.drain_packed()
-            tr = case.timed(fo, args.steps, dist, 1)
+            tr = case.timed(fo, args.steps, dist, args.repeats)
             del fo
             by_exchange[m] = {"value": round(case.nsamples * args.steps / to["dt"] / 1e6, 3), "ms_per_step": round(to["dt"] / args.steps * 1e3, 4),
                               "ms_per_step_hbm_resident": round(tr["dt"] / args.steps * 1e3, 4), "rank_ms_per_step": to.get("rank_ms_per_step")}
@@ -631,7 +645,7 @@ def main():
             "value": round(value, 3), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(t_host["dt"] / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "repeats": args.repeats, "value_is": f"median of {args.repeats} repeats of the K = {args.steps} timed steps",
+            "repeats": args.repeats, "clock_warmup_s": CLOCK_WARMUP_S, "value_is": f"median of {args.repeats} repeats of the K = {args.steps} timed steps",
             "ms_per_step_all_repeats": t_host["all_ms_per_step"], "ms_per_step_min": t_host["min_ms_per_step"],
             "steady_state": steady,
             "value_hbm_resident": round(value_hbm, 3), "ms_per_step_hbm_resident": round(t_hbm["dt"] / args.steps * 1e3, 4),
