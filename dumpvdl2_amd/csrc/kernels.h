@@ -662,7 +662,7 @@ __global__ __launch_bounds__(kK3Threads) void k_sync_screen(K3Args a) {
 	for(int q = 0; q < kK3Share; q++) {
 		// the first kScreenEarly taps bound the value from below: most wavefronts stop here
 		ScreenAcc acc;
-		screen_begin(acc, ph[q]);
+		screen_begin(acc);
 		screen_taps(&d[q], 1, kScreenEarly, acc);
 		float ps = screen_value(acc, kScreenEarly);
 		if(__any(ps < kScreenEarlyThr)) {

@@ -358,8 +358,10 @@ VDL2_HD constexpr int screen_dq(int i) {
 // decision; gmin: smallest ||u| - 0.5| over the others
 struct ScreenAcc { float e, m0, m1, m2, gmax, gmin; };
 
-VDL2_HD void screen_begin(ScreenAcc &a, float ph0) {   // tap 0: e[0] = phase - 0
-	a.e = ph0; a.m0 = ph0; a.m1 = 0.f; a.m2 = ph0 * ph0; a.gmax = 0.f; a.gmin = 1.f;
+// tap 0: e[0] = phase of tap 0 in the reference - taken as 0 here: the residual of a least-squares line does not change when a
+// constant is added to every point, the unwrap decisions never look at e[0], and three instructions per window go away
+VDL2_HD void screen_begin(ScreenAcc &a) {
+	a.e = 0.f; a.m0 = 0.f; a.m1 = 0.f; a.m2 = 0.f; a.gmax = 0.f; a.gmin = 1.f;
 }
 
 // taps i0 <= i < i1 (i0 >= 1), d[i] as above
@@ -401,7 +403,7 @@ VDL2_HD float sync_metric_screen(const float *ph, int ntaps = kPreamble) {
 	float d[kPreamble];
 	for(int i = 1; i < ntaps; i++) d[i] = ph[i] - ph[i - 1];
 	ScreenAcc a;
-	screen_begin(a, ph[0]);
+	screen_begin(a);
 	screen_taps(d, 1, ntaps, a);
 	return screen_value(a, ntaps);
 }

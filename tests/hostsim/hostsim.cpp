@@ -86,7 +86,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 				for(int i = 0; i < kPreamble; i++) { int64_t t = n - 150 + 10 * i; ph[i] = t < 0 ? 0.f : phase_fast(y[(uint32_t)t & s->mask]); }
 				float d[kPreamble];
 				for(int i = 1; i < kPreamble; i++) d[i] = ph[i] - ph[i - 1];
-				ScreenAcc a; screen_begin(a, ph[0]); screen_taps(d, 1, kScreenEarly, a);
+				ScreenAcc a; screen_begin(a); screen_taps(d, 1, kScreenEarly, a);
 				float v = screen_value(a, kScreenEarly);
 				if(v < kScreenEarlyThr) { screen_taps(d, kScreenEarly, kPreamble, a); v = screen_value(a, kPreamble); }
 				return v;
