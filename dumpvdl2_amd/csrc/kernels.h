@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	// and the tile is a whole number of 256-sample rows.
 	constexpr bool kPrefetch = OS != 0 && CR >= 4 && (64 * R * OS + 255) / 256 <= 10 && (64 * R * OS) % 256 == 0;
 	constexpr int kPre = kPrefetch ? (64 * R * OS) / 256 : 1;
+	constexpr bool kPipeGather = kPrefetch;
 	uint32_t pre[kPre]; bool have_pre = false;
 	#pragma unroll
 	for(int k = 0; k < kPre; k++) pre[k] = 0u;
@@ -215,7 +216,15 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	float4 *svp = carry + CR;                                   // zero-start state after the feed's last valid block
 	float4 *sendp = svp + CR;                                   // zero-start state at the end of the segment (what seg_end gets)
 	float4 *tsp = sendp + CR;                                   // true state at the segment start (fused fix-up)
-	float hold[CR][4];                                          // fused: tile 0's outputs wait here for the segment-start state
+	// fused: tile 0's outputs wait for the segment-start state - in registers (16 of them with four channels per wave), or, where the
+	// registers are worth more than a second trip through L2 (VDL2_K1_HOLD_IN_MEMORY), in the output stream itself: written as they are,
+	// read back by the lane that wrote them, corrected and written again at the very end
+#ifdef VDL2_K1_HOLD_IN_MEMORY
+	constexpr bool kHoldRegs = !(OS != 0 && CR >= 4);
+#else
+	constexpr bool kHoldRegs = true;
+#endif
+	float hold[CR][4];
 	#pragma unroll
 	for(int c = 0; c < CR; c++) hold[c][0] = hold[c][1] = hold[c][2] = hold[c][3] = 0.f;
 	#pragma unroll
@@ -302,6 +311,10 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			const float2 *trow = tile + (size_t)(i * os) * 65 + lane;
 			// Partially unrolled on purpose: a fully unrolled run makes the scheduler hoist every LUT
 			// gather (4 VGPRs each) to the top and spill.  Taps come from scalar loads (uniform index).
+			// the LUT gather of the NEXT channel-sample is issued before the current one is worked on (four channels per wave: the
+			// compiler otherwise waits for every gather right behind its issue; 1.9 % of K1 at 256 channels, 2.6 % at 32,
+			// profiles/r03_k1_variants.txt - the sample loop is bound by the LDS gather rate, so there is not much to hide)
+			float4 en = kPipeGather ? lut[(ph[0] >> 16) & 0xffu] : make_float4(0.f, 0.f, 0.f, 0.f);
 			#pragma unroll kK1Unroll
 			for(int j = 0; j < os; j++) {
 				const float2 x = trow[j * 65];
@@ -311,14 +324,19 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 				for(int c = 0; c < CR; c++) {
 					const uint32_t p = ph[c];
 					const float F = (float)(p & 0xffffu);                 // sincosf_lut(): fract * 65536
-					const float4 e = lut[(p >> 16) & 0xffu];
+					float4 e;
+					if(kPipeGather) {
+						e = en;
+						ph[c] = p + dph[c];
+						en = lut[(ph[(c + 1) % CR] >> 16) & 0xffu];       // (c+1, j), or (0, j+1) - whose phase has just been advanced
+					} else e = lut[(p >> 16) & 0xffu];
 					const v2f sc = __builtin_elementwise_fma(v2f{e.z, e.w}, v2f{F, F}, v2f{e.x, e.y});   // (sin, cos)
 					// multiply(): (re*cos - im*sin, im*cos + re*sin) = cos * x + sin * (i x), the product rounded as before
 					const v2f m = __builtin_elementwise_fma(v2f{sc.y, sc.y}, X, v2f{sc.x, sc.x} * Xr);
 					A0[c] = __builtin_elementwise_fma(v2f{g0, g0}, m, A0[c]);
 					A1[c] = __builtin_elementwise_fma(v2f{g1, g1}, m, A1[c]);
 					M[c] = m;
-					ph[c] = p + dph[c];
+					if(!kPipeGather) ph[c] = p + dph[c];
 				}
 			}
 			float a0r[CR], a0i[CR], a1r[CR], a1i[CR], lr[CR], li[CR];
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			if(R > 1) {
 				const float f1r = __builtin_fmaf(bf.cP[1][0], T0r, __builtin_fmaf(bf.cP[1][1], T1r, yb[c][0])), f1i = __builtin_fmaf(bf.cP[1][0], T0i, __builtin_fmaf(bf.cP[1][1], T1i, yb[c][1]));
 				const uint32_t s0 = (uint32_t)(a.k0 + kloc) & a.mask;
-				if(a.fuse && ts == 0) {
+				if(kHoldRegs && a.fuse && ts == 0) {
 					hold[c][0] = f0r; hold[c][1] = f0i; hold[c][2] = f1r; hold[c][3] = f1i;      // stored after the fix-up below
 				} else {
 					if(cvalid && kloc + 1 < a.D && (s0 & 1u) == 0) {
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 					}
 				}
 			} else {
-				if(a.fuse && ts == 0) { hold[c][0] = f0r; hold[c][1] = f0i; }
+				if(kHoldRegs && a.fuse && ts == 0) { hold[c][0] = f0r; hold[c][1] = f0i; }
 				else {
 					if(cvalid && kloc < a.D) yout[(uint32_t)(a.k0 + kloc) & a.mask] = cf32{f0r, f0i};
 				}
@@ -525,6 +543,15 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 		const int i0 = lane * R;
 		// exactly K2's arithmetic: v += cP[i][0] * ts.(x|y) + cP[i][1] * ts.(z|w)
 		float v0r = hold[c][0], v0i = hold[c][1], v1r = hold[c][2], v1i = hold[c][3];
+		if(!kHoldRegs) {
+			const cf32 *yin = a.y + (size_t)(cbase + c) * a.cap;
+			const uint32_t r0 = (uint32_t)(a.k0 + kloc0) & a.mask;
+			if(R > 1 && cvalid && kloc0 + 1 < a.D && (r0 & 1u) == 0) { const float4 q4 = *reinterpret_cast<const float4 *>(yin + r0); v0r = q4.x; v0i = q4.y; v1r = q4.z; v1i = q4.w; }
+			else {
+				if(cvalid && kloc0 < a.D) { const cf32 q2 = yin[r0]; v0r = q2.re; v0i = q2.im; }
+				if(R > 1 && cvalid && kloc0 + 1 < a.D) { const cf32 q2 = yin[(uint32_t)(a.k0 + kloc0 + 1) & a.mask]; v1r = q2.re; v1i = q2.im; }
+			}
+		}
 		v0r += a.bfd->cP[i0][0] * ts.x + a.bfd->cP[i0][1] * ts.z; v0i += a.bfd->cP[i0][0] * ts.y + a.bfd->cP[i0][1] * ts.w;
 		if(R > 1) { v1r += a.bfd->cP[i0 + 1][0] * ts.x + a.bfd->cP[i0 + 1][1] * ts.z; v1i += a.bfd->cP[i0 + 1][0] * ts.y + a.bfd->cP[i0 + 1][1] * ts.w; }
 		cf32 *yout = a.y + (size_t)(cbase + c) * a.cap;
