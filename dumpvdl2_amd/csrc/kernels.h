@@ -63,6 +63,7 @@ struct K1Args {
 	int64_t  k0;               // absolute index of the first decimated output of this feed
 	int64_t  D;                // decimated outputs produced by this feed
 	int32_t  fmt, nchan, os, nseg, gy;
+	int32_t  seg0, seg1;       // this launch does the workgroup segments seg0 <= s < seg1 (seg0 a multiple of 8); one launch: 0, nseg
 	const uint32_t *dphi;      // NCO step per channel (24-bit phase)
 	const Lut4 *lut;
 	K1Consts bf;
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	const int bid = blockIdx.x;
 	const int xcd = bid & 7, q = bid >> 3;
 	const int gy = q % a.gy;
-	const int seg = (q / a.gy) * 8 + xcd;         // workgroup segment = a.tiles tiles
-	if(seg >= a.nseg) return;
+	const int seg = a.seg0 + (q / a.gy) * 8 + xcd; // workgroup segment = a.tiles tiles
+	if(seg >= a.seg1) return;
 
 	// The raw samples of a tile are fetched into registers one tile ahead of their use (specialised builds; cs16 tiles that lie inside
 	// the block) - the first tile's right here, in flight together with the table loads below - so that the global-load latency of the

@@ -36,6 +36,8 @@ constexpr int kRun = VDL2_K1_RUN;        // decimated outputs per lane in K1 (sp
 constexpr int kRunGeneric = 2;
 constexpr int kHistory = 65536;          // decimated samples kept behind the newest block (> longest burst, 56 090)
 constexpr int kNumEv = 12;            // profiling: {start, stop} of K1, K2, K3, K4, K4b, K5
+constexpr int kColdParts = 4;         // pieces a cold-start block is copied and channelised in
+constexpr size_t kColdMinBytes = 8u << 20;
 constexpr int kSlots = 3;             // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered)
 
 }  // namespace
@@ -66,6 +68,9 @@ struct vdl2hip_ctx {
 	uint8_t *d_in[kSlots] = {}; hipEvent_t ev_copied[kSlots] = {}; size_t in_cap = 0;
 	hipStream_t stream_copy = nullptr, stream_out = nullptr;
 	hipEvent_t pinned_pending = nullptr;   // copy event of the last vdl2hip_feed_pinned() whose source buffer the caller may not touch yet
+	// cold start (nothing in flight) of a large page-locked block: the copy goes in kColdParts pieces and the channeliser is launched
+	// piece by piece behind them, so that the first block of a stream does not wait for its whole H2D (feed_host)
+	struct { int n = 0; uint64_t samples[kColdParts] = {}; hipEvent_t ev[kColdParts] = {}; } cold;
 	uint8_t *h_stage = nullptr; size_t stage_cap = 0;   // pinned D2H staging for frame records + octets
 	uint8_t *d_carry[2] = {nullptr, nullptr}; int carry_sel = 0; uint32_t ncarry = 0;
 	cf32 *d_y = nullptr, *d_pf = nullptr; uint64_t *d_cand = nullptr, *d_flag = nullptr;
@@ -113,7 +118,7 @@ static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds, 
 	const int groups = (c->C + cr - 1) / cr;
 	K1Args b = a;
 	b.gy = (groups + 3) / 4;
-	const int nseg8 = (a.nseg + 7) / 8 * 8;
+	const int nseg8 = (a.seg1 - a.seg0 + 7) / 8 * 8;
 	dim3 grid((unsigned)(nseg8 * b.gy)), block(256);
 	// e0/e1 (profiling only, else null): the runtime stamps them with the kernel's own start and stop, so the roofline figure is
 	// the kernel's duration and not the time the launch spent queued behind other streams' work
@@ -197,7 +202,7 @@ static int collect_pending(vdl2hip_ctx *c, int keep = 0) {
 	return rc;
 }
 
-static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
+static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool in_parts = false) {
 	const size_t sb = sample_bytes(c->fmt);
 	const uint64_t nnew = nbytes / sb;
 	const uint64_t nlogical = c->ncarry + nnew;
@@ -237,14 +242,32 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes) {
 	if(D > 0) {
 		const size_t lds = (size_t)c->run * c->os * 65 * sizeof(float2);   // the tile; the tables are static LDS
 		hipEvent_t e0 = prof ? ev[0] : nullptr, e1 = prof ? ev[1] : nullptr;
-		if(c->specialised) {
-			switch(c->os) {
-				case 20: launch_chanfir<20, kRun>(c, a, c->cr, lds, e0, e1); break;
-				case 13: launch_chanfir<13, kRun>(c, a, c->cr, lds, e0, e1); break;
-				default: launch_chanfir<10, kRun>(c, a, c->cr, lds, e0, e1); break;
+		auto launch = [&](int seg0, int seg1, hipEvent_t s_ev, hipEvent_t p_ev) {
+			a.seg0 = seg0; a.seg1 = seg1;
+			if(c->specialised) {
+				switch(c->os) {
+					case 20: launch_chanfir<20, kRun>(c, a, c->cr, lds, s_ev, p_ev); break;
+					case 13: launch_chanfir<13, kRun>(c, a, c->cr, lds, s_ev, p_ev); break;
+					default: launch_chanfir<10, kRun>(c, a, c->cr, lds, s_ev, p_ev); break;
+				}
+			} else {
+				launch_chanfir<0, kRunGeneric>(c, a, c->cr, lds, s_ev, p_ev);
 			}
-		} else {
-			launch_chanfir<0, kRunGeneric>(c, a, c->cr, lds, e0, e1);
+		};
+		if(!in_parts || c->cold.n <= 1) launch(0, a.nseg, e0, e1);
+		else {
+			// cold start: piece p of the block is on the device when cold.ev[p] fires; the workgroup segments whose input lies in the
+			// pieces that have arrived (whole multiples of 8, the XCD mapping) are launched behind it.  A segment reads nothing beyond its
+			// own input (its tiles, the next tile's prefetch inside the segment, the look-back to the segment before), so the results are
+			// those of one launch.
+			const uint64_t seg_in = (uint64_t)a.tiles * (uint64_t)seglen * (uint64_t)c->os;     // logical input samples per segment
+			int done = 0;
+			for(int p = 0; p < c->cold.n; p++) {
+				HIPCHK(hipStreamWaitEvent(st, c->cold.ev[p], 0));
+				int ready = a.nseg;
+				if(p < c->cold.n - 1) { const uint64_t r = (c->ncarry + c->cold.samples[p]) / seg_in; ready = r >= (uint64_t)a.nseg ? a.nseg : (int)(r & ~7ull); }
+				if(ready > done) { launch(done, ready, done == 0 ? e0 : (hipEvent_t) nullptr, ready == a.nseg ? e1 : (hipEvent_t) nullptr); done = ready; }
+			}
 		}
 		if(!a.fuse) {
 			K2Args k2{ c->d_y, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
@@ -385,6 +408,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(c->h_ctl_template) (void)hipHostFree(c->h_ctl_template);
 	if(c->h_stage) (void)hipHostFree(c->h_stage);
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
+	for(auto &e : c->cold.ev) if(e) (void)hipEventDestroy(e);
 	if(c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
 	if(c->stream_out) { (void)hipStreamSynchronize(c->stream_out); (void)hipStreamDestroy(c->stream_out); }
 	if(c->stream_sync) { (void)hipStreamSynchronize(c->stream_sync); (void)hipStreamDestroy(c->stream_sync); }
@@ -590,12 +614,32 @@ static int feed_host(vdl2hip_ctx *c, const void *buf, size_t nbytes, bool wait_c
 	// (In a stream of blocks this copy costs nothing: 200-step regions run at the same 5.51 ms per 256-channel block host-fed and
 	// HBM-resident.  What a short timed region sees is the FIRST copy, which nothing overlaps: 2.6 ms once.  Holding the copy back so that
 	// it lands beside the channeliser rather than the sync kernels changes nothing or makes it worse; profiles/r03_h2d_placement.txt)
-	HIPCHK(hipMemcpyAsync(c->d_in[k], buf, nbytes, hipMemcpyHostToDevice, c->stream_copy));
+	// Nothing in flight and a large block from page-locked memory (the first block of a stream, or of a timed region): the copy is cut in
+	// kColdParts pieces and the channeliser follows them piece by piece (feed_common), instead of idling for the whole transfer -
+	// 2.6 ms for a 134 MB block.  In a running stream the copy of block i+1 is hidden behind the kernels of block i and goes in one piece.
+	bool parts = !wait_copy && nbytes >= kColdMinBytes;
+	for(auto &sl : c->slot) if(sl.pending) parts = false;
+	c->cold.n = 0;
+	if(parts) {
+		const size_t piece = (nbytes / kColdParts) & ~(size_t)4095;
+		size_t off = 0;
+		for(int p = 0; p < kColdParts; p++) {
+			const size_t len = p == kColdParts - 1 ? nbytes - off : piece;
+			if(!c->cold.ev[p]) HIPCHK(hipEventCreateWithFlags(&c->cold.ev[p], hipEventDisableTiming));
+			HIPCHK(hipMemcpyAsync(c->d_in[k] + off, (const uint8_t *)buf + off, len, hipMemcpyHostToDevice, c->stream_copy));
+			HIPCHK(hipEventRecord(c->cold.ev[p], c->stream_copy));
+			off += len;
+			c->cold.samples[p] = off / sample_bytes(c->fmt);
+		}
+		c->cold.n = kColdParts;
+	} else {
+		HIPCHK(hipMemcpyAsync(c->d_in[k], buf, nbytes, hipMemcpyHostToDevice, c->stream_copy));
+	}
 	HIPCHK(hipEventRecord(c->ev_copied[k], c->stream_copy));
 	if(wait_copy) HIPCHK(hipEventSynchronize(c->ev_copied[k]));    // `buf` is only ours during the call
 	else c->pinned_pending = c->ev_copied[k];
-	HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copied[k], 0));
-	return feed_common(c, c->d_in[k], nbytes);
+	if(!parts) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copied[k], 0));
+	return feed_common(c, c->d_in[k], nbytes, parts);
 }
 
 int vdl2hip_feed(vdl2hip_ctx *c, const void *buf, size_t nbytes) { return feed_host(c, buf, nbytes, true); }

@@ -621,6 +621,40 @@ def test_group_of_virtual_shards_from_c(vh, devices):
     g.close()
 
 
+def test_cold_start_block_goes_in_pieces_and_gives_the_same_stream(vh):
+    """A large block from page-locked memory fed to an idle receiver is copied and channelised in four pieces (feed_host's cold
+    start).  The decimated stream must be the very floats one copy + one channeliser launch give (the pageable vdl2hip_feed() of
+    the same bytes never takes that path), frames and counters the golden ones; a second block, fed while the first is still
+    pending, goes in one piece and must agree as well."""
+    import torch
+    cfg, iq, _, gold = cases.load("config2_1s")
+    raw = torch.from_numpy(iq.copy()).view(torch.uint8)
+    reps = 5                                              # 1 s = 8.4 MB is the case; 5 x the same second makes the block 42 MB
+    big = raw.repeat(reps).contiguous()
+    assert big.numel() >= (8 << 20)
+    pin = big.pin_memory()
+    D = big.numel() // 4 // cfg.oversample
+    streams, frames = [], []
+    for how in ("pinned", "pageable"):
+        rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=big.numel())
+        if how == "pinned":
+            rx.set_drain_lag(2)
+            rx.feed_pinned(pin.data_ptr(), pin.numel())   # idle receiver: four pieces
+            rx.feed_pinned(pin.data_ptr(), pin.numel())   # the first still pending: one piece
+            rx.set_drain_lag(0)
+        else:
+            rx.feed(big.numpy()); rx.feed(big.numpy())
+        fr = rx.drain()
+        streams.append([rx.read_decimated(c, max(0, 2 * D - 40000), 40000) for c in range(len(cfg.freqs))])
+        frames.append([(f["chan"], f["idx"], bytes(f["octets"]), f["sync_sample"], f["frame_pwr_dbfs"], f["ppm_error"]) for f in fr])
+        st = rx.stats()
+        assert st["front_sync_timeouts"] == 0 and st["overflow_feeds"] == 0
+        rx.close()
+    assert len(frames[0]) >= len(gold["frames"]) and frames[0] == frames[1]
+    for a, b in zip(*streams):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_group_feed_pinned(vh):
     """vdl2hip_group_feed_pinned(): blocks from two alternating page-locked buffers, queued without waiting for the copy."""
     import torch
