@@ -152,7 +152,9 @@ void vdl2hip_destroy(vdl2hip_ctx *ctx);
 int  vdl2hip_feed(vdl2hip_ctx *ctx, const void *buf, size_t nbytes);
 /* Same for page-locked host memory (hipHostMalloc / hipHostRegister), without waiting for the copy: the call only queues.
  * `buf` must stay unmodified until the NEXT vdl2hip_feed*() call or vdl2hip_sync() has returned - i.e. a producer
- * alternating between two pinned buffers never waits for the device. */
+ * alternating between two pinned buffers never waits for the device.  (A block of 8 MiB or more handed to an idle receiver
+ * is copied in four pieces with the channeliser following piece by piece, so that the first block of a stream does not wait
+ * for its whole transfer; results do not depend on it.) */
 int  vdl2hip_feed_pinned(vdl2hip_ctx *ctx, const void *buf, size_t nbytes);
 /* Same, for a block that already lives in this device's memory (e.g. the
  * destination of an RCCL broadcast).  The block must stay valid until it has been drained
