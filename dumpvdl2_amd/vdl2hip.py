@@ -82,6 +82,13 @@ def load_library(path: str = None):
     if _lib is not None:
         return _lib
     path = path or os.environ.get("VDL2HIP_LIB") or LIB_PATH
+    # A ROCm build of PyTorch carries its own libamdhip64.so.7 / libhsa-runtime64.so.1, the same sonames the system ROCm has: whichever
+    # is loaded first serves the whole process.  Loaded after this library (which is linked against /opt/rocm), torch ends up on a
+    # runtime it was not built with and the next vdl2hip_create() fails with a device error - so where torch is installed it goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing - build it with dumpvdl2_amd.build.build(); there is no CPU fallback")
     L = C.CDLL(path)
