@@ -68,6 +68,7 @@ struct K1Args {
 	const Lut4 *lut;
 	K1Consts bf;
 	cf32 *y;                   // [nchan][cap]
+	float *ph;                 // [nchan][cap] screening-precision phase (turns) of every output, for the sync screening kernel (VDL2_K1_PHASE builds; else null)
 	float4 *seg_end;           // [nchan][nseg_cap] zero-start state at the end of each workgroup segment
 	const float4 *qpow;        // [64] Q^(l+1) row-major 2x2, Q = P^R
 	int32_t  tiles;            // tiles per workgroup segment
@@ -421,11 +422,25 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 						if(cvalid && kloc < a.D) yout[s0] = cf32{f0r, f0i};
 						if(cvalid && kloc + 1 < a.D) yout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = cf32{f1r, f1i};
 					}
+#ifdef VDL2_K1_PHASE
+					{
+						float *pout = a.ph + (size_t)(cbase + c) * a.cap;
+						const float p0 = phase_fast(cf32{f0r, f0i}), p1 = phase_fast(cf32{f1r, f1i});
+						if(cvalid && kloc + 1 < a.D && (s0 & 1u) == 0) *reinterpret_cast<float2 *>(pout + s0) = make_float2(p0, p1);
+						else {
+							if(cvalid && kloc < a.D) pout[s0] = p0;
+							if(cvalid && kloc + 1 < a.D) pout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = p1;
+						}
+					}
+#endif
 				}
 			} else {
 				if(kHoldRegs && a.fuse && ts == 0) { hold[c][0] = f0r; hold[c][1] = f0i; }
 				else {
 					if(cvalid && kloc < a.D) yout[(uint32_t)(a.k0 + kloc) & a.mask] = cf32{f0r, f0i};
+#ifdef VDL2_K1_PHASE
+					if(cvalid && kloc < a.D) a.ph[(size_t)(cbase + c) * a.cap + ((uint32_t)(a.k0 + kloc) & a.mask)] = phase_fast(cf32{f0r, f0i});
+#endif
 				}
 			}
 			if(cvalid && lane == lb && (rem <= L || ts == a.tiles - 1)) {
@@ -562,6 +577,17 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			if(cvalid && kloc0 < a.D) yout[s0] = cf32{v0r, v0i};
 			if(R > 1 && cvalid && kloc0 + 1 < a.D) yout[(uint32_t)(a.k0 + kloc0 + 1) & a.mask] = cf32{v1r, v1i};
 		}
+#ifdef VDL2_K1_PHASE
+		{
+			float *pout = a.ph + (size_t)(cbase + c) * a.cap;
+			const float p0 = phase_fast(cf32{v0r, v0i}), p1 = R > 1 ? phase_fast(cf32{v1r, v1i}) : 0.f;
+			if(R > 1 && cvalid && kloc0 + 1 < a.D && (s0 & 1u) == 0) *reinterpret_cast<float2 *>(pout + s0) = make_float2(p0, p1);
+			else {
+				if(cvalid && kloc0 < a.D) pout[s0] = p0;
+				if(R > 1 && cvalid && kloc0 + 1 < a.D) pout[(uint32_t)(a.k0 + kloc0 + 1) & a.mask] = p1;
+			}
+		}
+#endif
 		// the filter state handed to the next feed (K2's k == D-1 branch)
 		if(cvalid && lane == 0 && (int64_t)(seg + 1) * seglen >= a.D) {
 			const int64_t len = a.D - (int64_t)seg * seglen;
@@ -579,7 +605,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 }
 
 struct K2Args {
-	cf32 *y; const float4 *seg_end; const float4 *carry_in; float4 *carry_out;
+	float *ph; cf32 *y; const float4 *seg_end; const float4 *carry_in; float4 *carry_out;
 	const BlockForm *bf;
 	int64_t k0, D; uint32_t cap, mask, nseg_cap; int32_t seglen;
 };
@@ -598,6 +624,9 @@ __global__ __launch_bounds__(256) void k_fixup(K2Args a) {
 		v.re += bf.cP[i][0] * ts.x + bf.cP[i][1] * ts.z;
 		v.im += bf.cP[i][0] * ts.y + bf.cP[i][1] * ts.w;
 		a.y[(size_t)c * a.cap + slot] = v;
+#ifdef VDL2_K1_PHASE
+		a.ph[(size_t)c * a.cap + slot] = phase_fast(v);
+#endif
 	}
 	if(k == a.D - 1) {   // filter state handed to the next feed
 		const int len = i + 1;
@@ -627,7 +656,7 @@ __global__ void k_carry(K1Args a, void *carry_out, uint32_t nrem) {
 }
 
 struct K3Args {
-	const cf32 *y; cf32 *pf; uint64_t *cand; uint64_t *flag; const Tables *tab;
+	const float *ph; const cf32 *y; cf32 *pf; uint64_t *cand; uint64_t *flag; const Tables *tab;
 	int64_t nbase, k1;        // first sample to (re)compute (multiple of 64); one past the last valid sample
 	uint32_t cap, mask;
 	int32_t wpl;              // exact tier: flag words scanned per lane (1..kK3bWordsPerLane)
@@ -666,15 +695,29 @@ __global__ __launch_bounds__(kK3Threads) void k_sync_screen(K3Args a) {
 		// the whole tile and its history exist (all but the first and last block of a channel): no per-sample range tests, ring
 		// offsets in 32 bits, all loads in flight before the first phase is worked out
 		const uint32_t r0 = (uint32_t)(nblk - 150) + tid;
+#ifdef VDL2_K1_PHASE
+		// the channeliser has left the screening phase of every output beside it (K1Args::ph): half the bytes, no arithmetic
+		const float *ph = a.ph + (size_t)c * a.cap;
+		float v[kFull + 1];
+		#pragma unroll
+		for(int k = 0; k <= kFull; k++) if(k < kFull || tid < kRest) v[k] = ph[(r0 + kK3Threads * k) & a.mask];
+		#pragma unroll
+		for(int k = 0; k <= kFull; k++) if(k < kFull || tid < kRest) tile[tid + kK3Threads * k] = v[k];
+#else
 		cf32 v[kFull + 1];
 		#pragma unroll
 		for(int k = 0; k <= kFull; k++) if(k < kFull || tid < kRest) v[k] = y[(r0 + kK3Threads * k) & a.mask];
 		#pragma unroll
 		for(int k = 0; k <= kFull; k++) if(k < kFull || tid < kRest) tile[tid + kK3Threads * k] = phase_fast(v[k]);
+#endif
 	} else {
 		for(int j = tid; j < kK3Tile + 150; j += kK3Threads) {
 			const int64_t t = nblk - 150 + j;
+#ifdef VDL2_K1_PHASE
+			tile[j] = (t < 0 || t >= a.k1) ? 0.f : a.ph[(size_t)c * a.cap + ((uint32_t)t & a.mask)];
+#else
 			tile[j] = (t < 0 || t >= a.k1) ? 0.f : phase_fast(y[(uint32_t)t & a.mask]);
+#endif
 		}
 	}
 	__syncthreads();
@@ -1014,9 +1057,8 @@ __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_finish(K4bArgs a) {
 
 // Each channel's walker fills its own burst list (no atomics on its critical path); this one-wave kernel turns the
 // per-channel counts into offsets so that K5 can spread all bursts of the feed over its workgroups.
-__global__ __launch_bounds__(64) void k_burst_index(const uint32_t *nb_chan, uint32_t *bbase, int nchan, OutCtl *ctl, const uint32_t *front_timeouts) {
+__global__ __launch_bounds__(64) void k_burst_index(const uint32_t *nb_chan, uint32_t *bbase, int nchan, OutCtl *ctl) {
 	const int lane = threadIdx.x;
-	if(lane == 0) ctl->front_timeouts = *front_timeouts;   // runs after this feed's front: what the host checks before it trusts the feed
 	uint32_t carry = 0;
 	for(int c0 = 0; c0 < nchan; c0 += 64) {         // exclusive prefix sum, 64 channels per pass
 		const uint32_t v = c0 + lane < nchan ? nb_chan[c0 + lane] : 0u;

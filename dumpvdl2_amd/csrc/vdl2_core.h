@@ -62,26 +62,30 @@
 #define VDL2_CNT_ADD(arr, which, val) ((arr)[which] += (unsigned long long)(val))
 #endif
 
-// optional per-phase cycle probe of the burst decoder (development aid; compiled out by default)
+// optional per-phase cycle probes of the walker and the burst decoder (development aid, -DVDL2_K5_PROF; compiled out by default).
+// A wavefront keeps its sums in wave-uniform registers and adds them to one of 64 global slots once, when it is done: no atomics
+// inside what is being measured (round 3's probe did two atomics on one address per mark - thousands of waves queueing on them
+// were most of what it then reported).
 #if defined(__HIPCC__) && defined(VDL2_K5_PROF)
-__device__ unsigned long long vdl2_k5_prof[16];
-__device__ unsigned long long vdl2_k4_prof[16];
+__device__ unsigned long long vdl2_k5_prof[64][16];
+__device__ unsigned long long vdl2_k4_prof[64][24];
 #endif
 #if VDL2_DEVICE_PASS && defined(VDL2_K5_PROF)
-#define K4_BEGIN() unsigned long long k4_t0_ = __builtin_readcyclecounter()
-#define K4_MARK(k) do { if(VDL2_LANE() == 0) { unsigned long long t_ = __builtin_readcyclecounter(); \
-	atomicAdd(&vdl2_k4_prof[k], t_ - k4_t0_); atomicAdd(&vdl2_k4_prof[8 + k], 1ull); k4_t0_ = t_; } } while(0)
+#define K4_BEGIN() unsigned long long k4_t0_ = __builtin_readcyclecounter(); unsigned k4_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, k4_n_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define K4_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); k4_acc_[k] += (unsigned)(t_ - k4_t0_); k4_n_[k]++; k4_t0_ = t_; } while(0)
+#define K4_END() do { if(VDL2_LANE() == 0) { for(int k_ = 0; k_ < 10; k_++) { atomicAdd(&vdl2_k4_prof[blockIdx.x & 63][k_], (unsigned long long)k4_acc_[k_]); \
+	atomicAdd(&vdl2_k4_prof[blockIdx.x & 63][12 + k_], (unsigned long long)k4_n_[k_]); } } } while(0)
+#define K5_BEGIN() unsigned long long k5_t0_ = __builtin_readcyclecounter(); unsigned k5_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define K5_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); k5_acc_[k] += (unsigned)(t_ - k5_t0_); k5_t0_ = t_; } while(0)
+#define K5_END() do { if(VDL2_LANE() == 0) { for(int k_ = 0; k_ < 8; k_++) atomicAdd(&vdl2_k5_prof[blockIdx.x & 63][k_], (unsigned long long)k5_acc_[k_]); \
+	atomicAdd(&vdl2_k5_prof[blockIdx.x & 63][8], 1ull); } } while(0)
 #else
 #define K4_BEGIN() do {} while(0)
 #define K4_MARK(k) do {} while(0)
-#endif
-#if VDL2_DEVICE_PASS && defined(VDL2_K5_PROF)
-#define K5_MARK(k) do { if(VDL2_LANE() == 0) { unsigned long long t_ = __builtin_readcyclecounter(); \
-	atomicMax(&vdl2_k5_prof[k], t_ - k5_t0_); atomicAdd(&vdl2_k5_prof[8 + k], t_ - k5_t0_); k5_t0_ = t_; } } while(0)
-#define K5_BEGIN() unsigned long long k5_t0_ = __builtin_readcyclecounter()
-#else
+#define K4_END() do {} while(0)
 #define K5_MARK(k) do {} while(0)
 #define K5_BEGIN() do {} while(0)
+#define K5_END() do {} while(0)
 #endif
 
 namespace vdl2 {
@@ -182,8 +186,7 @@ struct OutFrame {
 struct OutCtl {
 	uint32_t nbursts, nframes, pool_used, overflow;
 	uint32_t cap_bursts, cap_frames, cap_pool, cap_log;
-	uint32_t front_timeouts;           // channeliser workgroups that gave up waiting for their predecessor's state (must be 0)
-	uint32_t pad_[3];
+	uint32_t pad_[4];
 };
 
 // A stretch of executed got_sync() evaluations: samples first, first+3, ..., first+3*(count-1).
@@ -704,6 +707,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 					const int lf = wave_first_flag(sh.flag);
 					if(lf >= 0) { fired = 1; fire_n = ((w0 + 4 * lf) << 6) + sh.found[lf]; }
 				}
+				K4_MARK(3);
 				if(fired) {
 					const int64_t n = fire_n;
 					// one round trip: the three metric values, the four possible sync-point phases (sclk = 2..5)
@@ -722,6 +726,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 						sh.u_y1 = sh.spec[40]; sh.u_y2 = sh.spec[41]; sh.u_y3 = sh.spec[42]; sh.u_prevd = sh.spec[43];
 						sh.spec_n = n;
 					LANE0_END
+					K4_MARK(8);
 					log_evals(sh, lg, ctl, e, (n - e) / 3 + 1);
 					K4_MARK(2);
 				} else {
@@ -747,6 +752,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 						sh.st.prev_dphi = sh.f[0];
 						sh.st.e = nl + 3;
 					LANE0_END
+					K4_MARK(9);
 				}
 			}
 			if(fired) {
@@ -833,6 +839,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 		}
 	}
 	K4_MARK(7);
+	K4_END();
 }
 
 // Process one channel up to (not including) decimated sample k_end.
@@ -1583,8 +1590,8 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		if(sh.u_ret < 0) failed = 1;
 		else if(sh.u_ret > 0) fec_fixed += sh.u_ret - (kRsPar - npar);
 	}
-	if(failed) return;
 	K5_MARK(3);
+	if(failed) { K5_END(); return; }
 
 	// 5. re-serialise the corrected rows LSB-first (decode.c:325-328), truncate to TL bits (decode.c:338-342),
 	//    then bitstream_copy_next_frame() (bitstream.c:109-150) for the whole burst at once:
@@ -1710,7 +1717,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 				}
 			}
 		LANE0_END
-		if(sh.u_kind != 1) { if(sh.u_kind == 4) break; return; }
+		if(sh.u_kind != 1) { if(sh.u_kind == 4) break; K5_MARK(5); K5_END(); return; }
 		if(sh.u_ok) {
 			// gather kept bits S+8i .. S+8i+7 into output octet i (LSB first, bitstream.c:70-81)
 			const uint32_t len = sh.u_L / 8, off = sh.u_off, S = sh.u_S;
@@ -1739,6 +1746,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 	LANE0
 		if(sh.u_pwr > 1.0f) VDL2_CNT_ADD(cnt, CNT_MSG_GOOD_LOUD, 1);
 	LANE0_END
+	K5_END();
 	(void)freq;
 }
 

@@ -50,6 +50,8 @@ struct OutSlot {
 	hipEvent_t done = nullptr, ev_front = nullptr, ev_chan = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
 	bool pending = false, ev_valid = false, fused = false; int ev_level = 0;
 	uint64_t seq = 0;
+	// the burst-rate back end of this feed (K4, K4b, K5, frame finish) still has to be queued: launch_back()
+	bool back_queued = false; int64_t back_D = 0, back_k0 = 0; hipEvent_t ev_k1 = nullptr;
 };
 
 struct vdl2hip_ctx {
@@ -73,7 +75,7 @@ struct vdl2hip_ctx {
 	struct { int n = 0; uint64_t samples[kColdParts] = {}; hipEvent_t ev[kColdParts] = {}; } cold;
 	uint8_t *h_stage = nullptr; size_t stage_cap = 0;   // pinned D2H staging for frame records + octets
 	uint8_t *d_carry[2] = {nullptr, nullptr}; int carry_sel = 0; uint32_t ncarry = 0;
-	cf32 *d_y = nullptr, *d_pf = nullptr; uint64_t *d_cand = nullptr, *d_flag = nullptr;
+	cf32 *d_y = nullptr, *d_pf = nullptr; uint64_t *d_cand = nullptr, *d_flag = nullptr; float *d_ph = nullptr;
 	uint32_t cap = 0;
 	float4 *d_segend = nullptr; uint32_t nseg_cap = 0;
 	float4 *d_qpow = nullptr;
@@ -95,6 +97,7 @@ struct vdl2hip_ctx {
 	int sync_on = 0; hipStream_t stream_sync = nullptr; int k3b_wpl = 0, tiles_force = 0; bool show_gaps = false; int ablate = 0;
 	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
+	bool defer_back = false;               // VDL2HIP_BACKEND=deferred: the back end of feed i is queued behind the channeliser of feed i+1 (launch_back)
 	std::vector<uint64_t> statsd_prev;
 	std::vector<HostFrame> queue;
 	int64_t k_total = 0; uint64_t n_total = 0;
@@ -129,8 +132,11 @@ static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds, 
 	}
 }
 
+static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate);
+
 static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 	if(!sl.pending) return VDL2HIP_OK;
+	if(sl.back_queued) { int r = launch_back(c, sl, nullptr); if(r != VDL2HIP_OK) return r; }   // nothing followed this feed: its back end goes now
 	HIPCHK(hipEventSynchronize(sl.done));
 	sl.pending = false;
 	if(c->profiling && sl.ev_valid) {
@@ -154,8 +160,6 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 	}
 	sl.ev_valid = false;
 	const OutCtl ctl = *sl.h_ctl;
-	// (ctl.front_timeouts: channeliser workgroups of feeds so far that stopped waiting for their predecessor's filter state and worked
-	// it out themselves - kernels.h, fused look-back.  Nothing is wrong with such a feed; vdl2hip_get_stats() reports the count.)
 	if(ctl.overflow) c->stats.overflow_feeds++;
 	c->stats.bursts += std::min(ctl.nbursts, ctl.cap_bursts);
 	const uint32_t nf = std::min(ctl.nframes, ctl.cap_frames);
@@ -220,7 +224,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 	a.in = dev_in; a.carry = c->d_carry[c->carry_sel]; a.ncarry = c->ncarry; a.nlogical = nlogical;
 	a.n0 = c->n_total - c->ncarry; a.k0 = c->k_total; a.D = D;
 	a.fmt = c->fmt; a.nchan = c->C; a.os = c->os; a.nseg = 0; a.gy = 1;
-	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.seg_end = c->d_segend;
+	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.ph = c->d_ph; a.seg_end = c->d_segend;
 	a.qpow = c->d_qpow; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap;
 	a.fuse = c->fuse_k2 && 64 * c->run == kFixW; a.carry_in = c->d_tcarry[c->tcarry_sel]; a.carry_out = c->d_tcarry[c->tcarry_sel ^ 1];
 	a.bfd = c->d_bf; a.seg_pub = c->d_segpub; a.epoch = (uint32_t)(c->feed_no + 1); a.sync_timeouts = c->d_synctmo;
@@ -237,7 +241,6 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		a.nseg = (int)((ntile + tiles - 1) / tiles);
 	}
 
-	HIPCHK(hipMemcpyAsync(sl.d_ctl, c->h_ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, sb_));
 	sl.ev_valid = false;
 	if(D > 0) {
 		const size_t lds = (size_t)c->run * c->os * 65 * sizeof(float2);   // the tile; the tables are static LDS
@@ -270,7 +273,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 			}
 		}
 		if(!a.fuse) {
-			K2Args k2{ c->d_y, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
+			K2Args k2{ c->d_ph, c->d_y, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
 			           c->k_total, D, c->cap, c->cap - 1, c->nseg_cap, seglen * a.tiles };
 			LAUNCH_EV(k_fixup, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), st, EV(2), EV(3), k2);
 		}
@@ -278,9 +281,19 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 	}
 	if(nrem) hipLaunchKernelGGL(k_carry, dim3(1), dim3(64), 0, st, a, (void *)c->d_carry[c->carry_sel ^ 1], nrem);
 	c->carry_sel ^= 1; c->ncarry = nrem;
+	// deferred mode: the back end of the feed before this one is queued now, behind this feed's channeliser
+	if(c->feed_no > 0) {
+		OutSlot &pv = c->slot[(c->feed_no - 1) % kSlots];
+		if(pv.pending && pv.back_queued) {
+			hipEvent_t gate = nullptr;
+			if(D > 0) { HIPCHK(hipEventRecord(sl.ev_k1, st)); gate = sl.ev_k1; }
+			int r = launch_back(c, pv, gate);
+			if(r != VDL2HIP_OK) return r;
+		}
+	}
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
-		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1 };
+		K3Args k3{ c->d_ph, c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1 };
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
 		// on the front stream than a separate hipEventRecord.  (VDL2HIP_SYNC_ON=walk puts the exact tier in front of the walk on
 		// the walk stream, VDL2HIP_SYNC_ON=own both sync kernels on a stream of their own, so that the front stream goes on
@@ -300,15 +313,39 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		if(c->k3b_form == 16) LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
 		else LAUNCH_EV(k_sync_exact4, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
 	}
-	// The burst-rate back end runs on three more streams, so that consecutive feeds overlap stage by stage:
-	//   stream_back   K4   walk(i) -> walk(i+1) -> ...             (each needs the previous one's FSM state)
-	//   stream_nf     K4b  noise floor of feed i, after walk(i)    (each needs the previous one's NfState)
-	//   stream_burst  K5   bursts of feed i, after walk(i); the frames get their noise-floor figure when K4b(i) is done
-	hipStream_t sn_ = c->stream_nf, s5_ = c->stream_burst;
 	if(D <= 0) HIPCHK(hipEventRecord(sl.ev_front, st));
+	if(D > 0) { sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0; c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C; }
+	sl.back_queued = true; sl.back_D = D; sl.back_k0 = c->k_total;
+	sl.pending = true; sl.seq = c->feed_no++;
+	c->k_total += D; c->n_total += nnew;
+	c->stats.feeds++; c->stats.input_samples += nnew;
+	// Eager mode queues this feed's back end right away (it then runs beside the NEXT feed's channeliser); deferred mode leaves it
+	// to the next feed call, which queues it behind its own channeliser (above), or to whoever collects this feed first.
+	if(!c->defer_back) { int r = launch_back(c, sl, nullptr); if(r != VDL2HIP_OK) return r; }
+	HIPCHK(hipGetLastError());
+	return VDL2HIP_OK;
+}
+
+// The burst-rate back end of one feed (K4 walk, K4b noise floor, K5 burst decoder, frame finish), on three streams of its own so
+// that consecutive feeds overlap stage by stage:
+//   stream_back   K4   walk(i) -> walk(i+1) -> ...             (each needs the previous one's FSM state)
+//   stream_nf     K4b  noise floor of feed i, after walk(i)    (each needs the previous one's NfState)
+//   stream_burst  K5   bursts of feed i, after walk(i); the frames get their noise-floor figure when K4b(i) is done
+// `gate` (deferred mode): an event of the FOLLOWING feed's front stream - the end of its channeliser - that the walk waits for as
+// well, so that these latency-bound kernels run beside the sync screening (few registers: they fit in beside it) instead of taking
+// workgroup slots from a channeliser (whose four waves per SIMD own the whole register file: every back-end workgroup keeps one
+// channeliser workgroup off its CU for as long as it lives).
+static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
+	const int64_t D = sl.back_D, k0 = sl.back_k0;
+	hipStream_t sb_ = c->stream_back, sn_ = c->stream_nf, s5_ = c->stream_burst;
+	hipEvent_t *ev = sl.ev;
+	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
+	sl.back_queued = false;
+	HIPCHK(hipMemcpyAsync(sl.d_ctl, c->h_ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, sb_));
 	HIPCHK(hipStreamWaitEvent(sb_, sl.ev_front, 0));
+	if(gate) HIPCHK(hipStreamWaitEvent(sb_, gate, 0));
 	if(D > 0) {
-		const int64_t k1 = c->k_total + D;
+		const int64_t k1 = k0 + D;
 		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C };
 		// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
@@ -316,7 +353,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		if(nseg >= 2) {
 			const int64_t seglen = (D + nseg - 1) / nseg;
 			nseg = (int)((D + seglen - 1) / seglen);
-			K4sArgs k4s{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, c->k_total, seglen, c->d_segstats };
+			K4sArgs k4s{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, k0, seglen, c->d_segstats };
 			if(!(c->ablate & 1))
 			LAUNCH_EV(k_walk_spec, dim3((unsigned)((1 + 3 * (nseg - 1) + kWalkWaves - 1) / kWalkWaves), (unsigned)c->C), dim3(64 * kWalkWaves), sb_, EV(6), (hipEvent_t) nullptr, k4s);
 			hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, EV(7), 0, k4s);
@@ -336,23 +373,18 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64 * kNfWaves), 0, sn_, k4b);
 		LAUNCH_EV(k_nf_finish, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), sn_, (hipEvent_t) nullptr, EV(9), k4b);
 		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
-		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl, (const uint32_t *)c->d_synctmo);
+		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl);
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
 		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: bbase[0] = 0 bursts to decode)
 		hipExtLaunchKernelGGL(k_burst, dim3(2048 / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)(sizeof(BurstShared) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
-		sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0;
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
 		hipLaunchKernelGGL(k_frame_finish, dim3(1024 / kFrameWaves), dim3(64 * kFrameWaves), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, (const OutCtl *)sl.d_ctl, (const Tables *)c->d_tab,
 		                   c->d_acnt, (const float *)c->d_nfring, c->nf_ring - 1);
-		c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C;
 	}
 	HIPCHK(hipMemcpyAsync(sl.h_ctl, sl.d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, s5_));
 	HIPCHK(hipEventRecord(sl.done, s5_));
 	HIPCHK(hipGetLastError());
-	sl.pending = true; sl.seq = c->feed_no++;
-	c->k_total += D; c->n_total += nnew;
-	c->stats.feeds++; c->stats.input_samples += nnew;
 	return VDL2HIP_OK;
 }
 
@@ -393,7 +425,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
+	                 c->d_cand, c->d_flag, c->d_ph, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
 		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl, sl.d_log, sl.d_nlog };
 		for(void *p : q) if(p) (void)hipFree(p);
@@ -403,6 +435,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 		if(sl.ev_front) (void)hipEventDestroy(sl.ev_front);
 		if(sl.ev_chan) (void)hipEventDestroy(sl.ev_chan);
 		if(sl.ev_nf) (void)hipEventDestroy(sl.ev_nf);
+		if(sl.ev_k1) (void)hipEventDestroy(sl.ev_k1);
 		for(int i = 0; i < kNumEv; i++) if(sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
 	}
 	if(c->h_ctl_template) (void)hipHostFree(c->h_ctl_template);
@@ -499,7 +532,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	for(auto &sl : c->slot) {
 		DEV_CHK(hipEventCreate(&sl.done)); for(int i = 0; i < kNumEv; i++) DEV_CHK(hipEventCreate(&sl.ev[i]));
 		DEV_CHK(hipEventCreateWithFlags(&sl.ev_walk, hipEventDisableTiming)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_nf, hipEventDisableTiming));
-		DEV_CHK(hipEventCreate(&sl.ev_front)); DEV_CHK(hipEventCreate(&sl.ev_chan));
+		DEV_CHK(hipEventCreate(&sl.ev_front)); DEV_CHK(hipEventCreate(&sl.ev_chan)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_k1, hipEventDisableTiming));
 	}
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
 	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count);
@@ -508,6 +541,9 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	const size_t nring = (size_t)count * cap;
 	DEV_ALLOC(c->d_y, nring * sizeof(cf32)); DEV_ALLOC(c->d_pf, nring * sizeof(cf32));
 	DEV_ALLOC(c->d_cand, nring / 8); DEV_ALLOC(c->d_flag, nring / 8);
+#ifdef VDL2_K1_PHASE
+	DEV_ALLOC(c->d_ph, nring * sizeof(float)); DEV_CHK(hipMemset(c->d_ph, 0, nring * sizeof(float)));
+#endif
 	DEV_ALLOC(c->d_segend, (size_t)count * c->nseg_cap * sizeof(float4));
 	DEV_ALLOC(c->d_qpow, 64 * sizeof(float4));
 	DEV_ALLOC(c->d_tcarry[0], count * sizeof(float4)); DEV_ALLOC(c->d_tcarry[1], count * sizeof(float4));
@@ -521,6 +557,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	// VDL2HIP_NO_FUSE=1 selects the separate fix-up kernel k_fixup instead (no inter-workgroup wait at all, bit-identical results,
 	// ~3 % slower): worth setting where the GPU is permanently shared, so that no time is spent waiting.
 	c->fuse_k2 = getenv("VDL2HIP_NO_FUSE") == nullptr;
+	if(const char *e = getenv("VDL2HIP_BACKEND")) c->defer_back = strcmp(e, "deferred") == 0;   // eager (default) | deferred
 	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, (size_t)count * kNumCounters * 8);
 	DEV_ALLOC(c->d_acnt, (size_t)count * kNumAvlcCounters * 8);
 	// a decodable burst occupies >= 22 symbols = 220 decimated samples (header + 3 data + 2 FEC octets)
@@ -529,7 +566,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	uint64_t cap_f = cap_b * 2; if(cap_f < 4096) cap_f = 4096;
 	uint64_t cap_p = cap_b * 512; if(cap_p < (1u << 22)) cap_p = 1u << 22; if(cap_p > (1u << 30)) cap_p = 1u << 30;
 	c->cap_log = 8192; c->cap_comb = c->cap_log + kNfTail; c->cap_hist = (uint32_t)(dmax / 3000 + 8);
-	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, c->cap_log, 0, {0, 0, 0} };
+	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, c->cap_log, {0, 0, 0, 0} };
 	DEV_ALLOC(c->d_nf, count * sizeof(NfState));
 	DEV_ALLOC(c->d_scfirst, (size_t)count * (c->cap_comb + 1) * 8); DEV_ALLOC(c->d_sccum, (size_t)count * (c->cap_comb + 1) * 8);
 	// noise-floor history: a frame looks up the value at its burst's sync, at most kSlots feeds + one burst ago
@@ -639,7 +676,9 @@ static int feed_host(vdl2hip_ctx *c, const void *buf, size_t nbytes, bool wait_c
 	if(wait_copy) HIPCHK(hipEventSynchronize(c->ev_copied[k]));    // `buf` is only ours during the call
 	else c->pinned_pending = c->ev_copied[k];
 	if(!parts) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_copied[k], 0));
-	return feed_common(c, c->d_in[k], nbytes, parts);
+	int r = feed_common(c, c->d_in[k], nbytes, parts);
+	if(r == VDL2HIP_E_DEVICE) c->failed = true;          // part of the block's work may be queued, part not: the context is out of step with itself
+	return r;
 }
 
 int vdl2hip_feed(vdl2hip_ctx *c, const void *buf, size_t nbytes) { return feed_host(c, buf, nbytes, true); }
@@ -652,7 +691,10 @@ int vdl2hip_feed_device(vdl2hip_ctx *c, const void *dev_buf, size_t nbytes) {
 	if(nbytes > c->in_cap) return VDL2HIP_E_TOOBIG;
 	if(((uintptr_t)dev_buf) % sample_bytes(c->fmt)) return VDL2HIP_E_INVAL;
 	nbytes -= nbytes % sample_bytes(c->fmt);
-	return feed_common(c, dev_buf, nbytes);
+	if(c->failed) return VDL2HIP_E_DEVICE;
+	int r = feed_common(c, dev_buf, nbytes);
+	if(r == VDL2HIP_E_DEVICE) c->failed = true;
+	return r;
 }
 
 int vdl2hip_sync(vdl2hip_ctx *c) {
@@ -874,11 +916,19 @@ int vdl2hip_debug_k1_prof(unsigned long long out[16], int reset) {
 #endif
 
 #ifdef VDL2_K5_PROF
-int vdl2hip_debug_k5_prof(unsigned long long out[16]) {
-	return hipMemcpyFromSymbol(out, HIP_SYMBOL(vdl2_k5_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+int vdl2hip_debug_k5_prof(unsigned long long out[16], int reset) {
+	static unsigned long long h[64][16];
+	if(hipMemcpyFromSymbol(h, HIP_SYMBOL(vdl2_k5_prof), sizeof h) != hipSuccess) return -3;
+	for(int k = 0; k < 16; k++) { out[k] = 0; for(int s = 0; s < 64; s++) out[k] += h[s][k]; }
+	if(reset) { memset(h, 0, sizeof h); if(hipMemcpyToSymbol(HIP_SYMBOL(vdl2_k5_prof), h, sizeof h) != hipSuccess) return -3; }
+	return 0;
 }
-int vdl2hip_debug_k4_prof(unsigned long long out[16]) {
-	return hipMemcpyFromSymbol(out, HIP_SYMBOL(vdl2_k4_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+int vdl2hip_debug_k4_prof(unsigned long long out[24], int reset) {
+	static unsigned long long h[64][24];
+	if(hipMemcpyFromSymbol(h, HIP_SYMBOL(vdl2_k4_prof), sizeof h) != hipSuccess) return -3;
+	for(int k = 0; k < 24; k++) { out[k] = 0; for(int s = 0; s < 64; s++) out[k] += h[s][k]; }
+	if(reset) { memset(h, 0, sizeof h); if(hipMemcpyToSymbol(HIP_SYMBOL(vdl2_k4_prof), h, sizeof h) != hipSuccess) return -3; }
+	return 0;
 }
 #endif
 

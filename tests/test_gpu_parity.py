@@ -183,6 +183,82 @@ def test_front_stream_handle_is_usable_from_torch(vh):
     rx.close()
 
 
+def _counters_of_a_noiseless_capture(o, rx, pos, n=16):
+    """All 20 counters of the tuned channel identical to the oracle's.  The other channels of these tests see the burst only as
+    leakage 50 kHz and more away on a capture WITHOUT noise: they lock on it 40-60 dB down, in the quantisation noise, where which
+    RS block or stuffing rule ends a doomed burst hinges on the 1e-5 by which the time-parallel filter differs from the sequential
+    one - for those, what was delivered must agree (frames: compared by the caller; locks and messages: here)."""
+    co = [list(o.counters(c).values()) for c in range(n)]
+    cg = [list(rx.counters(c).values()) for c in range(n)]
+    assert co[pos] == cg[pos]
+    for c in range(n):
+        assert (co[c][0], co[c][16], co[c][17]) == (cg[c][0], cg[c][16], cg[c][17]), (c, co[c], cg[c])   # demod.sync.good, decoder.msg.good, .good_loud
+
+
+@pytest.mark.parametrize("delta,pos", [(0, 0), (25000, 5), (-250000, 10), (100008, 15)])
+def test_reference_wav_at_2100kHz_hot_instantiation(vh, oracle_mod, delta, pos):
+    """k_chanfir<20, 2, 4> - oversample 20, four channels per wavefront: the instantiation the headline number and the roofline are
+    quoted on - against reference-held data: the reference's capture interpolated to 2.1 MS/s (tests/golden/resample_wav.py), as
+    one of 16 channels (>= 16 channels select four per wavefront; `pos` walks the tuned channel through the wavefront's four
+    slots and the workgroup's four waves).  Same expectations as tests/test_oracle_golden.py::test_reference_wav_at_2100kHz, and
+    the oracle beside it on all 16 channels."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import resample_wav as rw
+    from test_oracle_golden import _expect_resampled, hot_plan
+    raw = rw.upsampled2x(delta)
+    cf, freqs = hot_plan(delta, pos)
+    rx = vh.Receiver(cf, freqs, 20, vh.FMT_S16LE, max_block_bytes=raw.size)
+    assert rx.chan_count == 16
+    rx.feed(raw)                                        # one block: the tile-prefetching fast path of the specialised build
+    fr = rx.drain()
+    step = _expect_resampled([f for f in fr if f["chan"] == pos], delta, rw.FS2, oracle_mod.crc16_x25)
+    assert rx.nco_step(pos) & 0xFFFFFFFF == step & 0xFFFFFFFF
+    o = oracle_mod.Oracle(cf, freqs, oversample=20)
+    o.process(raw)
+    assert_frames_equal(o.frames(), fr, label=f"wav at 2.1 MS/s, moved by {delta} Hz")
+    _counters_of_a_noiseless_capture(o, rx, pos)
+    # ... and in the reference's own block size (dumpvdl2.h:48), which takes the tiles that straddle blocks through the carry path
+    rx2 = vh.Receiver(cf, freqs, 20, vh.FMT_S16LE)
+    for k in range(0, raw.size, 320000):
+        rx2.feed(raw[k:k + 320000])
+    _expect_resampled([f for f in rx2.drain() if f["chan"] == pos], delta, rw.FS2, oracle_mod.crc16_x25)
+    rx.close(); rx2.close()
+
+
+def test_reference_wav_as_u8(vh, oracle_mod):
+    """process_buf_uchar()'s path (demod.c:339-354) against reference-held data: the reference's capture re-quantised to u8
+    (tests/golden/resample_wav.py) at 1.05 MS/s on the centre, and interpolated to 2.1 MS/s off the centre as one of 16 channels
+    (k_chanfir<20, 2, 4> reading u8)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import resample_wav as rw
+    from test_oracle_golden import _expect_resampled, hot_plan
+    pw = -9.841 + rw.U8_GAIN_DB
+    raw = rw.as_u8()
+    rx = vh.Receiver(rw.CHANNEL, [rw.CHANNEL], 10, vh.FMT_U8)
+    for k in range(0, raw.size, 160000):
+        rx.feed(raw[k:k + 160000])
+    fr = rx.drain()
+    _expect_resampled(fr, 0, rw.FS, oracle_mod.crc16_x25, pwr_db=pw)
+    o = oracle_mod.Oracle(rw.CHANNEL, [rw.CHANNEL], oversample=10, sample_fmt=oracle_mod.FMT_U8)
+    o.process(raw)
+    assert_frames_equal(o.frames(), fr, label="wav as u8")
+    assert list(o.counters(0).values()) == list(rx.counters(0).values())
+    d, pos = 25000, 6
+    raw = rw.as_u8(rw.upsampled2x(d))
+    cf, freqs = hot_plan(d, pos)
+    rx2 = vh.Receiver(cf, freqs, 20, vh.FMT_U8, max_block_bytes=raw.size)
+    rx2.feed(raw)
+    fr = rx2.drain()
+    _expect_resampled([f for f in fr if f["chan"] == pos], d, rw.FS2, oracle_mod.crc16_x25, pwr_db=pw)
+    o = oracle_mod.Oracle(cf, freqs, oversample=20, sample_fmt=oracle_mod.FMT_U8)
+    o.process(raw)
+    assert_frames_equal(o.frames(), fr, label="wav as u8 at 2.1 MS/s")
+    _counters_of_a_noiseless_capture(o, rx2, pos)
+    rx.close(); rx2.close()
+
+
 def test_uint8_input(vh, oracle_mod):
     from dumpvdl2_amd import synth
     cfg = synth.SynthConfig(centerfreq=CF, freqs=[CF, CF + 40000], oversample=10, duration_s=0.6, seed=12, amplitude=0.3, noise_sigma=0.01)

@@ -107,3 +107,79 @@ def test_reference_wav_offset_tuned(oracle_mod, delta):
     m = oracle_mod.Oracle(sw.CHANNEL + delta, [sw.CHANNEL], oversample=10)
     m.process(raw)
     assert all(f["frame_pwr_dbfs"] < -40 for f in m.frames())
+
+
+# ---- the 2.1 MS/s path (oversample 20) and the u8 path against reference-held data: tests/golden/resample_wav.py ----
+HOT_CASES = [(0, 0), (25000, 5), (-250000, 10), (100008, 15)]     # (offset of the capture in Hz, index of the tuned channel among 16)
+
+
+def hot_plan(delta, pos, n=16, spacing=50000):
+    """16 channels 50 kHz apart with the capture's channel at index `pos`; receiver centre `delta` below that channel"""
+    import resample_wav as rw
+    return rw.CHANNEL - delta, [rw.CHANNEL + (k - pos) * spacing for k in range(n)]
+
+
+def _expect_resampled(frames, delta, fs, crc16, pwr_db=-9.841, tol_db=0.01, tol_ppm=0.015):
+    """The reference-held answer for a capture derived from the reference's WAV (resample_wav.py): the CI's two frames, S:0 L:504
+    F:0, the on-centre burst power (+ the u8 scale where it applies) and the carrier offset of SURVEY 4 (-0.0705 ppm) plus the
+    error of the fp32-rounded, truncated NCO step of demod.c:385.  tol_ppm = 0.015 pins the step to 2 Hz at 137 MHz."""
+    import resample_wav as rw
+    assert [len(f["octets"]) for f in frames] == [314, 186]
+    assert frames[0]["octets"][:12].hex() == "b2107684948a341f22544146" and frames[0]["octets"][-3:].hex() == "0a44bf"
+    assert frames[1]["octets"][:12].hex() == "b2107684948a341f344d4554" and frames[1]["octets"][-3:].hex() == "0a3ef9"
+    assert b" -RA BR OVC005\n" in frames[0]["octets"] and b" SLP135\n" in frames[1]["octets"]
+    cf = rw.CHANNEL - delta
+    step = int(np.float32(np.float32(cf) - np.float32(rw.CHANNEL)) / np.float32(fs) * np.float32(256.0) * np.float32(65536.0))
+    nco_hz = step / 2 ** 24 * fs
+    ppm = 10500 * -0.005778 / (2 * np.pi * rw.CHANNEL) * 1e6 + (delta + nco_hz) / rw.CHANNEL * 1e6
+    for f in frames:
+        assert crc16(f["octets"]) == 0xF0B8
+        assert (f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"]) == (0, 504, 0)
+        assert abs(f["frame_pwr_dbfs"] - pwr_db) < tol_db, f["frame_pwr_dbfs"]
+        assert abs(f["ppm_error"] - ppm) < tol_ppm, (f["ppm_error"], ppm)
+    return step
+
+
+def _golden_path():
+    import sys, os
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+@pytest.mark.parametrize("delta,pos", HOT_CASES)
+def test_reference_wav_at_2100kHz(oracle_mod, delta, pos):
+    """oversample 20 (input_lpf_init(2.1 MS/s), demod.c:367-370; the NCO at that rate) on the reference's capture interpolated to
+    2.1 MS/s, alone and as one of 16 channels (the others lie 50 kHz apart: on this noiseless capture some of them decode the
+    leaked burst too - whatever they do, the tuned channel must give the reference's answer)."""
+    _golden_path()
+    import resample_wav as rw
+    raw = rw.upsampled2x(delta)
+    o = oracle_mod.Oracle(rw.CHANNEL - delta, [rw.CHANNEL], oversample=20)
+    o.process(raw)
+    alone = o.frames()
+    step = _expect_resampled(alone, delta, rw.FS2, oracle_mod.crc16_x25)
+    assert o.dphi(0) == step & 0xFFFFFFFF
+    c = o.counters(0)
+    assert c["demod.sync.good"] == 1 and c["decoder.blocks.processed"] == 3 and c["decoder.blocks.fec_ok"] == 3 and c["decoder.msg.good"] == 2
+    cf, freqs = hot_plan(delta, pos)
+    o16 = oracle_mod.Oracle(cf, freqs, oversample=20)
+    o16.process(raw)
+    mine = [f for f in o16.frames() if f["chan"] == pos]
+    _expect_resampled(mine, delta, rw.FS2, oracle_mod.crc16_x25)
+    # same channel, same input: what it decodes does not depend on who else is configured
+    assert [(f["octets"], f["sync_sample"], f["ppm_error"]) for f in mine] == [(f["octets"], f["sync_sample"], f["ppm_error"]) for f in alone]
+
+
+def test_reference_wav_as_u8(oracle_mod):
+    """process_buf_uchar()'s conversion (demod.c:339-354) on the reference's capture re-quantised to u8: same frames, the burst
+    0.034 dB louder (the u8 table's scale), at 1.05 MS/s on the centre and at 2.1 MS/s off it."""
+    _golden_path()
+    import resample_wav as rw
+    o = oracle_mod.Oracle(rw.CHANNEL, [rw.CHANNEL], oversample=10, sample_fmt=oracle_mod.FMT_U8)
+    o.process(rw.as_u8())
+    _expect_resampled(o.frames(), 0, rw.FS, oracle_mod.crc16_x25, pwr_db=-9.841 + rw.U8_GAIN_DB)
+    d = 25000
+    o = oracle_mod.Oracle(rw.CHANNEL - d, [rw.CHANNEL], oversample=20, sample_fmt=oracle_mod.FMT_U8)
+    o.process(rw.as_u8(rw.upsampled2x(d)))
+    _expect_resampled(o.frames(), d, rw.FS2, oracle_mod.crc16_x25, pwr_db=-9.841 + rw.U8_GAIN_DB)
