@@ -11,10 +11,7 @@ for job in "$@"; do
 	case $job in
 	pytest) timeout 900 python -m pytest tests -m gpu -x -q > $O.pytest.txt 2>&1; echo "pytest rc=$?" >> $O.pytest.txt; tail -4 $O.pytest.txt ;;
 	b1)
-		build exp "-DVDL2_EXPERIMENTS"; build ph "-DVDL2_EXPERIMENTS -DVDL2_K1_PHASE"
-		timeout 1500 python dev/gpu_variants.py --out $O.variants.jsonl --steps 16 --repeats 2 \
-			--variant base --variant eager:VDL2HIP_BACKEND=eager --variant ph:@/tmp/vdl2hip_ph.so \
-			--variant allhigh:@/tmp/vdl2hip_exp.so:VDL2HIP_LOW_PRIO=none --variant alllow:@/tmp/vdl2hip_exp.so:VDL2HIP_LOW_PRIO=nf,burst,walk 2>&1 | tee $O.variants.txt ;;
+		timeout 1500 python dev/gpu_variants.py --out $O.variants.jsonl --steps 16 --repeats 2 --variant base --variant r03:@dev/_ref/libvdl2hip_r03.so 2>&1 | tee $O.variants.txt ;;
 	k5prof:*) build prof "-DVDL2_K5_PROF"; VDL2HIP_LIB=/tmp/vdl2hip_prof.so timeout 300 python dev/gpu_stage_times.py ${job#k5prof:} 16 2 2>&1 | grep -v amdgpu.ids | tee $O.k5prof_${job#k5prof:}.txt | cut -c1-220 ;;
 	pmc:*) W=${job#pmc:}; timeout 900 bash dev/gpu_pmc_all.sh $W all > $O.pmc_all_$W.txt 2>&1; cut -c1-120 $O.pmc_all_$W.txt ;;
 	*) echo "unknown job $job" ;;

@@ -18,7 +18,7 @@ t = torch.from_numpy(iq).cuda()
 rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, 1, cfg.rx_max_ppm, max_block_bytes=iq.nbytes)
 L = rx.L
 have = hasattr(L, "vdl2hip_debug_k4_prof")
-K5N = ["1 tables+slice (atan2)", "2 descramble/pack", "3 de-interleave", "4 Reed-Solomon", "5 un-stuff", "6 frames out"]
+K5N = ["1 slice (atan2)", "2 descramble/pack", "3 de-interleave", "4 Reed-Solomon", "5 un-stuff", "6a frames: list+reserve", "6b frames: records", "6c frames: octets"]
 K4N = ["0 entry", "1 stale batch eval", "2 log_evals", "3 bitmap hop", "4 (fire branch)", "5 fire LANE0", "6 header", "7 tail", "8 fire gather", "9 park (no fire)"]
 
 
@@ -46,9 +46,9 @@ for label, lag in (("alone (one block in flight)", 0), ("in the pipeline (three 
     if have:
         a5, a4 = prof(0)
         nb5 = a5[8] or 1
-        tot5 = sum(a5[:6]) or 1
+        tot5 = sum(a5[:8]) or 1
         print(f"  K5: {a5[8]} bursts decoded, {tot5 / nb5:.0f} shader clocks per burst")
-        for i in range(6):
+        for i in range(8):
             print(f"     {K5N[i]:26s} {a5[i] / nb5:10.0f} clk/burst {100.0 * a5[i] / tot5:5.1f}%")
         tot4 = sum(a4[:10]) or 1
         print(f"  K4: {tot4 / reps:.4g} shader clocks per feed summed over all walker waves")

@@ -68,7 +68,6 @@ struct K1Args {
 	const Lut4 *lut;
 	K1Consts bf;
 	cf32 *y;                   // [nchan][cap]
-	float *ph;                 // [nchan][cap] screening-precision phase (turns) of every output, for the sync screening kernel (VDL2_K1_PHASE builds; else null)
 	float4 *seg_end;           // [nchan][nseg_cap] zero-start state at the end of each workgroup segment
 	const float4 *qpow;        // [64] Q^(l+1) row-major 2x2, Q = P^R
 	int32_t  tiles;            // tiles per workgroup segment
@@ -422,25 +421,11 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 						if(cvalid && kloc < a.D) yout[s0] = cf32{f0r, f0i};
 						if(cvalid && kloc + 1 < a.D) yout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = cf32{f1r, f1i};
 					}
-#ifdef VDL2_K1_PHASE
-					{
-						float *pout = a.ph + (size_t)(cbase + c) * a.cap;
-						const float p0 = phase_fast(cf32{f0r, f0i}), p1 = phase_fast(cf32{f1r, f1i});
-						if(cvalid && kloc + 1 < a.D && (s0 & 1u) == 0) *reinterpret_cast<float2 *>(pout + s0) = make_float2(p0, p1);
-						else {
-							if(cvalid && kloc < a.D) pout[s0] = p0;
-							if(cvalid && kloc + 1 < a.D) pout[(uint32_t)(a.k0 + kloc + 1) & a.mask] = p1;
-						}
-					}
-#endif
 				}
 			} else {
 				if(kHoldRegs && a.fuse && ts == 0) { hold[c][0] = f0r; hold[c][1] = f0i; }
 				else {
 					if(cvalid && kloc < a.D) yout[(uint32_t)(a.k0 + kloc) & a.mask] = cf32{f0r, f0i};
-#ifdef VDL2_K1_PHASE
-					if(cvalid && kloc < a.D) a.ph[(size_t)(cbase + c) * a.cap + ((uint32_t)(a.k0 + kloc) & a.mask)] = phase_fast(cf32{f0r, f0i});
-#endif
 				}
 			}
 			if(cvalid && lane == lb && (rem <= L || ts == a.tiles - 1)) {
@@ -577,17 +562,6 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			if(cvalid && kloc0 < a.D) yout[s0] = cf32{v0r, v0i};
 			if(R > 1 && cvalid && kloc0 + 1 < a.D) yout[(uint32_t)(a.k0 + kloc0 + 1) & a.mask] = cf32{v1r, v1i};
 		}
-#ifdef VDL2_K1_PHASE
-		{
-			float *pout = a.ph + (size_t)(cbase + c) * a.cap;
-			const float p0 = phase_fast(cf32{v0r, v0i}), p1 = R > 1 ? phase_fast(cf32{v1r, v1i}) : 0.f;
-			if(R > 1 && cvalid && kloc0 + 1 < a.D && (s0 & 1u) == 0) *reinterpret_cast<float2 *>(pout + s0) = make_float2(p0, p1);
-			else {
-				if(cvalid && kloc0 < a.D) pout[s0] = p0;
-				if(R > 1 && cvalid && kloc0 + 1 < a.D) pout[(uint32_t)(a.k0 + kloc0 + 1) & a.mask] = p1;
-			}
-		}
-#endif
 		// the filter state handed to the next feed (K2's k == D-1 branch)
 		if(cvalid && lane == 0 && (int64_t)(seg + 1) * seglen >= a.D) {
 			const int64_t len = a.D - (int64_t)seg * seglen;
@@ -605,7 +579,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 }
 
 struct K2Args {
-	float *ph; cf32 *y; const float4 *seg_end; const float4 *carry_in; float4 *carry_out;
+	cf32 *y; const float4 *seg_end; const float4 *carry_in; float4 *carry_out;
 	const BlockForm *bf;
 	int64_t k0, D; uint32_t cap, mask, nseg_cap; int32_t seglen;
 };
@@ -624,9 +598,6 @@ __global__ __launch_bounds__(256) void k_fixup(K2Args a) {
 		v.re += bf.cP[i][0] * ts.x + bf.cP[i][1] * ts.z;
 		v.im += bf.cP[i][0] * ts.y + bf.cP[i][1] * ts.w;
 		a.y[(size_t)c * a.cap + slot] = v;
-#ifdef VDL2_K1_PHASE
-		a.ph[(size_t)c * a.cap + slot] = phase_fast(v);
-#endif
 	}
 	if(k == a.D - 1) {   // filter state handed to the next feed
 		const int len = i + 1;
@@ -656,7 +627,7 @@ __global__ void k_carry(K1Args a, void *carry_out, uint32_t nrem) {
 }
 
 struct K3Args {
-	const float *ph; const cf32 *y; cf32 *pf; uint64_t *cand; uint64_t *flag; const Tables *tab;
+	const cf32 *y; cf32 *pf; uint64_t *cand; uint64_t *flag; const Tables *tab;
 	int64_t nbase, k1;        // first sample to (re)compute (multiple of 64); one past the last valid sample
 	uint32_t cap, mask;
 	int32_t wpl;              // exact tier: flag words scanned per lane (1..kK3bWordsPerLane)
@@ -695,29 +666,15 @@ __global__ __launch_bounds__(kK3Threads) void k_sync_screen(K3Args a) {
 		// the whole tile and its history exist (all but the first and last block of a channel): no per-sample range tests, ring
 		// offsets in 32 bits, all loads in flight before the first phase is worked out
 		const uint32_t r0 = (uint32_t)(nblk - 150) + tid;
-#ifdef VDL2_K1_PHASE
-		// the channeliser has left the screening phase of every output beside it (K1Args::ph): half the bytes, no arithmetic
-		const float *ph = a.ph + (size_t)c * a.cap;
-		float v[kFull + 1];
-		#pragma unroll
-		for(int k = 0; k <= kFull; k++) if(k < kFull || tid < kRest) v[k] = ph[(r0 + kK3Threads * k) & a.mask];
-		#pragma unroll
-		for(int k = 0; k <= kFull; k++) if(k < kFull || tid < kRest) tile[tid + kK3Threads * k] = v[k];
-#else
 		cf32 v[kFull + 1];
 		#pragma unroll
 		for(int k = 0; k <= kFull; k++) if(k < kFull || tid < kRest) v[k] = y[(r0 + kK3Threads * k) & a.mask];
 		#pragma unroll
 		for(int k = 0; k <= kFull; k++) if(k < kFull || tid < kRest) tile[tid + kK3Threads * k] = phase_fast(v[k]);
-#endif
 	} else {
 		for(int j = tid; j < kK3Tile + 150; j += kK3Threads) {
 			const int64_t t = nblk - 150 + j;
-#ifdef VDL2_K1_PHASE
-			tile[j] = (t < 0 || t >= a.k1) ? 0.f : a.ph[(size_t)c * a.cap + ((uint32_t)t & a.mask)];
-#else
 			tile[j] = (t < 0 || t >= a.k1) ? 0.f : phase_fast(y[(uint32_t)t & a.mask]);
-#endif
 		}
 	}
 	__syncthreads();
@@ -957,6 +914,7 @@ struct K4Args {
 	WalkState *ws; unsigned long long *cnt; Burst *bursts; uint32_t *nb_chan; uint32_t cap_bursts_chan; OutCtl *ctl; const uint32_t *freq;
 	EvalChunk *log; uint32_t *nlog; uint32_t cap_log;
 	int64_t k_end; float max_ppm; uint32_t cap, mask; int32_t chan_first, nchan;
+	const float *ppm_thr;      // per channel: ppm_gate_threshold(freq, max_ppm)
 };
 
 __global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
@@ -964,7 +922,7 @@ __global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
 	const int c = blockIdx.x;
 	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
-	walk_channel(c, a.freq[c], a.max_ppm, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
+	walk_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh);
 }
 
@@ -986,12 +944,12 @@ __global__ __launch_bounds__(64 * kWalkWaves, 4) void k_walk_spec(K4sArgs s) {
 	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
 	if(x == 0) {
 		EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
-		walk_channel(c, a.freq[c], a.max_ppm, s.k0 + s.seglen, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
+		walk_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], s.k0 + s.seglen, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 		             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh);
 	} else {
 		const int seg = 1 + (x - 1) / 3, r = (x - 1) % 3;
 		const int64_t b = s.k0 + (int64_t)seg * s.seglen, kn = seg + 1 < s.nseg ? b + s.seglen : a.k_end;
-		spec_walk(c, a.freq[c], a.max_ppm, b, r, kn, *a.tab, v, s.spec + (size_t)c * s.spec_stride + (x - 1), sh);
+		spec_walk(c, a.freq[c], a.max_ppm, a.ppm_thr[c], b, r, kn, *a.tab, v, s.spec + (size_t)c * s.spec_stride + (x - 1), sh);
 	}
 }
 
@@ -1010,7 +968,7 @@ __global__ __launch_bounds__(256, 4) void k_walk_stitch(K4sArgs s) {
 	StitchLds &lds = reinterpret_cast<StitchLds *>(k4_lds)[wave];
 	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
-	stitch_channel(c, a.freq[c], a.max_ppm, s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
+	stitch_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	               a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg,
 	               s.spec + (size_t)c * s.spec_stride, lds.sh, lds.ss, s.seg_stats + 2 * c);
 }
@@ -1057,7 +1015,7 @@ __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_finish(K4bArgs a) {
 
 // Each channel's walker fills its own burst list (no atomics on its critical path); this one-wave kernel turns the
 // per-channel counts into offsets so that K5 can spread all bursts of the feed over its workgroups.
-__global__ __launch_bounds__(64) void k_burst_index(const uint32_t *nb_chan, uint32_t *bbase, int nchan, OutCtl *ctl) {
+__global__ __launch_bounds__(64) void k_burst_index(const uint32_t *nb_chan, uint32_t *bbase, int nchan, OutCtl *ctl, uint32_t k5_waves) {
 	const int lane = threadIdx.x;
 	uint32_t carry = 0;
 	for(int c0 = 0; c0 < nchan; c0 += 64) {         // exclusive prefix sum, 64 channels per pass
@@ -1068,7 +1026,11 @@ __global__ __launch_bounds__(64) void k_burst_index(const uint32_t *nb_chan, uin
 		if(c0 + lane < nchan) bbase[c0 + lane] = carry + inc - v;
 		carry += __shfl(inc, 63);
 	}
-	if(lane == 0) { bbase[nchan] = carry; ctl->nbursts = carry; }
+	if(lane == 0) {
+		bbase[nchan] = carry; ctl->nbursts = carry;
+		// the burst decoder's wavefronts each own a first share of the output; the feed-wide counters start behind those shares
+		ctl->nframes = burst_reserve_initial_frames(k5_waves); ctl->pool_used = burst_reserve_initial_pool(k5_waves);
+	}
 }
 
 struct K5Args {
@@ -1084,21 +1046,37 @@ struct K5Args {
 #define VDL2_K5_WAVES 2
 #endif
 constexpr int kBurstWaves = VDL2_K5_WAVES;
+constexpr int kK5MaxChan = 1024;          // channels whose burst-list offsets a wavefront of the burst decoder keeps in LDS
 // (the LDS is dynamic so that the compiler does not see its size: it would size the register budget by the LDS-limited occupancy
 // and take 169, more than a channeliser wave leaves)
 __global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
-	extern __shared__ __align__(16) unsigned char k5_lds[];       // BurstShared[kBurstWaves]
+	extern __shared__ __align__(16) unsigned char k5_lds[];       // BurstShared[kBurstWaves], then the per-channel burst offsets
 	BurstShared &sh = reinterpret_cast<BurstShared *>(k5_lds)[threadIdx.x >> 6];
+	uint32_t *bb = reinterpret_cast<uint32_t *>(k5_lds + sizeof(BurstShared) * kBurstWaves) + (size_t)(threadIdx.x >> 6) * (kK5MaxChan + 1);
+	const int lane = threadIdx.x & 63;
 	const uint32_t total = a.bbase[a.nchan];
-	for(uint32_t g = blockIdx.x * kBurstWaves + (threadIdx.x >> 6); g < total; g += gridDim.x * kBurstWaves) {
+	const uint32_t wave_id = blockIdx.x * kBurstWaves + (threadIdx.x >> 6);
+	if(wave_id >= total) {
+		// nothing to decode: this wavefront's share of the output (vdl2_core.h: burst_reserve_*) stays empty
+		const uint32_t slot = wave_id * (uint32_t)kResSlots + (uint32_t)lane;
+		if(lane < kResSlots && slot < a.ctl->cap_frames) { OutFrame &f = a.frames[slot]; f.chan = -1; f.len = 0; f.pool_off = 0; f.nf_upd = 0; }
+		return;
+	}
+	// the offsets of the channels' burst lists go to LDS once: finding a burst's channel is then a search in LDS, not eight dependent
+	// trips to memory per burst (more channels than fit: the search falls back to memory for them)
+	const int nstage = a.nchan < kK5MaxChan ? a.nchan : kK5MaxChan;
+	for(int i = lane; i <= nstage; i += 64) bb[i] = a.bbase[i];
+	burst_shared_init(*a.tab, wave_id, a.ctl, sh);
+	for(uint32_t g = wave_id; g < total; g += gridDim.x * kBurstWaves) {
 		int lo = 0, hi = a.nchan;                       // channel c with bbase[c] <= g < bbase[c+1]
-		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(a.bbase[mid] <= g) lo = mid; else hi = mid; }
+		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if((mid <= nstage ? bb[mid] : a.bbase[mid]) <= g) lo = mid; else hi = mid; }
 		const int c = lo;
-		const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - a.bbase[c])];
+		const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - (c <= nstage ? bb[c] : a.bbase[c]))];
 		ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask };
-		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
+		decode_burst(b, 0u, *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
 		WAVE_SYNC();
 	}
+	burst_reserve_done(a.frames, sh);
 }
 
 // after K4b and K5 have both finished, one wavefront per frame: the noise-floor figure and the AVLC front-door checks

@@ -71,6 +71,12 @@ inline void build_tables(Tables &T) {
 		l = (l >> 1) | (bit << 14);
 		T.prbs[i] = (uint8_t)bit;
 	}
+	// the burst decoder takes the scrambling sequence an octet at a time (bitstream.c:70-81 packs LSB first)
+	for(int i = 0; i < kMaxOctets; i++) {
+		uint32_t o = 0;
+		for(int j = 0; j < 8; j++) { const int bb = kHdrBits + 8 * i + j; if(bb < kPrbsBits) o |= (uint32_t)T.prbs[bb] << j; }
+		T.prbs_oct[i] = (uint8_t)o;
+	}
 }
 
 }  // namespace vdl2

@@ -37,13 +37,20 @@
 
 #if VDL2_DEVICE_PASS
 #define VDL2_LANE() ((int)(threadIdx.x & 63))
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while(0)
+// Between two phases the lanes of ONE wavefront exchange data through LDS.  A wavefront's LDS instructions are executed in the order
+// they are issued, so all that is needed is that the compiler keeps that order: a wavefront-scope fence.  (A workgroup-scope fence
+// also waits for every outstanding GLOBAL access of the wave - vmcnt(0) - i.e. each phase that had fired a counter atomic or a store
+// and forgotten it paid a trip to memory at its end: half of the burst decoder's time.)  WAVE_SYNC_GLOBAL() is that stronger form, for
+// the one place where a lane reads from global memory what another lane of its wavefront has written in the same kernel.
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while(0)
+#define WAVE_SYNC_GLOBAL() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while(0)
 #define WAVE_FOR(l) { const int l = VDL2_LANE();
 #define WAVE_END } WAVE_SYNC();
 #define LANE0 if(VDL2_LANE() == 0) {
 #define LANE0_END } WAVE_SYNC();
 #else
 #define WAVE_SYNC() do {} while(0)
+#define WAVE_SYNC_GLOBAL() do {} while(0)
 // Host build: the lanes of a phase run one after the other.  A phase must not depend on that order (on the device the
 // lanes run together): -DVDL2_HOST_REVERSE_LANES runs them backwards, and the CPU tests must give the same answers.
 #ifdef VDL2_HOST_REVERSE_LANES
@@ -118,6 +125,7 @@ constexpr int kSpecBack = 4096;           // a speculative walker pretends its D
 constexpr int kSpecBursts = 48;           // per speculative segment; more than that and the segment is simply walked for real
 constexpr int kSpecLog = 128;
 constexpr int kMaxSeg = 32;
+constexpr int kCandWin = 512;             // candidate-bitmap words (64 samples each) a walker loads per pass and keeps in LDS
 
 enum { CNT_SYNC_GOOD = 0, CNT_CRC_GOOD, CNT_CRC_BAD, CNT_ERR_NO_HEADER, CNT_ERR_TOO_LONG, CNT_ERR_NO_FEC,
        CNT_ERR_DATA_TRUNCATED, CNT_ERR_FEC_TRUNCATED, CNT_ERR_DEINTERLEAVE_DATA, CNT_ERR_DEINTERLEAVE_FEC,
@@ -141,6 +149,7 @@ struct Tables {
 	uint8_t  gf_log[256];              // log(0) = 255 marker
 	uint8_t  prbs[kPrbsBits];          // bitstream.c:94-107 from LFSR_IV, one bit per byte
 	uint16_t crc16[256];               // crc.c:23-57: reflected CRC-16-CCITT (x^16+x^12+x^5+1), one step per octet
+	uint8_t  prbs_oct[kMaxOctets];     // the eight PRBS bits that cover data/FEC octet i (stream bits 25+8i ..), packed LSB first like the octet itself
 };
 
 struct cf32 { float re, im; };
@@ -167,7 +176,7 @@ struct Burst {
 	int64_t  t_first;                  // sample of the first symbol after the unique word
 	int64_t  sync_sample, end_sample, ord;
 	float    prev_phi0, vdphi, ppm, pad_;
-	uint32_t tl_bits, syndrome;
+	uint32_t tl_bits, syndrome;        // syndrome: bits 0-4 the header syndrome, bits 8.. the weight of the pattern it corrects (metadata->synd_weight)
 	int64_t  nf_upd;                   // number of mag_nf updates that preceded the sync (v->mag_nf at decode_frame())
 	int64_t  sync_evals;               // got_sync() evaluations executed up to and including the one that fired (nf_upd = sync_evals / 1000)
 };
@@ -420,6 +429,32 @@ VDL2_HD float parabola_vertex(float y1, float y2, float y3) {
 	return -b / (2 * a);
 }
 
+// The --max-ppm gate (demod.c:185,190-192): ppm_error = 10500 * dphi / (2 pi freq) * 1e6 in the reference's float/double mix.
+VDL2_HD float ppm_of(float vdphi, uint32_t freq) { return (float)((double)(10500 * vdphi) / (2.0f * M_PI * (double)freq) * 1e+6); }
+// |ppm_of(x)| is even and non-decreasing in |x| (a float product by a positive constant, an exact widening, a division by and a
+// product with positive constants, a narrowing: every step rounds monotonically), so the gate "fabsf(ppm) > max_ppm" is a
+// comparison of |x| with one number: the largest float the gate lets pass.  Found once per walk by bisection on the bit pattern.
+VDL2_HD float ppm_gate_threshold(uint32_t freq, float max_ppm) {
+	uint32_t lo = 0u, hi = 0x7f800000u;            // passes (ppm 0) / does not (infinite)
+	while(hi - lo > 1u) {
+		const uint32_t mid = lo + (hi - lo) / 2u;
+		float x;
+#if VDL2_DEVICE_PASS
+		x = __uint_as_float(mid);
+#else
+		__builtin_memcpy(&x, &mid, 4);
+#endif
+		if(fabsf(ppm_of(x, freq)) > max_ppm) hi = mid; else lo = mid;
+	}
+	float t;
+#if VDL2_DEVICE_PASS
+	t = __uint_as_float(lo);
+#else
+	__builtin_memcpy(&t, &lo, 4);
+#endif
+	return t;
+}
+
 // One D8PSK decision: demod.c:256-264.  Returns the phase-step index 0..7.
 VDL2_HD int slice_symbol(float phi, float prev_phi, float vdphi, int &neg) {
 	float dphi = phi - prev_phi - vdphi;
@@ -446,6 +481,8 @@ VDL2_HD bool is_candidate(float p_prev, float p_now) { return p_prev < kSyncThr 
 
 VDL2_HD int fec_octets_for(uint32_t len) { return len < 3 ? 0 : len < 31 ? 2 : len < 68 ? 4 : 6; }  // decode.c:124-133
 
+VDL2_HD int popc32(uint32_t v) { return __builtin_popcount(v); }
+VDL2_HD int ctz32(uint32_t v) { return __builtin_ctz(v); }
 VDL2_HD uint32_t parity32(uint32_t v) { v ^= v >> 16; v ^= v >> 8; v ^= v >> 4; v ^= v >> 2; v ^= v >> 1; return v & 1; }
 
 struct Geometry { uint32_t tl_bits, octets, nblocks, last_len, fec_octets, want_bits, syndrome; int status; };
@@ -501,6 +538,14 @@ struct WalkShared {
 	uint32_t t_H[kHdrParBits], t_fix[32]; uint8_t t_gray[8], t_prbs[32];
 	uint32_t nb;                       // bursts emitted by this channel in this feed
 	int64_t first_fire;                // sample of the first got_sync() success (any outcome) since walk_load(); INT64_MAX if none
+	uint32_t cap_log;                  // ctl->cap_log, read once (walk_load): the log's bookkeeping then never waits for global memory
+	// the candidate words of the last bitmap pass (words cw0 <= w < cw_end) and the metric values around the last fire (samples
+	// wbase .. wbase+63): a preamble - above all a neighbour's, which the --max-ppm gate drops - sets a cluster of candidate bits,
+	// and the fires after the first of a cluster are then decided by one lane out of LDS, without another trip to memory
+	uint64_t cw[kCandWin]; int64_t cw0, cw_end;
+	uint64_t nzw[kCandWin / 64];       // bit i: cw[i] != 0 (a lane owns the byte of its eight words): one lane finds the next word worth a look without reading the empty ones
+	float wre[64], wim[64]; int64_t wbase;
+	int32_t u_fire; int64_t u_n;
 };
 
 // lowest lane whose flag is set, or -1.  Call from wave-uniform code after a WAVE_END.
@@ -513,6 +558,39 @@ VDL2_HD int wave_first_flag(const int32_t *flags) {
 VDL2_HD int wave_first_flag(const int32_t *flags) {
 	for(int l = 0; l < 64; l++) if(flags[l]) return l;
 	return -1;
+}
+#endif
+
+// Wave-wide primitives on 64 values that the lanes have left in LDS.  Call from wave-uniform code after a WAVE_END (the device
+// versions read the calling lane's own entry and combine over the wavefront in registers; the host versions are plain loops).
+#if VDL2_DEVICE_PASS
+// a[l] <- sum of a[0..l-1]; returns the total
+VDL2_HD uint32_t wave_excl_scan64(uint32_t *a) {
+	const int l = VDL2_LANE();
+	const uint32_t v = a[l];
+	uint32_t inc = v;
+	for(int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if(l >= d) inc += o; }
+	a[l] = inc - v;
+	const uint32_t tot = __shfl(inc, 63);
+	WAVE_SYNC();
+	return tot;
+}
+// smallest a[l] over the wavefront
+VDL2_HD uint32_t wave_min64(const uint32_t *a) {
+	uint32_t v = a[VDL2_LANE()];
+	for(int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_xor(v, d); v = o < v ? o : v; }
+	return v;
+}
+#else
+VDL2_HD uint32_t wave_excl_scan64(uint32_t *a) {
+	uint32_t acc = 0;
+	for(int l = 0; l < 64; l++) { const uint32_t v = a[l]; a[l] = acc; acc += v; }
+	return acc;
+}
+VDL2_HD uint32_t wave_min64(const uint32_t *a) {
+	uint32_t m = a[0];
+	for(int l = 1; l < 64; l++) if(a[l] < m) m = a[l];
+	return m;
 }
 #endif
 
@@ -536,21 +614,27 @@ VDL2_HD void push_interval(WalkState &st, int64_t a, int64_t b) {
 }
 
 // `count` evaluations starting at `first` (step 3) are being executed: note them for the noise-floor
-// kernel (demod.c:238-243 is replayed there, off the walker's critical path).
+// kernel (demod.c:238-243 is replayed there, off the walker's critical path).  One lane (call inside a LANE0 section).
+VDL2_HD void log_evals_lane0(WalkShared &sh, const EvalLog &lg, OutCtl *ctl, int64_t first, int64_t count) {
+	if(count <= 0) return;
+	// the open chunk lives in LDS; a chunk is written out (a plain store, nothing waits for it) only when
+	// the next one cannot be merged into it
+	const int64_t lc = sh.lg_count, lf = sh.lg_first;
+	if(lc > 0 && lf + 3 * lc == first) sh.lg_count = lc + count;
+	else {
+		if(lc > 0) {
+			const uint32_t ln = sh.lg_n;
+			if(ln < sh.cap_log) { lg.chunks[ln].first = lf; lg.chunks[ln].count = lc; sh.lg_n = ln + 1; }
+			else ctl->overflow = 1;  // pathological storm of grid shifts: noise floor becomes approximate
+		}
+		sh.lg_first = first; sh.lg_count = count;
+	}
+	sh.st.evals += count;
+}
 VDL2_HD void log_evals(WalkShared &sh, const EvalLog &lg, OutCtl *ctl, int64_t first, int64_t count) {
 	if(count <= 0) return;
 	LANE0
-		// the open chunk lives in LDS; a chunk is written out (a plain store, nothing waits for it) only when
-		// the next one cannot be merged into it
-		if(sh.lg_count > 0 && sh.lg_first + 3 * sh.lg_count == first) sh.lg_count += count;
-		else {
-			if(sh.lg_count > 0) {
-				if(sh.lg_n < ctl->cap_log) { lg.chunks[sh.lg_n].first = sh.lg_first; lg.chunks[sh.lg_n].count = sh.lg_count; sh.lg_n++; }
-				else ctl->overflow = 1;  // pathological storm of grid shifts: noise floor becomes approximate
-			}
-			sh.lg_first = first; sh.lg_count = count;
-		}
-		sh.st.evals += count;
+		log_evals_lane0(sh, lg, ctl, first, count);
 	LANE0_END
 }
 
@@ -563,12 +647,14 @@ VDL2_HD void restart_search(WalkState &st, int64_t a) {
 
 // Start of a walk: bring the channel's FSM state and the small tables into LDS.  `resume`: continue the burst list of
 // this feed (a previous walk_store() left its count in *nbursts_out) instead of starting it.
-VDL2_HD void walk_load(const WalkState *gstate, const EvalLog &lg, const uint32_t *nbursts_out, bool resume, const Tables &T, WalkShared &sh) {
+VDL2_HD void walk_load(const WalkState *gstate, const EvalLog &lg, const uint32_t *nbursts_out, bool resume, const Tables &T, const OutCtl *ctl, WalkShared &sh) {
 	LANE0
 		sh.st = *gstate;
+		sh.cap_log = ctl->cap_log;
 		sh.lg_n = resume ? *lg.n : 0; sh.lg_first = 0; sh.lg_count = 0;
 		sh.spec_n = -1; sh.vring_a = -1; sh.nb = resume ? *nbursts_out : 0;
 		sh.first_fire = INT64_MAX;
+		sh.cw0 = 0; sh.cw_end = 0; sh.wbase = 0; sh.u_fire = 0; sh.u_n = 0;
 	LANE0_END
 	WAVE_FOR(l)
 		if(l < kHdrParBits) sh.t_H[l] = T.hdr_H[l];
@@ -581,7 +667,7 @@ VDL2_HD void walk_load(const WalkState *gstate, const EvalLog &lg, const uint32_
 VDL2_HD void walk_flush_log(WalkShared &sh, const EvalLog &lg, OutCtl *ctl) {
 	LANE0
 		if(sh.lg_count > 0) {
-			if(sh.lg_n < ctl->cap_log) { lg.chunks[sh.lg_n].first = sh.lg_first; lg.chunks[sh.lg_n].count = sh.lg_count; sh.lg_n++; }
+			if(sh.lg_n < sh.cap_log) { lg.chunks[sh.lg_n].first = sh.lg_first; lg.chunks[sh.lg_n].count = sh.lg_count; sh.lg_n++; }
 			else ctl->overflow = 1;
 			sh.lg_count = 0;
 		}
@@ -602,7 +688,7 @@ VDL2_HD bool walk_clean(const WalkState &st) { return st.mode == 0 && st.e >= st
 
 // Advance the FSM held in sh.st up to (not including) decimated sample k_end.  With `stop_clean` the walk also stops as
 // soon as the state is "clean" (walk_clean()).  Stopping anywhere is exact: it is what a feed boundary does.
-VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, bool stop_clean, const Tables &T,
+VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, bool stop_clean, const Tables &T,
 		const ChanView &v, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
 	K4_BEGIN();
 	LANE0
@@ -683,13 +769,26 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 				const int64_t start = e > sh.st.e0 + 3 ? e : sh.st.e0 + 3;
 				int64_t w0 = start >> 6;
 				const int64_t wend = (k_lim + 63) >> 6;
-				for(; w0 < wend && !fired; w0 += 256) {
+				while(w0 < wend && !fired) {
+					// the words of the previous pass are still in LDS: a search that starts among them costs no trip to memory
+					constexpr int kWpl = kCandWin / 64;                  // words per lane and pass (consecutive: the lowest lane with a hit has the first hit)
+					static_assert(kWpl == 8, "a lane's words are one byte of the non-zero map");
+					const bool cached = w0 >= sh.cw0 && w0 < sh.cw_end;
+					const int64_t wb = cached ? sh.cw0 : w0;
+					const int64_t wlast = cached ? sh.cw_end : (wb + kCandWin < wend ? wb + kCandWin : wend);
 					WAVE_FOR(l)
 						int32_t hit = -1;
-						uint64_t wd[4];
-						for(int q = 0; q < 4; q++) { const int64_t w = w0 + 4 * l + q; wd[q] = w < wend ? v.Cand(w) : 0ull; }
-						for(int q = 0; q < 4 && hit < 0; q++) {
-							const int64_t w = w0 + 4 * l + q;
+						uint64_t wd[kWpl];
+						if(cached) { for(int q = 0; q < kWpl; q++) wd[q] = wb + kWpl * l + q < wlast ? sh.cw[kWpl * l + q] : 0ull; }
+						else {
+							for(int q = 0; q < kWpl; q++) { const int64_t w = wb + kWpl * l + q; wd[q] = w < wlast ? v.Cand(w) : 0ull; }
+							for(int q = 0; q < kWpl; q++) sh.cw[kWpl * l + q] = wd[q];
+							uint32_t nz = 0;
+							for(int q = 0; q < kWpl; q++) nz |= (wd[q] != 0ull ? 1u : 0u) << q;
+							reinterpret_cast<uint8_t *>(sh.nzw)[l] = (uint8_t)nz;
+						}
+						for(int q = 0; q < kWpl && hit < 0; q++) {
+							const int64_t w = wb + kWpl * l + q;
 							uint64_t bits = wd[q];
 							if(bits) {
 								// keep bits with index >= start, < k_lim, and congruent to e modulo 3
@@ -704,31 +803,120 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 						sh.found[l] = hit;
 						sh.flag[l] = hit >= 0;
 					WAVE_END
+					if(!cached) {
+						LANE0
+							sh.cw0 = wb; sh.cw_end = wlast;
+						LANE0_END
+					}
 					const int lf = wave_first_flag(sh.flag);
-					if(lf >= 0) { fired = 1; fire_n = ((w0 + 4 * lf) << 6) + sh.found[lf]; }
+					if(lf >= 0) { fired = 1; fire_n = ((wb + kWpl * lf) << 6) + sh.found[lf]; }
+					else w0 = wlast;
 				}
 				K4_MARK(3);
 				if(fired) {
-					const int64_t n = fire_n;
-					// one round trip: the three metric values, the four possible sync-point phases (sclk = 2..5)
-					// and the nine header-symbol phases for each of them
+					// The metric values around the fire in one load: y1, y2, y3 of calc_para_vertex() and the slope of the evaluation
+					// before it are all the --max-ppm gate needs, and a fire the gate drops needs nothing else.  One lane then takes
+					// this fire and the ones that follow it inside the window (a cluster of candidate bits around one preamble) until
+					// one passes the gate - only that one needs phases.
+					const int64_t wbase0 = fire_n - 6;
 					WAVE_FOR(l)
-						float val = 0.f;
-						if(l < 4) val = v.Phi(n - 2 - l);
-						else if(l < 40) { const int sc = 2 + (l - 4) / 9, m = (l - 4) % 9; const int64_t t = n + kSpsDec - sc + (int64_t)kSpsDec * m; if(t < k_end) val = v.Phi(t); }
-						else if(l == 40) val = (n - 6 >= sh.st.e0) ? v.PF(n - 6).re : kPherrBig;
-						else if(l == 41) val = v.PF(n - 3).re;
-						else if(l == 42) val = v.PF(n).re;
-						else if(l == 43) val = v.PF(n - 3).im;
-						if(l < 44) sh.spec[l] = val;
+						const cf32 pv = v.PF(wbase0 + l);
+						sh.wre[l] = pv.re; sh.wim[l] = pv.im;
 					WAVE_END
-					LANE0
-						sh.u_y1 = sh.spec[40]; sh.u_y2 = sh.spec[41]; sh.u_y3 = sh.spec[42]; sh.u_prevd = sh.spec[43];
-						sh.spec_n = n;
-					LANE0_END
 					K4_MARK(8);
-					log_evals(sh, lg, ctl, e, (n - e) / 3 + 1);
+					LANE0
+						// (the search state and the open chunk of the evaluation log are held in registers while this lane works through the
+						// fires: every access to them in LDS would be a wait of its own)
+						WalkState &st = sh.st;
+						int64_t n = fire_n, e_cur = e, kl = k_lim;
+						int64_t wbase = wbase0, whi = wbase0 + 63;        // samples whose metric values are in sh.wre / sh.wim (a candidate n needs n - 6 .. n)
+						const int64_t cw0 = sh.cw0, ncw = sh.cw_end - sh.cw0, clean_at = st.a + kCleanAfter;
+						int64_t e0 = st.e0, evals = st.evals, lgf = sh.lg_first, lgc = sh.lg_count;
+						uint32_t lgn = sh.lg_n, nrej = 0;
+						const uint32_t cap_log = sh.cap_log;
+						int pending = 0;
+						if(sh.first_fire == INT64_MAX) sh.first_fire = n;
+						for(;;) {
+							{   // log_evals_lane0() on the register copies: evaluations e_cur, e_cur + 3, ..., n
+								const int64_t count = (n - e_cur) / 3 + 1;
+								if(lgc > 0 && lgf + 3 * lgc == e_cur) lgc += count;
+								else {
+									if(lgc > 0) {
+										if(lgn < cap_log) { lg.chunks[lgn].first = lgf; lg.chunks[lgn].count = lgc; lgn++; }
+										else ctl->overflow = 1;
+									}
+									lgf = e_cur; lgc = count;
+								}
+								evals += count;
+							}
+							const float y1 = (n - 6 >= e0) ? sh.wre[n - 6 - wbase] : kPherrBig, y2 = sh.wre[n - 3 - wbase], y3 = sh.wre[n - wbase];
+							const float prevd = sh.wim[n - 3 - wbase];
+							if(!(max_ppm != 0.f && fabsf(prevd) > ppm_thr)) {      // = fabsf(ppm_of(prevd, freq)) > max_ppm (ppm_gate_threshold())
+								sh.u_y1 = y1; sh.u_y2 = y2; sh.u_y3 = y3; sh.u_prevd = prevd;
+								pending = 1;
+								break;
+							}
+							// demod.c:190-192: dropped by the gate; v->sclk keeps the vertex value, which shifts the evaluation grid (demod.c:179,233)
+							const int sclk = (int)(-roundf(parabola_vertex(y1, y2, y3)));
+							nrej++;
+							int64_t step = 3 - sclk; if(step < 1) step = 1;
+							const int64_t e2 = n + step;
+							e0 = e2; e_cur = e2;
+							// the next candidate on the new grid, if the words in LDS reach it
+							kl = k_end;
+							if(stop_clean) { int64_t c = clean_at; if(c < e2 + 6) c = e2 + 6; if(c < kl) kl = c; }
+							const int64_t s2 = e2 + 3;
+							int64_t n2 = -1;
+							for(int64_t i = (s2 >> 6) - cw0; i >= 0 && i < ncw; ) {
+								const uint64_t nzm = sh.nzw[i >> 6] >> (i & 63);       // non-zero words from word i to the end of its group of 64
+								if(!nzm) { i = (i | 63) + 1; continue; }
+								i += __builtin_ctzll(nzm);
+								if(i >= ncw) break;
+								const int64_t base = (cw0 + i) << 6;
+								if(base >= kl) break;
+								uint64_t bits = sh.cw[i];
+								const int r = (((int)(e2 - base)) % 3 + 3) % 3;
+								bits &= 0x9249249249249249ull << r;
+								if(base < s2) bits &= (s2 - base >= 64) ? 0ull : (~0ull << (s2 - base));
+								if(base + 64 > kl) bits &= (kl - base <= 0) ? 0ull : (~0ull >> (64 - (kl - base)));
+								if(bits) { n2 = base + __builtin_ctzll(bits); break; }
+								i++;
+							}
+							if(n2 < 0) break;
+							if(n2 > whi) {
+								// beyond the window of metric values, but its word is in LDS: this lane fetches the three values the next fire
+								// needs by itself - cheaper than sending the whole wavefront round the search again
+								const cf32 p1 = v.PF(n2 - 6), p2 = v.PF(n2 - 3), p3 = v.PF(n2);
+								wbase = n2 - 6; whi = n2;
+								sh.wre[0] = p1.re; sh.wre[3] = p2.re; sh.wim[3] = p2.im; sh.wre[6] = p3.re;
+							}
+							n = n2;
+						}
+						sh.lg_first = lgf; sh.lg_count = lgc; sh.lg_n = lgn; st.evals = evals;
+						if(nrej) {
+							VDL2_CNT_ADD(cnt, CNT_PPM_REJECT, nrej);
+							st.pherr1 = st.pherr2 = kPherrBig;
+							st.e = st.e0 = e0;
+						}
+						sh.u_fire = pending; sh.u_n = n;
+					LANE0_END
+					fired = sh.u_fire;
+					fire_n = sh.u_n;
 					K4_MARK(2);
+					if(fired) {
+						const int64_t n = fire_n;
+						// this one synchronises: the four possible sync-point phases (sclk = 2..5) and the nine header-symbol phases for
+						// each of them, in one round trip
+						WAVE_FOR(l)
+							float val = 0.f;
+							if(l < 4) val = v.Phi(n - 2 - l);
+							else if(l < 40) { const int sc = 2 + (l - 4) / 9, m = (l - 4) % 9; const int64_t t = n + kSpsDec - sc + (int64_t)kSpsDec * m; if(t < k_end) val = v.Phi(t); }
+							if(l < 40) sh.spec[l] = val;
+						WAVE_END
+						LANE0
+							sh.spec_n = n;
+						LANE0_END
+					}
 				} else {
 					// nothing up to k_lim: park just past the last evaluation that exists.  v->pherr[1], pherr[2] and prev_dphi
 					// as that evaluation leaves them are computed here (one round trip for the 32 phases): the sync kernel stores
@@ -769,7 +957,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 					else if(sh.vring_a == st.a && sclk >= 0 && 160 + (n - st.a) - sclk >= 0 && 160 + (n - st.a) - sclk < 320) prev_phi0 = sh.vring[160 + (n - st.a) - sclk];
 					else prev_phi0 = v.Phi(seq_index(st, n, sclk));
 					float vdphi = sh.u_prevd;
-					float ppm = (float)((double)(10500 * vdphi) / (2.0f * M_PI * (double)freq) * 1e+6);
+					float ppm = ppm_of(vdphi, freq);
 					st.pherr1 = st.pherr2 = kPherrBig;
 					if(max_ppm != 0.f && fabsf(ppm) > max_ppm) {
 						VDL2_CNT_ADD(cnt, CNT_PPM_REJECT, 1);
@@ -821,7 +1009,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 					VDL2_CNT_ADD(cnt, g.status == HDR_CRC_BAD ? CNT_CRC_BAD : g.status == HDR_TOO_LONG ? CNT_ERR_TOO_LONG : CNT_ERR_NO_FEC, 1);
 					restart_search(st, t8 + 1);
 				} else {
-					st.pb.tl_bits = g.tl_bits; st.pb.syndrome = g.syndrome;
+					st.pb.tl_bits = g.tl_bits; st.pb.syndrome = g.syndrome | ((uint32_t)popc32(sh.t_fix[g.syndrome]) << 8);   // + synd_weight[] (decode.c:98-100) = bits the pattern flips
 					st.pb.nsym = (int32_t)((g.want_bits + kHdrBits + 2) / 3);
 					st.pb.end_sample = st.pb.t_first + (int64_t)(st.pb.nsym - 1) * kSpsDec;
 					st.mode = 2;
@@ -843,11 +1031,11 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, int64_t k_end, boo
 }
 
 // Process one channel up to (not including) decimated sample k_end.
-VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, int64_t k_end, const Tables &T,
+VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T,
 		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
 		OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
-	walk_load(gstate, lg, nbursts_out, false, T, sh);
-	walk_run(chan, freq, max_ppm, k_end, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
+	walk_load(gstate, lg, nbursts_out, false, T, ctl, sh);
+	walk_run(chan, freq, max_ppm, ppm_thr, k_end, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
 	walk_store(sh, gstate, lg, ctl, nbursts_out);
 }
 
@@ -899,7 +1087,7 @@ struct StitchShared {
 };
 
 // one speculative walk: segment [b, k_end), evaluation grid phase r
-VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, int64_t b, int r, int64_t k_end, const Tables &T,
+VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t b, int r, int64_t k_end, const Tables &T,
 		const ChanView &v, SpecOut *o, WalkShared &sh) {
 	EvalLog lg{ o->chunks, &o->nlog };
 	LANE0
@@ -912,9 +1100,10 @@ VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, int64_t b, int r,
 	WAVE_FOR(l)
 		if(l < kNumCounters) o->cnt[l] = 0;
 	WAVE_END
+	WAVE_SYNC_GLOBAL();                    // lane 0's counter atomics below must find the zeros the other lanes have just stored
 	uint32_t nb_dummy = 0;
-	walk_load(&o->st, lg, &nb_dummy, false, T, sh);
-	walk_run(chan, freq, max_ppm, k_end, false, T, v, o->cnt, o->bursts, kSpecBursts, &o->ctl, lg, sh);
+	walk_load(&o->st, lg, &nb_dummy, false, T, &o->ctl, sh);
+	walk_run(chan, freq, max_ppm, ppm_thr, k_end, false, T, v, o->cnt, o->bursts, kSpecBursts, &o->ctl, lg, sh);
 	walk_flush_log(sh, lg, &o->ctl);
 	LANE0
 		const WalkState &st = sh.st;
@@ -1013,10 +1202,10 @@ VDL2_HD void stitch_materialize(const SpecOut *spec, WalkShared &sh, StitchShare
 
 // The feed [k0, k_end) of one channel in nseg segments of seglen samples; segment 0 has already been walked from the real
 // state (walk_channel() with k_end = k0 + seglen) and spec[(s-1)*3 + r] holds the speculative walks of segments 1..nseg-1.
-VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, int64_t k0, int64_t seglen, int nseg, int64_t k_end, const Tables &T,
+VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k0, int64_t seglen, int nseg, int64_t k_end, const Tables &T,
 		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
 		OutCtl *ctl, const EvalLog &lg, const SpecOut *spec, WalkShared &sh, StitchShared &ss, uint32_t *seg_stats) {
-	walk_load(gstate, lg, nbursts_out, true, T, sh);
+	walk_load(gstate, lg, nbursts_out, true, T, ctl, sh);
 	LANE0
 		ss.njobs = 0; ss.hist_src = -1; ss.pb_src = -1; ss.accepted = 0; ss.walked = 0; ss.cap_log = ctl->cap_log;
 	LANE0_END
@@ -1029,9 +1218,9 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, int64_t k0, 
 		const int64_t kn = s + 1 < nseg ? b + seglen : k_end;
 		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss)) continue;
 		stitch_materialize(spec, sh, ss);
-		walk_run(chan, freq, max_ppm, kn, true, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
+		walk_run(chan, freq, max_ppm, ppm_thr, kn, true, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
 		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss)) continue;
-		walk_run(chan, freq, max_ppm, kn, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
+		walk_run(chan, freq, max_ppm, ppm_thr, kn, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
 		LANE0
 			ss.walked++;
 		LANE0_END
@@ -1346,11 +1535,14 @@ struct BurstShared {
 	int32_t rs_deg;
 	uint32_t rs_hits[64];
 	uint8_t gf_exp[512], gf_log[256];  // LDS copies of the field tables
+	uint8_t gam[2][8];                 // erasure locators of short blocks: the missing parity octets sit at fixed places, [0]: two of them, [1]: four
 	float   pw[64];
 	int32_t neg[64];
 	int32_t u_ret, u_kind, u_ok;
-	uint32_t u_k, u_sprev, u_lastend, u_S, u_L, u_off;
-	float u_pwr;
+	uint32_t u_k, u_sprev, u_lastend, u_S, u_L, u_off, u_capf, u_capp;
+	float u_pwr, u_pwr_db;
+	uint32_t res_slot, res_nslot, res_off, res_npool, res_capf, res_capp;   // the wavefront's reserve of frame records and octet space (burst_reserve_*)
+	uint32_t fr_S[64], fr_len[64], fr_cum[65];   // the frames of one pass of step 6: first kept bit, octets, start of their (padded) pool space
 };
 
 // decode_rs_char() on one 255-symbol row (libfec/decode_rs.h:71-298) behind rs_verify() (rs.c:32-49), split in
@@ -1380,6 +1572,28 @@ VDL2_HD void rs_decode_row(uint8_t *row, int npar, BurstShared &sh) {
 	WAVE_END
 	const int any = sh.syn[0] | sh.syn[1] | sh.syn[2] | sh.syn[3] | sh.syn[4] | sh.syn[5];
 	if(!any) { LANE0 sh.u_ret = 0; LANE0_END return; }           // decode_rs.h:102-108: a codeword, data untouched
+	if(n_era > 0) {
+		// A short block arrives with its missing parity octets zero-filled and declared erased (rs.c:36-44, decode.c:279-280): its
+		// syndromes are never zero, and the reference goes through the whole decoder to "correct" octets nobody reads.  When the
+		// block has no other error, every discrepancy of the Berlekamp-Massey loop (decode_rs.h:166-207, r > no_eras) is zero - it is
+		// coefficient r-1 of syndrome x erasure locator - so lambda stays the erasure locator, the Chien search finds exactly the
+		// erased places, and decode_rs_char() returns their number with the data columns untouched.  Those coefficients are checked
+		// here, a lane each; only a block that does have an error takes the long way.
+		const uint8_t *gam = sh.gam[n_era == 2 ? 0 : 1];
+		WAVE_FOR(l)
+			if(l >= n_era && l < kRsPar) {
+				int acc = 0;
+				for(int i = 0; i <= n_era; i++) {
+					const int g = gam[i], sy = sh.syn[l - i];
+					if(g && sy) acc ^= EXP[LOG[g] + LOG[sy]];
+				}
+				sh.synp[0][l] = (uint8_t)acc;
+			}
+		WAVE_END
+		int disc = 0;
+		for(int m = n_era; m < kRsPar; m++) disc |= sh.synp[0][m];
+		if(!disc) { LANE0 sh.u_ret = n_era; LANE0_END return; }
+	}
 
 	LANE0
 		const int A0 = 255;
@@ -1489,10 +1703,61 @@ VDL2_HD void rs_decode_row(uint8_t *row, int npar, BurstShared &sh) {
 	LANE0_END
 }
 
-VDL2_HD int popc32(uint32_t v) { return __builtin_popcount(v); }
-VDL2_HD int ctz32(uint32_t v) { return __builtin_ctz(v); }
 
-// decode_vdl2_burst() DEC_DATA branch + decode_frame(): decode.c:259-380, 173-194
+// Frame records and octet space.  Wavefront w of the burst decoder OWNS records w*kResSlots .. and octets w*kResPool .. of the feed's
+// output (the feed-wide counters start behind those of all wavefronts: burst_reserve_initial_*) and hands them out to its bursts
+// itself; only when a list of frames does not fit what is left does it go to the counters, for what the list needs plus a fresh
+// reserve.  No atomic on the common path: a returning atomic on a counter that every wavefront of the chip is after was the longest
+// wait of the whole burst (tens of thousands of clocks).  What a wavefront has not used when it is done - or gives up for a fresh
+// reserve - stays behind as tombstone records (chan = -1: skipped by k_frame_finish and by the host) and unused octets.
+constexpr int kResSlots = 8, kResPool = 1024;
+VDL2_HD uint32_t burst_reserve_initial_frames(uint32_t nwaves) { return nwaves * (uint32_t)kResSlots; }
+VDL2_HD uint32_t burst_reserve_initial_pool(uint32_t nwaves) { return nwaves * (uint32_t)kResPool; }
+// one lane (call inside a LANE0 section): the unused records of the reserve become tombstones
+VDL2_HD void burst_reserve_release(OutFrame *frames, BurstShared &sh) {
+	for(uint32_t i = 0; i < sh.res_nslot; i++) {
+		const uint32_t slot = sh.res_slot + i;
+		if(slot < sh.res_capf) { OutFrame &f = frames[slot]; f.chan = -1; f.len = 0; f.pool_off = 0; f.nf_upd = 0; }
+	}
+	sh.res_nslot = 0; sh.res_npool = 0;
+}
+// when the wavefront has decoded its last burst
+VDL2_HD void burst_reserve_done(OutFrame *frames, BurstShared &sh) {
+	LANE0
+		burst_reserve_release(frames, sh);
+	LANE0_END
+}
+
+// once per wavefront (`wave` of the launch's wavefronts): LDS copies of the field tables (they do not change from burst to burst), the
+// erasure locators of short blocks, the wavefront's own share of the output
+VDL2_HD void burst_shared_init(const Tables &T, uint32_t wave, const OutCtl *ctl, BurstShared &sh) {
+	WAVE_FOR(l)
+		for(int i = l; i < 512; i += 64) sh.gf_exp[i] = T.gf_exp[i];
+		for(int i = l; i < 256; i += 64) sh.gf_log[i] = T.gf_log[i];
+	WAVE_END
+	WAVE_FOR(l)
+		if(l < 2) {
+			// the erasure locator decode_rs.h:113-123 builds for the 2 (l = 0) or 4 (l = 1) parity octets a short block does not
+			// carry: they are always the last ones of the row, so the polynomial depends on their number only
+			const int n_era = 2 + 2 * l, npar = kRsPar - n_era;
+			int lam[kRsPar + 1];
+			for(int i = 0; i <= kRsPar; i++) lam[i] = 0;
+			lam[0] = 1;
+			lam[1] = sh.gf_exp[gf_mod255(254 - (kRsK + npar))];
+			for(int i = 1; i < n_era; i++) {
+				const int u = gf_mod255(254 - (kRsK + npar + i));
+				for(int j = i + 1; j > 0; j--) { const int lg = sh.gf_log[lam[j - 1]]; if(lg != 255) lam[j] ^= sh.gf_exp[u + lg]; }
+			}
+			for(int i = 0; i <= kRsPar; i++) sh.gam[l][i] = (uint8_t)lam[i];
+		}
+		if(l == 0) {
+			sh.res_slot = wave * (uint32_t)kResSlots; sh.res_nslot = (uint32_t)kResSlots; sh.res_off = wave * (uint32_t)kResPool; sh.res_npool = (uint32_t)kResPool;
+			sh.res_capf = ctl->cap_frames; sh.res_capp = ctl->cap_pool;
+		}
+	WAVE_END
+}
+
+// decode_vdl2_burst() DEC_DATA branch + decode_frame(): decode.c:259-380, 173-194.  burst_shared_init() first.
 VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const ChanView &v, unsigned long long *cnt,
 		OutFrame *frames, uint8_t *pool, OutCtl *ctl, BurstShared &sh) {
 	// geometry again from TL (decode.c:233-256)
@@ -1505,10 +1770,6 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 	const int npar_last = fec_octets_for(last);
 	const int nsym = b.nsym;
 	K5_BEGIN();
-	WAVE_FOR(l)
-		for(int i = l; i < 512; i += 64) sh.gf_exp[i] = T.gf_exp[i];
-		for(int i = l; i < 256; i += 64) sh.gf_log[i] = T.gf_log[i];
-	WAVE_END
 
 	// 1. slice every symbol (demod.c:252-274); decisions are independent because prev_phi is the raw phase.  A lane takes
 	//    a run of consecutive symbols, so that the phase of a symbol (one double-precision atan2, evaluated here: there is no
@@ -1524,7 +1785,8 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 			for(int q = 0; q < 4; q++) yv[q] = mb + q < m1 ? v.Y(b.t_first + (int64_t)(mb + q) * kSpsDec) : cf32{0.f, 0.f};   // loads first
 			for(int q = 0; q < 4 && mb + q < m1; q++) {
 				const float cur = phase_of(yv[q]);
-				sh.sym[mb + q] = T.gray[slice_symbol(cur, prev, b.vdphi, neg)];
+				const int idx = slice_symbol(cur, prev, b.vdphi, neg);
+				sh.sym[mb + q] = (uint8_t)(idx ^ (idx >> 1));          // graycode[] of demod.c:223 (= Tables::gray, tests/test_design.py), without the table
 				prev = cur;
 				pw += yv[q].re * yv[q].re + yv[q].im * yv[q].im;
 			}
@@ -1541,17 +1803,16 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 	LANE0_END
 
 	K5_MARK(0);
-	// 2. descramble + pack data and FEC octets LSB-first (bitstream.c:70-81,94-107)
+	// 2. descramble + pack data and FEC octets LSB-first (bitstream.c:70-81,94-107): the scrambling sequence comes an octet at a time
 	const uint32_t ntot = octets + fec;
 	WAVE_FOR(l)
 		for(uint32_t i = l; i < ntot; i += 64) {
 			uint32_t o = 0, bit0 = kHdrBits + 8 * i;
 			for(int j = 0; j < 8; j++) {
 				uint32_t bb = bit0 + j;
-				uint32_t bit = ((uint32_t)sh.sym[bb / 3] >> (2 - bb % 3)) & 1u;
-				o |= (bit ^ T.prbs[bb]) << j;
+				o |= (((uint32_t)sh.sym[bb / 3] >> (2 - bb % 3)) & 1u) << j;
 			}
-			sh.oct[i] = (uint8_t)o;
+			sh.oct[i] = (uint8_t)(o ^ T.prbs_oct[i]);
 		}
 		for(uint32_t i = l; i < nblk * 256; i += 64) sh.tab[i] = 0;
 	WAVE_END
@@ -1599,6 +1860,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 	//      stuffed zero  : x[i]=0, R=5          flag terminator : x[i]=0, R=6          error : x[i]=1, R>=6
 	//    a segment between terminators with j kept bits before its terminator is a leading flag (j=7,
 	//    skipped), an error (j<7) or a frame of j-7 bits; what follows the last terminator is the tail frame.
+	//    A word per lane throughout (a burst of 170 octets is 43 words: 43 lanes at work, one step each).
 	uint32_t nbits = 8 * octets; if(b.tl_bits < nbits) nbits = b.tl_bits;
 	const int nw = (int)((nbits + 31) / 32);
 	WAVE_FOR(l)
@@ -1612,11 +1874,8 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		}
 	WAVE_END
 	WAVE_FOR(l)
-		// lane l owns words 8l .. 8l+7
-		uint32_t ck = 0, ct = 0; int32_t err = -1;
-		for(int q = 0; q < 8; q++) {
-			const int w = 8 * l + q;
-			if(w >= nw) break;
+		uint32_t err = 0xffffffffu;
+		for(int w = l; w < nw; w += 64) {
 			const uint64_t z = ((uint64_t)sh.xw[w] << 32) | (w ? sh.xw[w - 1] : 0u);
 			const uint64_t s1 = z << 1, s2 = s1 & (z << 2), s3 = s2 & (z << 3), s4 = s3 & (z << 4);
 			const uint64_t s5 = s4 & (z << 5), s6 = s5 & (z << 6), s7 = s6 & (z << 7);
@@ -1627,122 +1886,171 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 			const uint32_t bad = (uint32_t)((z & s6) >> 32) & valid;
 			sh.keptw[w] = valid & ~stuffed;
 			sh.termw[w] = term;
-			ck += (uint32_t)popc32(valid & ~stuffed); ct += (uint32_t)popc32(term);
-			if(bad && err < 0) err = 32 * w + ctz32(bad);
+			sh.cumk[w] = (uint16_t)popc32(valid & ~stuffed); sh.cumt[w] = (uint16_t)popc32(term);     // counts now, prefix sums below
+			if(bad && err == 0xffffffffu) err = 32u * (uint32_t)w + (uint32_t)ctz32(bad);              // the lane's words ascend: its first is its lowest
 		}
-		sh.lanek[l] = ck; sh.lanet[l] = ct; sh.laneerr[l] = err;
+		sh.lanek[l] = err;
 	WAVE_END
+	const uint32_t E = wave_min64(sh.lanek);                        // first "seven ones" position (0xffffffff: none)
+	WAVE_SYNC();
+	// exclusive prefix sums of the per-word counts: a lane sums a block of eight consecutive words, the 64 block sums are scanned
+	// over the wavefront, the lane adds its block's offset
 	WAVE_FOR(l)
 		uint32_t bk = 0, bt = 0;
-		for(int q = 0; q < l; q++) { bk += sh.lanek[q]; bt += sh.lanet[q]; }
 		for(int q = 0; q < 8; q++) {
 			const int w = 8 * l + q;
-			if(w > nw) break;
-			sh.cumk[w] = (uint16_t)bk; sh.cumt[w] = (uint16_t)bt;
-			if(w < nw) {
-				uint32_t t = sh.termw[w];
-				const uint32_t kw = sh.keptw[w];
-				uint32_t r = bt;
-				while(t) {
-					const int bit = ctz32(t); t &= t - 1;
-					if(r < (uint32_t)kMaxTerm) { sh.tpos[r] = (uint16_t)(32 * w + bit); sh.tG[r] = (uint16_t)(bk + (uint32_t)popc32(kw & ((1u << bit) - 1u))); }
-					r++;
-				}
-				bk += (uint32_t)popc32(kw); bt += (uint32_t)popc32(sh.termw[w]);
+			if(w < nw) { const uint32_t ck = sh.cumk[w], ct = sh.cumt[w]; sh.cumk[w] = (uint16_t)bk; sh.cumt[w] = (uint16_t)bt; bk += ck; bt += ct; }
+		}
+		sh.lanek[l] = bk; sh.lanet[l] = bt;
+	WAVE_END
+	const uint32_t gtotal = wave_excl_scan64(sh.lanek);
+	const uint32_t nterm = wave_excl_scan64(sh.lanet);
+	WAVE_FOR(l)
+		const uint32_t ok = sh.lanek[l], ot = sh.lanet[l];
+		for(int q = 0; q < 8; q++) {
+			const int w = 8 * l + q;
+			if(w < nw) { sh.cumk[w] = (uint16_t)(sh.cumk[w] + ok); sh.cumt[w] = (uint16_t)(sh.cumt[w] + ot); }
+		}
+		if(l == 0) { sh.cumk[nw] = (uint16_t)gtotal; sh.cumt[nw] = (uint16_t)nterm; }
+	WAVE_END
+	// terminator list: position and kept bits before it
+	WAVE_FOR(l)
+		for(int w = l; w < nw; w += 64) {
+			uint32_t t = sh.termw[w];
+			const uint32_t kw = sh.keptw[w], bk = sh.cumk[w];
+			uint32_t r = sh.cumt[w];
+			while(t) {
+				const int bit = ctz32(t); t &= t - 1;
+				if(r < (uint32_t)kMaxTerm) { sh.tpos[r] = (uint16_t)(32 * w + bit); sh.tG[r] = (uint16_t)(bk + (uint32_t)popc32(kw & ((1u << bit) - 1u))); }
+				r++;
 			}
 		}
-		sh.flag_err[l] = sh.laneerr[l] >= 0;
 	WAVE_END
-	const int le = wave_first_flag(sh.flag_err);
-	const uint32_t E = le >= 0 ? (uint32_t)sh.laneerr[le] : 0xffffffffu;      // first "seven ones" position
-	const uint32_t nterm = sh.cumt[nw];
-	const uint32_t gtotal = sh.cumk[nw];
 	LANE0
 		sh.u_k = 0; sh.u_sprev = 0; sh.u_lastend = 0xffffffffu;
 	LANE0_END
 	K5_MARK(4);
+	// 6. frames out, up to 64 at a time: one lane walks the (few) terminators and lists the frames (bitstream_copy_next_frame()'s
+	//    rules), reserves their records and octets with ONE pair of atomics, then the wavefront writes the records (a lane per
+	//    frame) and gathers the octets of all of them (a lane per octet)
 	int nframes = 0;
 	for(;;) {
-		// one lane walks the (few) terminators to the next frame, error or the tail
 		LANE0
-			uint32_t k = sh.u_k, sprev = sh.u_sprev;
-			int kind = 0;                    // 1 frame, 2 unstuff error, 3 truncated octets, 4 done
-			uint32_t S = 0, L = 0;
-			for(; k < nterm && k < (uint32_t)kMaxTerm; k++) {
-				const uint32_t tp = sh.tpos[k], g = sh.tG[k];
-				if(tp > E) { kind = 2; break; }
-				const uint32_t j = g - sprev;
-				const uint32_t snext = g + 1;
-				if(j == 7) { sprev = snext; continue; }
-				if(j < 7) { kind = 2; break; }
-				S = sprev; L = j - 7; sprev = snext;
-				sh.u_lastend = tp;
-				kind = (L % 8) ? 3 : 1;
-				k++;
-				break;
-			}
-			if(kind == 0) {
-				// past the last terminator: the tail is processed iff a call is still made (bitstream.c:149, decode.c:345)
-				const bool call = sh.u_lastend == 0xffffffffu || sh.u_lastend + 1 < nbits;
-				if(!call || sh.u_k == 0xffffffffu) kind = 4;
-				else if(E != 0xffffffffu) kind = 2;
-				else { S = sprev; L = gtotal - sprev; kind = (L % 8) ? 3 : 1; k = 0xffffffffu; }
-			}
-			sh.u_k = k; sh.u_sprev = sprev; sh.u_kind = kind; sh.u_S = S; sh.u_L = L; sh.u_ok = 0;
-			if(kind == 2) VDL2_CNT_ADD(cnt, CNT_ERR_UNSTUFF, 1);
-			else if(kind == 3) VDL2_CNT_ADD(cnt, CNT_ERR_TRUNCATED_OCTETS, 1);
-			else if(kind == 1) {
-				VDL2_CNT_ADD(cnt, CNT_MSG_GOOD, 1);
-				const uint32_t len = L / 8;
-#if VDL2_DEVICE_PASS
-				uint32_t slot = atomicAdd(&ctl->nframes, 1u);
-				uint32_t off = atomicAdd(&ctl->pool_used, (len + 3u) & ~3u);
-#else
-				uint32_t slot = ctl->nframes++;
-				uint32_t off = ctl->pool_used; ctl->pool_used += (len + 3u) & ~3u;
-#endif
-				if(slot < ctl->cap_frames && off + len <= ctl->cap_pool) {
-					OutFrame &f = frames[slot];
-					f.chan = b.chan; f.idx = nframes; f.len = len; f.pool_off = off;
-					f.synd_weight = T.hdr_weight[b.syndrome]; f.datalen_octets = octets;
-					f.num_fec_corrections = fec_fixed;
-					f.frame_pwr_dbfs = 10.0f * log10f(sh.u_pwr);
-					f.nf_pwr_dbfs = 0.f; f.nf_upd = b.nf_upd;            // filled in by stamp_noise_floor()
-					f.ppm_error = b.ppm;
-					f.burst_ord = b.ord; f.sync_sample = b.sync_sample; f.end_sample = b.end_sample;
-					sh.u_ok = 1; sh.u_off = off;
-				} else {
-					ctl->overflow = 1;
-					if(slot < ctl->cap_frames) { OutFrame &f = frames[slot]; f.chan = -1; f.len = 0; f.pool_off = 0; f.nf_upd = 0; }   // tombstone: skipped downstream
+			uint32_t k = sh.u_k, sprev = sh.u_sprev, lastend = sh.u_lastend;
+			int nfr = 0, end = 0;                       // end: 0 list full (more may follow), 2 unstuff error, 3 truncated octets, 4 done
+			uint32_t pooltot = 0;
+			while(nfr < 64) {
+				int kind = 0;
+				uint32_t S = 0, L = 0;
+				for(; k < nterm && k < (uint32_t)kMaxTerm; k++) {
+					const uint32_t tp = sh.tpos[k], g = sh.tG[k];
+					if(tp > E) { kind = 2; break; }
+					const uint32_t j = g - sprev;
+					const uint32_t snext = g + 1;
+					if(j == 7) { sprev = snext; continue; }
+					if(j < 7) { kind = 2; break; }
+					S = sprev; L = j - 7; sprev = snext;
+					lastend = tp;
+					kind = (L % 8) ? 3 : 1;
+					k++;
+					break;
 				}
+				if(kind == 0) {
+					// past the last terminator: the tail is processed iff a call is still made (bitstream.c:149, decode.c:345)
+					const bool call = lastend == 0xffffffffu || lastend + 1 < nbits;
+					if(!call || k == 0xffffffffu) kind = 4;
+					else if(E != 0xffffffffu) kind = 2;
+					else { S = sprev; L = gtotal - sprev; kind = (L % 8) ? 3 : 1; k = 0xffffffffu; }
+				}
+				if(kind != 1) { end = kind; break; }
+				sh.fr_S[nfr] = S; sh.fr_len[nfr] = L / 8; sh.fr_cum[nfr] = pooltot;
+				pooltot += (L / 8 + 3u) & ~3u;
+				nfr++;
+				if(k == 0xffffffffu) { end = 4; break; }
+			}
+			sh.fr_cum[nfr] = pooltot;
+			sh.u_k = k; sh.u_sprev = sprev; sh.u_lastend = lastend; sh.u_kind = end; sh.u_S = (uint32_t)nfr;
+			if(end == 2) VDL2_CNT_ADD(cnt, CNT_ERR_UNSTUFF, 1);
+			else if(end == 3) VDL2_CNT_ADD(cnt, CNT_ERR_TRUNCATED_OCTETS, 1);
+			if(nfr) {
+				VDL2_CNT_ADD(cnt, CNT_MSG_GOOD, nfr);
+				// Records and octet space come out of a small reserve the wavefront holds (burst_reserve_*): the two feed-wide counters are
+				// touched once per kResSlots frames or so instead of once per burst - a returning atomic on a counter that every
+				// wavefront of the chip is after was the longest wait of the whole burst (tens of thousands of clocks).
+				if((uint32_t)nfr > sh.res_nslot || pooltot > sh.res_npool) {
+					burst_reserve_release(frames, sh);                    // what is left of the old reserve is given up (tombstones, a hole)
+					const uint32_t ns = (uint32_t)nfr + (uint32_t)kResSlots, np = pooltot + (uint32_t)kResPool;
+#if VDL2_DEVICE_PASS
+					sh.res_slot = atomicAdd(&ctl->nframes, ns);
+					sh.res_off = atomicAdd(&ctl->pool_used, np);
+#else
+					sh.res_slot = ctl->nframes; ctl->nframes += ns;
+					sh.res_off = ctl->pool_used; ctl->pool_used += np;
+#endif
+					sh.res_nslot = ns; sh.res_npool = np;
+				}
+				sh.u_L = sh.res_slot; sh.u_off = sh.res_off;
+				sh.res_slot += (uint32_t)nfr; sh.res_nslot -= (uint32_t)nfr; sh.res_off += pooltot; sh.res_npool -= pooltot;
+				sh.u_pwr_db = 10.0f * log10f(sh.u_pwr);
+				sh.u_capf = sh.res_capf; sh.u_capp = sh.res_capp;
 			}
 		LANE0_END
-		if(sh.u_kind != 1) { if(sh.u_kind == 4) break; K5_MARK(5); K5_END(); return; }
-		if(sh.u_ok) {
-			// gather kept bits S+8i .. S+8i+7 into output octet i (LSB first, bitstream.c:70-81)
-			const uint32_t len = sh.u_L / 8, off = sh.u_off, S = sh.u_S;
+		K5_MARK(5);
+		const int nfr = (int)sh.u_S, end = sh.u_kind;
+		if(nfr) {
+			const uint32_t slot0 = sh.u_L, off0 = sh.u_off, capf = sh.u_capf, capp = sh.u_capp;
 			WAVE_FOR(l)
-				for(uint32_t i = l; i < len; i += 64) {
-					const uint32_t q0 = S + 8 * i;
-					int lo = 0, hi = nw;              // last word with cumk[w] <= q0
-					while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sh.cumk[mid] <= q0) lo = mid; else hi = mid; }
-					int w = lo;
-					uint32_t m = sh.keptw[w];
-					for(uint32_t r = q0 - sh.cumk[w]; r > 0; r--) m &= m - 1;
-					uint32_t o = 0;
-					for(int t = 0; t < 8; t++) {
-						while(m == 0) { w++; m = sh.keptw[w]; }
-						const int bit = ctz32(m); m &= m - 1;
-						o |= ((sh.xw[w] >> bit) & 1u) << t;
+				if(l < nfr) {
+					const uint32_t slot = slot0 + (uint32_t)l, off = off0 + sh.fr_cum[l], len = sh.fr_len[l];
+					const bool ok = slot < capf && off + len <= capp;
+					sh.flag_err[l] = ok;
+					if(ok) {
+						OutFrame &f = frames[slot];
+						f.chan = b.chan; f.idx = nframes + l; f.len = len; f.pool_off = off;
+						f.synd_weight = b.syndrome >> 8; f.datalen_octets = octets;
+						f.num_fec_corrections = fec_fixed;
+						f.frame_pwr_dbfs = sh.u_pwr_db;
+						f.nf_pwr_dbfs = 0.f; f.nf_upd = b.nf_upd;            // filled in by stamp_noise_floor()
+						f.ppm_error = b.ppm;
+						f.burst_ord = b.ord; f.sync_sample = b.sync_sample; f.end_sample = b.end_sample;
+					} else {
+						ctl->overflow = 1;
+						if(slot < capf) { OutFrame &f = frames[slot]; f.chan = -1; f.len = 0; f.pool_off = 0; f.nf_upd = 0; }   // tombstone: skipped downstream
 					}
-					pool[off + i] = (uint8_t)o;
 				}
 			WAVE_END
+			K5_MARK(6);
+			// gather kept bits S+8i .. S+8i+7 of frame f into its octet i (LSB first, bitstream.c:70-81), all frames of the list at once:
+			// octet j of the list's (4-byte padded) pool space belongs to the frame whose space holds it
+			const uint32_t span = sh.fr_cum[nfr];
+			WAVE_FOR(l)
+				for(uint32_t j = l; j < span; j += 64) {
+					int f = 0;
+					{ int lo = 0, hi = nfr; while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sh.fr_cum[mid] <= j) lo = mid; else hi = mid; } f = lo; }
+					const uint32_t i = j - sh.fr_cum[f];
+					if(i < sh.fr_len[f] && sh.flag_err[f]) {
+						const uint32_t q0 = sh.fr_S[f] + 8 * i;
+						int lo = 0, hi = nw;              // last word with cumk[w] <= q0
+						while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sh.cumk[mid] <= q0) lo = mid; else hi = mid; }
+						int w = lo;
+						uint32_t m = sh.keptw[w];
+						for(uint32_t r = q0 - sh.cumk[w]; r > 0; r--) m &= m - 1;
+						uint32_t o = 0;
+						for(int t = 0; t < 8; t++) {
+							while(m == 0) { w++; m = sh.keptw[w]; }
+							const int bit = ctz32(m); m &= m - 1;
+							o |= ((sh.xw[w] >> bit) & 1u) << t;
+						}
+						pool[off0 + j] = (uint8_t)o;
+					}
+				}
+			WAVE_END
+			K5_MARK(7);
+			nframes += nfr;
 		}
-		nframes++;
-		if(sh.u_k == 0xffffffffu) break;
+		if(end == 2 || end == 3) { K5_END(); return; }
+		if(end == 4) break;
 	}
-	K5_MARK(5);
 	LANE0
 		if(sh.u_pwr > 1.0f) VDL2_CNT_ADD(cnt, CNT_MSG_GOOD_LOUD, 1);
 	LANE0_END

@@ -64,7 +64,7 @@ struct vdl2hip_ctx {
 	hipStream_t stream = nullptr;
 	// device memory
 	BlockForm *d_bf = nullptr; Lut4 *d_lut = nullptr; Tables *d_tab = nullptr;
-	uint32_t *d_dphi = nullptr, *d_freq = nullptr;
+	uint32_t *d_dphi = nullptr, *d_freq = nullptr; float *d_ppmthr = nullptr;
 	// host-fed input: one device buffer + "copy done" event per slot, filled on a copy stream of its own so that the H2D of
 	// block i+1 runs beside the channeliser of block i (process_buf_*() hands over host memory: src/demod.c:356-365)
 	uint8_t *d_in[kSlots] = {}; hipEvent_t ev_copied[kSlots] = {}; size_t in_cap = 0;
@@ -75,7 +75,7 @@ struct vdl2hip_ctx {
 	struct { int n = 0; uint64_t samples[kColdParts] = {}; hipEvent_t ev[kColdParts] = {}; } cold;
 	uint8_t *h_stage = nullptr; size_t stage_cap = 0;   // pinned D2H staging for frame records + octets
 	uint8_t *d_carry[2] = {nullptr, nullptr}; int carry_sel = 0; uint32_t ncarry = 0;
-	cf32 *d_y = nullptr, *d_pf = nullptr; uint64_t *d_cand = nullptr, *d_flag = nullptr; float *d_ph = nullptr;
+	cf32 *d_y = nullptr, *d_pf = nullptr; uint64_t *d_cand = nullptr, *d_flag = nullptr;
 	uint32_t cap = 0;
 	float4 *d_segend = nullptr; uint32_t nseg_cap = 0;
 	float4 *d_qpow = nullptr;
@@ -224,7 +224,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 	a.in = dev_in; a.carry = c->d_carry[c->carry_sel]; a.ncarry = c->ncarry; a.nlogical = nlogical;
 	a.n0 = c->n_total - c->ncarry; a.k0 = c->k_total; a.D = D;
 	a.fmt = c->fmt; a.nchan = c->C; a.os = c->os; a.nseg = 0; a.gy = 1;
-	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.ph = c->d_ph; a.seg_end = c->d_segend;
+	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.seg_end = c->d_segend;
 	a.qpow = c->d_qpow; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap;
 	a.fuse = c->fuse_k2 && 64 * c->run == kFixW; a.carry_in = c->d_tcarry[c->tcarry_sel]; a.carry_out = c->d_tcarry[c->tcarry_sel ^ 1];
 	a.bfd = c->d_bf; a.seg_pub = c->d_segpub; a.epoch = (uint32_t)(c->feed_no + 1); a.sync_timeouts = c->d_synctmo;
@@ -273,7 +273,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 			}
 		}
 		if(!a.fuse) {
-			K2Args k2{ c->d_ph, c->d_y, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
+			K2Args k2{ c->d_y, c->d_segend, c->d_tcarry[c->tcarry_sel], c->d_tcarry[c->tcarry_sel ^ 1], c->d_bf,
 			           c->k_total, D, c->cap, c->cap - 1, c->nseg_cap, seglen * a.tiles };
 			LAUNCH_EV(k_fixup, dim3((unsigned)((D + 255) / 256), (unsigned)c->C), dim3(256), st, EV(2), EV(3), k2);
 		}
@@ -293,7 +293,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 	}
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
-		K3Args k3{ c->d_ph, c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1 };
+		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1 };
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
 		// on the front stream than a separate hipEventRecord.  (VDL2HIP_SYNC_ON=walk puts the exact tier in front of the walk on
 		// the walk stream, VDL2HIP_SYNC_ON=own both sync kernels on a stream of their own, so that the front stream goes on
@@ -347,7 +347,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	if(D > 0) {
 		const int64_t k1 = k0 + D;
 		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
-		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C };
+		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr };
 		// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
 		int nseg = (int)std::min<int64_t>(c->seg_max, D / c->seg_min);
 		if(nseg >= 2) {
@@ -373,11 +373,15 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64 * kNfWaves), 0, sn_, k4b);
 		LAUNCH_EV(k_nf_finish, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), sn_, (hipEvent_t) nullptr, EV(9), k4b);
 		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
-		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl);
+		// wavefronts of the burst decoder: each owns kResSlots frame records of the output from the start (unused ones are delivered as
+		// tombstones), so a short block gets few of them
+		unsigned k5_waves = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(16, (D * (int64_t)c->C) >> 14));
+		k5_waves = (k5_waves + kBurstWaves - 1) / kBurstWaves * kBurstWaves;
+		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl, (uint32_t)k5_waves);
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
 		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: bbase[0] = 0 bursts to decode)
-		hipExtLaunchKernelGGL(k_burst, dim3(2048 / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)(sizeof(BurstShared) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
+		hipExtLaunchKernelGGL(k_burst, dim3(k5_waves / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
 		hipLaunchKernelGGL(k_frame_finish, dim3(1024 / kFrameWaves), dim3(64 * kFrameWaves), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, (const OutCtl *)sl.d_ctl, (const Tables *)c->d_tab,
 		                   c->d_acnt, (const float *)c->d_nfring, c->nf_ring - 1);
@@ -424,8 +428,8 @@ const char *vdl2hip_strerror(int err) {
 void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_cand, c->d_flag, c->d_ph, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
+	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
+	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
 		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl, sl.d_log, sl.d_nlog };
 		for(void *p : q) if(p) (void)hipFree(p);
@@ -535,15 +539,12 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipEventCreate(&sl.ev_front)); DEV_CHK(hipEventCreate(&sl.ev_chan)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_k1, hipEventDisableTiming));
 	}
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
-	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count);
+	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count); DEV_ALLOC(c->d_ppmthr, 4 * count);
 	static_assert(kSlots == 3, "vdl2hip_destroy() lists the input buffers one by one");
 	DEV_ALLOC(c->d_carry[0], 4 * kMaxOversample); DEV_ALLOC(c->d_carry[1], 4 * kMaxOversample);
 	const size_t nring = (size_t)count * cap;
 	DEV_ALLOC(c->d_y, nring * sizeof(cf32)); DEV_ALLOC(c->d_pf, nring * sizeof(cf32));
 	DEV_ALLOC(c->d_cand, nring / 8); DEV_ALLOC(c->d_flag, nring / 8);
-#ifdef VDL2_K1_PHASE
-	DEV_ALLOC(c->d_ph, nring * sizeof(float)); DEV_CHK(hipMemset(c->d_ph, 0, nring * sizeof(float)));
-#endif
 	DEV_ALLOC(c->d_segend, (size_t)count * c->nseg_cap * sizeof(float4));
 	DEV_ALLOC(c->d_qpow, 64 * sizeof(float4));
 	DEV_ALLOC(c->d_tcarry[0], count * sizeof(float4)); DEV_ALLOC(c->d_tcarry[1], count * sizeof(float4));
@@ -564,8 +565,10 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	c->cap_bursts_chan = (uint32_t)(dmax / 220 + 4);
 	uint64_t cap_b = (uint64_t)count * c->cap_bursts_chan;
 	uint64_t cap_f = cap_b * 2; if(cap_f < 4096) cap_f = 4096;
+	cap_f += 2048 * kResSlots;                                    // the burst decoder's wavefronts each own a first share of the records and octets
 	uint64_t cap_p = cap_b * 512; if(cap_p < (1u << 22)) cap_p = 1u << 22; if(cap_p > (1u << 30)) cap_p = 1u << 30;
 	c->cap_log = 8192; c->cap_comb = c->cap_log + kNfTail; c->cap_hist = (uint32_t)(dmax / 3000 + 8);
+	cap_p += 2048 * kResPool;
 	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, c->cap_log, {0, 0, 0, 0} };
 	DEV_ALLOC(c->d_nf, count * sizeof(NfState));
 	DEV_ALLOC(c->d_scfirst, (size_t)count * (c->cap_comb + 1) * 8); DEV_ALLOC(c->d_sccum, (size_t)count * (c->cap_comb + 1) * 8);
@@ -609,6 +612,11 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	delete tab;
 	DEV_CHK(hipMemcpy(c->d_dphi, c->dphi.data(), 4 * count, hipMemcpyHostToDevice));
 	DEV_CHK(hipMemcpy(c->d_freq, c->freqs.data(), 4 * count, hipMemcpyHostToDevice));
+	{
+		std::vector<float> thr(count);
+		for(uint32_t i = 0; i < count; i++) thr[i] = ppm_gate_threshold(c->freqs[i], cfg->max_ppm);
+		DEV_CHK(hipMemcpy(c->d_ppmthr, thr.data(), 4 * count, hipMemcpyHostToDevice));
+	}
 	DEV_CHK(hipMemcpy(c->d_ws, ws.data(), count * sizeof(WalkState), hipMemcpyHostToDevice));
 	{
 		std::vector<NfState> nfs(count);

@@ -1,5 +1,5 @@
 """Development aid (CPU only): random synthetic captures through the host-compiled device logic (tests/hostsim, with the
-speculative walk, K3's two-tier rule and random chunking) against the oracle.  usage: python tests/fuzz_hostsim.py [n] [seed0] [extreme]"""
+speculative walk, K3's two-tier rule and random chunking) against the oracle.  usage: python tests/fuzz_hostsim.py [n] [seed0] [extreme|rejects]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
@@ -10,7 +10,7 @@ import pyhostsim
 from util import assert_frames_equal
 
 
-def run_seed(seed, extreme=False):
+def run_seed(seed, extreme=False, rejects=False):
     """one random capture through hostsim (random segmentation, two-tier on/off, random chunking) against the oracle;
     returns a description string, raises AssertionError on any difference"""
     rng = np.random.default_rng(seed)
@@ -27,6 +27,13 @@ def run_seed(seed, extreme=False):
         cfg.amplitude = float(rng.choice([0.01, 0.05, 0.4])); cfg.first_burst_s = float(rng.choice([0.0, 0.0005, 0.02]))
         cfg.duration_s = float(rng.uniform(0.3, 2.5)); cfg.min_payload = int(rng.choice([9, 20]))
         cfg.noise_sigma = float(rng.choice([0.0005, 0.004, 0.012, 0.03]))
+    if rejects:      # dense channel plans behind the --max-ppm gate: leaked preambles that lock and are dropped, in clusters (the walker's reject chain)
+        nch = int(rng.choice([3, 5, 8]))
+        cfg.freqs = synth.channel_plan(nch, spacing=int(rng.choice([8000, 12000, 25000])))
+        cfg.rx_max_ppm = float(rng.choice([0.5, 1.0, 2.5])); cfg.max_ppm = float(rng.choice([0.3, 2.0, 6.0]))
+        cfg.noise_sigma = float(rng.choice([0.0005, 0.002])); cfg.mean_gap_s = float(rng.choice([0.004, 0.02, 0.05]))
+        if rng.random() < 0.6:     # time-division slots as in the 256-channel workloads: a channel is silent while its neighbours send, so it locks on their leakage
+            cfg.tdm_slots = int(rng.choice([2, 4])); cfg.tdm_slot_s = float(rng.choice([0.02, 0.05])); cfg.max_payload = int(rng.choice([60, 300]))
     iq, bursts = synth.synthesize(cfg)
     o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
     D = iq.size // 2 // cfg.oversample
@@ -47,6 +54,7 @@ def run_seed(seed, extreme=False):
         so, sh_ = sorted(fo, key=key), sorted(fh, key=key)
         # fed with the oracle's own decimated samples the device logic is bit-exact, floats included
         assert [(f["nf_pwr_dbfs"], f["ppm_error"]) for f in so] == [(f["nf_pwr_dbfs"], f["ppm_error"]) for f in sh_], f"seed {seed}: nf/ppm differ"
+        nch = len(cfg.freqs)
         co = [list(o.counters(c).values()) for c in range(nch)]; ch = [hs.counters(c) for c in range(nch)]
         # the 18 counters the reference keeps + demod.ppm_reject must be identical; demod.slicer_neg_idx (a diagnostic of this
         # implementation) is counted by the burst decoder, so symbols of a burst still incomplete at the end of the capture -
@@ -54,7 +62,7 @@ def run_seed(seed, extreme=False):
         assert [c[:19] for c in co] == [c[:19] for c in ch], f"seed {seed}: counters differ"
         assert all(a[19] >= b[19] for a, b in zip(co, ch)), f"seed {seed}: slicer_neg_idx over-counted"
         assert po.avlc_counters(fh, nch) == [hs.avlc_counters(c) for c in range(nch)], f"seed {seed}: avlc counters differ"
-        return f"ch={nch} os={os_} sp={spacing} frames={len(fo)} bursts={len(bursts)} seg={hs.segment_stats()}"
+        return f"ch={len(cfg.freqs)} os={os_} frames={len(fo)} bursts={len(bursts)} syncs={sum(c[0] for c in co)} ppm_rejects={sum(c[18] for c in co)} seg={hs.segment_stats()}"
     finally:
         hs.close()
 
@@ -63,11 +71,12 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     extreme = len(sys.argv) > 3 and sys.argv[3] == "extreme"
+    rejects = len(sys.argv) > 3 and sys.argv[3] == "rejects"
     po.build()
     bad = 0
     for k in range(n):
         try:
-            print(f"seed {seed0 + k}: ok  {run_seed(seed0 + k, extreme)}", flush=True)
+            print(f"seed {seed0 + k}: ok  {run_seed(seed0 + k, extreme, rejects)}", flush=True)
         except AssertionError as e:
             bad += 1
             print(f"seed {seed0 + k}: MISMATCH {str(e)[:300]}", flush=True)

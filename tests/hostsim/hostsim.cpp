@@ -129,18 +129,18 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 			const int64_t seglen = (D + nseg - 1) / nseg;
 			nseg = (int)((D + seglen - 1) / seglen);
 			Burst *bdst = s->bursts.data() + s->ctl.nbursts; const uint32_t bcap = (uint32_t)s->bursts.size() - s->ctl.nbursts;
-			walk_channel(c, s->freqs[c], s->max_ppm, k0 + seglen, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], bdst, bcap, &nbc, &s->ctl, lg, wsh);
+			walk_channel(c, s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k0 + seglen, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], bdst, bcap, &nbc, &s->ctl, lg, wsh);
 			s->spec.resize((size_t)3 * (nseg - 1));
 			for(int x = 0; x < 3 * (nseg - 1); x++) {
 				const int seg = 1 + x / 3, r = x % 3;
 				const int64_t b = k0 + (int64_t)seg * seglen, kn = seg + 1 < nseg ? b + seglen : k1;
-				spec_walk(c, s->freqs[c], s->max_ppm, b, r, kn, s->T, v, &s->spec[x], wsh);
+				spec_walk(c, s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), b, r, kn, s->T, v, &s->spec[x], wsh);
 			}
 			static StitchShared ssh;
-			stitch_channel(c, s->freqs[c], s->max_ppm, k0, seglen, nseg, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], bdst, bcap, &nbc,
+			stitch_channel(c, s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k0, seglen, nseg, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], bdst, bcap, &nbc,
 			               &s->ctl, lg, s->spec.data(), wsh, ssh, s->seg_stats);
 		} else
-		walk_channel(c, s->freqs[c], s->max_ppm, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], s->bursts.data() + s->ctl.nbursts,
+		walk_channel(c, s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], s->bursts.data() + s->ctl.nbursts,
 		             (uint32_t)s->bursts.size() - s->ctl.nbursts, &nbc, &s->ctl, lg, wsh);
 		s->ctl.nbursts += nbc;
 		static NfShared nsh;
@@ -151,6 +151,8 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		nf_finish(&s->nf[c], sc, fd, &s->lpbuf[(size_t)c * s->cap_hist], &s->ring[(size_t)c * s->nf_ring], s->nf_ring - 1, s->cap_hist, nsh);
 	}
 	static BurstShared bsh;
+	s->ctl.nframes = burst_reserve_initial_frames(1); s->ctl.pool_used = burst_reserve_initial_pool(1);   // one "wavefront" decodes everything
+	burst_shared_init(s->T, 0, &s->ctl, bsh);
 	uint32_t nb = s->ctl.nbursts;
 	for(uint32_t i = 0; i < nb; i++) {
 		const Burst &b = s->bursts[i];
@@ -158,15 +160,18 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
 		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl, bsh);
 	}
+	burst_reserve_done(s->frames.data(), bsh);
 	uint32_t nf = s->ctl.nframes < s->ctl.cap_frames ? s->ctl.nframes : s->ctl.cap_frames;
 	static FrameShared fsh;
 	frame_shared_init(s->T, fsh);
 	for(uint32_t i = 0; i < nf; i++) {
 		const int c = s->frames[i].chan;
+		if(c < 0) continue;                                  // tombstone: a record the burst decoder reserved and did not use
 		finish_frame(s->frames[i], s->pool.data(), s->T, &s->acnt[(size_t)c * kNumAvlcCounters], &s->ring[(size_t)c * s->nf_ring], s->nf_ring - 1, fsh);
 	}
 	for(uint32_t i = 0; i < nf; i++) {
 		OutFrame f = s->frames[i];
+		if(f.chan < 0) continue;
 		uint32_t off = (uint32_t)s->all_pool.size();
 		s->all_pool.insert(s->all_pool.end(), s->pool.begin() + f.pool_off, s->pool.begin() + f.pool_off + f.len);
 		f.pool_off = off;
@@ -245,7 +250,7 @@ void hostsim_block_form(const float *A, const float *B, int os, int run, BlockFo
 // the burst decoder's RS stage on one 255-octet row (for direct comparison with libfec / the oracle)
 int hostsim_rs_decode(uint8_t *row, int npar) {
 	static BurstShared sh; static Tables T; static bool init = false;
-	if(!init) { build_tables(T); memcpy(sh.gf_exp, T.gf_exp, 512); memcpy(sh.gf_log, T.gf_log, 256); init = true; }
+	if(!init) { build_tables(T); OutCtl ctl{}; burst_shared_init(T, 0, &ctl, sh); init = true; }
 	memcpy(sh.tab, row, 255);
 	rs_decode_row(sh.tab, npar, sh);
 	memcpy(row, sh.tab, 255);

@@ -94,6 +94,7 @@ def test_device_rs_stage_matches_libfec(oracle_mod, libfec):
     H.hostsim_rs_decode.argtypes = [C.c_void_p, C.c_int]
     L, rs = libfec
     rng = np.random.default_rng(77)
+    n_short = 0
     for trial in range(4000):
         fec = int(rng.choice([6, 6, 4, 2, 0]))
         if trial % 3 == 0:
@@ -108,4 +109,12 @@ def test_device_rs_stage_matches_libfec(oracle_mod, libfec):
         r_ref, out_ref = ref_verify(L, rs, block, fec)
         d = (C.c_uint8 * 255)(*block)
         r_dev = H.hostsim_rs_decode(d, fec)
-        assert (r_dev, bytes(d)) == (r_ref, out_ref), f"trial {trial} fec {fec}"
+        # what the stage owes the burst decoder: libfec's return value and the 249 data octets.  A short block (fec < 6) without
+        # errors is recognised early (vdl2_core.h: the Berlekamp-Massey discrepancies of an erasures-only block are zero) and its
+        # erased parity octets - which nothing reads - are then not filled in; every other block must come out as libfec leaves it
+        assert r_dev == r_ref and bytes(d)[:249] == bytes(out_ref)[:249], f"trial {trial} fec {fec}"
+        if not (fec < 6 and r_ref == 6 - fec):
+            assert bytes(d) == bytes(out_ref), f"trial {trial} fec {fec}"
+        else:
+            n_short += 1
+    assert n_short > 100
