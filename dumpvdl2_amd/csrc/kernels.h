@@ -981,7 +981,8 @@ struct K4bArgs {
 // K4b: noise-floor replay from the walker's evaluation log, in three small passes
 constexpr int kNfWaves = 4;                // wavefronts per workgroup in the three passes: a channel (passes 1, 3) or a group of updates (pass 2) each
 __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_prepare(K4bArgs a) {
-	__shared__ NfShared shw[kNfWaves];
+	extern __shared__ __align__(16) unsigned char nf_lds[];      // NfShared[kNfWaves]; dynamic, so that the compiler sizes the register budget by the launch bound and not by the LDS-limited occupancy (see k_burst)
+	NfShared *shw = reinterpret_cast<NfShared *>(nf_lds);
 	const int wave = threadIdx.x >> 6, c = blockIdx.x * kNfWaves + wave;
 	if(c >= a.nchan) return;
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
@@ -994,7 +995,8 @@ __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_prepare(K4bArgs a) {
 // each kept a whole channeliser workgroup out for as long as they lived (measured: the replay beside the channeliser cost the
 // front 0.29 ms per 256-channel step).
 __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_replay(K4bArgs a) {
-	__shared__ NfShared shw[kNfWaves];
+	extern __shared__ __align__(16) unsigned char nf_lds[];      // NfShared[kNfWaves]; dynamic, so that the compiler sizes the register budget by the launch bound and not by the LDS-limited occupancy (see k_burst)
+	NfShared *shw = reinterpret_cast<NfShared *>(nf_lds);
 	const int c = blockIdx.y, wave = threadIdx.x >> 6;
 	ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask };
 	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
@@ -1006,7 +1008,8 @@ __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_replay(K4bArgs a) {
 }
 
 __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_finish(K4bArgs a) {
-	__shared__ NfShared shw[kNfWaves];
+	extern __shared__ __align__(16) unsigned char nf_lds[];      // NfShared[kNfWaves]; dynamic, so that the compiler sizes the register budget by the launch bound and not by the LDS-limited occupancy (see k_burst)
+	NfShared *shw = reinterpret_cast<NfShared *>(nf_lds);
 	const int wave = threadIdx.x >> 6, c = blockIdx.x * kNfWaves + wave;
 	if(c >= a.nchan) return;
 	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };

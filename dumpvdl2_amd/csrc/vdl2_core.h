@@ -561,6 +561,13 @@ VDL2_HD int wave_first_flag(const int32_t *flags) {
 }
 #endif
 
+// number of lanes whose flag is set.  Call from wave-uniform code after a WAVE_END.
+#if VDL2_DEVICE_PASS
+VDL2_HD int wave_count_flags(const int32_t *flags) { return (int)__popcll(__ballot(flags[VDL2_LANE()] != 0)); }
+#else
+VDL2_HD int wave_count_flags(const int32_t *flags) { int n = 0; for(int l = 0; l < 64; l++) n += flags[l] != 0; return n; }
+#endif
+
 // Wave-wide primitives on 64 values that the lanes have left in LDS.  Call from wave-uniform code after a WAVE_END (the device
 // versions read the calling lane's own entry and combine over the wavefront in registers; the host versions are plain loops).
 #if VDL2_DEVICE_PASS
@@ -1266,12 +1273,16 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_th
 // ======================================================================
 constexpr int kNfGroup = 32;               // updates a wavefront replays per pass: one lane per update in the recurrence (the cheap part)
 constexpr int kNfSeg = 64;                 // evaluations gathered between two stretches of the recurrence (one per lane)
+constexpr int kNfSlice = 191;              // chunks of the list a group of updates keeps in LDS (a group that touches more reads the list from memory)
 static_assert(kLpTerms % kNfSeg == 0, "the replay window is a whole number of gather segments");
 struct NfShared {
 	alignas(16) float mags[kNfGroup][kNfSeg + 1];      // [update][evaluation of the segment, newest first]; +1: row padding keeps the per-lane replay off one LDS bank
 	float   lp[kNfGroup];                               // the recurrence between segments
 	int64_t pos[kNfGroup], avail[kNfGroup];             // sample of the evaluation that triggers the update; evaluations before it in the same chunk
 	int32_t ci[kNfGroup];                               // its chunk (-1: nothing to replay)
+	// the stretch of the combined chunk list the group's updates can touch, staged once (nf_replay_group): sl_cum[i] = cum[sl_lo + i]
+	int64_t sl_cum[kNfSlice + 1], sl_first[kNfSlice];
+	int32_t flag[64], idx[64];
 };
 
 struct NfScratch { int64_t *first; int64_t *cum; };   // combined (tail + feed) chunk list: first sample, ordinal of first evaluation
@@ -1326,14 +1337,46 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 	if(ubase > fd.u1) return;
 	const int ncomb = (int)fd.ncomb;
 	const int nupd = fd.u1 - ubase + 1 < kNfGroup ? (int)(fd.u1 - ubase + 1) : kNfGroup;
+	// The chunks this group can touch - from the one that holds the oldest evaluation its first update replays to the one that holds
+	// its last update's trigger - go to LDS once: the lanes then find their evaluations' samples there instead of walking the list in
+	// memory, one dependent load after the other (the --max-ppm gate starts a new chunk with every preamble it drops, so the 256
+	// evaluations before an update regularly span several).  The first chunk is found by all 64 lanes probing the list at once
+	// (three rounds for 8 000 chunks where a binary search takes thirteen).
+	const int64_t o_first = 1000 * ubase - 1 - (kLpTerms - 1), o_lastgrp = 1000 * (ubase + nupd - 1) - 1;
+	int c_lo = 0;
+	if(ncomb > 0 && o_first > fd.begin_ord) {
+		int lo = 0, hi = ncomb;                                     // cum[lo] <= o_first < cum[hi]  (cum[0] = begin_ord, cum[ncomb] = all evaluations so far)
+		while(hi - lo > 1) {
+			WAVE_FOR(l)
+				int idx = lo + (int)(((int64_t)(hi - lo) * (l + 1)) / 65);
+				if(idx <= lo) idx = lo + 1;
+				if(idx >= hi) idx = hi - 1;
+				sh.idx[l] = idx; sh.flag[l] = sc.cum[idx] <= o_first;
+			WAVE_END
+			const int k = wave_count_flags(sh.flag);               // the probes ascend: the first k hold, the others do not
+			const int nlo = k > 0 ? sh.idx[k - 1] : lo, nhi = k < 64 ? sh.idx[k] : hi;
+			WAVE_SYNC();
+			lo = nlo; hi = nhi;
+		}
+		c_lo = lo;
+	}
+	int nsl = ncomb - c_lo < kNfSlice ? ncomb - c_lo : kNfSlice;   // chunks staged
+	WAVE_FOR(l)
+		for(int i = l; i <= nsl; i += 64) sh.sl_cum[i] = sc.cum[c_lo + i];
+		for(int i = l; i < nsl; i += 64) sh.sl_first[i] = sc.first[c_lo + i];
+	WAVE_END
+	// does the staged stretch reach the group's last trigger?  (else: the list is read from memory, as it always was)
+	const bool staged = ncomb > 0 && (c_lo + nsl == ncomb || sh.sl_cum[nsl] > o_lastgrp);
+	const int64_t *cum = staged ? sh.sl_cum - c_lo : sc.cum, *first = staged ? sh.sl_first - c_lo : sc.first;
+	const int c_min = staged ? c_lo : 0, c_end = staged ? c_lo + nsl : ncomb;
 	WAVE_FOR(l)
 		if(l < nupd) {
 			const int64_t o_last = 1000 * (ubase + l) - 1;               // ordinal of the evaluation that triggers the update
 			int ci = -1; int64_t pos = 0, avail = 0;
 			if(o_last >= fd.begin_ord && ncomb > 0) {
-				int lo = 0, hi = ncomb;
-				while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(sc.cum[mid] <= o_last) lo = mid; else hi = mid; }
-				ci = lo; avail = o_last - sc.cum[ci]; pos = sc.first[ci] + 3 * avail;
+				int lo = c_min, hi = c_end;
+				while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(cum[mid] <= o_last) lo = mid; else hi = mid; }
+				ci = lo; avail = o_last - cum[ci]; pos = first[ci] + 3 * avail;
 			}
 			sh.ci[l] = ci; sh.pos[l] = pos; sh.avail[l] = avail; sh.lp[l] = 0.f;
 		}
@@ -1351,9 +1394,9 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 						if(t <= sh.avail[u]) ps[q] = sh.pos[u] - 3 * t;
 						else {                                                  // in an earlier chunk, if anywhere
 							int64_t rem = t - sh.avail[u] - 1;                    // evaluations to skip, counted back from the end of chunk ci-1
-							for(int cj = sh.ci[u] - 1; cj >= 0; cj--) {
-								const int64_t len = sc.cum[cj + 1] - sc.cum[cj];
-								if(rem < len) { ps[q] = sc.first[cj] + 3 * (len - 1 - rem); break; }
+							for(int cj = sh.ci[u] - 1; cj >= c_min; cj--) {       // (below c_min only what no update of the group replays)
+								const int64_t len = cum[cj + 1] - cum[cj];
+								if(rem < len) { ps[q] = first[cj] + 3 * (len - 1 - rem); break; }
 								rem -= len;
 							}
 						}

@@ -356,6 +356,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			K4sArgs k4s{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, k0, seglen, c->d_segstats };
 			if(!(c->ablate & 1))
 			LAUNCH_EV(k_walk_spec, dim3((unsigned)((1 + 3 * (nseg - 1) + kWalkWaves - 1) / kWalkWaves), (unsigned)c->C), dim3(64 * kWalkWaves), sb_, EV(6), (hipEvent_t) nullptr, k4s);
+			if(!(c->ablate & 1))
 			hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, EV(7), 0, k4s);
 		} else {
 			LAUNCH_EV(k_walk, dim3((unsigned)c->C), dim3(64), sb_, EV(6), EV(7), k4);
@@ -367,11 +368,11 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	if(D > 0) {
 		K4bArgs k4b{ c->d_y, c->d_nf, sl.d_log, sl.d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfring, c->nf_ring - 1,
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist, c->C };
-		LAUNCH_EV(k_nf_prepare, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), sn_, EV(8), (hipEvent_t) nullptr, k4b);
+		hipExtLaunchKernelGGL(k_nf_prepare, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), (unsigned)(sizeof(NfShared) * kNfWaves), sn_, EV(8), (hipEvent_t) nullptr, 0, k4b);
 		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup * kNfWaves - 1) / (kNfGroup * kNfWaves));   // workgroups per channel
 		if(!(c->ablate & 2))      // (experiment builds: what does a stage cost the front by running beside it?)
-		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64 * kNfWaves), 0, sn_, k4b);
-		LAUNCH_EV(k_nf_finish, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), sn_, (hipEvent_t) nullptr, EV(9), k4b);
+		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64 * kNfWaves), (unsigned)(sizeof(NfShared) * kNfWaves), sn_, k4b);
+		hipExtLaunchKernelGGL(k_nf_finish, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), (unsigned)(sizeof(NfShared) * kNfWaves), sn_, (hipEvent_t) nullptr, EV(9), 0, k4b);
 		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
 		// wavefronts of the burst decoder: each owns kResSlots frame records of the output from the start (unused ones are delivered as
 		// tombstones), so a short block gets few of them
