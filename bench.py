@@ -296,7 +296,7 @@ def cpu_baseline_of(case, po, raw, first_pass_s, full=True):
         return dt
 
     ncpu = cpus_available()
-    ref = [first_pass_s] + ([one("strict", "run", mode=po.RUN_THREAD_PER_CHANNEL)] if full else [])
+    ref = [first_pass_s] + ([one("strict", "run", mode=po.RUN_THREAD_PER_CHANNEL) for _ in range(2)] if full else [])
     best = min(ref)
     mss = lambda s: round(case.nsamples / s / 1e6, 4)       # noqa: E731
     nspt = lambda s, thr: round(s * min(thr, ncpu) / (case.nsamples * case.C) * 1e9, 2)     # noqa: E731  ns of one CPU per channel-sample
@@ -315,6 +315,9 @@ def cpu_baseline_of(case, po, raw, first_pass_s, full=True):
         return out
     try:
         wq = [one("strict", "run", mode=po.RUN_WORKQUEUE, nthreads=ncpu, block=1 << 22) for _ in range(2)]
+        # the figure to divide by for a GPU/CPU ratio: the best this CPU does with the same arithmetic, however it is threaded
+        out["best_value"] = max(out["value"], mss(min(wq)))
+        out["best_value_is"] = "the faster of the reference threading (`value`) and the work-queue variant: the CPU figure meant for speed-up ratios"
         out["workqueue"] = {"value": mss(min(wq)), "unit": "MS/s", "threads": ncpu, "block_bytes": 1 << 22, "passes_s": [round(x, 3) for x in wq],
                             "ns_per_channel_sample_per_cpu": nspt(min(wq), ncpu),
                             "note": "best-effort CPU: one persistent worker per available CPU, conversion spread over them, channels handed out "
@@ -347,42 +350,35 @@ def oracle_gate(case, frames, po, label, strict_counters=True):
     ofr = o.frames()
     cmp = compare_at_full_size(ofr, frames, label=label)
     # the reference's own 18 statsd counters per channel (the last two are this repo's diagnostics: preambles dropped by
-    # --max-ppm and out-of-range slicer indices, which a timing tie can move by one)
-    nref, ndiff, nref_diff, which = 18, 0, 0, {}
+    # --max-ppm and out-of-range slicer indices, which a timing tie can move by one).  strict: identical on every channel.  Otherwise
+    # (the lock-dense secondary workload): util.compare_reference_counters asserts the SHAPE of the one exception DESIGN 5 allows - the
+    # failure bookkeeping of bursts that deliver nothing, by <= 2, on <= 1 % of the channels; every other counter identical.
+    from util import compare_reference_counters
+    nref = 18
     names = list(o.counters(case.first).keys())
-    decisive = [names.index(k) for k in ("demod.sync.good", "decoder.crc.good", "decoder.crc.bad", "decoder.msg.good", "decoder.msg.good_loud")]
-    for ch in range(case.first, case.first + case.count):
-        co, cg = list(o.counters(ch).values()), list(case.rx.counters(ch).values())
-        if strict_counters:
-            assert co[:nref] == cg[:nref], f"{label}: reference counters of channel {ch} differ from the oracle's: {co} vs {cg}"
-        else:
-            # A burst that dies in the decoder (a lock on a neighbour's leaked preamble: symbols sliced out of noise) delivers no frame,
-            # and WHERE it dies - which RS block first fails - can hinge on one noise-level symbol decision, i.e. on the 1e-5 by which
-            # the time-parallel filter differs from the sequential one.  Workloads dense in such locks are held to: every
-            # frame identical (above), the counters of what WAS delivered identical, the failure bookkeeping reported.
-            assert [co[i] for i in decisive] == [cg[i] for i in decisive], f"{label}: decisive counters of channel {ch} differ: {co} vs {cg}"
-            if co[:nref] != cg[:nref]:
-                nref_diff += 1
-                for i in range(nref):
-                    if co[i] != cg[i]:
-                        which[names[i]] = which.get(names[i], 0) + abs(co[i] - cg[i])
-        ndiff += co[nref:] != cg[nref:]
+    co = [list(o.counters(ch).values()) for ch in range(case.first, case.first + case.count)]
+    cg = [list(case.rx.counters(ch).values()) for ch in range(case.first, case.first + case.count)]
+    which, nref_diff = compare_reference_counters(names, co, cg, label=label, strict=strict_counters, nref=nref)
+    ndiff = sum(a[nref:] != b[nref:] for a, b in zip(co, cg))
     o.close()
     ties, nft = cmp["timing_ties"], cmp["nf_update_ties"]
     return {"tx_frames": want, "decoded": len(frames), "oracle_window_s": cfg.duration_s, "oracle_frames": len(ofr),
-            # octets, frame order, integer metadata and the reference's 18 counters per channel are identical (asserted above);
-            "frames_and_integer_metadata_identical": True,
+            # compare_at_full_size() has asserted octets, frame order and integer metadata of every frame; compare_reference_counters() the counters
+            "frames_and_integer_metadata_identical": cmp["frames"] == len(ofr) == len(frames),
+            "reference_counters": "identical on every channel (asserted)" if strict_counters else
+                                  "identical except the failure bookkeeping of bursts that deliver nothing (<= 2, on <= 1 % of the channels: asserted)",
             # ... the float metadata is held to SURVEY 8.5's tolerances except on "ties" (DESIGN 5), which are counted and bounded:
-            "oracle_identical": ties == 0 and nft == 0,
+            "oracle_identical": ties == 0 and nft == 0 and nref_diff == 0,
             "oracle_parity_within_tolerance": True,
             "timing_ties": ties, "nf_update_ties": nft,
             "tolerances": {"frame_pwr_db": TOL_DB, "nf_pwr_db": TOL_DB, "ppm": TOL_PPM,
                            "on_a_timing_tie": {"sync/end sample": 2, "ppm": 0.5}, "on_a_nf_update_tie": {"nf_pwr_db": 1.5},
                            "max_tie_fraction": 5e-3},
             "max_abs_diff": cmp["max_abs_diff"],
+            "max_abs_diff_on_ties": cmp["max_abs_diff_on_ties"],
             "channels_with_reference_counters_identical": case.count - nref_diff, "channels_with_diagnostic_counter_diff": int(ndiff),
             "reference_counter_differences": which or None,
-            "channels_with_frames": len({f["chan"] for f in frames})}, tc
+            "channels_with_frames": len({f["chan"] for f in frames})}, tc, ofr
 
 
 def measure_secondary(c2, name, oracle_check, args, dist, po):
@@ -417,6 +413,47 @@ def measure_secondary(c2, name, oracle_check, args, dist, po):
             # is the burst-rate back end (walk, noise floor, burst decoder: own streams) hidden behind the sample-rate front?
             "front_ms": round(st["chanfir_ms"] + st["sync_ms"], 4), "step_minus_front_ms": round(step_hbm - st["chanfir_ms"] - st["sync_ms"], 4),
             "k_chanfir_ms": rl["avg_launch_ms"], "valu_frac": rl["frac"], "hbm_algorithmic_frac": rl["hbm_algorithmic"]["frac"]}
+
+
+def group_from_c(case, args, torch, local, members=8):
+    """vdl2hip_group_* (the multi-GPU path from plain C) with `members` virtual shards on this GPU: every transmitted frame recovered
+    in both exchange forms, K timed steps each (three blocks in flight, frames drained without a callback)"""
+    from util import truth_is_subset
+    vh = case.vdl2hip
+    cfg = case.cfg
+    pin = case.host.pin_memory()
+    out = {"members": members, "devices": [local] * members, "source": "page-locked host memory (vdl2hip_group_feed_pinned)", "forms": {}}
+    g = vh.ReceiverGroup(cfg.centerfreq, list(cfg.freqs), [local] * members, cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=case.nbytes)
+    try:
+        for form in ("allgather", "broadcast"):
+            g.set_exchange(form)
+            g.set_drain_lag(0)
+            g.feed_pinned(pin.data_ptr(), case.nbytes)
+            fr = g.drain()
+            want = sum(len(b.frames) for b in case.bursts if b.decodable)
+            assert truth_is_subset(case.bursts, fr) == 0 and (len(fr) >= want if cfg.error_injection else len(fr) == want), f"group {form}: frames missing"
+            g.set_drain_lag(2)
+            for _ in range(3):
+                g.feed_pinned(pin.data_ptr(), case.nbytes); g.drain_count()
+            g.set_drain_lag(0); g.drain_count(); g.sync()
+            g.set_drain_lag(2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 0
+            for _ in range(args.steps):
+                g.feed_pinned(pin.data_ptr(), case.nbytes)
+                n += g.drain_count()
+            g.set_drain_lag(0)
+            n += g.drain_count()
+            g.sync()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out["forms"][form] = {"ms_per_step": round(dt / args.steps * 1e3, 4), "value": round(case.nsamples * args.steps / dt / 1e6, 3),
+                                  "frames_per_step": n / args.steps, "ran_as": g.exchange()}
+    finally:
+        g.close()
+        del pin
+    return out
 
 
 def h2d_ms(torch, host_pinned, device, iters=3):
@@ -512,13 +549,14 @@ def main():
     f_host = case.feeder(mode, "host")
     verified = None
     cpu_baseline = None
+    oracle_frames = None
     fr = case.frames_of_step(f_host)
     allfr = vdist.gather_frames(fr, dst=0) if world > 1 else fr
     if rank == 0 and not args.no_verify:
         from oracle import pyoracle as po
         # N > 1: rank 0 holds the merged frames of all ranks - the frame / metadata comparison covers all channels, the counter
         # comparison rank 0's own (the other ranks' counters stay on their GPUs)
-        verified, tc = oracle_gate(case, allfr, po, "bench oracle gate" + (" (all ranks)" if world > 1 else ""))
+        verified, tc, oracle_frames = oracle_gate(case, allfr, po, "bench oracle gate" + (" (all ranks)" if world > 1 else ""))
         if world == 1 and not args.no_cpu_baseline:
             cpu_baseline = cpu_baseline_of(case, po, case.iq.view(np.uint8), tc)
     if world > 1:
@@ -587,11 +625,17 @@ def main():
             mine = [b for b in case.bursts if r * per <= b.chan < (r + 1) * per]
             from util import truth_is_subset
             assert truth_is_subset(mine, got) == 0, f"shard {r}: transmitted frames missing"
+            vs_oracle = None
+            if oracle_frames is not None:      # ... and the oracle's frames of exactly these channels (the whole-block pass of the parity gate above)
+                from util import compare_at_full_size
+                c = compare_at_full_size([f for f in oracle_frames if r * per <= f["chan"] < (r + 1) * per], got, label=f"shard {r} vs oracle")
+                vs_oracle = {"frames": c["frames"], "timing_ties": c["timing_ties"], "nf_update_ties": c["nf_update_ties"], "max_abs_diff": c["max_abs_diff"]}
             fd.step(); fd.step(); cs.rx.set_drain_lag(0); cs.rx.drain_packed()
             ts = cs.timed(fd, args.steps, dist, args.repeats)
             st = cs.stage_times(fd)
             shards.append({"rank": r, "channels": [r * per, (r + 1) * per - 1], "ms_per_step": round(ts["dt"] / args.steps * 1e3, 4),
-                           "min_ms_per_step": ts["min_ms_per_step"], "k_chanfir_ms": round(ts["k1_ms"], 4), "stage_ms_per_step": st})
+                           "min_ms_per_step": ts["min_ms_per_step"], "k_chanfir_ms": round(ts["k1_ms"], 4), "stage_ms_per_step": st,
+                           "frames_identical_to_the_oracle": vs_oracle})
             del fd
             cs.close()
         t256 = t_hbm["dt"] / args.steps * 1e3
@@ -614,6 +658,14 @@ def main():
                                                   "allgather_into_each_gpu_over_7_links": round(case.nbytes * 7 / 8 / (7 * 76.5e9) * 1e3, 3),
                                                   "source": "spec link rates, not measured"},
                      "note": "projection from one GPU, not a measurement of 8; the driver's N = 8 run reports by_exchange / rank_ms_per_step"}
+        # ... and the same split driven FROM C: vdl2hip_group_* over 8 members, all of them on this GPU ("virtual shards"), fed from
+        # page-locked host memory, both exchange forms.  One GPU does the work of eight here, so the time per step is to be read against
+        # t_all_channels_ms: what it shows is what the C path adds (8 x ~12 launches per block from one host thread, the stripes' H2D
+        # copies and the peer copies that stand in for xGMI) - not a speed-up.
+        try:
+            projected["group_from_c"] = group_from_c(case, args, torch, local)
+        except Exception as e:  # noqa: BLE001
+            projected["group_from_c"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     except Exception as e:  # noqa: BLE001 - informational block: a failure here must not take the headline line with it
         projected = {"error": f"{type(e).__name__}: {str(e)[:400]}"}
 

@@ -1082,21 +1082,48 @@ __global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
 	burst_reserve_done(a.frames, sh);
 }
 
-// after K4b and K5 have both finished, one wavefront per frame: the noise-floor figure and the AVLC front-door checks
+// After K4b and K5 have both finished: the noise-floor figure and the AVLC front-door checks of every frame (one wavefront per
+// frame), and the feed's output made compact.  The burst decoder's wavefronts write into shares of the record array and the octet
+// pool that they own (vdl2_core.h: burst_reserve_*), which leaves tombstone records and unused octets behind; a wavefront here takes
+// 64 records at a time, counts the real ones, reserves their places in the delivered arrays with ONE pair of atomics, and writes each
+// finished frame - record and octets - there.  The host copies exactly what is delivered.
 constexpr int kFrameWaves = 4;
-__global__ __launch_bounds__(64 * kFrameWaves) void k_frame_finish(OutFrame *frames, const uint8_t *pool, const OutCtl *ctl, const Tables *tab,
-		unsigned long long *acnt, const float *ring, uint32_t ring_mask) {
+__global__ __launch_bounds__(64 * kFrameWaves) void k_frame_finish(OutFrame *frames, const uint8_t *pool, OutCtl *ctl, const Tables *tab,
+		unsigned long long *acnt, const float *ring, uint32_t ring_mask, OutFrame *frames_out, uint8_t *pool_out) {
 	__shared__ FrameShared shw[kFrameWaves];
+	__shared__ uint32_t s_off[kFrameWaves][64];
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint32_t n = ctl->nframes < ctl->cap_frames ? ctl->nframes : ctl->cap_frames;
-	const uint32_t first = blockIdx.x * kFrameWaves + (threadIdx.x >> 6);
+	const uint32_t first = (blockIdx.x * kFrameWaves + wave) * 64u;
 	if(first >= n) return;
-	FrameShared &sh = shw[threadIdx.x >> 6];
+	FrameShared &sh = shw[wave];
 	frame_shared_init(*tab, sh);
-	for(uint32_t i = first; i < n; i += gridDim.x * kFrameWaves) {
-		const int c = frames[i].chan;
-		if(c < 0) continue;                              // tombstone (octet pool overflow): wave-uniform
-		finish_frame(frames[i], pool, *tab, acnt + (size_t)c * kNumAvlcCounters, ring + (size_t)c * (ring_mask + 1), ring_mask, sh);
+	for(uint32_t c0 = first; c0 < n; c0 += gridDim.x * kFrameWaves * 64u) {
+		const uint32_t i = c0 + (uint32_t)lane;
+		const bool valid = i < n && frames[i].chan >= 0;            // not a tombstone
+		const uint32_t padded = valid ? (frames[i].len + 3u) & ~3u : 0u;
+		const unsigned long long vm = __ballot(valid);
+		uint32_t inc = padded;                                       // inclusive scan of the octet space over the wavefront
+		#pragma unroll
+		for(int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if(lane >= d) inc += o; }
+		s_off[wave][lane] = inc - padded;
+		const uint32_t tot = __shfl(inc, 63), cnt = (uint32_t)__popcll(vm);
+		uint32_t slot0 = 0, off0 = 0;
+		if(lane == 0 && cnt) { slot0 = atomicAdd(&ctl->nvalid, cnt); off0 = atomicAdd(&ctl->pool_out_used, tot); }
+		slot0 = __shfl(slot0, 0); off0 = __shfl(off0, 0);
 		WAVE_SYNC();
+		uint32_t rank = 0;
+		for(unsigned long long m = vm; m; m &= m - 1, rank++) {
+			const int l = __builtin_ctzll(m);
+			OutFrame &f = frames[c0 + (uint32_t)l];
+			const int c = f.chan;
+			finish_frame(f, pool, *tab, acnt + (size_t)c * kNumAvlcCounters, ring + (size_t)c * (ring_mask + 1), ring_mask, sh);
+			// deliver: the record with its octets' new place, the octets themselves (finish_frame() has left them in sh.buf)
+			const uint32_t len = f.len, src_off = f.pool_off, dst_off = off0 + s_off[wave][l];
+			if(lane == 0) { OutFrame g = f; g.pool_off = dst_off; frames_out[slot0 + rank] = g; }
+			for(uint32_t k = (uint32_t)lane; k < len; k += 64) pool_out[dst_off + k] = k < (uint32_t)sizeof sh.buf ? sh.buf[k] : pool[src_off + k];
+			WAVE_SYNC();
+		}
 	}
 }
 

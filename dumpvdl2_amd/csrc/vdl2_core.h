@@ -195,7 +195,8 @@ struct OutFrame {
 struct OutCtl {
 	uint32_t nbursts, nframes, pool_used, overflow;
 	uint32_t cap_bursts, cap_frames, cap_pool, cap_log;
-	uint32_t pad_[4];
+	uint32_t nvalid, pool_out_used;    // what k_frame_finish delivers: records without the tombstones, octets without the holes (the host copies these)
+	uint32_t pad_[2];
 };
 
 // A stretch of executed got_sync() evaluations: samples first, first+3, ..., first+3*(count-1).

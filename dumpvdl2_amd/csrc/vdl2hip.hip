@@ -45,6 +45,7 @@ constexpr int kSlots = 3;             // feeds in flight (vdl2hip_set_drain_lag:
 struct OutSlot {
 	Burst *d_bursts = nullptr; uint32_t *d_nbchan = nullptr, *d_bbase = nullptr;
 	OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
+	OutFrame *d_frames_out = nullptr; uint8_t *d_pool_out = nullptr;    // what k_frame_finish delivers (no tombstones, no holes): what the host copies
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
 	OutCtl *h_ctl = nullptr;               // pinned
 	hipEvent_t done = nullptr, ev_front = nullptr, ev_chan = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
@@ -162,11 +163,11 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 	const OutCtl ctl = *sl.h_ctl;
 	if(ctl.overflow) c->stats.overflow_feeds++;
 	c->stats.bursts += std::min(ctl.nbursts, ctl.cap_bursts);
-	const uint32_t nf = std::min(ctl.nframes, ctl.cap_frames);
+	const uint32_t nf = std::min(ctl.nvalid, ctl.cap_frames);
 	if(nf) {
 		// one pinned staging buffer, two asynchronous copies on a stream of their own (the burst stream may already hold the
 		// next feeds' kernels), one wait
-		const uint32_t pool_n = std::min(ctl.pool_used, ctl.cap_pool);
+		const uint32_t pool_n = std::min(ctl.pool_out_used, ctl.cap_pool);
 		const size_t fr_bytes = sizeof(OutFrame) * (size_t)nf, need = fr_bytes + pool_n;
 		if(need > c->stage_cap) {
 			if(c->h_stage) (void)hipHostFree(c->h_stage);
@@ -175,8 +176,8 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 			HIPCHK(hipHostMalloc((void **)&c->h_stage, cap, hipHostMallocDefault));
 			c->stage_cap = cap;
 		}
-		HIPCHK(hipMemcpyAsync(c->h_stage, sl.d_frames, fr_bytes, hipMemcpyDeviceToHost, c->stream_out));
-		if(pool_n) HIPCHK(hipMemcpyAsync(c->h_stage + fr_bytes, sl.d_pool, pool_n, hipMemcpyDeviceToHost, c->stream_out));
+		HIPCHK(hipMemcpyAsync(c->h_stage, sl.d_frames_out, fr_bytes, hipMemcpyDeviceToHost, c->stream_out));
+		if(pool_n) HIPCHK(hipMemcpyAsync(c->h_stage + fr_bytes, sl.d_pool_out, pool_n, hipMemcpyDeviceToHost, c->stream_out));
 		HIPCHK(hipStreamSynchronize(c->stream_out));
 		const OutFrame *fr = reinterpret_cast<const OutFrame *>(c->h_stage);
 		auto pool = std::make_shared<std::vector<uint8_t>>(c->h_stage + fr_bytes, c->h_stage + fr_bytes + pool_n);
@@ -384,8 +385,8 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: bbase[0] = 0 bursts to decode)
 		hipExtLaunchKernelGGL(k_burst, dim3(k5_waves / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
-		hipLaunchKernelGGL(k_frame_finish, dim3(1024 / kFrameWaves), dim3(64 * kFrameWaves), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, (const OutCtl *)sl.d_ctl, (const Tables *)c->d_tab,
-		                   c->d_acnt, (const float *)c->d_nfring, c->nf_ring - 1);
+		hipLaunchKernelGGL(k_frame_finish, dim3(1024 / kFrameWaves), dim3(64 * kFrameWaves), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, sl.d_ctl, (const Tables *)c->d_tab,
+		                   c->d_acnt, (const float *)c->d_nfring, c->nf_ring - 1, sl.d_frames_out, sl.d_pool_out);
 	}
 	HIPCHK(hipMemcpyAsync(sl.h_ctl, sl.d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, s5_));
 	HIPCHK(hipEventRecord(sl.done, s5_));
@@ -432,7 +433,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
 	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
-		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_ctl, sl.d_log, sl.d_nlog };
+		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_ctl, sl.d_log, sl.d_nlog };
 		for(void *p : q) if(p) (void)hipFree(p);
 		if(sl.h_ctl) (void)hipHostFree(sl.h_ctl);
 		if(sl.done) (void)hipEventDestroy(sl.done);
@@ -570,7 +571,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	uint64_t cap_p = cap_b * 512; if(cap_p < (1u << 22)) cap_p = 1u << 22; if(cap_p > (1u << 30)) cap_p = 1u << 30;
 	c->cap_log = 8192; c->cap_comb = c->cap_log + kNfTail; c->cap_hist = (uint32_t)(dmax / 3000 + 8);
 	cap_p += 2048 * kResPool;
-	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, c->cap_log, {0, 0, 0, 0} };
+	c->ctl_template = OutCtl{ 0, 0, 0, 0, (uint32_t)cap_b, (uint32_t)cap_f, (uint32_t)cap_p, c->cap_log, 0, 0, {0, 0} };
 	DEV_ALLOC(c->d_nf, count * sizeof(NfState));
 	DEV_ALLOC(c->d_scfirst, (size_t)count * (c->cap_comb + 1) * 8); DEV_ALLOC(c->d_sccum, (size_t)count * (c->cap_comb + 1) * 8);
 	// noise-floor history: a frame looks up the value at its burst's sync, at most kSlots feeds + one burst ago
@@ -595,6 +596,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	for(auto &sl : c->slot) {
 		DEV_ALLOC(sl.d_bursts, cap_b * sizeof(Burst)); DEV_ALLOC(sl.d_nbchan, count * 4); DEV_ALLOC(sl.d_bbase, (count + 1) * 4);
 		DEV_ALLOC(sl.d_frames, cap_f * sizeof(OutFrame)); DEV_ALLOC(sl.d_pool, cap_p); DEV_ALLOC(sl.d_ctl, sizeof(OutCtl));
+		DEV_ALLOC(sl.d_frames_out, cap_f * sizeof(OutFrame)); DEV_ALLOC(sl.d_pool_out, cap_p);
 		DEV_ALLOC(sl.d_log, (size_t)count * c->cap_log * sizeof(EvalChunk)); DEV_ALLOC(sl.d_nlog, count * 4);
 		DEV_CHK(hipMemset(sl.d_nlog, 0, count * 4));
 		DEV_CHK(hipHostMalloc((void **)&sl.h_ctl, sizeof(OutCtl), hipHostMallocDefault));

@@ -40,7 +40,7 @@ EXPORTS = [
     "vdl2hip_avlc_counters", "vdl2hip_set_avlc_filter", "vdl2hip_statsd_lines", "vdl2hip_feed_pinned",
     "vdl2hip_group_create", "vdl2hip_group_destroy", "vdl2hip_group_feed", "vdl2hip_group_feed_pinned", "vdl2hip_group_sync", "vdl2hip_group_drain",
     "vdl2hip_group_set_drain_lag", "vdl2hip_group_counters", "vdl2hip_group_avlc_counters", "vdl2hip_group_size", "vdl2hip_group_ctx",
-    "vdl2hip_group_uses_rccl",
+    "vdl2hip_group_uses_rccl", "vdl2hip_group_set_exchange", "vdl2hip_group_exchange",
 ]
 
 
@@ -130,6 +130,11 @@ def load_library(path: str = None):
     L.vdl2hip_group_ctx.restype = C.c_void_p
     L.vdl2hip_group_ctx.argtypes = [C.c_void_p, C.c_uint32]
     L.vdl2hip_group_uses_rccl.argtypes = [C.c_void_p]
+    if hasattr(L, "vdl2hip_group_set_exchange"):            # (absent from older builds loaded through VDL2HIP_LIB for comparisons)
+        L.vdl2hip_group_set_exchange.argtypes = [C.c_void_p, C.c_int]
+        L.vdl2hip_group_exchange.argtypes = [C.c_void_p]
+    L.vdl2hip_group_ctx.restype = C.c_void_p
+    L.vdl2hip_group_ctx.argtypes = [C.c_void_p, C.c_uint32]
     _lib = L
     return L
 
@@ -355,6 +360,10 @@ class ReceiverGroup:
         self._chk(self.L.vdl2hip_group_drain(self.h, self._cb, None), "vdl2hip_group_drain")
         return out
 
+    def drain_count(self) -> int:
+        """deliver (and drop) every finished frame without a callback: the number of frames (throughput loops)"""
+        return self._chk(self.L.vdl2hip_group_drain(self.h, C.cast(None, FRAME_CB), None), "vdl2hip_group_drain")
+
     def counters(self, chan: int) -> dict:
         a = (C.c_uint64 * NUM_COUNTERS)()
         self._chk(self.L.vdl2hip_group_counters(self.h, chan, a), "vdl2hip_group_counters")
@@ -365,6 +374,26 @@ class ReceiverGroup:
 
     def uses_rccl(self) -> bool:
         return bool(self.L.vdl2hip_group_uses_rccl(self.h))
+
+    EXCHANGE_FORMS = {"allgather": 0, "broadcast": 1}
+
+    def set_exchange(self, form: str) -> None:
+        """how the next blocks reach the members: 'allgather' (striped ingest over every member's own PCIe link, default) or 'broadcast'"""
+        self._chk(self.L.vdl2hip_group_set_exchange(self.h, self.EXCHANGE_FORMS[form]), "vdl2hip_group_set_exchange")
+
+    def exchange(self) -> str:
+        """what the last feed did"""
+        return {0: "broadcast/peer-copy", 1: "broadcast/rccl", 2: "allgather/peer-copy", 3: "allgather/rccl"}.get(self.L.vdl2hip_group_exchange(self.h), "none yet")
+
+    def read_decimated(self, chan: int, first: int, count: int):
+        """`count` decimated (re, im) pairs of channel `chan` from the member that owns it (parity tests)"""
+        for i in range(self.size()):
+            ctx = self.L.vdl2hip_group_ctx(self.h, i)
+            buf = np.empty(2 * count, dtype=np.float32)
+            n = self.L.vdl2hip_read_decimated(C.c_void_p(ctx), chan, first, buf.ctypes.data, count)
+            if n >= 0:
+                return buf[:2 * n].reshape(-1, 2)
+        raise Vdl2HipError("no member owns that channel")
 
     def close(self):
         if getattr(self, "h", None):

@@ -24,9 +24,11 @@
 extern "C" {
 #endif
 
-#define VDL2HIP_ABI_VERSION 3   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added
+#define VDL2HIP_ABI_VERSION 4   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added
                                  * 3: vdl2hip_feed_pinned(); vdl2hip_stats.overflow_feeds; vdl2hip_group_*: one receiver over several
-                                 *    GPUs from C (a channeliser look-back that gives up is no longer an error: it falls back) */
+                                 *    GPUs from C (a channeliser look-back that gives up is no longer an error: it falls back)
+                                 * 4: vdl2hip_group_set_exchange() / vdl2hip_group_exchange(): striped ingest + all-gather is the group's
+                                 *    default exchange, broadcast stays selectable; RCCL is opt-in (VDL2HIP_USE_RCCL=1) */
 
 /* enum sample_formats, src/dumpvdl2.h:319 */
 #define VDL2HIP_FMT_U8     0
@@ -133,8 +135,11 @@ typedef struct {
 	uint64_t seg_adopted;       /* segmented walk: speculative segments adopted ... */
 	uint64_t seg_walked;        /* ... and segments walked sequentially because a burst straddled their start */
 	uint64_t front_sync_timeouts; /* channeliser workgroups that stopped waiting for their predecessor's filter state and worked it out
-	                               * themselves (one more tile of work each; results unaffected).  0 with one process per GPU; non-zero
-	                               * where the GPU is time-sliced between processes - consider VDL2HIP_NO_FUSE=1 there */
+	                               * themselves (one more tile of work each).  The state they compute equals the published one up to fp32
+	                               * rounding (a sum instead of a scan), i.e. the first 128 decimated outputs of such a segment may differ
+	                               * from a run without fall-backs by ~1e-5 of the signal: NOT bit-identical, and which workgroups fall
+	                               * back depends on scheduling.  0 with one process per GPU; non-zero where the GPU is time-sliced
+	                               * between processes - set VDL2HIP_NO_FUSE=1 there if bit-reproducible output is required */
 	uint64_t overflow_feeds;    /* feeds in which a device-side burst/frame/octet buffer ran out (bursts or frames were dropped);
 	                             * vdl2hip_sync() returns VDL2HIP_E_OVERFLOW for those, the drain calls only count here */
 } vdl2hip_stats;
@@ -209,15 +214,20 @@ void *vdl2hip_stream(vdl2hip_ctx *ctx);                 /* the hipStream_t all w
 
 /* ---- One receiver over several GPUs of this process (src/dumpvdl2.c:117-135: one worker per channel over a shared block;
  * here the workers are grouped by device).  Member k of n decodes channels [k*nchan/n, (k+1)*nchan/n) of cfg->freqs on
- * devices[k]; cfg->device, chan_first and chan_count are ignored/must be 0.  A block handed to vdl2hip_group_feed() crosses
- * PCIe once, into devices[0], and reaches the other devices over xGMI: RCCL ncclBroadcast when librccl.so can be loaded and
- * the devices are distinct, hipMemcpyPeerAsync fan-out otherwise (a device may be listed more than once: "virtual shards",
- * which is how the path is tested on one GPU).  Frames are delivered merged, in vdl2hip_drain()'s order.
- * EXPERIMENTAL where it uses RCCL: the ncclBroadcast branch has been built and reviewed but has not yet run on hardware (the
- * development boxes have one GPU; tests/test_gpu_parity.py::test_group_over_two_real_gpus covers it where two are visible);
- * VDL2HIP_NO_RCCL=1 selects the peer-copy fan-out, which has.  A failure part-way through a group feed disables the group
- * (every later call returns VDL2HIP_E_DEVICE). ---- */
+ * devices[k]; cfg->device, chan_first and chan_count are ignored/must be 0.  A block handed to vdl2hip_group_feed() is put on
+ * every member in one of two ways (vdl2hip_group_set_exchange(), or VDL2HIP_GROUP_EXCHANGE=allgather|broadcast at create):
+ *   VDL2HIP_GROUP_ALLGATHER (default)  the block is cut into n stripes; member k copies stripe k from `buf` over ITS OWN PCIe
+ *                                      link, then fetches the stripes it lacks from its peers over xGMI, all links at once;
+ *   VDL2HIP_GROUP_BROADCAST            the whole block crosses PCIe once, into devices[0], and is sent from there to the others
+ *                                      (BASELINE's literal form; bound by that one host copy).
+ * Both give every member the same bytes, hence the same frames.  Data moves with hipMemcpyPeerAsync - the path that has run on
+ * hardware; a device may be listed more than once ("virtual shards", which is how the path is tested on one GPU).  RCCL
+ * (ncclAllGather / ncclBroadcast, loaded at run time) is used only with VDL2HIP_USE_RCCL=1 in the environment: those calls have
+ * been built and reviewed but not yet run on a multi-GPU node (tests/test_gpu_parity.py::test_group_over_two_real_gpus covers them
+ * where two GPUs are visible); a failing RCCL call falls back to peer copies.  Frames are delivered merged, in vdl2hip_drain()'s
+ * order.  A failure part-way through a group feed disables the group (every later call returns VDL2HIP_E_DEVICE). ---- */
 typedef struct vdl2hip_group vdl2hip_group;
+enum { VDL2HIP_GROUP_ALLGATHER = 0, VDL2HIP_GROUP_BROADCAST = 1 };
 int  vdl2hip_group_create(const vdl2hip_cfg *cfg, const int32_t *devices, uint32_t ndev, vdl2hip_group **out);
 void vdl2hip_group_destroy(vdl2hip_group *g);
 int  vdl2hip_group_feed(vdl2hip_group *g, const void *buf, size_t nbytes);      /* = process_buf_*(), blocking like vdl2hip_feed() */
@@ -231,7 +241,10 @@ int  vdl2hip_group_counters(vdl2hip_group *g, uint32_t chan, uint64_t out[VDL2HI
 int  vdl2hip_group_avlc_counters(vdl2hip_group *g, uint32_t chan, uint64_t out[VDL2HIP_NUM_AVLC_COUNTERS]);
 uint32_t vdl2hip_group_size(vdl2hip_group *g);
 vdl2hip_ctx *vdl2hip_group_ctx(vdl2hip_group *g, uint32_t member);            /* for the per-context calls above (stats, statsd, ...) */
-int  vdl2hip_group_uses_rccl(vdl2hip_group *g);                                /* 1: ncclBroadcast, 0: peer copies */
+int  vdl2hip_group_uses_rccl(vdl2hip_group *g);                                /* 1: RCCL loaded and in use, 0: peer copies */
+int  vdl2hip_group_set_exchange(vdl2hip_group *g, int form);                   /* VDL2HIP_GROUP_ALLGATHER / _BROADCAST, for the feeds that follow */
+/* what the last feed did: 0 broadcast by peer copies, 1 broadcast by RCCL, 2 all-gather by peer copies, 3 all-gather by RCCL; -1 before the first feed */
+int  vdl2hip_group_exchange(vdl2hip_group *g);
 
 /* Introspection used by the parity tests (host copies of what the kernels use) */
 int  vdl2hip_get_lpf(vdl2hip_ctx *ctx, float A[3], float B[3]);      /* = static A/B of src/demod.c:55 */
