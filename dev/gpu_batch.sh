@@ -15,6 +15,8 @@ for job in "$@"; do
 		timeout 1500 python dev/gpu_variants.py --out $O.variants.jsonl --steps 16 --repeats 3 --variant base --variant r03:@dev/_ref/libvdl2hip_r03.so --variant syncwalk:@/tmp/vdl2hip_exp.so:VDL2HIP_SYNC_ON=walk --variant base2 2>&1 | tee $O.variants.txt ;;
 	k5prof:*) build prof "-DVDL2_K5_PROF"; VDL2HIP_LIB=/tmp/vdl2hip_prof.so timeout 300 python dev/gpu_stage_times.py ${job#k5prof:} 16 2 2>&1 | grep -v amdgpu.ids | tee $O.k5prof_${job#k5prof:}.txt | cut -c1-220 ;;
 	bench) timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O.bench_default.json 2> $O.bench_default.err; echo "bench rc=$?"; tail -c 600 $O.bench_default.err; cut -c1-700 $O.bench_default.json ;;
+	dropin) for w in config4 config2; do timeout 300 python dev/gpu_dropin_rate.py $w 4 2>&1 | grep -v amdgpu.ids | tee -a $O.dropin.txt; done ;;
+	b2) timeout 900 python dev/gpu_variants.py --out $O.variants2.jsonl --steps 16 --repeats 3 --workloads config2,config3 --parts all --variant base --variant r03:@dev/_ref/libvdl2hip_r03.so 2>&1 | tee $O.variants2.txt ;;
 	ablate)
 		build exp "-DVDL2_EXPERIMENTS"
 		timeout 1500 python dev/gpu_variants.py --out $O.ablate.jsonl --steps 16 --repeats 3 --workloads config4,config4_bursty --variant full:@/tmp/vdl2hip_exp.so --variant nowalk:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=walk --variant nonf:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=nf --variant noburst:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=burst --variant noback:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=walk,nf,burst 2>&1 | tee $O.ablate.txt ;;

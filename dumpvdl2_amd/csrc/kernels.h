@@ -626,11 +626,20 @@ __global__ void k_carry(K1Args a, void *carry_out, uint32_t nrem) {
 	}
 }
 
+// the per-feed counters of the output control block start at zero - the record and octet counters behind the shares the burst
+// decoder's wavefronts own from the start (vdl2_core.h: burst_reserve_*); the capacities stay
+__device__ __forceinline__ void reset_out_ctl(OutCtl *ctl, uint32_t k5_waves) {
+	ctl->nbursts = 0; ctl->overflow = 0; ctl->nvalid = 0; ctl->pool_out_used = 0;
+	ctl->nframes = burst_reserve_initial_frames(k5_waves); ctl->pool_used = burst_reserve_initial_pool(k5_waves);
+}
+__global__ void k_reset_ctl(OutCtl *ctl, uint32_t k5_waves) { reset_out_ctl(ctl, k5_waves); }   // for a feed too short to have a front
+
 struct K3Args {
 	const cf32 *y; cf32 *pf; uint64_t *cand; uint64_t *flag; const Tables *tab;
 	int64_t nbase, k1;        // first sample to (re)compute (multiple of 64); one past the last valid sample
 	uint32_t cap, mask;
 	int32_t wpl;              // exact tier: flag words scanned per lane (1..kK3bWordsPerLane)
+	OutCtl *ctl; uint32_t k5_waves;   // the feed's output control block, reset here (the last kernel of the front, so that no copy has to do it)
 };
 
 // K3: got_sync() metric (contiguous ring) + the candidate bitmap, in two tiers and two kernels.
@@ -737,6 +746,7 @@ __device__ __forceinline__ void k3_exact(const cf32 *y, uint32_t mask, int64_t n
 // channeliser wave leaves behind; see k_walk_stitch)
 constexpr int kK3bWordsPerLane = 4;      // at most; fewer when that leaves the chip short of wavefronts (few channels)
 __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
+	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) reset_out_ctl(a.ctl, a.k5_waves);
 	__shared__ float psh[4][4][64 + 3];                  // [wave][quarter][3 + bit]: metric of sample word*64 + bit, entries 0..2 = the three samples before the word
 	__shared__ uint64_t s_need[4][64 * kK3bWordsPerLane];
 	__shared__ uint8_t s_fprev[4][64 * kK3bWordsPerLane];
@@ -823,6 +833,7 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
 // kernel is latency-bound: its arithmetic is a quarter of its run time) and how many lanes have work (a cluster around a preamble
 // is ~13 samples: 13 of 64 lanes busy in the 16-lanes-per-word form, 52 of 64 here).
 __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
+	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) reset_out_ctl(a.ctl, a.k5_waves);
 	__shared__ float psh[4][64 + 3];                     // [wave][3 + bit]: metric of sample word*64 + bit, entries 0..2 = the three samples before the word
 	__shared__ float phs[4][16][kPreamble + 1];          // [wave][sample slot][tap]: exact phases (floats, as the reference keeps them)
 	__shared__ uint8_t items[4][64 + 3];                 // [wave][e]: bit number of the e-th sample to work out (64..66: the three before the word)
@@ -1016,29 +1027,30 @@ __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_finish(K4bArgs a) {
 	nf_finish(&a.nf[c], sc, a.feed[c], a.lpbuf + (size_t)c * a.cap_hist, a.ring + (size_t)c * (a.ring_mask + 1), a.ring_mask, a.cap_hist, shw[wave]);
 }
 
-// Each channel's walker fills its own burst list (no atomics on its critical path); this one-wave kernel turns the
-// per-channel counts into offsets so that K5 can spread all bursts of the feed over its workgroups.
-__global__ __launch_bounds__(64) void k_burst_index(const uint32_t *nb_chan, uint32_t *bbase, int nchan, OutCtl *ctl, uint32_t k5_waves) {
-	const int lane = threadIdx.x;
-	uint32_t carry = 0;
-	for(int c0 = 0; c0 < nchan; c0 += 64) {         // exclusive prefix sum, 64 channels per pass
-		const uint32_t v = c0 + lane < nchan ? nb_chan[c0 + lane] : 0u;
-		uint32_t inc = v;
-		#pragma unroll
-		for(int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if(lane >= d) inc += o; }
-		if(c0 + lane < nchan) bbase[c0 + lane] = carry + inc - v;
-		carry += __shfl(inc, 63);
+// The three passes in one kernel, a wavefront per channel: for short blocks, where there are one or two updates per channel and
+// three launches would cost more than the work (the reference's own block size, dumpvdl2.h:48: 4 000 decimated samples)
+__global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_all(K4bArgs a) {
+	extern __shared__ __align__(16) unsigned char nf_lds[];
+	NfShared *shw = reinterpret_cast<NfShared *>(nf_lds);
+	const int wave = threadIdx.x >> 6, c = blockIdx.x * kNfWaves + wave;
+	if(c >= a.nchan) return;
+	ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask };
+	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
+	NfScratch sc{ a.sc_first + (size_t)c * (a.cap_comb + 1), a.sc_cum + (size_t)c * (a.cap_comb + 1) };
+	nf_prepare(&a.nf[c], lg, sc, a.cap_comb, &a.feed[c], shw[wave]);
+	WAVE_SYNC_GLOBAL();                    // the combined chunk list and the feed record are read back by other lanes
+	const NfFeed fd = a.feed[c];
+	for(int64_t g = 0; fd.u0 + 1 + kNfGroup * g <= fd.u1; g++) {
+		nf_replay_group(v, sc, fd, g, a.lpbuf + (size_t)c * a.cap_hist, a.cap_hist, shw[wave]);
+		WAVE_SYNC();
 	}
-	if(lane == 0) {
-		bbase[nchan] = carry; ctl->nbursts = carry;
-		// the burst decoder's wavefronts each own a first share of the output; the feed-wide counters start behind those shares
-		ctl->nframes = burst_reserve_initial_frames(k5_waves); ctl->pool_used = burst_reserve_initial_pool(k5_waves);
-	}
+	WAVE_SYNC_GLOBAL();                    // ... and so are the replayed mag_lp values
+	nf_finish(&a.nf[c], sc, fd, a.lpbuf + (size_t)c * a.cap_hist, a.ring + (size_t)c * (a.ring_mask + 1), a.ring_mask, a.cap_hist, shw[wave]);
 }
 
 struct K5Args {
 	const cf32 *y; const Tables *tab; unsigned long long *cnt;
-	const Burst *bursts; const uint32_t *bbase; uint32_t cap_bursts_chan; int32_t nchan;
+	const Burst *bursts; const uint32_t *nb_chan; uint32_t cap_bursts_chan; int32_t nchan;   // nb_chan[c]: bursts the walker has listed for channel c (its own list: no atomics on its critical path)
 	OutFrame *frames; uint8_t *pool; OutCtl *ctl; const uint32_t *freq;
 	uint32_t cap, mask;
 };
@@ -1049,7 +1061,7 @@ struct K5Args {
 #define VDL2_K5_WAVES 2
 #endif
 constexpr int kBurstWaves = VDL2_K5_WAVES;
-constexpr int kK5MaxChan = 1024;          // channels whose burst-list offsets a wavefront of the burst decoder keeps in LDS
+constexpr int kK5MaxChan = 1024;          // most channels a receiver may have (vdl2hip_create): a wavefront of the burst decoder keeps all their burst-list offsets in LDS
 // (the LDS is dynamic so that the compiler does not see its size: it would size the register budget by the LDS-limited occupancy
 // and take 169, more than a channeliser wave leaves)
 __global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
@@ -1057,24 +1069,33 @@ __global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
 	BurstShared &sh = reinterpret_cast<BurstShared *>(k5_lds)[threadIdx.x >> 6];
 	uint32_t *bb = reinterpret_cast<uint32_t *>(k5_lds + sizeof(BurstShared) * kBurstWaves) + (size_t)(threadIdx.x >> 6) * (kK5MaxChan + 1);
 	const int lane = threadIdx.x & 63;
-	const uint32_t total = a.bbase[a.nchan];
 	const uint32_t wave_id = blockIdx.x * kBurstWaves + (threadIdx.x >> 6);
+	// Every wavefront turns the per-channel burst counts into offsets for itself, in LDS (one load per lane and 64 channels, one scan):
+	// finding a burst's channel is then a search in LDS, not eight dependent trips to memory per burst - and no kernel of its own has to
+	// run between the walker and this one.
+	uint32_t total = 0;
+	for(int c0 = 0; c0 < a.nchan; c0 += 64) {
+		const uint32_t v = c0 + lane < a.nchan ? a.nb_chan[c0 + lane] : 0u;
+		uint32_t inc = v;
+		#pragma unroll
+		for(int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if(lane >= d) inc += o; }
+		if(c0 + lane < a.nchan) bb[c0 + lane] = total + inc - v;
+		total += __shfl(inc, 63);
+	}
+	if(lane == 0) { bb[a.nchan] = total; if(wave_id == 0) a.ctl->nbursts = total; }
+	WAVE_SYNC();
 	if(wave_id >= total) {
 		// nothing to decode: this wavefront's share of the output (vdl2_core.h: burst_reserve_*) stays empty
 		const uint32_t slot = wave_id * (uint32_t)kResSlots + (uint32_t)lane;
 		if(lane < kResSlots && slot < a.ctl->cap_frames) { OutFrame &f = a.frames[slot]; f.chan = -1; f.len = 0; f.pool_off = 0; f.nf_upd = 0; }
 		return;
 	}
-	// the offsets of the channels' burst lists go to LDS once: finding a burst's channel is then a search in LDS, not eight dependent
-	// trips to memory per burst (more channels than fit: the search falls back to memory for them)
-	const int nstage = a.nchan < kK5MaxChan ? a.nchan : kK5MaxChan;
-	for(int i = lane; i <= nstage; i += 64) bb[i] = a.bbase[i];
 	burst_shared_init(*a.tab, wave_id, a.ctl, sh);
 	for(uint32_t g = wave_id; g < total; g += gridDim.x * kBurstWaves) {
-		int lo = 0, hi = a.nchan;                       // channel c with bbase[c] <= g < bbase[c+1]
-		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if((mid <= nstage ? bb[mid] : a.bbase[mid]) <= g) lo = mid; else hi = mid; }
+		int lo = 0, hi = a.nchan;                       // channel c with bb[c] <= g < bb[c+1]
+		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(bb[mid] <= g) lo = mid; else hi = mid; }
 		const int c = lo;
-		const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - (c <= nstage ? bb[c] : a.bbase[c]))];
+		const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - bb[c])];
 		ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask };
 		decode_burst(b, 0u, *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
 		WAVE_SYNC();
@@ -1087,29 +1108,35 @@ __global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
 // pool that they own (vdl2_core.h: burst_reserve_*), which leaves tombstone records and unused octets behind; a wavefront here takes
 // 64 records at a time, counts the real ones, reserves their places in the delivered arrays with ONE pair of atomics, and writes each
 // finished frame - record and octets - there.  The host copies exactly what is delivered.
-constexpr int kFrameWaves = 4;
-__global__ __launch_bounds__(64 * kFrameWaves) void k_frame_finish(OutFrame *frames, const uint8_t *pool, OutCtl *ctl, const Tables *tab,
+constexpr int kFrameWaves = 4, kFrameChunk = 16;
+// what one small copy brings the host together with the control block (most blocks of a live receiver hold a handful of frames)
+constexpr int kMailFrames = 8, kMailPool = 2048;
+struct OutMail { OutCtl ctl; OutFrame frames[kMailFrames]; uint8_t pool[kMailPool]; };
+__global__ __launch_bounds__(64 * kFrameWaves) void k_frame_finish(OutFrame *frames, const uint8_t *pool, OutMail *mail, const Tables *tab,
 		unsigned long long *acnt, const float *ring, uint32_t ring_mask, OutFrame *frames_out, uint8_t *pool_out) {
 	__shared__ FrameShared shw[kFrameWaves];
 	__shared__ uint32_t s_off[kFrameWaves][64];
+	OutCtl *ctl = &mail->ctl;
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const uint32_t n = ctl->nframes < ctl->cap_frames ? ctl->nframes : ctl->cap_frames;
-	const uint32_t first = (blockIdx.x * kFrameWaves + wave) * 64u;
+	const uint32_t first = (blockIdx.x * kFrameWaves + wave) * (uint32_t)kFrameChunk;
 	if(first >= n) return;
 	FrameShared &sh = shw[wave];
-	frame_shared_init(*tab, sh);
-	for(uint32_t c0 = first; c0 < n; c0 += gridDim.x * kFrameWaves * 64u) {
+	bool init = false;
+	for(uint32_t c0 = first; c0 < n; c0 += gridDim.x * kFrameWaves * (uint32_t)kFrameChunk) {
 		const uint32_t i = c0 + (uint32_t)lane;
-		const bool valid = i < n && frames[i].chan >= 0;            // not a tombstone
+		const bool valid = lane < kFrameChunk && i < n && frames[i].chan >= 0;     // not a tombstone
 		const uint32_t padded = valid ? (frames[i].len + 3u) & ~3u : 0u;
 		const unsigned long long vm = __ballot(valid);
-		uint32_t inc = padded;                                       // inclusive scan of the octet space over the wavefront
+		if(!vm) continue;
+		uint32_t inc = padded;                                       // inclusive scan of the octet space over the chunk
 		#pragma unroll
-		for(int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if(lane >= d) inc += o; }
+		for(int d = 1; d < kFrameChunk; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if(lane >= d) inc += o; }
 		s_off[wave][lane] = inc - padded;
-		const uint32_t tot = __shfl(inc, 63), cnt = (uint32_t)__popcll(vm);
+		const uint32_t tot = __shfl(inc, kFrameChunk - 1), cnt = (uint32_t)__popcll(vm);
 		uint32_t slot0 = 0, off0 = 0;
-		if(lane == 0 && cnt) { slot0 = atomicAdd(&ctl->nvalid, cnt); off0 = atomicAdd(&ctl->pool_out_used, tot); }
+		if(lane == 0) { slot0 = atomicAdd(&ctl->nvalid, cnt); off0 = atomicAdd(&ctl->pool_out_used, tot); }
+		if(!init) { frame_shared_init(*tab, sh); init = true; }      // (while the atomics are under way)
 		slot0 = __shfl(slot0, 0); off0 = __shfl(off0, 0);
 		WAVE_SYNC();
 		uint32_t rank = 0;
@@ -1119,9 +1146,14 @@ __global__ __launch_bounds__(64 * kFrameWaves) void k_frame_finish(OutFrame *fra
 			const int c = f.chan;
 			finish_frame(f, pool, *tab, acnt + (size_t)c * kNumAvlcCounters, ring + (size_t)c * (ring_mask + 1), ring_mask, sh);
 			// deliver: the record with its octets' new place, the octets themselves (finish_frame() has left them in sh.buf)
-			const uint32_t len = f.len, src_off = f.pool_off, dst_off = off0 + s_off[wave][l];
-			if(lane == 0) { OutFrame g = f; g.pool_off = dst_off; frames_out[slot0 + rank] = g; }
-			for(uint32_t k = (uint32_t)lane; k < len; k += 64) pool_out[dst_off + k] = k < (uint32_t)sizeof sh.buf ? sh.buf[k] : pool[src_off + k];
+			const uint32_t len = f.len, src_off = f.pool_off, dst_off = off0 + s_off[wave][l], slot = slot0 + rank;
+			const bool in_mail = slot < (uint32_t)kMailFrames && dst_off + len <= (uint32_t)kMailPool;
+			if(lane == 0) { OutFrame g = f; g.pool_off = dst_off; frames_out[slot] = g; if(slot < (uint32_t)kMailFrames) mail->frames[slot] = g; }
+			for(uint32_t k = (uint32_t)lane; k < len; k += 64) {
+				const uint8_t o = k < (uint32_t)sizeof sh.buf ? sh.buf[k] : pool[src_off + k];
+				pool_out[dst_off + k] = o;
+				if(in_mail) mail->pool[dst_off + k] = o;
+			}
 			WAVE_SYNC();
 		}
 	}

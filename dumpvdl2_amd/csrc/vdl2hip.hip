@@ -43,16 +43,18 @@ constexpr int kSlots = 3;             // feeds in flight (vdl2hip_set_drain_lag:
 }  // namespace
 
 struct OutSlot {
-	Burst *d_bursts = nullptr; uint32_t *d_nbchan = nullptr, *d_bbase = nullptr;
-	OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr; OutCtl *d_ctl = nullptr;
+	Burst *d_bursts = nullptr; uint32_t *d_nbchan = nullptr;
+	OutFrame *d_frames = nullptr; uint8_t *d_pool = nullptr;
+	OutMail *d_mail = nullptr; OutCtl *d_ctl = nullptr;   // control block + the first few delivered frames, contiguous (d_ctl = &d_mail->ctl): one small copy brings both
 	OutFrame *d_frames_out = nullptr; uint8_t *d_pool_out = nullptr;    // what k_frame_finish delivers (no tombstones, no holes): what the host copies
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
-	OutCtl *h_ctl = nullptr;               // pinned
+	OutMail *h_mail = nullptr;             // pinned
 	hipEvent_t done = nullptr, ev_front = nullptr, ev_chan = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
 	bool pending = false, ev_valid = false, fused = false; int ev_level = 0;
 	uint64_t seq = 0;
 	// the burst-rate back end of this feed (K4, K4b, K5, frame finish) still has to be queued: launch_back()
 	bool back_queued = false; int64_t back_D = 0, back_k0 = 0; hipEvent_t ev_k1 = nullptr;
+	unsigned k5_waves = 0; bool small = false;   // wavefronts of this feed's burst decoder; short feed: its whole back end runs on the front stream
 };
 
 struct vdl2hip_ctx {
@@ -96,7 +98,7 @@ struct vdl2hip_ctx {
 	// workgroup segment / K3b words per lane instead of the values chosen from the channel count.
 	int k3b_form = 4;                      // lanes per sample in the exact tier of the sync metric: 4 = k_sync_exact4, 16 = k_sync_exact (test hook "k3b_form")
 	int sync_on = 0; hipStream_t stream_sync = nullptr; int k3b_wpl = 0, tiles_force = 0; bool show_gaps = false; int ablate = 0;
-	OutCtl ctl_template{}; OutCtl *h_ctl_template = nullptr;   // pinned copy: a pageable source would make the per-feed reset a blocking copy
+	OutCtl ctl_template{};                 // the capacities of a feed's output buffers (the counters are reset on the device: reset_out_ctl)
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
 	bool defer_back = false;               // VDL2HIP_BACKEND=deferred: the back end of feed i is queued behind the channeliser of feed i+1 (launch_back)
 	std::vector<uint64_t> statsd_prev;
@@ -160,32 +162,38 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 		}
 	}
 	sl.ev_valid = false;
-	const OutCtl ctl = *sl.h_ctl;
+	const OutCtl ctl = sl.h_mail->ctl;
 	if(ctl.overflow) c->stats.overflow_feeds++;
 	c->stats.bursts += std::min(ctl.nbursts, ctl.cap_bursts);
 	const uint32_t nf = std::min(ctl.nvalid, ctl.cap_frames);
 	if(nf) {
-		// one pinned staging buffer, two asynchronous copies on a stream of their own (the burst stream may already hold the
-		// next feeds' kernels), one wait
 		const uint32_t pool_n = std::min(ctl.pool_out_used, ctl.cap_pool);
-		const size_t fr_bytes = sizeof(OutFrame) * (size_t)nf, need = fr_bytes + pool_n;
-		if(need > c->stage_cap) {
-			if(c->h_stage) (void)hipHostFree(c->h_stage);
-			c->h_stage = nullptr; c->stage_cap = 0;
-			size_t cap = std::max<size_t>(need + need / 2, 1u << 20);
-			HIPCHK(hipHostMalloc((void **)&c->h_stage, cap, hipHostMallocDefault));
-			c->stage_cap = cap;
+		const OutFrame *fr; const uint8_t *po;
+		if(nf <= (uint32_t)kMailFrames && pool_n <= (uint32_t)kMailPool) {
+			// a handful of frames (the usual case for a block of a live receiver): they have come with the control block
+			fr = sl.h_mail->frames; po = sl.h_mail->pool;
+		} else {
+			// one pinned staging buffer, two asynchronous copies on a stream of their own (the burst stream may already hold the
+			// next feeds' kernels), one wait
+			const size_t fr_bytes = sizeof(OutFrame) * (size_t)nf, need = fr_bytes + pool_n;
+			if(need > c->stage_cap) {
+				if(c->h_stage) (void)hipHostFree(c->h_stage);
+				c->h_stage = nullptr; c->stage_cap = 0;
+				size_t cap = std::max<size_t>(need + need / 2, 1u << 20);
+				HIPCHK(hipHostMalloc((void **)&c->h_stage, cap, hipHostMallocDefault));
+				c->stage_cap = cap;
+			}
+			HIPCHK(hipMemcpyAsync(c->h_stage, sl.d_frames_out, fr_bytes, hipMemcpyDeviceToHost, c->stream_out));
+			if(pool_n) HIPCHK(hipMemcpyAsync(c->h_stage + fr_bytes, sl.d_pool_out, pool_n, hipMemcpyDeviceToHost, c->stream_out));
+			HIPCHK(hipStreamSynchronize(c->stream_out));
+			fr = reinterpret_cast<const OutFrame *>(c->h_stage); po = c->h_stage + fr_bytes;
 		}
-		HIPCHK(hipMemcpyAsync(c->h_stage, sl.d_frames_out, fr_bytes, hipMemcpyDeviceToHost, c->stream_out));
-		if(pool_n) HIPCHK(hipMemcpyAsync(c->h_stage + fr_bytes, sl.d_pool_out, pool_n, hipMemcpyDeviceToHost, c->stream_out));
-		HIPCHK(hipStreamSynchronize(c->stream_out));
-		const OutFrame *fr = reinterpret_cast<const OutFrame *>(c->h_stage);
-		auto pool = std::make_shared<std::vector<uint8_t>>(c->h_stage + fr_bytes, c->h_stage + fr_bytes + pool_n);
+		auto pool = std::make_shared<std::vector<uint8_t>>(po, po + pool_n);
 		// frames of one feed are sorted when they are drained, so that feeds can be appended to the queue in order
 		c->queue.reserve(c->queue.size() + nf);
 		for(uint32_t i = 0; i < nf; i++) {
-			if(fr[i].chan < 0 || fr[i].chan >= c->C) continue;           // a slot reserved past the octet pool's end (overflow): decode_burst() left a tombstone
-			c->stats.frames++;                                           // frames the decoder produced (before the optional AVLC filter), tombstones not counted
+			if(fr[i].chan < 0 || fr[i].chan >= c->C) continue;
+			c->stats.frames++;                                           // frames the decoder produced (before the optional AVLC filter)
 			if(!c->avlc_filter || fr[i].avlc_status == AVLC_OK) c->queue.push_back(HostFrame{ fr[i], pool });
 		}
 	}
@@ -294,7 +302,10 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 	}
 	if(D > 0) {
 		const int64_t k1 = c->k_total + D, nbase = c->k_total & ~63ll;
-		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1 };
+		// wavefronts of this feed's burst decoder: each owns kResSlots frame records of the output from the start, so a short block gets few
+		sl.k5_waves = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(16, (D * (int64_t)c->C) >> 14));
+		sl.k5_waves = (sl.k5_waves + kBurstWaves - 1) / kBurstWaves * kBurstWaves;
+		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves };
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
 		// on the front stream than a separate hipEventRecord.  (VDL2HIP_SYNC_ON=walk puts the exact tier in front of the walk on
 		// the walk stream, VDL2HIP_SYNC_ON=own both sync kernels on a stream of their own, so that the front stream goes on
@@ -338,19 +349,29 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 // channeliser workgroup off its CU for as long as it lives).
 static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	const int64_t D = sl.back_D, k0 = sl.back_k0;
-	hipStream_t sb_ = c->stream_back, sn_ = c->stream_nf, s5_ = c->stream_burst;
+	// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
+	int nseg = (int)std::min<int64_t>(c->seg_max, D / c->seg_min);
+	// A short feed (the reference's own 320 000-byte blocks: 4 000 decimated samples) is a chain of kernels that each run for
+	// microseconds: its whole back end goes onto the FRONT stream, behind its own sync kernels - no event hand-offs between streams -
+	// with the three noise-floor passes as one kernel.  Whoever follows on the front stream is then behind it anyway.
+	const bool small = D > 0 && nseg < 2 && !c->defer_back;
+	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst;
 	hipEvent_t *ev = sl.ev;
 	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
-	sl.back_queued = false;
-	HIPCHK(hipMemcpyAsync(sl.d_ctl, c->h_ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice, sb_));
-	HIPCHK(hipStreamWaitEvent(sb_, sl.ev_front, 0));
-	if(gate) HIPCHK(hipStreamWaitEvent(sb_, gate, 0));
+	sl.back_queued = false; sl.small = small;
+	if(small) {
+		// the walker, the noise floor and the burst list carry state from feed to feed: wait for a predecessor whose back end is on the other streams
+		OutSlot &pv = c->slot[(sl.seq + kSlots - 1) % kSlots];
+		if(sl.seq > 0 && pv.pending && !pv.small && !pv.back_queued) HIPCHK(hipStreamWaitEvent(sb_, pv.done, 0));
+	} else {
+		HIPCHK(hipStreamWaitEvent(sb_, sl.ev_front, 0));
+		if(gate) HIPCHK(hipStreamWaitEvent(sb_, gate, 0));
+	}
+	if(D <= 0) hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(1), 0, sb_, sl.d_ctl, 0u);     // (a feed with a front has had it reset by its last sync kernel)
 	if(D > 0) {
 		const int64_t k1 = k0 + D;
 		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr };
-		// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
-		int nseg = (int)std::min<int64_t>(c->seg_max, D / c->seg_min);
 		if(nseg >= 2) {
 			const int64_t seglen = (D + nseg - 1) / nseg;
 			nseg = (int)((D + seglen - 1) / seglen);
@@ -363,32 +384,38 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			LAUNCH_EV(k_walk, dim3((unsigned)c->C), dim3(64), sb_, EV(6), EV(7), k4);
 		}
 	}
-	HIPCHK(hipEventRecord(sl.ev_walk, sb_));
-	HIPCHK(hipStreamWaitEvent(sn_, sl.ev_walk, 0));
-	HIPCHK(hipStreamWaitEvent(s5_, sl.ev_walk, 0));
+	if(!small) {
+		HIPCHK(hipEventRecord(sl.ev_walk, sb_));
+		HIPCHK(hipStreamWaitEvent(sn_, sl.ev_walk, 0));
+		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_walk, 0));
+	}
 	if(D > 0) {
 		K4bArgs k4b{ c->d_y, c->d_nf, sl.d_log, sl.d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfring, c->nf_ring - 1,
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist, c->C };
-		hipExtLaunchKernelGGL(k_nf_prepare, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), (unsigned)(sizeof(NfShared) * kNfWaves), sn_, EV(8), (hipEvent_t) nullptr, 0, k4b);
-		const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup * kNfWaves - 1) / (kNfGroup * kNfWaves));   // workgroups per channel
-		if(!(c->ablate & 2))      // (experiment builds: what does a stage cost the front by running beside it?)
-		hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64 * kNfWaves), (unsigned)(sizeof(NfShared) * kNfWaves), sn_, k4b);
-		hipExtLaunchKernelGGL(k_nf_finish, dim3((unsigned)((c->C + kNfWaves - 1) / kNfWaves)), dim3(64 * kNfWaves), (unsigned)(sizeof(NfShared) * kNfWaves), sn_, (hipEvent_t) nullptr, EV(9), 0, k4b);
-		HIPCHK(hipEventRecord(sl.ev_nf, sn_));
-		// wavefronts of the burst decoder: each owns kResSlots frame records of the output from the start (unused ones are delivered as
-		// tombstones), so a short block gets few of them
-		unsigned k5_waves = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(16, (D * (int64_t)c->C) >> 14));
-		k5_waves = (k5_waves + kBurstWaves - 1) / kBurstWaves * kBurstWaves;
-		hipLaunchKernelGGL(k_burst_index, dim3(1), dim3(64), 0, s5_, (const uint32_t *)sl.d_nbchan, sl.d_bbase, c->C, sl.d_ctl, (uint32_t)k5_waves);
-		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_bbase, c->cap_bursts_chan, c->C,
+		const unsigned nf_lds = (unsigned)(sizeof(NfShared) * kNfWaves), nf_grid = (unsigned)((c->C + kNfWaves - 1) / kNfWaves);
+		if(small) {
+			if(!(c->ablate & 2))
+			hipExtLaunchKernelGGL(k_nf_all, dim3(nf_grid), dim3(64 * kNfWaves), nf_lds, sn_, EV(8), EV(9), 0, k4b);
+		} else {
+			hipExtLaunchKernelGGL(k_nf_prepare, dim3(nf_grid), dim3(64 * kNfWaves), nf_lds, sn_, EV(8), (hipEvent_t) nullptr, 0, k4b);
+			const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup * kNfWaves - 1) / (kNfGroup * kNfWaves));   // workgroups per channel
+			if(!(c->ablate & 2))      // (experiment builds: what does a stage cost the front by running beside it?)
+			hipLaunchKernelGGL(k_nf_replay, dim3(ngrp, (unsigned)c->C), dim3(64 * kNfWaves), nf_lds, sn_, k4b);
+			hipExtLaunchKernelGGL(k_nf_finish, dim3(nf_grid), dim3(64 * kNfWaves), nf_lds, sn_, (hipEvent_t) nullptr, EV(9), 0, k4b);
+			HIPCHK(hipEventRecord(sl.ev_nf, sn_));
+		}
+		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
-		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: bbase[0] = 0 bursts to decode)
-		hipExtLaunchKernelGGL(k_burst, dim3(k5_waves / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
-		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
-		hipLaunchKernelGGL(k_frame_finish, dim3(1024 / kFrameWaves), dim3(64 * kFrameWaves), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, sl.d_ctl, (const Tables *)c->d_tab,
+		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: no bursts to decode)
+		hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
+		if(!small) HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
+		// record chunks of kFrameChunk: enough workgroups for the records the burst decoder's wavefronts own, at most 256
+		const unsigned ff_grid = std::min(256u, (sl.k5_waves * (unsigned)kResSlots * 2 / kFrameChunk + kFrameWaves - 1) / kFrameWaves);
+		hipLaunchKernelGGL(k_frame_finish, dim3(ff_grid), dim3(64 * kFrameWaves), 0, s5_, sl.d_frames, (const uint8_t *)sl.d_pool, sl.d_mail, (const Tables *)c->d_tab,
 		                   c->d_acnt, (const float *)c->d_nfring, c->nf_ring - 1, sl.d_frames_out, sl.d_pool_out);
 	}
-	HIPCHK(hipMemcpyAsync(sl.h_ctl, sl.d_ctl, sizeof(OutCtl), hipMemcpyDeviceToHost, s5_));
+	// the control block and the first few delivered frames in one copy (collect_slot)
+	HIPCHK(hipMemcpyAsync(sl.h_mail, sl.d_mail, sizeof(OutMail), hipMemcpyDeviceToHost, s5_));
 	HIPCHK(hipEventRecord(sl.done, s5_));
 	HIPCHK(hipGetLastError());
 	return VDL2HIP_OK;
@@ -433,9 +460,9 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
 	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
-		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_bbase, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_ctl, sl.d_log, sl.d_nlog };
+		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog };
 		for(void *p : q) if(p) (void)hipFree(p);
-		if(sl.h_ctl) (void)hipHostFree(sl.h_ctl);
+		if(sl.h_mail) (void)hipHostFree(sl.h_mail);
 		if(sl.done) (void)hipEventDestroy(sl.done);
 		if(sl.ev_walk) (void)hipEventDestroy(sl.ev_walk);
 		if(sl.ev_front) (void)hipEventDestroy(sl.ev_front);
@@ -444,7 +471,6 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 		if(sl.ev_k1) (void)hipEventDestroy(sl.ev_k1);
 		for(int i = 0; i < kNumEv; i++) if(sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
 	}
-	if(c->h_ctl_template) (void)hipHostFree(c->h_ctl_template);
 	if(c->h_stage) (void)hipHostFree(c->h_stage);
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
 	for(auto &e : c->cold.ev) if(e) (void)hipEventDestroy(e);
@@ -464,7 +490,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	if(cfg->oversample == 0 || cfg->oversample > (uint32_t)kMaxOversample) return VDL2HIP_E_INVAL;
 	if(cfg->sample_fmt != VDL2HIP_FMT_U8 && cfg->sample_fmt != VDL2HIP_FMT_S16LE) return VDL2HIP_E_INVAL;
 	uint32_t first = cfg->chan_first, count = cfg->chan_count ? cfg->chan_count : cfg->nchan - first;
-	if(first >= cfg->nchan || first + count > cfg->nchan) return VDL2HIP_E_INVAL;
+	if(first >= cfg->nchan || first + count > cfg->nchan || count > (uint32_t)kK5MaxChan) return VDL2HIP_E_INVAL;
 	*out = nullptr;
 	int ndev = 0;
 	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -591,16 +617,17 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_ALLOC(c->d_segstats, (size_t)count * 2 * 4);
 		DEV_CHK(hipMemset(c->d_segstats, 0, (size_t)count * 2 * 4));
 	}
-	DEV_CHK(hipHostMalloc((void **)&c->h_ctl_template, sizeof(OutCtl), hipHostMallocDefault));
-	*c->h_ctl_template = c->ctl_template;
 	for(auto &sl : c->slot) {
-		DEV_ALLOC(sl.d_bursts, cap_b * sizeof(Burst)); DEV_ALLOC(sl.d_nbchan, count * 4); DEV_ALLOC(sl.d_bbase, (count + 1) * 4);
-		DEV_ALLOC(sl.d_frames, cap_f * sizeof(OutFrame)); DEV_ALLOC(sl.d_pool, cap_p); DEV_ALLOC(sl.d_ctl, sizeof(OutCtl));
+		DEV_ALLOC(sl.d_bursts, cap_b * sizeof(Burst)); DEV_ALLOC(sl.d_nbchan, count * 4);
+		DEV_ALLOC(sl.d_frames, cap_f * sizeof(OutFrame)); DEV_ALLOC(sl.d_pool, cap_p); DEV_ALLOC(sl.d_mail, sizeof(OutMail));
+		sl.d_ctl = &sl.d_mail->ctl;
+		DEV_CHK(hipMemset(sl.d_mail, 0, sizeof(OutMail)));
+		DEV_CHK(hipMemcpy(sl.d_ctl, &c->ctl_template, sizeof(OutCtl), hipMemcpyHostToDevice));
 		DEV_ALLOC(sl.d_frames_out, cap_f * sizeof(OutFrame)); DEV_ALLOC(sl.d_pool_out, cap_p);
 		DEV_ALLOC(sl.d_log, (size_t)count * c->cap_log * sizeof(EvalChunk)); DEV_ALLOC(sl.d_nlog, count * 4);
 		DEV_CHK(hipMemset(sl.d_nlog, 0, count * 4));
-		DEV_CHK(hipHostMalloc((void **)&sl.h_ctl, sizeof(OutCtl), hipHostMallocDefault));
-		memset(sl.h_ctl, 0, sizeof(OutCtl));
+		DEV_CHK(hipHostMalloc((void **)&sl.h_mail, sizeof(OutMail), hipHostMallocDefault));
+		memset(sl.h_mail, 0, sizeof(OutMail));
 		DEV_CHK(hipMemset(sl.d_nbchan, 0, count * 4));
 	}
 
