@@ -200,6 +200,9 @@ class Case:
         out.update({"dt": dt, "frames": nframes, "k1_ms": k1_ms, "k1_chan_samples": k1_cs,
                     # channeliser workgroups that stopped waiting for their predecessor and recomputed its state (0 with one process per GPU)
                     "lookback_fallbacks": s1["front_sync_timeouts"] - s0["front_sync_timeouts"],
+                    # blocks fed to an idle receiver from page-locked memory (the first of a host-fed region): channelised in pieces behind the
+                    # pieces of their copy; their channeliser launches are not part of k1_ms
+                    "cold_start_feeds": s1.get("cold_start_feeds", 0) - s0.get("cold_start_feeds", 0),
                     "seg_adopted": (s1["seg_adopted"] - s0["seg_adopted"]) / steps, "seg_walked": (s1["seg_walked"] - s0["seg_walked"]) / steps})
         return out
 
@@ -236,15 +239,9 @@ def roofline_of(t, traffic):
     out = {"bound": "valu", "kernel": "k_chanfir", "achieved": round(tf, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(tf / VALU_PEAK_TFLOPS, 4), "traffic": tr_bytes,
            "flop_per_chan_sample": FLOP_PER_CHAN_SAMPLE, "avg_launch_ms": round(k1_ms, 5), "chan_samples_per_launch": cs,
-           "issue_rate_ceiling": {"v_fma_f32": 126.0, "v_pk_fma_f32": 140.0, "unit": "TFLOP/s", "shader_clock_GHz": 2.3,
-                                  "note": "what back-to-back independent FMAs reach with the chip at its working clock (dev/gpu_ubench_clock.hip, "
-                                          "profiles/r03_ubench_clock.txt, r03_clocks_under_load.txt): 2.4 / 4.4 clocks per wave instruction"},
-           "co_bound": {"pipe": "LDS gather", "clocks_per_random_16B_wave_gather_per_CU": 10.7,
-                        "clocks_per_chan_sample_wave_per_SIMD": {"lds_gather_rate": 43, "valu_issue_cost_of_the_sample_loop": 31, "measured_sample_loop": 45},
-                        "share_of_a_tile": {"sample_loop": 0.77, "scan_outputs_carry": 0.16, "staging": 0.05, "barriers": 0.02},
-                        "note": "k_chanfir needs one LUT gather (ds_read_b128 at 64 unrelated entries) per channel-sample; the CU's one LDS pipe serves four "
-                                "SIMDs, so the sample loop runs at the gather rate with the VALU ~70 % busy (profiles/r03_ubench_clock.txt, "
-                                "r03_k1_phase_probe.txt; constants from those files, not measured in this run)"},
+           # the rates that bound the sample loop, measured in THIS run right after the timed regions (measured_rates(): the library's
+           # vdl2hip_debug_ubench micro-kernels, chip at its working clock); None if the library does not export the hook
+           "issue_rate_ceiling": None, "co_bound": None,
            "hbm_algorithmic": {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                                "bytes_per_chan_sample": ALGO_BYTES, "bytes_per_launch": cs * ALGO_BYTES,
                                "note": "SURVEY 8.5's accounting: the cs16 block charged once per channel (the reference's access pattern) + one "
@@ -256,6 +253,30 @@ def roofline_of(t, traffic):
                                "frac": round(tr_bytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic_over_algorithmic": round(tr_bytes / (cs * ALGO_BYTES), 4)}
         out["traffic_source"] = traffic["source"]
     return out
+
+
+def measured_rates(vh, device):
+    """issue_rate_ceiling / co_bound of the roofline line from micro-kernels run in this process (csrc/ubench.inc, ~0.1 s): back-to-back
+    FMAs, a random 16-byte LDS wave-gather, and the channeliser's sample loop in miniature with and without its gather"""
+    import ctypes as C
+    L = vh.load_library()
+    if not hasattr(L, "vdl2hip_debug_ubench"):
+        return None, None
+    a = (C.c_double * 8)()
+    L.vdl2hip_debug_ubench.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    if L.vdl2hip_debug_ubench(device, a) != 0:
+        return None, None
+    ghz = a[2] / 1e3
+    issue = {"v_fma_f32": round(a[0], 1), "v_pk_fma_f32": round(a[1], 1), "unit": "TFLOP/s", "shader_clock_GHz": round(ghz, 3),
+             "note": "back-to-back independent FMAs, 4 waves per SIMD, measured in this run (vdl2hip_debug_ubench, " + f"{a[7]:.0f} ms)"}
+    co = {"pipe": "LDS gather", "clocks_per_random_16B_wave_gather_per_CU": round(a[3], 2),
+          # one gather per channel-sample and wavefront, four SIMDs per LDS pipe: what the pipe allows each SIMD
+          "lds_bound_clocks_per_chan_sample_wave_per_SIMD": round(4 * a[3], 1),
+          "compute_units": int(a[6]),
+          "note": "k_chanfir needs one LUT gather (ds_read_b128 at 64 unrelated entries) per channel-sample and wavefront; the CU's one LDS pipe serves "
+                  "four SIMDs.  Both figures measured in this run (vdl2hip_debug_ubench); `k_chanfir_clocks_per_chan_sample_wave_per_SIMD` is the "
+                  "kernel's own time in the same unit (all of it: sample loop, wave scan, staging, look-back)"}
+    return issue, co
 
 
 def pmc_traffic(workload, case):
@@ -456,6 +477,36 @@ def group_from_c(case, args, torch, local, members=8):
     return out
 
 
+def dropin_block_rate(case, torch, seconds=2.0, block=320000):
+    """The drop-in way of using the library (csrc/dropin.c under an unmodified dumpvdl2 --iq-file): the reference's own block size
+    (FILE_BUFSIZE = 320 000 bytes = 80 000 samples, dumpvdl2.h:48) from pageable memory, one vdl2hip_feed() + drain per block.  Lag 0 is
+    the blocking process_buf_*() semantics (every frame of a block delivered before the next block is handed over); lag 1 is what the
+    adapter's split gives a file reader (the first channel's thread delivers block i while main() reads and hands over block i+1)."""
+    vh = case.vdl2hip
+    cfg = case.cfg
+    raw = case.iq.view(np.uint8)[: int(seconds * 2100000) * 4]
+    nblk = (raw.size + block - 1) // block
+    out = {"workload": f"dropin_320kB_block: {case.C} channels, {seconds:g} s of the same capture in {nblk} blocks of {block} bytes from pageable memory, "
+                       f"one feed + drain per block", "block_bytes": block, "blocks": nblk}
+    for lag in (0, 1):
+        rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, device=case.local, max_block_bytes=block)
+        rx.set_drain_lag(lag)
+        for k in range(0, 20 * block, block):          # warm
+            rx.feed(raw[k:k + block]); rx.drain_packed()
+        rx.set_drain_lag(0); rx.drain_packed(); rx.set_drain_lag(lag)
+        n = 0
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(0, raw.size, block):
+            rx.feed(raw[k:k + block])
+            n += rx.drain_packed()[0]
+        rx.set_drain_lag(0); n += rx.drain_packed()[0]
+        dt = time.perf_counter() - t0
+        rx.close()
+        out[f"lag{lag}"] = {"ms_per_block": round(dt / nblk * 1e3, 4), "value": round(raw.size / 4 / dt / 1e6, 2), "x_real_time": round(raw.size / 4 / dt / 2.1e6, 1), "frames": n}
+    out["note"] = "MS/s of IQ with all channels decoded; the 16 s blocks of the headline are what the throughput metric wants, this is what a live receiver or an unmodified --iq-file run sees"
+    return out
+
+
 def h2d_ms(torch, host_pinned, device, iters=3):
     """one plain H2D copy of the block from page-locked memory: this rank's PCIe link, nothing else running"""
     dst = torch.empty_like(host_pinned, device=device)
@@ -587,6 +638,7 @@ def main():
     t_hbm = case.timed(f_hbm, args.steps, dist, args.repeats)
     stage_ms_hbm = case.stage_times(f_hbm)
     del f_hbm
+    measured = measured_rates(vdl2hip, local) if rank == 0 else (None, None)     # right behind the timed regions: the clock is up
 
     # ---- N > 1: the other exchange form, demodulating, beside the chosen one ----
     by_exchange = None
@@ -671,6 +723,10 @@ def main():
 
     if world == 1 and not args.no_secondary and args.workload == "config4":
         from oracle import pyoracle as po
+        try:
+            secondary.append(dropin_block_rate(case, torch))
+        except Exception as e:  # noqa: BLE001
+            secondary.append({"workload": "dropin_320kB_block", "error": f"{type(e).__name__}: {str(e)[:300]}"})
         for name, oracle_check in (("config3", True), ("config2", False), ("config4_bursty", True)):
             # a failure in a SECONDARY configuration is reported in its entry, it does not take the headline line with it
             c2 = None
@@ -721,11 +777,17 @@ def main():
                        "stage_ms_per_step_hbm_resident": stage_ms_hbm,
                        "walk_segments_per_step": {"adopted": t_host["seg_adopted"], "walked_sequentially": t_host["seg_walked"]},
                        "lookback_fallbacks_per_step": t_host["lookback_fallbacks"] / args.steps,
+                       "cold_start_feeds_in_the_timed_region": t_host["cold_start_feeds"],
                        "verified": verified,
                        "synth_s": round(case.t_synth, 1),
                        "secondary": secondary},
             "roofline": roofline_of(t_hbm, pmc_traffic(args.workload, case)),
         }
+        out["roofline"]["issue_rate_ceiling"], out["roofline"]["co_bound"] = measured
+        if measured[0] and measured[1]:
+            rl = out["roofline"]
+            items = rl["chan_samples_per_launch"] / 64.0 / (4 * measured[1]["compute_units"])          # wavefront-items per SIMD and launch
+            rl["co_bound"]["k_chanfir_clocks_per_chan_sample_wave_per_SIMD"] = round(rl["avg_launch_ms"] * 1e-3 * measured[0]["shader_clock_GHz"] * 1e9 / items, 1)
         out["roofline"]["measured_in"] = "the HBM-resident timed region (HIP start/stop events attached to each k_chanfir launch; median of the repeats)"
         out["roofline"]["avg_launch_ms_host_fed"] = round(t_host["k1_ms"], 5)
         if projected is not None:

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvdl2hip.so")
-SOURCES = ["vdl2hip.hip", "group.inc", "kernels.h", "vdl2_core.h", "design.h", "tables.h"]
+SOURCES = ["vdl2hip.hip", "group.inc", "ubench.inc", "kernels.h", "vdl2_core.h", "design.h", "tables.h"]
 # -ffp-contract=off: the walker/burst code must keep the reference's mul/add sequence;
 # the channeliser asks for FMAs explicitly where it wants them.
 # -fno-slp-vectorize: packed FP32 issues at half rate on CDNA4, so a v_pk_add the SLP vectoriser glues together from two scalar

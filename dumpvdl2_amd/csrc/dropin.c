@@ -5,10 +5,16 @@
  * Threading contract kept from the reference (src/dumpvdl2.c:117-135, src/demod.c:300-301,
  * 342-346,360-364): main() creates two barriers of count N+1 and N threads running
  * process_samples(); the producer calls process_buf_*() per block and, after the last block,
- * waits once more on demods_ready (src/dumpvdl2.c:1170).  Here the N threads are parked on the
- * barriers and the producer thread does the work between them: feed the block to the GPU, drain
- * the frames of that block and push them.  Everything has been pushed when process_buf_*()
- * returns, hence also before main()'s final barrier wait and avlc_decoder_shutdown().
+ * waits once more on demods_ready (src/dumpvdl2.c:1170).  The work is placed where the reference
+ * places it: process_buf_*() - between the two barriers, on the producer's thread - hands the
+ * block to the GPU (the reference converts it to floats there) and returns; the FIRST channel's
+ * process_samples() thread then does what the reference's demodulator threads do in that slot,
+ * after samples_ready and before it comes back to demods_ready: it waits for the block's frames
+ * and pushes them, while the producer is already reading the next block.  The other N-1 threads
+ * only take part in the barriers.  So the device works on block i while main() reads block i+1,
+ * every frame of a block has been pushed before process_buf_*() of the next block gets past
+ * demods_ready, and main()'s final demods_ready wait returns only when the last block's frames
+ * are out - before avlc_decoder_shutdown(), as in the reference.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -16,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <sys/time.h>
 #ifdef VDL2HIP_IN_TREE
 #include "dumpvdl2.h"
 #include "output-common.h"
@@ -28,6 +35,7 @@ extern pthread_barrier_t demods_ready, samples_ready;   /* src/dumpvdl2.c:66-67 
 
 #define MAX_CHANNELS 1024
 #define BLOCK_MAX (4u << 20)
+#define ARRIVALS 256
 
 float *sbuf;                       /* callers allocate it (src/dumpvdl2.c:342,346; src/rtl.c:194); never read here */
 
@@ -38,6 +46,11 @@ static struct {
 	vdl2hip_group *grp;            /* one member per GPU listed in VDL2HIP_DEVICES (default: device 0) */
 	uint64_t overflow_seen;
 	int fmt;
+	void *first_chan;              /* the channel whose process_samples() thread delivers the frames */
+	uint64_t samples_total;        /* complex input samples handed over so far */
+	/* when each of the last blocks arrived and which decimated samples (105 kS/s clock) it begins with: burst_timestamp */
+	struct { int64_t k_first; struct timeval tv; } arrival[ARRIVALS];
+	uint64_t nblocks;
 #ifndef VDL2HIP_IN_TREE
 	float max_ppm;
 	char *station_id;
@@ -66,10 +79,11 @@ vdl2_channel_t *vdl2_channel_init(uint32_t centerfreq, uint32_t freq, uint32_t s
 #ifdef VDL2HIP_IN_TREE
 	vdl2_channel_t *v = must_calloc(1, sizeof(vdl2_channel_t));
 	v->freq = freq; v->oversample = oversample;
-	return v;
 #else
-	return (vdl2_channel_t *)must_calloc(1, 4096);
+	vdl2_channel_t *v = (vdl2_channel_t *)must_calloc(1, 4096);
 #endif
+	if(!G.first_chan) G.first_chan = v;
+	return v;
 }
 
 /* the tables and coefficients these set up are derived inside vdl2hip_create() */
@@ -79,13 +93,25 @@ void input_lpf_init(uint32_t sample_rate) { G.source_rate = sample_rate; }
 void process_buf_uchar_init(void) {}
 int rs_init(void) { return 0; }
 
+static void deliver_block(void);
+
 void *process_samples(void *arg) {
-	(void)arg;
+	const int delivers = arg == G.first_chan;
 	for(;;) {                                  /* same two waits as src/demod.c:300-301 */
 		pthread_barrier_wait(&demods_ready);
 		pthread_barrier_wait(&samples_ready);
+		if(delivers) deliver_block();          /* the slot in which the reference's threads demodulate the block */
 	}
 	return NULL;
+}
+
+static struct timeval arrival_of(int64_t sync_sample) {
+	uint64_t n = G.nblocks < ARRIVALS ? G.nblocks : ARRIVALS;
+	for(uint64_t i = 0; i < n; i++) {          /* newest first */
+		uint64_t j = (G.nblocks - 1 - i) % ARRIVALS;
+		if(G.arrival[j].k_first <= sync_sample || i + 1 == n) return G.arrival[j].tv;
+	}
+	struct timeval now; gettimeofday(&now, NULL); return now;
 }
 
 static void push_frame(const vdl2hip_frame *f, void *user) {
@@ -98,7 +124,9 @@ static void push_frame(const vdl2hip_frame *f, void *user) {
 	m->frame_pwr_dbfs = f->frame_pwr_dbfs;
 	m->nf_pwr_dbfs = f->nf_pwr_dbfs;
 	m->ppm_error = f->ppm_error;
-	gettimeofday(&m->burst_timestamp, NULL);    /* the reference stamps wall-clock at sync (src/demod.c:246) */
+	/* the reference stamps the wall clock when it finds the sync (src/demod.c:246), i.e. while it works through the block the
+	 * burst's preamble lies in, right after that block arrived: the arrival time of that block */
+	m->burst_timestamp = arrival_of(f->sync_sample);
 	m->datalen_octets = f->datalen_octets;
 	m->synd_weight = f->synd_weight;
 	m->num_fec_corrections = f->num_fec_corrections;
@@ -147,11 +175,21 @@ static void feed_block(unsigned char *buf, uint32_t len, int fmt) {
 		if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_group_create: %s\n", vdl2hip_strerror(r)); _exit(2); }
 		G.fmt = fmt;
 	}
+	uint64_t slot = G.nblocks % ARRIVALS;
+	G.arrival[slot].k_first = (int64_t)(G.samples_total / G.oversample);
+	gettimeofday(&G.arrival[slot].tv, NULL);
+	G.nblocks++;
+	G.samples_total += len / (fmt == VDL2HIP_FMT_S16LE ? 4u : 2u);
 	for(uint32_t off = 0; off < len; off += BLOCK_MAX) {
 		uint32_t n = len - off < BLOCK_MAX ? len - off : BLOCK_MAX;
-		int r = vdl2hip_group_feed(G.grp, buf + off, n);
+		int r = vdl2hip_group_feed(G.grp, buf + off, n);     /* returns when the copy out of buf is complete: buf is only ours during the call */
 		if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_group_feed: %s\n", vdl2hip_strerror(r)); _exit(2); }
 	}
+}
+
+/* wait for the frames of the block(s) handed over and push them (first channel's thread, between samples_ready and demods_ready) */
+static void deliver_block(void) {
+	if(!G.grp) return;
 	int r = vdl2hip_group_drain(G.grp, push_frame, NULL);
 	if(r < 0) { fprintf(stderr, "vdl2hip_group_drain: %s\n", vdl2hip_strerror(r)); _exit(2); }
 	/* the drain calls only count device-side buffer overflows (bursts or frames dropped): say so once per occurrence */

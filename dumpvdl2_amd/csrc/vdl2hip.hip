@@ -54,6 +54,7 @@ struct OutSlot {
 	uint64_t seq = 0;
 	// the burst-rate back end of this feed (K4, K4b, K5, frame finish) still has to be queued: launch_back()
 	bool back_queued = false; int64_t back_D = 0, back_k0 = 0; hipEvent_t ev_k1 = nullptr;
+	bool k1_timed = false;                 // the channeliser launch of this feed carries start/stop events (not on a cold-start feed: its pieces wait for copies in between)
 	unsigned k5_waves = 0; bool small = false;   // wavefronts of this feed's burst decoder; short feed: its whole back end runs on the front stream
 };
 
@@ -145,7 +146,7 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 	if(c->profiling && sl.ev_valid) {
 		hipEvent_t *ev = sl.ev;
 		float ms = 0.f;
-		if(hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) c->stats.chanfir_ms += ms;
+		if(sl.k1_timed && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) { c->stats.chanfir_ms += ms; c->stats.chanfir_launches++; }
 		if(sl.ev_level >= 2) {
 		if(!sl.fused && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.phase_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[4], sl.ev_front) == hipSuccess) c->stats.sync_ms += ms;
@@ -253,7 +254,11 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 	sl.ev_valid = false;
 	if(D > 0) {
 		const size_t lds = (size_t)c->run * c->os * 65 * sizeof(float2);   // the tile; the tables are static LDS
-		hipEvent_t e0 = prof ? ev[0] : nullptr, e1 = prof ? ev[1] : nullptr;
+		// (a cold-start feed launches the channeliser in pieces that wait for the pieces of the copy: not a kernel duration, not timed)
+		const bool cold = in_parts && c->cold.n > 1;
+		if(cold) c->stats.cold_start_feeds++;
+		sl.k1_timed = prof && !cold;
+		hipEvent_t e0 = sl.k1_timed ? ev[0] : nullptr, e1 = sl.k1_timed ? ev[1] : nullptr;
 		auto launch = [&](int seg0, int seg1, hipEvent_t s_ev, hipEvent_t p_ev) {
 			a.seg0 = seg0; a.seg1 = seg1;
 			if(c->specialised) {
@@ -326,7 +331,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		else LAUNCH_EV(k_sync_exact4, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
 	}
 	if(D <= 0) HIPCHK(hipEventRecord(sl.ev_front, st));
-	if(D > 0) { sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0; c->stats.chanfir_launches++; c->stats.chan_samples += (uint64_t)D * c->os * c->C; }
+	if(D > 0) { sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0; if(sl.k1_timed) c->stats.chan_samples += (uint64_t)D * c->os * c->C; } else sl.k1_timed = false;
 	sl.back_queued = true; sl.back_D = D; sl.back_k0 = c->k_total;
 	sl.pending = true; sl.seq = c->feed_no++;
 	c->k_total += D; c->n_total += nnew;
@@ -1002,3 +1007,4 @@ int vdl2hip_read_decimated(vdl2hip_ctx *c, uint32_t chan, int64_t first, float *
 }  // extern "C"
 
 #include "group.inc"   // vdl2hip_group_*: one receiver over several GPUs of this process (needs the statics above)
+#include "ubench.inc"  // vdl2hip_debug_ubench(): issue and LDS-gather rates measured on the spot (bench.py's roofline line)

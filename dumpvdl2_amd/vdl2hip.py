@@ -65,7 +65,7 @@ class Stats(C.Structure):
                 ("sync_ms", C.c_double), ("walk_ms", C.c_double), ("burst_ms", C.c_double), ("nf_ms", C.c_double),
                 ("bursts", C.c_uint64), ("frames", C.c_uint64),
                 ("seg_adopted", C.c_uint64), ("seg_walked", C.c_uint64), ("front_sync_timeouts", C.c_uint64),
-                ("overflow_feeds", C.c_uint64)]
+                ("overflow_feeds", C.c_uint64), ("cold_start_feeds", C.c_uint64)]
 
 
 class PackedFrame(C.Structure):

@@ -125,13 +125,13 @@ typedef void (*vdl2hip_frame_cb)(const vdl2hip_frame *frame, void *user);
 typedef struct {
 	uint64_t feeds;             /* feed calls so far */
 	uint64_t input_samples;     /* complex input samples consumed */
-	uint64_t chan_samples;      /* channel-samples processed by the channeliser kernel */
-	uint64_t chanfir_launches;  /* launches of the channeliser kernel */
-	double   chanfir_ms;        /* summed HIP-event time of those launches (needs profiling on) */
+	uint64_t chan_samples;      /* channel-samples processed by the TIMED launches of the channeliser kernel (profiling on) */
+	uint64_t chanfir_launches;  /* timed launches of the channeliser kernel: feeds with profiling on, except cold-start feeds */
+	double   chanfir_ms;        /* summed HIP-event time of those launches */
 	double   phase_ms, sync_ms, walk_ms, burst_ms;   /* other kernels, same convention */
 	double   nf_ms;             /* noise-floor passes */
 	uint64_t bursts;            /* bursts handed to the burst decoder */
-	uint64_t frames;            /* frames produced */
+	uint64_t frames;            /* frames the burst decoder produced (before the optional AVLC filter of vdl2hip_set_avlc_filter) */
 	uint64_t seg_adopted;       /* segmented walk: speculative segments adopted ... */
 	uint64_t seg_walked;        /* ... and segments walked sequentially because a burst straddled their start */
 	uint64_t front_sync_timeouts; /* channeliser workgroups that stopped waiting for their predecessor's filter state and worked it out
@@ -142,6 +142,8 @@ typedef struct {
 	                               * between processes - set VDL2HIP_NO_FUSE=1 there if bit-reproducible output is required */
 	uint64_t overflow_feeds;    /* feeds in which a device-side burst/frame/octet buffer ran out (bursts or frames were dropped);
 	                             * vdl2hip_sync() returns VDL2HIP_E_OVERFLOW for those, the drain calls only count here */
+	uint64_t cold_start_feeds;  /* large page-locked blocks fed to an idle receiver: copied and channelised in pieces (vdl2hip_feed_pinned);
+	                             * their channeliser launches are not in chanfir_ms / chanfir_launches */
 } vdl2hip_stats;
 
 int  vdl2hip_abi_version(void);
