@@ -4,11 +4,12 @@
 R="$(cd "$(dirname "$0")/.." && pwd)"
 W=${1:-config4}
 cd /tmp && export TMPDIR=/tmp
-echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on \`bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary\` (16 s = 33.6 M samples per launch)"
+python $R/dev/gpu_variants.py --synth-only --workloads $W > /dev/null 2>&1
+echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on \`dev/gpu_variants.py --child --workload $W --parts all --steps 3 --repeats 1\`: the 16 s block (33.6 M samples) resident in HBM, every channeliser launch a whole block (no cold-start pieces)"
 echo "# units: KB per dispatch, averaged over dispatches.  FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)"
 for CN in FETCH_SIZE WRITE_SIZE; do
 	rm -rf /tmp/pmc_$CN
-	rocprofv3 --kernel-trace --pmc $CN -d /tmp/pmc_$CN -o p -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary > /tmp/pmc_$CN.log 2>&1
+	rocprofv3 --kernel-trace --pmc $CN -d /tmp/pmc_$CN -o p -- python $R/dev/gpu_variants.py --child --workload $W --parts all --steps 3 --repeats 1 > /tmp/pmc_$CN.log 2>&1
 	python - "$CN" <<'PY'
 import sqlite3, sys, glob
 cn = sys.argv[1]
