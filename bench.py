@@ -443,7 +443,11 @@ def group_from_c(case, args, torch, local, members=8):
     vh = case.vdl2hip
     cfg = case.cfg
     pin = case.host.pin_memory()
-    out = {"members": members, "devices": [local] * members, "source": "page-locked host memory (vdl2hip_group_feed_pinned)", "forms": {}}
+    out = {"members": members, "devices": [local] * members, "source": "page-locked host memory (vdl2hip_group_feed_pinned)", "forms": {},
+           "note": "ONE GPU does the work of all members here (each decodes its share of the channels of every block), so ms_per_step is to be read "
+                   "against t_all_channels_ms, not against t_rank_ms_max: it bounds what the C path adds when everything shares a device - 8 receivers' "
+                   "48 streams on one GPU's hardware queues, 8 x ~10 launches per block from one host thread, the stripes' H2D copies and the "
+                   "same-device copies that stand in for xGMI - and proves both exchange forms end to end; it is not a projection of 8 GPUs"}
     g = vh.ReceiverGroup(cfg.centerfreq, list(cfg.freqs), [local] * members, cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=case.nbytes)
     try:
         for form in ("allgather", "broadcast"):

@@ -619,6 +619,27 @@ def test_both_forms_of_the_exact_sync_tier_agree(vh, name):
     assert out[0] == out[2] and out[1] == out[3]          # (whole and chunked feeds differ from each other in float rounding)
 
 
+@pytest.mark.parametrize("name", ["config2_1s", "config4_0p4s"])
+def test_deferred_back_end_gives_the_same_answer(vh, monkeypatch, name):
+    """VDL2HIP_BACKEND=deferred queues the back end of feed i behind the channeliser of feed i+1 (DESIGN 8: measured, not the default);
+    whoever collects a feed first flushes it.  Golden frames, timing and counters with three blocks in flight and with one."""
+    monkeypatch.setenv("VDL2HIP_BACKEND", "deferred")
+    cfg, iq, _, gold = cases.load(name)
+    raw = iq.view(np.uint8)
+    for lag in (2, 0):
+        rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=1 << 20)
+        rx.set_drain_lag(lag)
+        got = []
+        for k in range(0, raw.size, 1 << 20):
+            rx.feed(raw[k:k + (1 << 20)])
+            got += rx.drain()
+        rx.set_drain_lag(0)
+        got += rx.drain()
+        cases.check_against_golden(got, [list(rx.counters(c).values()) for c in range(len(cfg.freqs))], gold, label=f"deferred back end, lag {lag}",
+                                   exact_diagnostics=False)
+        rx.close()
+
+
 def test_pinned_feed_overlaps_and_matches(vh):
     """vdl2hip_feed_pinned(): blocks queued from two alternating page-locked buffers without waiting for the copies give
     the golden answers; so does the blocking vdl2hip_feed() from pageable memory with three blocks in flight (the copy of
