@@ -385,6 +385,16 @@ class ReceiverGroup:
         """what the last feed did"""
         return {0: "broadcast/peer-copy", 1: "broadcast/rccl", 2: "allgather/peer-copy", 3: "allgather/rccl"}.get(self.L.vdl2hip_group_exchange(self.h), "none yet")
 
+    def stats(self) -> dict:
+        """the members' statistics, summed"""
+        tot = {}
+        for i in range(self.size()):
+            st = Stats()
+            self._chk(self.L.vdl2hip_get_stats(C.c_void_p(self.L.vdl2hip_group_ctx(self.h, i)), C.byref(st)), "vdl2hip_get_stats")
+            for k, _ in Stats._fields_:
+                tot[k] = tot.get(k, 0) + getattr(st, k)
+        return tot
+
     def read_decimated(self, chan: int, first: int, count: int):
         """`count` decimated (re, im) pairs of channel `chan` from the member that owns it (parity tests)"""
         for i in range(self.size()):

@@ -769,15 +769,21 @@ def test_group_exchange_forms_agree(vh, devices):
         cnt = [list(g.counters(c).values()) for c in range(len(cfg.freqs))]
         cases.check_against_golden(got, cnt, gold, label=f"group {form}", exact_diagnostics=False)
         y = [g.read_decimated(c, D - 20000, 20000).copy() for c in range(len(cfg.freqs))]
-        res[form] = (got, cnt, y)
+        res[form] = (got, cnt, y, g.stats()["front_sync_timeouts"])
         g.close()
     a, b = res["allgather"], res["broadcast"]
     assert a[1] == b[1]
     key = lambda f: (f["chan"], f["burst_ord"], f["idx"])
     fa, fb = sorted(a[0], key=key), sorted(b[0], key=key)
-    assert [tuple(sorted(f.items())) for f in fa] == [tuple(sorted(f.items())) for f in fb]
+    if a[3] == 0 and b[3] == 0:
+        assert [tuple(sorted(f.items())) for f in fa] == [tuple(sorted(f.items())) for f in fb]
+    else:
+        assert_frames_equal(fa, fb, label="group exchange forms (with look-back fall-backs)")
     for ya, yb in zip(a[2], b[2]):
-        assert ya.tobytes() == yb.tobytes()
+        if a[3] == 0 and b[3] == 0:
+            assert ya.tobytes() == yb.tobytes()
+        else:       # a channeliser look-back fell back (a GPU shared with another process): equal up to fp32 rounding of the segment-start state
+            assert np.abs(ya - yb).max() <= 1e-4 * float(np.abs(ya).max())
 
 
 def test_cold_start_block_goes_in_pieces_and_gives_the_same_stream(vh):
