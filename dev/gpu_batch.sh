@@ -17,6 +17,7 @@ for job in "$@"; do
 	bench) timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O.bench_default.json 2> $O.bench_default.err; echo "bench rc=$?"; tail -c 600 $O.bench_default.err; cut -c1-700 $O.bench_default.json ;;
 	dropin) for w in config4 config2; do timeout 300 python dev/gpu_dropin_rate.py $w 4 2>&1 | grep -v amdgpu.ids | tee -a $O.dropin.txt; done ;;
 	b2) timeout 900 python dev/gpu_variants.py --out $O.variants2.jsonl --steps 16 --repeats 3 --workloads config2,config3 --parts all --variant base --variant r03:@dev/_ref/libvdl2hip_r03.so 2>&1 | tee $O.variants2.txt ;;
+	segs) timeout 1500 python dev/gpu_variants.py --out $O.segs.jsonl --steps 16 --repeats 3 --variant base --variant seg1:VDL2HIP_SEG_MAX=1 --variant seg2:VDL2HIP_SEG_MAX=2 --variant seg4:VDL2HIP_SEG_MAX=4 --variant seg6:VDL2HIP_SEG_MAX=6 --variant base2 2>&1 | tee $O.segs.txt ;;
 	ablate)
 		build exp "-DVDL2_EXPERIMENTS"
 		timeout 1500 python dev/gpu_variants.py --out $O.ablate.jsonl --steps 16 --repeats 3 --workloads config4,config4_bursty --variant full:@/tmp/vdl2hip_exp.so --variant nowalk:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=walk --variant nonf:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=nf --variant noburst:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=burst --variant noback:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=walk,nf,burst 2>&1 | tee $O.ablate.txt ;;

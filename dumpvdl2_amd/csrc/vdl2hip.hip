@@ -356,10 +356,10 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	const int64_t D = sl.back_D, k0 = sl.back_k0;
 	// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
 	int nseg = (int)std::min<int64_t>(c->seg_max, D / c->seg_min);
-	// A short feed (the reference's own 320 000-byte blocks: 4 000 decimated samples) is a chain of kernels that each run for
+	// A short feed (fewer than two walk segments' worth of samples; the reference's own 320 000-byte blocks are 4 000) is a chain of kernels that each run for
 	// microseconds: its whole back end goes onto the FRONT stream, behind its own sync kernels - no event hand-offs between streams -
 	// with the three noise-floor passes as one kernel.  Whoever follows on the front stream is then behind it anyway.
-	const bool small = D > 0 && nseg < 2 && !c->defer_back;
+	const bool small = D > 0 && D < 2 * c->seg_min && nseg < 2 && !c->defer_back;
 	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst;
 	hipEvent_t *ev = sl.ev;
 	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
