@@ -1029,10 +1029,9 @@ __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_finish(K4bArgs a) {
 
 // The three passes in one kernel, a wavefront per channel: for short blocks, where there are one or two updates per channel and
 // three launches would cost more than the work (the reference's own block size, dumpvdl2.h:48: 4 000 decimated samples)
-__global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_all(K4bArgs a) {
-	extern __shared__ __align__(16) unsigned char nf_lds[];
-	NfShared *shw = reinterpret_cast<NfShared *>(nf_lds);
-	const int wave = threadIdx.x >> 6, c = blockIdx.x * kNfWaves + wave;
+__device__ __forceinline__ void nf_all_body(const K4bArgs &a, unsigned char *lds, int block) {
+	NfShared *shw = reinterpret_cast<NfShared *>(lds);
+	const int wave = threadIdx.x >> 6, c = block * kNfWaves + wave;
 	if(c >= a.nchan) return;
 	ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
@@ -1046,6 +1045,10 @@ __global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_all(K4bArgs a) {
 	}
 	WAVE_SYNC_GLOBAL();                    // ... and so are the replayed mag_lp values
 	nf_finish(&a.nf[c], sc, fd, a.lpbuf + (size_t)c * a.cap_hist, a.ring + (size_t)c * (a.ring_mask + 1), a.ring_mask, a.cap_hist, shw[wave]);
+}
+__global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_all(K4bArgs a) {
+	extern __shared__ __align__(16) unsigned char nf_lds[];
+	nf_all_body(a, nf_lds, (int)blockIdx.x);
 }
 
 struct K5Args {
@@ -1064,12 +1067,13 @@ constexpr int kBurstWaves = VDL2_K5_WAVES;
 constexpr int kK5MaxChan = 1024;          // most channels a receiver may have (vdl2hip_create): a wavefront of the burst decoder keeps all their burst-list offsets in LDS
 // (the LDS is dynamic so that the compiler does not see its size: it would size the register budget by the LDS-limited occupancy
 // and take 169, more than a channeliser wave leaves)
-__global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
-	extern __shared__ __align__(16) unsigned char k5_lds[];       // BurstShared[kBurstWaves], then the per-channel burst offsets
+// (the body of k_burst: `block` of `nblocks` workgroups of kBurstWaves wavefronts)
+__device__ __forceinline__ void burst_body(const K5Args &a, unsigned char *k5_lds, uint32_t block, uint32_t nblocks) {
+	if((threadIdx.x >> 6) >= kBurstWaves) return;
 	BurstShared &sh = reinterpret_cast<BurstShared *>(k5_lds)[threadIdx.x >> 6];
 	uint32_t *bb = reinterpret_cast<uint32_t *>(k5_lds + sizeof(BurstShared) * kBurstWaves) + (size_t)(threadIdx.x >> 6) * (kK5MaxChan + 1);
 	const int lane = threadIdx.x & 63;
-	const uint32_t wave_id = blockIdx.x * kBurstWaves + (threadIdx.x >> 6);
+	const uint32_t wave_id = block * kBurstWaves + (threadIdx.x >> 6);
 	// Every wavefront turns the per-channel burst counts into offsets for itself, in LDS (one load per lane and 64 channels, one scan):
 	// finding a burst's channel is then a search in LDS, not eight dependent trips to memory per burst - and no kernel of its own has to
 	// run between the walker and this one.
@@ -1091,7 +1095,7 @@ __global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
 		return;
 	}
 	burst_shared_init(*a.tab, wave_id, a.ctl, sh);
-	for(uint32_t g = wave_id; g < total; g += gridDim.x * kBurstWaves) {
+	for(uint32_t g = wave_id; g < total; g += nblocks * kBurstWaves) {
 		int lo = 0, hi = a.nchan;                       // channel c with bb[c] <= g < bb[c+1]
 		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(bb[mid] <= g) lo = mid; else hi = mid; }
 		const int c = lo;
@@ -1101,6 +1105,22 @@ __global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
 		WAVE_SYNC();
 	}
 	burst_reserve_done(a.frames, sh);
+}
+
+__global__ __launch_bounds__(256, 4) void k_burst(K5Args a) {
+	extern __shared__ __align__(16) unsigned char k5_lds[];       // BurstShared[kBurstWaves], then the per-channel burst offsets
+	burst_body(a, k5_lds, blockIdx.x, gridDim.x);
+}
+
+// Short feeds: the noise floor (needs the walker's evaluation log) and the burst decoder (needs its burst lists) do not need each other,
+// so they run as ONE launch of two kinds of workgroups - the first nf_blocks are k_nf_all's, the rest k_burst's - instead of one kernel
+// after the other on the short feed's single stream.  (Block size 64 * kNfWaves; the burst decoder's workgroups use their first
+// kBurstWaves wavefronts.)
+static_assert(kNfWaves >= kBurstWaves, "a workgroup of the joint launch holds either kind");
+__global__ __launch_bounds__(64 * kNfWaves, 4) void k_nf_burst(K4bArgs nf, K5Args k5, uint32_t nf_blocks) {
+	extern __shared__ __align__(16) unsigned char back_lds[];
+	if(blockIdx.x < nf_blocks) nf_all_body(nf, back_lds, (int)blockIdx.x);
+	else burst_body(k5, back_lds, blockIdx.x - nf_blocks, gridDim.x - nf_blocks);
 }
 
 // After K4b and K5 have both finished: the noise-floor figure and the AVLC front-door checks of every frame (one wavefront per

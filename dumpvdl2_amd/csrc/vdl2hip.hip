@@ -399,8 +399,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		             c->cap, c->cap - 1, c->cap_log, c->cap_comb, c->cap_hist, c->C };
 		const unsigned nf_lds = (unsigned)(sizeof(NfShared) * kNfWaves), nf_grid = (unsigned)((c->C + kNfWaves - 1) / kNfWaves);
 		if(small) {
-			if(!(c->ablate & 2))
-			hipExtLaunchKernelGGL(k_nf_all, dim3(nf_grid), dim3(64 * kNfWaves), nf_lds, sn_, EV(8), EV(9), 0, k4b);
+			// (queued below, together with the burst decoder: k_nf_burst)
 		} else {
 			hipExtLaunchKernelGGL(k_nf_prepare, dim3(nf_grid), dim3(64 * kNfWaves), nf_lds, sn_, EV(8), (hipEvent_t) nullptr, 0, k4b);
 			const unsigned ngrp = (unsigned)std::min<uint64_t>(64, (c->cap_hist + kNfGroup * kNfWaves - 1) / (kNfGroup * kNfWaves));   // workgroups per channel
@@ -412,7 +411,9 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
 		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: no bursts to decode)
-		hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves), s5_, EV(10), EV(11), 0, k5);
+		const unsigned k5_lds = (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves);
+		if(small) hipExtLaunchKernelGGL(k_nf_burst, dim3(nf_grid + sl.k5_waves / kBurstWaves), dim3(64 * kNfWaves), std::max(nf_lds, k5_lds), s5_, EV(8), EV(11), 0, k4b, k5, (uint32_t)nf_grid);
+		else hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), EV(11), 0, k5);
 		if(!small) HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
 		// record chunks of kFrameChunk: enough workgroups for the records the burst decoder's wavefronts own, at most 256
 		const unsigned ff_grid = std::min(256u, (sl.k5_waves * (unsigned)kResSlots * 2 / kFrameChunk + kFrameWaves - 1) / kFrameWaves);
