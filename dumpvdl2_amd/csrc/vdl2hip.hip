@@ -115,6 +115,14 @@ struct vdl2hip_ctx {
 
 static size_t sample_bytes(int fmt) { return fmt == VDL2HIP_FMT_S16LE ? 4 : 2; }
 
+// Every entry point works on the context's own device whatever the calling thread's current device is (a process may hold
+// receivers on several GPUs), and leaves the thread's device as it found it.
+struct OnDevice {
+	int prev = -1; bool switched = false;
+	explicit OnDevice(const vdl2hip_ctx *c) { if(c && hipGetDevice(&prev) == hipSuccess && prev != c->cfg.device) switched = hipSetDevice(c->cfg.device) == hipSuccess; }
+	~OnDevice() { if(switched) (void)hipSetDevice(prev); }
+};
+
 // Launch with the kernel's own start/stop stamped into two events (null: plain launch).  Used instead of hipEventRecord
 // pairs, which are separate queue entries and cost a few microseconds of stream time each.
 #define LAUNCH_EV(kernel, grid, block, stream, e0, e1, ...) hipExtLaunchKernelGGL(kernel, grid, block, 0u, stream, e0, e1, 0, __VA_ARGS__)
@@ -151,8 +159,12 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 		if(!sl.fused && hipEventElapsedTime(&ms, ev[2], ev[3]) == hipSuccess) c->stats.phase_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[4], sl.ev_front) == hipSuccess) c->stats.sync_ms += ms;
 		if(hipEventElapsedTime(&ms, ev[6], ev[7]) == hipSuccess) c->stats.walk_ms += ms;
-		if(hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) c->stats.nf_ms += ms;
-		if(hipEventElapsedTime(&ms, ev[10], ev[11]) == hipSuccess) c->stats.burst_ms += ms;
+		if(sl.small) {        // noise floor and burst decoder were one launch (k_nf_burst): booked under the burst decoder
+			if(hipEventElapsedTime(&ms, ev[8], ev[11]) == hipSuccess) c->stats.burst_ms += ms;
+		} else {
+			if(hipEventElapsedTime(&ms, ev[8], ev[9]) == hipSuccess) c->stats.nf_ms += ms;
+			if(hipEventElapsedTime(&ms, ev[10], ev[11]) == hipSuccess) c->stats.burst_ms += ms;
+		}
 		if(c->show_gaps) {   // development: idle time of the front stream between its kernels
 			float g12 = 0, g23 = 0, g31 = -1;
 			if(!sl.fused) { (void)hipEventElapsedTime(&g12, ev[1], ev[2]); (void)hipEventElapsedTime(&g23, ev[3], ev[4]); } else (void)hipEventElapsedTime(&g23, ev[1], ev[4]);
@@ -162,6 +174,7 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 		}
 		}
 	}
+	if(sl.ev_valid) (void)hipGetLastError();   // (an event query that failed above is not a device error of the next feed)
 	sl.ev_valid = false;
 	const OutCtl ctl = sl.h_mail->ctl;
 	if(ctl.overflow) c->stats.overflow_feeds++;
@@ -462,6 +475,7 @@ const char *vdl2hip_strerror(int err) {
 
 void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
+	OnDevice dev_guard(c);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
 	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
@@ -503,6 +517,8 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		fprintf(stderr, "vdl2hip: no HIP device available - this library has no CPU path\n");
 		return VDL2HIP_E_DEVICE;
 	}
+	if(cfg->device < 0 || cfg->device >= ndev) return VDL2HIP_E_INVAL;
+	struct Restore { int prev = -1; Restore() { (void)hipGetDevice(&prev); } ~Restore() { if(prev >= 0) (void)hipSetDevice(prev); } } restore_device;
 	HIPCHK(hipSetDevice(cfg->device));
 	vdl2hip_ctx *c = new(std::nothrow) vdl2hip_ctx();
 	if(!c) return VDL2HIP_E_NOMEM;
@@ -681,6 +697,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 // collect_slot() has seen complete.  So the H2D of block i+1 overlaps the kernels of block i (and i-1, i-2 further down).
 static int feed_host(vdl2hip_ctx *c, const void *buf, size_t nbytes, bool wait_copy) {
 	if(!c || (!buf && nbytes)) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	if(c->failed) return VDL2HIP_E_DEVICE;
 	if(nbytes == 0) return VDL2HIP_OK;                             // process_buf_*: len == 0 is a no-op (demod.c:341,358)
 	if(nbytes > c->in_cap) return VDL2HIP_E_TOOBIG;
@@ -731,6 +748,7 @@ int vdl2hip_feed_pinned(vdl2hip_ctx *c, const void *buf, size_t nbytes) { return
 
 int vdl2hip_feed_device(vdl2hip_ctx *c, const void *dev_buf, size_t nbytes) {
 	if(!c || (!dev_buf && nbytes)) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	if(nbytes == 0) return VDL2HIP_OK;
 	if(nbytes > c->in_cap) return VDL2HIP_E_TOOBIG;
 	if(((uintptr_t)dev_buf) % sample_bytes(c->fmt)) return VDL2HIP_E_INVAL;
@@ -743,6 +761,7 @@ int vdl2hip_feed_device(vdl2hip_ctx *c, const void *dev_buf, size_t nbytes) {
 
 int vdl2hip_sync(vdl2hip_ctx *c) {
 	if(!c) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	if(c->pinned_pending) { HIPCHK(hipEventSynchronize(c->pinned_pending)); c->pinned_pending = nullptr; }
 	if(c->failed) return VDL2HIP_E_DEVICE;
 	return collect_pending(c);
@@ -750,6 +769,7 @@ int vdl2hip_sync(vdl2hip_ctx *c) {
 
 int vdl2hip_drain(vdl2hip_ctx *c, vdl2hip_frame_cb cb, void *user) {
 	if(!c) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	if(c->failed) return VDL2HIP_E_DEVICE;
 	int r = collect_pending(c, c->drain_lag);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
@@ -770,6 +790,7 @@ int vdl2hip_drain(vdl2hip_ctx *c, vdl2hip_frame_cb cb, void *user) {
 int vdl2hip_drain_packed(vdl2hip_ctx *c, vdl2hip_packed_frame *frames, size_t cap_frames,
 		uint8_t *octets, size_t cap_octets, size_t *octets_used) {
 	if(!c || (!frames && cap_frames) || (!octets && cap_octets)) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	if(c->failed) return VDL2HIP_E_DEVICE;
 	int r = collect_pending(c, c->drain_lag);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
@@ -831,6 +852,7 @@ int vdl2hip_pack_raw_frame(const vdl2hip_frame *f, const char *station_id, int64
 
 int vdl2hip_counters(vdl2hip_ctx *c, uint32_t chan, uint64_t out[VDL2HIP_NUM_COUNTERS]) {
 	if(!c || !out || chan < (uint32_t)c->chan_first || chan >= (uint32_t)(c->chan_first + c->C)) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	int r = collect_pending(c);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	HIPCHK(hipMemcpy(out, c->d_cnt + (size_t)(chan - c->chan_first) * kNumCounters, 8 * kNumCounters, hipMemcpyDeviceToHost));
@@ -839,6 +861,7 @@ int vdl2hip_counters(vdl2hip_ctx *c, uint32_t chan, uint64_t out[VDL2HIP_NUM_COU
 
 int vdl2hip_avlc_counters(vdl2hip_ctx *c, uint32_t chan, uint64_t out[VDL2HIP_NUM_AVLC_COUNTERS]) {
 	if(!c || !out || chan < (uint32_t)c->chan_first || chan >= (uint32_t)(c->chan_first + c->C)) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	int r = collect_pending(c);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	HIPCHK(hipMemcpy(out, c->d_acnt + (size_t)(chan - c->chan_first) * kNumAvlcCounters, 8 * kNumAvlcCounters, hipMemcpyDeviceToHost));
@@ -865,13 +888,19 @@ static const char *const kAvlcCounterNames[VDL2HIP_NUM_AVLC_COUNTERS] = {
 
 int vdl2hip_statsd_lines(vdl2hip_ctx *c, const char *ns, char *out, size_t cap) {
 	if(!c || !ns || !out) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	int r = collect_pending(c);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	const size_t per = VDL2HIP_NUM_COUNTERS + VDL2HIP_NUM_AVLC_COUNTERS;
 	std::vector<uint64_t> now((size_t)c->C * per);
-	for(int ch = 0; ch < c->C; ch++) {
-		HIPCHK(hipMemcpy(&now[ch * per], c->d_cnt + (size_t)ch * kNumCounters, 8 * kNumCounters, hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(&now[ch * per + kNumCounters], c->d_acnt + (size_t)ch * kNumAvlcCounters, 8 * kNumAvlcCounters, hipMemcpyDeviceToHost));
+	{
+		std::vector<uint64_t> a((size_t)c->C * kNumCounters), b((size_t)c->C * kNumAvlcCounters);      // two copies, whatever the channel count
+		HIPCHK(hipMemcpy(a.data(), c->d_cnt, a.size() * 8, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(b.data(), c->d_acnt, b.size() * 8, hipMemcpyDeviceToHost));
+		for(int ch = 0; ch < c->C; ch++) {
+			std::copy(a.begin() + (size_t)ch * kNumCounters, a.begin() + (size_t)(ch + 1) * kNumCounters, now.begin() + ch * per);
+			std::copy(b.begin() + (size_t)ch * kNumAvlcCounters, b.begin() + (size_t)(ch + 1) * kNumAvlcCounters, now.begin() + ch * per + kNumCounters);
+		}
 	}
 	const bool first = c->statsd_prev.empty();
 	if(first) c->statsd_prev.assign(now.size(), 0);
@@ -893,6 +922,7 @@ int vdl2hip_statsd_lines(vdl2hip_ctx *c, const char *ns, char *out, size_t cap) 
 
 int vdl2hip_set_profiling(vdl2hip_ctx *c, int on) {
 	if(!c) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	int r = collect_pending(c);
 	c->profiling = on < 0 ? 0 : on > 2 ? 2 : on;
 	return r == VDL2HIP_E_OVERFLOW ? VDL2HIP_OK : r;
@@ -900,6 +930,7 @@ int vdl2hip_set_profiling(vdl2hip_ctx *c, int on) {
 
 int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) {
 	if(!c || !out) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	int r = collect_pending(c);
 	{
 		std::vector<uint32_t> ss((size_t)c->C * 2);
@@ -927,6 +958,7 @@ int vdl2hip_set_drain_lag(vdl2hip_ctx *c, int lag) {
 // under a wrong epoch), so that the fall-back path is taken by every workgroup and can be tested
 int vdl2hip_debug_option(vdl2hip_ctx *c, const char *name, long value) {
 	if(!c || !name) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	int r = collect_pending(c);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	if(strcmp(name, "no_fuse") == 0) { c->fuse_k2 = value == 0; return VDL2HIP_OK; }
@@ -990,6 +1022,7 @@ int vdl2hip_get_nco_step(vdl2hip_ctx *c, uint32_t chan, uint32_t *dphi) {
 
 int vdl2hip_read_decimated(vdl2hip_ctx *c, uint32_t chan, int64_t first, float *dst, size_t cap) {
 	if(!c || !dst || chan < (uint32_t)c->chan_first || chan >= (uint32_t)(c->chan_first + c->C)) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
 	int r = collect_pending(c);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	if(first < 0 || first > c->k_total || c->k_total - first > (int64_t)c->cap) return VDL2HIP_E_INVAL;

@@ -78,7 +78,8 @@ typedef struct {
 	uint32_t nchan;
 	const uint32_t *freqs;      /* nchan channel frequencies, Hz */
 	float    max_ppm;           /* Config.max_ppm; 0 disables (src/demod.c:192) */
-	int32_t  device;            /* HIP device ordinal */
+	int32_t  device;            /* HIP device ordinal.  Every call on the context runs on this device whatever the calling thread's
+	                             * current device is, and leaves the thread's current device as it found it */
 	uint32_t max_block_bytes;   /* largest block a feed call may carry; 0 = 320000 (FILE_BUFSIZE) */
 	uint32_t chan_first;        /* multi-GPU sharding: this context decodes channels            */
 	uint32_t chan_count;        /*   [chan_first, chan_first+chan_count) of freqs[]; 0 = all     */
