@@ -578,7 +578,20 @@ def main():
     forms = ["broadcast"]
     if world > 1:
         forms = ["broadcast", "allgather"] if case.nbytes % world == 0 else ["broadcast"]
-        exchange_info = {"uses_rccl": not rehearsal, "backend": dist.get_backend()}
+        exchange_info = {"uses_rccl": not rehearsal, "backend": dist.get_backend(), "nranks": dist.get_world_size()}
+        try:       # which collective library this is, and that the ranks sit on different GPUs (the first N > 1 run is the proof of both)
+            exchange_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if not rehearsal else None
+        except Exception as e:     # noqa: BLE001 - a missing version query must not stop a benchmark
+            exchange_info["rccl_version"] = f"unavailable ({type(e).__name__})"
+        try:
+            prop = torch.cuda.get_device_properties(local)
+            ident = f"{local}:{getattr(prop, 'uuid', '')}:{getattr(prop, 'pci_bus_id', '')}"
+        except Exception:          # noqa: BLE001
+            ident = str(local)
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        exchange_info["devices_by_rank"] = idents
+        exchange_info["distinct_devices"] = len(set(idents))
         for src_kind in ("host", "hbm"):
             for m in forms:
                 secs, ok = vdist.time_exchange(case.host, world, rank, m, src_kind, case.device)
