@@ -22,7 +22,7 @@ for job in "$@"; do
 		build exp "-DVDL2_EXPERIMENTS"
 		timeout 1500 python dev/gpu_variants.py --out $O.ablate.jsonl --steps 16 --repeats 3 --workloads config4,config4_bursty --variant full:@/tmp/vdl2hip_exp.so --variant nowalk:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=walk --variant nonf:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=nf --variant noburst:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=burst --variant noback:@/tmp/vdl2hip_exp.so:VDL2HIP_ABLATE=walk,nf,burst 2>&1 | tee $O.ablate.txt ;;
 	pmc:*) W=${job#pmc:}; timeout 900 bash dev/gpu_pmc_all.sh $W all > $O.pmc_all_$W.txt 2>&1; cut -c1-120 $O.pmc_all_$W.txt ;;
-	fuzz:*) timeout $(( ${job#fuzz:} + 120 )) python tests/fuzz_gpu.py ${job#fuzz:} ${FUZZ_SEED0:-1} all 2>&1 | grep -v amdgpu.ids > $O.fuzz_gpu.txt; echo "fuzz rc=$?"; grep -c ': ok' $O.fuzz_gpu.txt; grep -v ': ok' $O.fuzz_gpu.txt | cut -c1-600 | tail -12 ;;
+	fuzz:*) timeout $(( ${job#fuzz:} + 120 )) python tests/fuzz_gpu.py ${job#fuzz:} ${FUZZ_SEED0:-1} all > $O.fuzz_gpu.txt 2>&1; echo "fuzz rc=$?"; grep -c ': ok' $O.fuzz_gpu.txt; grep -v ': ok' $O.fuzz_gpu.txt | cut -c1-600 | tail -12 ;;
 	*) echo "unknown job $job" ;;
 	esac
 done
