@@ -7,6 +7,7 @@
 #   shard32       dev/gpu_shard32.py: the rank-sized workload (32 of 256 channels), ranks 0,3,7
 #   trace32       rocprofv3 --kernel-trace --stats of the rank-sized workload (rank 3)
 #   trace256      rocprofv3 --kernel-trace --stats of bench.py config4
+#   tracedropin   the same of dev/gpu_dropin_rate.py config4 (320 000-byte blocks)
 #   pmc256        HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of bench.py config4
 #   sq_k1:<C>     SQ counters of the channeliser on C channels of noise;  sq_k3a:<C> the same for k_sync_screen
 #   iso           per-stage kernel times of config4, nothing overlapped
@@ -53,6 +54,7 @@ for r in j['ranks']: print(j['env'], 'rank', r['rank'], r['ms_per_step'], 'K1', 
 " | tee -a $O.shard32q.txt ;;
 	sweep32:*) timeout 900 python dev/gpu_shard32.py --ranks 3 --repeats 2 --sweep "${job#sweep32:}" --json $O.sweep32_$(date +%s).json 2>&1 >/dev/null | grep '^{' | cut -c1-330 | tee -a $O.sweep32.txt ;;
 	trace32) trace shard32 python $R/dev/gpu_shard32.py --ranks 3 --repeats 1 --no-check ;;
+	tracedropin) trace dropin python $R/dev/gpu_dropin_rate.py config4 2 ;;
 	trace256) trace bench_config4 python $R/bench.py --workload config4 --steps 10 --warmup 2 --no-cpu-baseline --no-verify --no-secondary ;;
 	pmc256) timeout 500 bash dev/gpu_pmc_traffic.sh config4 > $O.pmc_hbm_traffic_config4.txt 2>&1; cat $O.pmc_hbm_traffic_config4.txt | cut -c1-160 ;;
 	sq_k1:*) timeout 500 bash dev/gpu_k1_pmc.sh ${job#sq_k1:} > $O.sq_k1_${job#sq_k1:}ch.txt 2>&1; cut -c1-140 $O.sq_k1_${job#sq_k1:}ch.txt ;;
