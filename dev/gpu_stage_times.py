@@ -22,10 +22,16 @@ K5N = ["1 slice (atan2)", "2 descramble/pack", "3 de-interleave", "4 Reed-Solomo
 K4N = ["0 entry", "1 stale batch eval", "2 log_evals", "3 bitmap hop", "4 (fire branch)", "5 fire LANE0", "6 header", "7 tail", "8 fire gather", "9 park (no fire)"]
 
 
+NFN = ["0 first chunk (64-way search)", "1 stage chunk list", "2 per-update search", "3 positions of a batch", "4 wait for the batch's loads", "5 hypot + LDS store", "6 recurrence (64 steps)", "7 store"]
+have_nf = hasattr(L, "vdl2hip_debug_nf_prof")
+
+
 def prof(reset):
-    a5 = (C.c_ulonglong * 16)(); a4 = (C.c_ulonglong * 24)()
+    a5 = (C.c_ulonglong * 16)(); a4 = (C.c_ulonglong * 24)(); an = (C.c_ulonglong * 16)()
     L.vdl2hip_debug_k5_prof(a5, reset); L.vdl2hip_debug_k4_prof(a4, reset)
-    return list(a5), list(a4)
+    if have_nf:
+        L.vdl2hip_debug_nf_prof(an, reset)
+    return list(a5), list(a4), list(an)
 
 
 for label, lag in (("alone (one block in flight)", 0), ("in the pipeline (three blocks in flight)", 2)):
@@ -44,7 +50,7 @@ for label, lag in (("alone (one block in flight)", 0), ("in the pipeline (three 
     nb = (s["bursts"] - s0["bursts"]) / reps
     print(f"{name} {secs:g} s, {label}:", {k: round(v, 4) for k, v in d.items()}, "bursts/feed", nb, "env", {k: v for k, v in os.environ.items() if k.startswith("VDL2HIP_")})
     if have:
-        a5, a4 = prof(0)
+        a5, a4, an = prof(0)
         nb5 = a5[8] or 1
         tot5 = sum(a5[:8]) or 1
         print(f"  K5: {a5[8]} bursts decoded, {tot5 / nb5:.0f} shader clocks per burst")
@@ -55,3 +61,8 @@ for label, lag in (("alone (one block in flight)", 0), ("in the pipeline (three 
         for i in range(10):
             n = a4[12 + i] or 1
             print(f"     {K4N[i]:20s} {100.0 * a4[i] / tot4:5.1f}%  n/feed={a4[12 + i] / reps:9.0f}  clk each={a4[i] / n:9.0f}")
+        if have_nf and an[8]:
+            totn = sum(an[:8]) or 1
+            print(f"  NF replay: {an[8] / reps:.0f} groups of 32 updates per feed, {totn / an[8]:.0f} shader clocks per group")
+            for i in range(8):
+                print(f"     {NFN[i]:32s} {an[i] / an[8]:10.0f} clk/group {100.0 * an[i] / totn:5.1f}%")

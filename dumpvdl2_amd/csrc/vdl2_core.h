@@ -76,6 +76,7 @@
 #if defined(__HIPCC__) && defined(VDL2_K5_PROF)
 __device__ unsigned long long vdl2_k5_prof[64][16];
 __device__ unsigned long long vdl2_k4_prof[64][24];
+__device__ unsigned long long vdl2_nf_prof[64][16];
 #endif
 #if VDL2_DEVICE_PASS && defined(VDL2_K5_PROF)
 #define K4_BEGIN() unsigned long long k4_t0_ = __builtin_readcyclecounter(); unsigned k4_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, k4_n_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
@@ -86,6 +87,11 @@ __device__ unsigned long long vdl2_k4_prof[64][24];
 #define K5_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); k5_acc_[k] += (unsigned)(t_ - k5_t0_); k5_t0_ = t_; } while(0)
 #define K5_END() do { if(VDL2_LANE() == 0) { for(int k_ = 0; k_ < 8; k_++) atomicAdd(&vdl2_k5_prof[blockIdx.x & 63][k_], (unsigned long long)k5_acc_[k_]); \
 	atomicAdd(&vdl2_k5_prof[blockIdx.x & 63][8], 1ull); } } while(0)
+#define NF_BEGIN() unsigned long long nf_t0_ = __builtin_readcyclecounter(); unsigned nf_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define NF_MARK(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); nf_acc_[k] += (unsigned)(t_ - nf_t0_); nf_t0_ = t_; } while(0)
+#define NF_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define NF_END() do { if(VDL2_LANE() == 0) { for(int k_ = 0; k_ < 8; k_++) atomicAdd(&vdl2_nf_prof[blockIdx.x & 63][k_], (unsigned long long)nf_acc_[k_]); \
+	atomicAdd(&vdl2_nf_prof[blockIdx.x & 63][8], 1ull); } } while(0)
 #else
 #define K4_BEGIN() do {} while(0)
 #define K4_MARK(k) do {} while(0)
@@ -93,6 +99,10 @@ __device__ unsigned long long vdl2_k4_prof[64][24];
 #define K5_MARK(k) do {} while(0)
 #define K5_BEGIN() do {} while(0)
 #define K5_END() do {} while(0)
+#define NF_BEGIN() do {} while(0)
+#define NF_MARK(k) do {} while(0)
+#define NF_WAIT_LOADS() do {} while(0)
+#define NF_END() do {} while(0)
 #endif
 
 namespace vdl2 {
@@ -1344,6 +1354,7 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 	// evaluations before an update regularly span several).  The first chunk is found by all 64 lanes probing the list at once
 	// (three rounds for 8 000 chunks where a binary search takes thirteen).
 	const int64_t o_first = 1000 * ubase - 1 - (kLpTerms - 1), o_lastgrp = 1000 * (ubase + nupd - 1) - 1;
+	NF_BEGIN();
 	int c_lo = 0;
 	if(ncomb > 0 && o_first > fd.begin_ord) {
 		int lo = 0, hi = ncomb;                                     // cum[lo] <= o_first < cum[hi]  (cum[0] = begin_ord, cum[ncomb] = all evaluations so far)
@@ -1361,6 +1372,7 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 		}
 		c_lo = lo;
 	}
+	NF_MARK(0);
 	int nsl = ncomb - c_lo < kNfSlice ? ncomb - c_lo : kNfSlice;   // chunks staged
 	WAVE_FOR(l)
 		for(int i = l; i <= nsl; i += 64) sh.sl_cum[i] = sc.cum[c_lo + i];
@@ -1370,6 +1382,7 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 	const bool staged = ncomb > 0 && (c_lo + nsl == ncomb || sh.sl_cum[nsl] > o_lastgrp);
 	const int64_t *cum = staged ? sh.sl_cum - c_lo : sc.cum, *first = staged ? sh.sl_first - c_lo : sc.first;
 	const int c_min = staged ? c_lo : 0, c_end = staged ? c_lo + nsl : ncomb;
+	NF_MARK(1);
 	WAVE_FOR(l)
 		if(l < nupd) {
 			const int64_t o_last = 1000 * (ubase + l) - 1;               // ordinal of the evaluation that triggers the update
@@ -1382,6 +1395,7 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 			sh.ci[l] = ci; sh.pos[l] = pos; sh.avail[l] = avail; sh.lp[l] = 0.f;
 		}
 	WAVE_END
+	NF_MARK(2);
 	for(int seg = kLpTerms / kNfSeg - 1; seg >= 0; seg--) {
 		WAVE_FOR(l)
 			const int64_t t = (int64_t)kNfSeg * seg + l;                  // this lane's evaluation: the t-th before the triggering one
@@ -1403,8 +1417,11 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 						}
 					}
 				}
+				NF_MARK(3);
 				for(int q = 0; q < kBatch; q++) yv[q] = ps[q] >= 0 ? v.Y(ps[q]) : cf32{0.f, 0.f};
+				NF_WAIT_LOADS(); NF_MARK(4);
 				for(int q = 0; q < kBatch; q++) if(u0 + q < nupd) sh.mags[u0 + q][l] = ps[q] >= 0 ? mag_of(yv[q]) : -1.f;
+				NF_MARK(5);
 			}
 		WAVE_END
 		WAVE_FOR(l)
@@ -1417,11 +1434,14 @@ VDL2_HD void nf_replay_group(const ChanView &v, const NfScratch &sc, const NfFee
 				sh.lp[l] = lp;
 			}
 		WAVE_END
+		NF_MARK(6);
 	}
 	WAVE_FOR(l)
 		const int64_t i = ubase + l - fd.u0;
 		if(l < nupd && i < (int64_t)cap_hist) lpbuf[i] = sh.lp[l];
 	WAVE_END
+	NF_MARK(7);
+	NF_END();
 }
 
 // pass 3: the mag_nf chain over this feed's updates (sequential, so it runs out of LDS) into the per-channel history

@@ -999,6 +999,13 @@ int vdl2hip_debug_k5_prof(unsigned long long out[16], int reset) {
 	if(reset) { memset(h, 0, sizeof h); if(hipMemcpyToSymbol(HIP_SYMBOL(vdl2_k5_prof), h, sizeof h) != hipSuccess) return -3; }
 	return 0;
 }
+int vdl2hip_debug_nf_prof(unsigned long long out[16], int reset) {
+	static unsigned long long h[64][16];
+	if(hipMemcpyFromSymbol(h, HIP_SYMBOL(vdl2_nf_prof), sizeof h) != hipSuccess) return -3;
+	for(int k = 0; k < 16; k++) { out[k] = 0; for(int s = 0; s < 64; s++) out[k] += h[s][k]; }
+	if(reset) { memset(h, 0, sizeof h); if(hipMemcpyToSymbol(HIP_SYMBOL(vdl2_nf_prof), h, sizeof h) != hipSuccess) return -3; }
+	return 0;
+}
 int vdl2hip_debug_k4_prof(unsigned long long out[24], int reset) {
 	static unsigned long long h[64][24];
 	if(hipMemcpyFromSymbol(h, HIP_SYMBOL(vdl2_k4_prof), sizeof h) != hipSuccess) return -3;
