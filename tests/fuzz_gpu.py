@@ -93,14 +93,31 @@ def run_seed(seed, profile, always_check=False):
     iq, _ = synth.synthesize(cfg)
     raw = iq.view(np.uint8)
     nch = len(cfg.freqs)
-    o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+    # seeds from 2000 on also vary the sample format (the RTL-SDR's offset-binary u8, process_buf_uchar) and the receiver: one
+    # context, or a vdl2hip_group of 2-3 virtual shards on this GPU with either exchange form (seeds below 2000 stay what they were)
+    rng2 = np.random.default_rng(seed + 7_000_000)
+    fmt, sb = vdl2hip.FMT_S16LE, 4
+    ndev, form = 1, None
+    if seed >= 2000:
+        if rng2.random() < 0.25:
+            fmt, sb = vdl2hip.FMT_U8, 2
+            raw = np.clip(np.rint(iq.astype(np.float64) / 256.0 + 127.5), 0, 255).astype(np.uint8)
+        if rng2.random() < 0.25 and nch >= 3:
+            ndev, form = int(rng2.choice([2, 3])), str(rng2.choice(["allgather", "broadcast"]))
+    o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, sample_fmt=fmt, max_ppm=cfg.rx_max_ppm)
     o.process(raw, block_bytes=1 << 24, nthreads=8)
     fo = o.frames()
     # the pieces: mostly a few long feeds with runs of short ones (the reference's own 320 000-byte blocks, odd sizes, tiny ones) between them
     style = int(rng.integers(0, 4))
     big = int(rng.choice([1 << 20, 3 << 20, 8 << 20]))
     # (max_block_bytes >= the capture: the whole decimated stream then stays inside the device's history ring for the check below)
-    rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=max(big, raw.size))
+    if ndev == 1:
+        rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, fmt, cfg.rx_max_ppm, max_block_bytes=max(big, raw.size))
+        take = lambda: vdl2hip.Receiver.unpack(*rx.drain_packed())
+    else:
+        rx = vdl2hip.ReceiverGroup(cfg.centerfreq, list(cfg.freqs), [0] * ndev, cfg.oversample, fmt, cfg.rx_max_ppm, max_block_bytes=max(big, raw.size))
+        rx.set_exchange(form)
+        take = rx.drain
     lag = int(rng.integers(0, 3))
     rx.set_drain_lag(lag)
     got = []
@@ -121,11 +138,11 @@ def run_seed(seed, profile, always_check=False):
         if m <= 0:
             break
         rx.feed(raw[t:t + m]); t += m; nfeeds += 1
-        nsmall += (m // 4 // cfg.oversample) < 32768
+        nsmall += (m // sb // cfg.oversample) < 32768
         if rng.random() < 0.7:
-            got += vdl2hip.Receiver.unpack(*rx.drain_packed())
+            got += take()
     rx.set_drain_lag(0)
-    got += vdl2hip.Receiver.unpack(*rx.drain_packed())
+    got += take()
     label = f"seed {seed} {profile}"
     names = list(o.counters(0).keys())
     co = [list(o.counters(c).values()) for c in range(nch)]
@@ -138,7 +155,7 @@ def run_seed(seed, profile, always_check=False):
         which, nbad = compare_reference_counters(names, co, cg, label=label, strict=False, max_channels=max(1, nch // 4))
     except AssertionError as e:
         ok, why, y = device_logic_on_device_samples(rx, cfg, D, got, cg)
-        tr = o2_trace(cfg, raw, D)
+        tr = o2_trace(cfg, raw, D, fmt)
         rms = np.sqrt((tr.astype(np.float64) ** 2).sum(axis=2).mean(axis=1))
         rel = float((np.sqrt(((y.astype(np.float64) - tr) ** 2).sum(axis=2).mean(axis=1)) / rms).max())
         rx.close()
@@ -150,12 +167,13 @@ def run_seed(seed, profile, always_check=False):
         check = True
     rx.close()
     return {"frames": len(fo), "ties": st["timing_ties"], "nf_ties": st["nf_update_ties"], "bookkeeping_channels": nbad, "feeds": nfeeds,
-            "short_feeds": int(nsmall), "lag": lag, "nch": nch, "os": cfg.oversample, "fallbacks": s["front_sync_timeouts"], "host_build_check": check}
+            "short_feeds": int(nsmall), "lag": lag, "nch": nch, "os": cfg.oversample, "fallbacks": s["front_sync_timeouts"], "host_build_check": check,
+            "fmt": "u8" if fmt == vdl2hip.FMT_U8 else "s16", "receiver": "one context" if ndev == 1 else f"group of {ndev}, {form}"}
 
 
-def o2_trace(cfg, raw, D):
+def o2_trace(cfg, raw, D, fmt):
     """the oracle's decimated samples of the capture (a second oracle run with tracing on)"""
-    o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+    o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, sample_fmt=fmt, max_ppm=cfg.rx_max_ppm)
     tr = o.trace_all(D + 4)
     o.process(raw, block_bytes=1 << 24, nthreads=8)
     return tr[:, :D, :]
