@@ -1,4 +1,4 @@
-"""A/B of the table-free channeliser build (-DVDL2_K1_NOLUT, dev/gpu_k1_nolut.sh builds it) against the in-tree library on ONE
+"""A/B of channeliser builds (first written for the table-free build (-DVDL2_K1_NOLUT, dev/gpu_k1_nolut.sh builds it) against the in-tree library on ONE
 GPU box, without PyTorch (its first import on a fresh box costs a minute or two): per library, in a process of its own,
   * the committed golden captures through the library -> frames / metadata / counters against tests/golden/*.json,
   * the decimated stream of a few channels saved for the parent to compare between the libraries,
@@ -36,9 +36,20 @@ def child(lib):
         except AssertionError as e:
             out[name] = f"DIFFERS: {str(e)[:300]}"
         D = iq.size // 2 // cfg.oversample
-        ys = np.stack([rx.read_decimated(c, 0, D) for c in sorted({0, 1, len(cfg.freqs) // 2, len(cfg.freqs) - 1})])
+        chans = sorted({0, 1, len(cfg.freqs) // 2, len(cfg.freqs) - 1})
+        ys = np.stack([rx.read_decimated(c, 0, D) for c in chans])
         np.save(f"/tmp/k1ab_{tag}_{name}.npy", ys)
         rx.close()
+        # ... and against the oracle's sequential scan of the same channels (the reference's own arithmetic)
+        from oracle import pyoracle as po
+        o = po.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample)
+        tr = o.trace_all(D)
+        o.process(iq.view(np.uint8), block_bytes=320000)
+        ref = tr[chans, :D, :]
+        d = np.asarray(ys, dtype=np.float64).reshape(ref.shape) - ref
+        peak = float(np.abs(ref).max())
+        out[name + "_vs_oracle"] = {"max_over_peak": float(np.abs(d).max() / peak), "rms_over_peak": float(np.sqrt(np.mean(d * d) * 2) / peak)}
+        o.close()
     rng = np.random.default_rng(5)
     for C, secs in ((256, 16.0), (32, 16.0)):
         n = int(secs * 2100000)
@@ -70,23 +81,29 @@ def main():
         return child(sys.argv[2])
     import numpy as np
     libs = sys.argv[1:]
-    res = []
+    first = None
     for lib in libs:
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", lib], capture_output=True, text=True, timeout=240)
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", lib], capture_output=True, text=True, timeout=150)
+        except subprocess.TimeoutExpired:
+            print(f"{lib}: TIMEOUT", flush=True)
+            continue
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if not line:
             print(f"{lib}: FAILED rc={p.returncode}\n{p.stderr[-1500:]}", flush=True)
             continue
-        r = json.loads(line[-1]); res.append(r)
+        r = json.loads(line[-1])
         print(json.dumps(r), flush=True)
-    if len(res) >= 2:
-        ta, tb = (os.path.basename(r["lib"]).replace(".so", "") for r in res[:2])
-        for name in CASES:
+        if first is None:
+            first = r
+            continue
+        ta, tb = (os.path.basename(x["lib"]).replace(".so", "") for x in (first, r))
+        for name in CASES:          # each library's result is compared with the first one's as soon as it is in (a call may be cut short)
             a, b = np.load(f"/tmp/k1ab_{ta}_{name}.npy"), np.load(f"/tmp/k1ab_{tb}_{name}.npy")
             peak = float(np.abs(a).max())
             print(f"{name}: decimated stream {tb} vs {ta}: max |diff| / peak = {float(np.abs(a - b).max()) / peak:.3e} (peak {peak:.4f}, {a.shape})", flush=True)
         for k in ("noise_256ch", "noise_32ch"):
-            print(f"{k}: k_chanfir {res[0][k]['k_chanfir_ms']} -> {res[1][k]['k_chanfir_ms']} ms ({(res[1][k]['k_chanfir_ms'] / res[0][k]['k_chanfir_ms'] - 1) * 100:+.1f} %)", flush=True)
+            print(f"{k}: k_chanfir {ta} {first[k]['k_chanfir_ms']} -> {tb} {r[k]['k_chanfir_ms']} ms ({(r[k]['k_chanfir_ms'] / first[k]['k_chanfir_ms'] - 1) * 100:+.1f} %)", flush=True)
 
 
 if __name__ == "__main__":

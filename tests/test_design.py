@@ -16,7 +16,7 @@ class BlockForm(C.Structure):
     _fields_ = [("os", C.c_int), ("run", C.c_int), ("g0", C.c_float * K_MAXOS), ("g1", C.c_float * K_MAXOS),
                 ("P", C.c_float * 4), ("c0", C.c_float), ("c1", C.c_float), ("c2", C.c_float),
                 ("cP", (C.c_float * 2) * K_FIX), ("Ppow", (C.c_float * 4) * (K_FIX + 1)), ("Q", (C.c_float * 4) * 6),
-                ("Qpow", (C.c_float * 4) * 64)]
+                ("Qpow", (C.c_float * 4) * 64), ("basis", C.c_float * 4)]
 
 
 @pytest.fixture(scope="module")
@@ -64,7 +64,9 @@ def test_nco_lut_is_sincosf_lut(hs):
 @pytest.mark.parametrize("os_,run", [(20, 2), (10, 2), (13, 2), (7, 2)])
 def test_block_form_reproduces_the_direct_form(hs, os_, run):
     """y[n] = A0 x[n] + A1 x[n-1] + A2 x[n-2] + B1 y[n-1] + B2 y[n-2] (chebyshev.c / demod.c:58-79), decimated by os, against
-    the block recurrence K1 runs: t_k = P t_{k-1} + sum_j (g0[j], g1[j]) x[os k + j], y_k = c0 t0 + c1 t1 + c2 x[last]."""
+    the block recurrence K1 runs: t_k = P t_{k-1} + sum_j (g0[j], g1[j]) x[os k + j], y_k = c0 t0 + c1 t1 + c2 x[last] - with the
+    state in the normal form of the recursion matrix (design.h: derive_block_form), where the single-precision constants and the
+    single-precision arithmetic both leave ~1e-7 of the signal level instead of the ~1e-4 of the (v[n], v[n-1]) basis."""
     A, B = lpf(hs, os_)
     bf = BlockForm()
     hs.hostsim_block_form(A, B, os_, run, C.byref(bf))
@@ -84,15 +86,28 @@ def test_block_form_reproduces_the_direct_form(hs, os_, run):
         blk = x[k * os_:(k + 1) * os_]
         t = P @ t + np.array([g0 @ blk, g1 @ blk])
         got[k] = bf.c0 * t[0] + bf.c1 * t[1] + bf.c2 * blk[-1]
-    # fp32-rounded P, taps and c0..c2 in a filter whose poles sit at radius 0.985: the same ~1e-5 of the signal level that
-    # separates any two evaluation orders of this IIR in fp32
-    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    # fp32-rounded P, taps and c0..c2, arithmetic in double: in the normal form the rounded constants cost ~1e-7 of the signal
+    # level (in the basis of the recursion itself, where P = [[15.1, -14.2], [14.7, -13.7]] at oversample 20, they cost ~1e-5)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    # ... and the same recurrence carried in single precision (every product and sum rounded) stays as close
+    t32 = np.zeros(2, dtype=np.float32); got32 = np.zeros(nblk)
+    P32 = P.astype(np.float32); g32 = np.stack([g0, g1]).astype(np.float32); c32 = np.array([bf.c0, bf.c1, bf.c2], dtype=np.float32)
+    for k in range(nblk):
+        blk = x[k * os_:(k + 1) * os_].astype(np.float32)
+        t32 = (P32 @ t32 + g32 @ blk).astype(np.float32)
+        got32[k] = np.float32(c32[0] * t32[0] + c32[1] * t32[1] + c32[2] * blk[-1])
+    assert np.abs(got32 - want).max() <= 5e-6 * np.abs(want).max()
     # the tables the wave scan and the fix-ups use are powers of the same P
-    # (derived in double from M = [[B1, B2], [1, 0]], P = M^os, then rounded once - so compare with the double powers)
-    Pd = np.linalg.matrix_power(np.array([[b[1], b[2]], [1.0, 0.0]]), os_)
+    # (derived in double from M = [[B1, B2], [1, 0]], P = T M^os T^-1, then rounded once - so compare with the double powers)
+    r = np.sqrt(-b[2]); ct = b[1] / (2 * r); st = np.sqrt(1 - ct * ct)
+    Ti = np.array([[r * ct, r * st], [1.0, 0.0]]); T = np.linalg.inv(Ti)          # columns of T^-1: Re and Im of M's eigenvector (lambda, 1)
+    assert np.abs(np.array(bf.basis[:], dtype=np.float64).reshape(2, 2) - T).max() <= 1e-7 * np.abs(T).max()
+    Pd = T @ np.linalg.matrix_power(np.array([[b[1], b[2]], [1.0, 0.0]]), os_) @ Ti
     assert np.abs(P - Pd).max() <= 6e-8 * np.abs(Pd).max()
-    Pp = np.array([list(r) for r in bf.Ppow], dtype=np.float64).reshape(-1, 2, 2)
-    c01 = np.array([a[0] + a[2] / b[2], a[1] - a[2] * b[1] / b[2]])
+    # a rotation scaled by |lambda|^os: nothing cancels in P t
+    assert np.abs(Pd @ Pd.T - (r ** (2 * os_)) * np.eye(2)).max() <= 1e-9 * r ** (2 * os_)
+    Pp = np.array([list(r_) for r_ in bf.Ppow], dtype=np.float64).reshape(-1, 2, 2)
+    c01 = np.array([a[0] + a[2] / b[2], a[1] - a[2] * b[1] / b[2]]) @ Ti
     assert abs(bf.c0 - c01[0]) <= 1e-7 * abs(c01[0]) and abs(bf.c1 - c01[1]) <= 1e-7 * abs(c01[1]) and abs(bf.c2 + a[2] / b[2]) <= 1e-7 * abs(a[2] / b[2])
     acc = np.eye(2)
     for i in range(K_FIX + 1):
