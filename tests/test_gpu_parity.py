@@ -100,8 +100,10 @@ def test_chunking_does_not_change_the_answer(vh, name, chunks):
 
 
 def test_decimated_stream_close_to_reference(vh, oracle_mod):
-    """K1+K2 against the reference's sequential IIR: not bit-equal by construction, but within the
-    reference filter's own rounding noise (~1e-5 of full scale of the channel)."""
+    """K1 against the reference's sequential IIR: not bit-equal by construction (no time-parallel evaluation can repeat the
+    rounding history of a sequential fp32 scan), but as close as EXACT arithmetic is - what is left is the reference's own rounding
+    noise (3.2e-5 of the channel's peak, 4.4e-6 rms on this capture; dev/k1_state_basis.py).  The bounds below fail for the block
+    form carried in the recursion's own basis (v[n], v[n-1]) (7.1e-5 / 7.0e-6): they guard design.h's normal-form state."""
     cfg, iq, _, _ = cases.load("config2_1s")
     o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample)
     D = iq.size // 2 // cfg.oversample
@@ -111,7 +113,10 @@ def test_decimated_stream_close_to_reference(vh, oracle_mod):
     for c in range(len(cfg.freqs)):
         y = rx.read_decimated(c, 0, D)
         ref = tr[c, :len(y)]
-        assert np.abs(y - ref).max() <= 3e-4 * np.abs(ref).max()
+        d = (np.asarray(y, dtype=np.float64).reshape(-1, 2) - np.asarray(ref, dtype=np.float64).reshape(-1, 2))
+        peak = float(np.abs(ref).max())
+        assert np.abs(d).max() <= 5e-5 * peak, f"channel {c}: {np.abs(d).max() / peak:.2e} of the peak"
+        assert np.sqrt((d * d).sum(axis=1).mean()) <= 6.5e-6 * peak, f"channel {c}: rms {np.sqrt((d * d).sum(axis=1).mean()) / peak:.2e} of the peak"
         assert o.dphi(c) & 0xFFFFFF == rx.nco_step(c) & 0xFFFFFF
     rx.close()
 
@@ -934,14 +939,14 @@ def test_dpp_primitives_behave_as_the_scan_assumes(vh):
 def test_random_capture_in_random_pieces(vh, seed, profile):
     """tests/fuzz_gpu.py's seeds as a test: a random capture fed in random pieces (long feeds with the speculative walk and the back
     end on its own streams, short ones with everything on the front stream, in one stream; random drain lag).  Either the answer is
-    the oracle's (within util.compare_at_full_size / compare_reference_counters), or - seeds 55, 145, 104 are such cases, found by the
-    300 s run in profiles/r04_gpu_fuzz.txt - a frame or counter differs and the difference is *decided*: the decimated stream is
+    the oracle's (within util.compare_at_full_size / compare_reference_counters), or - seeds 55, 145, 104 were such cases in the 300 s run of
+    profiles/r04_gpu_fuzz.txt, before the channeliser's state went into normal form; they agree now - a frame or counter differs and the difference is *decided*: the decimated stream is
     read back from the GPU and run through the host build of the device logic, which must reproduce the GPU's frames, burst timing
-    and 18 counters exactly (then the channeliser's ~2e-5 is the cause).  In both cases the host-build check is made."""
+    and 18 counters exactly (then the ~1e-5 by which the samples differ - the reference's own rounding - is the cause).  In both cases the host-build check is made."""
     import fuzz_gpu
     try:
         r = fuzz_gpu.run_seed(seed, profile, always_check=True)
         assert r["host_build_check"] is True and r["frames"] > 0
     except fuzz_gpu.Differs as e:
         assert e.from_samples, str(e)
-        assert e.rel < 2e-4, f"the decimated stream differs from the oracle's by {e.rel:.2e} rms"
+        assert e.rel < 5e-5, f"the decimated stream differs from the oracle's by {e.rel:.2e} rms"
