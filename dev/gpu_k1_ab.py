@@ -1,9 +1,9 @@
-"""A/B of channeliser builds (first written for the table-free build (-DVDL2_K1_NOLUT, dev/gpu_k1_nolut.sh builds it) against the in-tree library on ONE
+"""A/B of channeliser builds (first written for the table-free NCO experiment, history 60803f7, then the state-basis change) on ONE
 GPU box, without PyTorch (its first import on a fresh box costs a minute or two): per library, in a process of its own,
   * the committed golden captures through the library -> frames / metadata / counters against tests/golden/*.json,
   * the decimated stream of a few channels saved for the parent to compare between the libraries,
   * the channeliser's own time per launch (HIP events of the launch) on a 256-channel 16 s block of noise and on a 32-channel one.
-usage: python dev/gpu_k1_nolut.py <lib_a.so> <lib_b.so> ...   (child: --child <lib>)"""
+usage: python dev/gpu_k1_ab.py <lib_a.so> <lib_b.so> ...   (child: --child <lib>)"""
 import json
 import os
 import subprocess

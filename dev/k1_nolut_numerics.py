@@ -1,4 +1,5 @@
-"""CPU check of the table-free NCO formulation of K1 (kernels.h, -DVDL2_K1_NOLUT) before it goes to a GPU.
+"""CPU check of the table-free NCO formulation of K1 (the -DVDL2_K1_NOLUT experiment: commit 60803f7; measured on the GPU: correct, not
+faster - profiles/r04_k1_table_free_nco_ab.txt) before it went to a GPU.
 
 The reference mixes every input sample with a 256-entry, linearly interpolated sine table (sincosf_lut(), src/demod.c:58-72):
 lut(phi) = e^{j theta_i} (1 + f (e^{j delta} - 1)), theta_i the cell start, f the position in the cell, delta = 2 pi / 256.

@@ -157,28 +157,5 @@ inline BlockForm derive_block_form(const LpfCoeffs &lp, int os, int run) {
 	return bf;
 }
 
-// Table-free NCO for the channeliser (kernels.h, -DVDL2_K1_NOLUT).  sincosf_lut() (src/demod.c:58-72) interpolates a 256-entry table
-// linearly: lut(phi) = e^{j theta_i} (1 + f (e^{j delta} - 1)) with theta_i the start of the cell, f the position in it and
-// delta = 2 pi / 256.  Against the exact carrier that is lut(phi) = e^{j phi} g(f), g(f) = (1 + f (e^{j delta} - 1)) e^{-j f delta}
-// = 1 - (1 - cos delta) f (1 - f) + j O(2.4e-7): a per-sample amplitude dip of at most 7.5e-5 on an exact rotation.  The rotation
-// by e^{j j dphi} within a block is the same for every block of a channel, so it moves into the taps:
-//   sum_j hap[.] x_j lut(phi_0 + j dphi)  =  e^{j phi_0} sum_j (hap[.] e^{j j dphi}) (x_j (1 - kappa f_j (1 - f_j)))
-// and the table is looked up once per block (for e^{j phi_0}) instead of once per sample.  dev/k1_nolut_numerics.py measures both
-// forms against the sequential scan.  Entry j < os of a channel's table: {Re G0, Re G1, Im G0, Im G1}, G0/G1 = g0/g1[j] e^{j j dphi};
-// entry kMaxOversample: {Re w, Im w, df, 0}, w = e^{j (os-1) dphi} (the block's last sample: the c2 xm[n] term), df = the step of f.
-constexpr int kTapStride = kMaxOversample + 1;
-inline double nco_kappa() { return 1.0 - cos(2.0 * M_PI / 256.0); }
-inline void build_channel_taps(const BlockForm &bf, uint32_t dphi, float out[kTapStride][4]) {
-	for(int j = 0; j < kTapStride; j++) out[j][0] = out[j][1] = out[j][2] = out[j][3] = 0.f;
-	for(int j = 0; j < bf.os; j++) {
-		const uint32_t p = (uint32_t)(((uint64_t)j * dphi) & 0xffffffu);
-		const double a = 2.0 * M_PI * (double)p / 16777216.0;
-		const double wr = p ? cos(a) : 1.0, wi = p ? sin(a) : 0.0;
-		out[j][0] = (float)((double)bf.g0[j] * wr); out[j][1] = (float)((double)bf.g1[j] * wr);
-		out[j][2] = (float)((double)bf.g0[j] * wi); out[j][3] = (float)((double)bf.g1[j] * wi);
-		if(j == bf.os - 1) { out[kMaxOversample][0] = (float)wr; out[kMaxOversample][1] = (float)wi; }
-	}
-	out[kMaxOversample][2] = (float)(dphi & 0xffffu) / 65536.0f;
-}
 
 }  // namespace vdl2

@@ -32,7 +32,6 @@ namespace vdl2 {
 
 constexpr int kK1Unroll = VDL2_K1_UNROLL;
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 // the slice of BlockForm K1 needs, passed by value so that it lives in the kernarg segment
 // (constant address space -> scalar loads into SGPRs)
@@ -67,8 +66,6 @@ struct K1Args {
 	int32_t  seg0, seg1;       // this launch does the workgroup segments seg0 <= s < seg1 (seg0 a multiple of 8); one launch: 0, nseg
 	const uint32_t *dphi;      // NCO step per channel (24-bit phase)
 	const Lut4 *lut;
-	const float4 *gtab;        // [nchan][kTapStride] per-channel complex taps of the table-free NCO (design.h: build_channel_taps)
-	float kappa;               // 1 - cos(2 pi / 256): depth of the interpolated table's amplitude dip (design.h: nco_kappa)
 	K1Consts bf;
 	cf32 *y;                   // [nchan][cap]
 	float4 *seg_end;           // [nchan][nseg_cap] zero-start state at the end of each workgroup segment
@@ -192,9 +189,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	// and the tile is a whole number of 256-sample rows.
 	constexpr bool kPrefetch = OS != 0 && CR >= 4 && (64 * R * OS + 255) / 256 <= 10 && (64 * R * OS) % 256 == 0;
 	constexpr int kPre = kPrefetch ? (64 * R * OS) / 256 : 1;
-#ifndef VDL2_K1_NOLUT
 	constexpr bool kPipeGather = kPrefetch;
-#endif
 	uint32_t pre[kPre]; bool have_pre = false;
 	#pragma unroll
 	for(int k = 0; k < kPre; k++) pre[k] = 0u;
@@ -218,11 +213,6 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	const int L = 64 * R;                         // decimated outputs per tile
 
 	uint32_t dph[CR];
-#ifdef VDL2_K1_NOLUT
-	// the channel's tap table through the constant address space: uniform addresses there are scalar loads
-	typedef const __attribute__((address_space(4))) v4f *ctap_t;
-	ctap_t gt[CR]; float df[CR]; uint32_t dphos[CR];
-#endif
 	float4 *carry = (float4 *)(park + wave * (4 * CR * 4));    // state carried into the current tile (zero at the segment start)
 	float4 *svp = carry + CR;                                   // zero-start state after the feed's last valid block
 	float4 *sendp = svp + CR;                                   // zero-start state at the end of the segment (what seg_end gets)
@@ -242,11 +232,6 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	for(int c = 0; c < CR; c++) {
 		const int ch = cbase + c < a.nchan ? cbase + c : a.nchan - 1;
 		dph[c] = a.dphi[ch];
-#ifdef VDL2_K1_NOLUT
-		gt[c] = (ctap_t)(uintptr_t)(a.gtab + (size_t)ch * kTapStride);
-		df[c] = gt[c][kMaxOversample].z;
-		dphos[c] = dph[c] * (uint32_t)os;
-#endif
 		if(lane == 0) carry[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 	}
 	const float P0 = bf.P[0], P1 = bf.P[1], P2 = bf.P[2], P3 = bf.P[3];
@@ -320,59 +305,6 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 		// The block loop stays rolled: one iteration = OS samples x CR channels of straight-line code.
 		#pragma unroll 1
 		for(int i = 0; i < R; i++) {
-#ifdef VDL2_K1_NOLUT
-			// Table-free NCO (design.h: build_channel_taps): the rotation inside the block sits in the channel's complex taps G (scalar
-			// loads: the channel is wave-uniform), the interpolated table's amplitude dip is put onto the sample - s = 1 - kappa f (1 - f),
-			// f the position in the table cell, stepped in single precision (it only feeds a 3e-4 correction) - and the carrier at the
-			// block's first sample multiplies the two sums once, behind the loop.  Per channel-sample: three scalar and five packed
-			// operations and no look-up, against three integer, five packed and a 16-byte gather.
-			v2f Sr[CR], Si[CR], XL[CR];
-			float fq[CR];
-			#pragma unroll
-			for(int c = 0; c < CR; c++) {
-				Sr[c] = v2f{0.f, 0.f}; Si[c] = v2f{0.f, 0.f}; XL[c] = v2f{0.f, 0.f};
-				fq[c] = (float)(ph[c] & 0xffffu) * (1.0f / 65536.0f);
-			}
-			const float2 *trow = tile + (size_t)(i * os) * 65 + lane;
-			#pragma unroll kK1Unroll
-			for(int j = 0; j < os; j++) {
-				const float2 x = trow[j * 65];
-				const v2f X = v2f{x.x, x.y}, Xk = X * v2f{a.kappa, a.kappa};
-				#pragma unroll
-				for(int c = 0; c < CR; c++) {
-					const v4f g = gt[c][j];
-					const float f = fq[c];
-					const float t = __builtin_fmaf(f, f, -f);                               // -f (1 - f)
-					const v2f xs = __builtin_elementwise_fma(Xk, v2f{t, t}, X);
-					Sr[c] = __builtin_elementwise_fma(v2f{g.x, g.y}, v2f{xs.x, xs.x}, Sr[c]);
-					Sr[c] = __builtin_elementwise_fma(v2f{g.z, g.w}, v2f{-xs.y, -xs.y}, Sr[c]);
-					Si[c] = __builtin_elementwise_fma(v2f{g.x, g.y}, v2f{xs.y, xs.y}, Si[c]);
-					Si[c] = __builtin_elementwise_fma(v2f{g.z, g.w}, v2f{xs.x, xs.x}, Si[c]);
-					XL[c] = xs;
-					fq[c] = __builtin_amdgcn_fractf(f + df[c]);
-				}
-			}
-			float a0r[CR], a0i[CR], a1r[CR], a1i[CR], lr[CR], li[CR];
-			#pragma unroll
-			for(int c = 0; c < CR; c++) {
-				// the carrier at the block's first sample: the table entry of its cell turned on by the rest of the angle (|r| < 2 pi / 256)
-				const uint32_t p = ph[c];
-				ph[c] = p + dphos[c];
-				const float4 e = lut[(p >> 16) & 0xffu];
-				const float r = (float)(p & 0xffffu) * (float)(2.0 * M_PI / 256.0 / 65536.0);
-				const float r2 = r * r;
-				const float cr = __builtin_fmaf(r2, __builtin_fmaf(r2, 1.0f / 24.0f, -0.5f), 1.0f);
-				const float sr = __builtin_fmaf(r * r2, -1.0f / 6.0f, r);
-				const float Ec = __builtin_fmaf(e.y, cr, -(e.x * sr)), Es = __builtin_fmaf(e.x, cr, e.y * sr);
-				const v2f Ar = __builtin_elementwise_fma(v2f{Ec, Ec}, Sr[c], -(v2f{Es, Es} * Si[c]));
-				const v2f Ai = __builtin_elementwise_fma(v2f{Ec, Ec}, Si[c], v2f{Es, Es} * Sr[c]);
-				a0r[c] = Ar.x; a1r[c] = Ar.y; a0i[c] = Ai.x; a1i[c] = Ai.y;
-				// the mixed last sample of the block (the c2 xm[n] term of y): e^{j phi_0} w x_s, w = e^{j (os-1) dphi}
-				const v4f w = gt[c][kMaxOversample];
-				const float wr = __builtin_fmaf(w.x, XL[c].x, -(w.y * XL[c].y)), wi = __builtin_fmaf(w.x, XL[c].y, w.y * XL[c].x);
-				lr[c] = __builtin_fmaf(Ec, wr, -(Es * wi)); li[c] = __builtin_fmaf(Ec, wi, Es * wr);
-			}
-#else
 			// (re, im) pairs throughout, so that the mix and the two tap sums are packed FP32 operations
 			v2f A0[CR], A1[CR], M[CR];
 			#pragma unroll
@@ -411,7 +343,6 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 			float a0r[CR], a0i[CR], a1r[CR], a1i[CR], lr[CR], li[CR];
 			#pragma unroll
 			for(int c = 0; c < CR; c++) { a0r[c] = A0[c].x; a0i[c] = A0[c].y; a1r[c] = A1[c].x; a1i[c] = A1[c].y; lr[c] = M[c].x; li[c] = M[c].y; }
-#endif
 			#pragma unroll
 			for(int c = 0; c < CR; c++) {
 				// state update t <- P t + acc, then y = c0*v[n] + c1*v[n-1] + c2*xm[n] (zero-start part)

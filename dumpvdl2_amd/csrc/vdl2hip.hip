@@ -69,7 +69,6 @@ struct vdl2hip_ctx {
 	// device memory
 	BlockForm *d_bf = nullptr; Lut4 *d_lut = nullptr; Tables *d_tab = nullptr;
 	uint32_t *d_dphi = nullptr, *d_freq = nullptr; float *d_ppmthr = nullptr;
-	float4 *d_gtab = nullptr;              // per-channel complex taps of the table-free NCO (design.h: build_channel_taps; read by -DVDL2_K1_NOLUT builds)
 	// host-fed input: one device buffer + "copy done" event per slot, filled on a copy stream of its own so that the H2D of
 	// block i+1 runs beside the channeliser of block i (process_buf_*() hands over host memory: src/demod.c:356-365)
 	uint8_t *d_in[kSlots] = {}; hipEvent_t ev_copied[kSlots] = {}; size_t in_cap = 0;
@@ -248,7 +247,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 	a.in = dev_in; a.carry = c->d_carry[c->carry_sel]; a.ncarry = c->ncarry; a.nlogical = nlogical;
 	a.n0 = c->n_total - c->ncarry; a.k0 = c->k_total; a.D = D;
 	a.fmt = c->fmt; a.nchan = c->C; a.os = c->os; a.nseg = 0; a.gy = 1;
-	a.dphi = c->d_dphi; a.lut = c->d_lut; a.gtab = c->d_gtab; a.kappa = (float)nco_kappa(); a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.seg_end = c->d_segend;
+	a.dphi = c->d_dphi; a.lut = c->d_lut; a.bf = make_k1_consts(c->bf); a.y = c->d_y; a.seg_end = c->d_segend;
 	a.qpow = c->d_qpow; a.cap = c->cap; a.mask = c->cap - 1; a.nseg_cap = c->nseg_cap;
 	a.fuse = c->fuse_k2 && 64 * c->run == kFixW; a.carry_in = c->d_tcarry[c->tcarry_sel]; a.carry_out = c->d_tcarry[c->tcarry_sel ^ 1];
 	a.bfd = c->d_bf; a.seg_pub = c->d_segpub; a.epoch = (uint32_t)(c->feed_no + 1); a.sync_timeouts = c->d_synctmo;
@@ -479,7 +478,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	OnDevice dev_guard(c);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_gtab, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
+	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
 		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog };
 		for(void *p : q) if(p) (void)hipFree(p);
@@ -591,7 +590,6 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	}
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
 	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count); DEV_ALLOC(c->d_ppmthr, 4 * count);
-	DEV_ALLOC(c->d_gtab, (size_t)count * kTapStride * sizeof(float4));
 	static_assert(kSlots == 3, "vdl2hip_destroy() lists the input buffers one by one");
 	DEV_ALLOC(c->d_carry[0], 4 * kMaxOversample); DEV_ALLOC(c->d_carry[1], 4 * kMaxOversample);
 	const size_t nring = (size_t)count * cap;
@@ -665,11 +663,6 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_CHK(hipMemcpy(c->d_tab, tab, sizeof(Tables), hipMemcpyHostToDevice));
 	delete tab;
 	DEV_CHK(hipMemcpy(c->d_dphi, c->dphi.data(), 4 * count, hipMemcpyHostToDevice));
-	{
-		std::vector<float> taps((size_t)count * kTapStride * 4);
-		for(uint32_t i = 0; i < count; i++) build_channel_taps(c->bf, c->dphi[i], reinterpret_cast<float (*)[4]>(taps.data() + (size_t)i * kTapStride * 4));
-		DEV_CHK(hipMemcpy(c->d_gtab, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
-	}
 	DEV_CHK(hipMemcpy(c->d_freq, c->freqs.data(), 4 * count, hipMemcpyHostToDevice));
 	{
 		std::vector<float> thr(count);
