@@ -138,8 +138,9 @@ typedef struct {
 	uint64_t front_sync_timeouts; /* channeliser workgroups that stopped waiting for their predecessor's filter state and worked it out
 	                               * themselves (one more tile of work each).  The state they compute equals the published one up to fp32
 	                               * rounding (a sum instead of a scan), i.e. the first 128 decimated outputs of such a segment may differ
-	                               * from a run without fall-backs by ~1e-5 of the signal: NOT bit-identical, and which workgroups fall
-	                               * back depends on scheduling.  0 with one process per GPU; non-zero where the GPU is time-sliced
+	                               * from a run without fall-backs in their last bit (measured with every workgroup forced to fall back:
+	                               * <= 2e-7 of the signal's peak, a fiftieth of the reference's own rounding noise): NOT bit-identical, and
+	                               * which workgroups fall back depends on scheduling.  0 with one process per GPU; non-zero where the GPU is time-sliced
 	                               * between processes - set VDL2HIP_NO_FUSE=1 there if bit-reproducible output is required */
 	uint64_t overflow_feeds;    /* feeds in which a device-side burst/frame/octet buffer ran out (bursts or frames were dropped);
 	                             * vdl2hip_sync() returns VDL2HIP_E_OVERFLOW for those, the drain calls only count here */

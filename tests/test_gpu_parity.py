@@ -687,9 +687,10 @@ def test_lookback_fallback_recovers(vh, name, chunks):
     peak = float(np.abs(np.asarray(iq).astype(np.float32)).max()) / 32768.0
     for c in range(min(len(cfg.freqs), 16)):
         a, b = rx.read_decimated(c, max(0, D - 30000), 30000), rx2.read_decimated(c, max(0, D - 30000), 30000)
-        # a sum of the lanes' states instead of a scan: the state differs in its last bit, which this filter form turns into ~1e-5 of
-        # the signal on the first 128 outputs of a segment - the same size as its distance from the reference's own rounding
-        assert np.abs(a - b).max() <= 1e-4 * peak
+        # a sum of the lanes' states instead of a scan: the state differs in its last bit, and so - with the state in the normal form
+        # of the recursion matrix (design.h) - do the first 128 outputs of a segment: 1.6e-7 of the stream's peak measured
+        # (dev/gpu_fallback_diff.py); in the recursion's own basis the same last bit was ~1e-5 of the signal
+        assert np.abs(a - b).max() <= 1e-6 * peak
     rx.close(); rx2.close()
 
 
