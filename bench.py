@@ -275,7 +275,8 @@ def measured_rates(vh, device):
           "compute_units": int(a[6]),
           "note": "k_chanfir needs one LUT gather (ds_read_b128 at 64 unrelated entries) per channel-sample and wavefront; the CU's one LDS pipe serves "
                   "four SIMDs.  Both figures measured in this run (vdl2hip_debug_ubench); `k_chanfir_clocks_per_chan_sample_wave_per_SIMD` is the "
-                  "kernel's own time in the same unit (all of it: sample loop, wave scan, staging, look-back)"}
+                  "kernel's own time in the same unit (all of it: sample loop, wave scan, staging, look-back).  The pipe runs level with VALU "
+                  "issue but is not what binds: a build without any per-sample gather (round 4, profiles/r04_k1_table_free_nco_ab.txt) is exactly as fast"}
     return issue, co
 
 
