@@ -1,0 +1,30 @@
+"""The whole path on the CPU from raw IQ, with the channel filter evaluated in DOUBLE precision (dev/predict_gpu_parity.py: the
+reference's table mixer and coefficients, scipy's lfilter) and everything behind it by the host build of the device logic: since
+the channeliser's state is carried in normal form the GPU's stream IS that filter to 2e-7 of the peak, so this is
+what the GPU answers - checked seed by seed against the GPU in profiles/r04_cpu_prediction_of_gpu_parity.txt (12 of 12).
+
+Ordinary captures must give the oracle's frames, timing and counters exactly.  Seed 175 is one of the few (6 of 963) where a
+decision of the reference hinges on the rounding noise of its own sequential fp32 scan: exact arithmetic, and the GPU, count one
+corrected octet where the fp32 reference counts two - pinned here so that the irreducible difference stays what it is."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dev"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
+
+
+@pytest.mark.parametrize("seed,profile", [(55, "plain"), (104, "extreme"), (2274, "plain")])
+def test_exact_arithmetic_gives_the_oracles_answer(seed, profile):
+    """(seeds on which the GPU differed from the oracle while its state was in the recursion's own basis, and agrees now)"""
+    import predict_gpu_parity as p
+    s, prof, verdict, info = p.run_seed(seed, profile)
+    assert verdict == "ok" and info["frames"] > 40 and info["ties"] == 0, info
+
+
+def test_a_decision_that_hinges_on_the_references_own_rounding():
+    import predict_gpu_parity as p
+    s, prof, verdict, info = p.run_seed(175, "plain")
+    assert verdict == "differs" and "frame (6, 8, 0) field num_fec_corrections: 1 != 2" in info["why"], info
