@@ -28,3 +28,23 @@ def test_a_decision_that_hinges_on_the_references_own_rounding():
     import predict_gpu_parity as p
     s, prof, verdict, info = p.run_seed(175, "plain")
     assert verdict == "differs" and "frame (6, 8, 0) field num_fec_corrections: 1 != 2" in info["why"], info
+
+
+@pytest.mark.parametrize("name", ["config2_1s", "os10_noisy_1s", "dirty25k_1s"])
+def test_exact_arithmetic_on_the_golden_captures(oracle_mod, name):
+    """the committed oracle answers (frames, timing, counters) from raw IQ, the way the -m gpu tests get them from the device"""
+    import numpy as np
+    import cases
+    import predict_gpu_parity as p
+    import pyhostsim
+    cfg, iq, _, gold = cases.load(name)
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+    A, B = o.lpf()
+    D = iq.size // 2 // cfg.oversample
+    y = p.exact_stream(cfg, iq.view(np.uint8), 1, A, B, [o.dphi(c) for c in range(len(cfg.freqs))], D)
+    hs = pyhostsim.HostSim(list(cfg.freqs), cfg.rx_max_ppm, cap_log2=int(np.ceil(np.log2(D + 70000))))
+    hs.set_segments(6000, 8)
+    hs.feed(y)
+    cases.check_against_golden(hs.frames(), [list(hs.counters(c)) for c in range(len(cfg.freqs))], gold, label=f"{name}, filter in double precision",
+                               exact_diagnostics=False)
+    hs.close(); o.close()
