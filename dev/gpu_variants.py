@@ -98,6 +98,7 @@ def child(args):
         r.update(measure(rx, torch, dev_block, nbytes, args.steps, args.repeats))
         st = rx.stats()
         r["fallbacks"] = st["front_sync_timeouts"]
+        r["referee"] = {k[8:]: st[k] for k in st if k.startswith("referee_")}; r["feeds"] = st["feeds"]
         res[label] = r
         rx.close()
     print(json.dumps(res), flush=True)
@@ -150,7 +151,7 @@ def main():
             if "error" in j:
                 print(parts[0], w, "ERROR", j["error"][-300:], flush=True)
             else:
-                print(parts[0], w, " ".join(f"{lab}: {j[lab]['ms']} ms (K1 {j[lab]['k1']}; {j[lab]['stage']}; frames {j[lab]['frames']}/{j[lab]['tx_frames']} missing {j[lab]['missing']})"
+                print(parts[0], w, " ".join(f"{lab}: {j[lab]['ms']} ms (K1 {j[lab]['k1']}; {j[lab]['stage']}; frames {j[lab]['frames']}/{j[lab]['tx_frames']} missing {j[lab]['missing']}; referee {j[lab].get('referee')} in {j[lab].get('feeds')} feeds)"
                                             for lab in ("all", "shard") if lab in j), flush=True)
 
 

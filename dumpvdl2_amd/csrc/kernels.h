@@ -16,6 +16,7 @@
 // of K3, the walker, K5 - and K3's screening tier uses a single-precision phase of its own (vdl2_core.h: ChanView::Phi, phase_fast).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "vdl2_core.h"
 #include "design.h"
 
@@ -32,6 +33,255 @@ namespace vdl2 {
 
 constexpr int kK1Unroll = VDL2_K1_UNROLL;
 typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ======================================================================
+// Referee (vdl2_core.h "Referee"): the reference's own samples of a stretch of one channel's decimated stream.
+//
+// process_samples() (src/demod.c:302-329) is a sequential scan per channel: sincosf_lut() (:58-72), multiply() (:200-203),
+// chebyshev_lpf_2pole() (:74-79) on I and Q, every product and sum rounded to float in exactly that order.  Two such scans over
+// the same input started from different filter states become BIT-IDENTICAL after a while - the difference of two fp32
+// trajectories of a contracting recursion does not shrink below an ulp, it hits zero (measured on the bench workloads:
+// exponentially distributed, 1.5e4 input samples per component on average, never more than 1.2e5 in 1 100 trials;
+// dev/iir_state_coalescence.c).  So the reference's trajectory over [n_lo, n_hi] is obtained by running ITS arithmetic from
+// `warm` (default 2^18) input samples earlier with a zero state: wrong with probability ~2 exp(-warm / 1.5e4) = 1e-7.
+//
+// One wavefront does it.  The part without a recursion - sample conversion, NCO, mixer, the three feed-forward taps - is done
+// for 64 input samples at a time by the 64 lanes; the recursion y = r0 + (B1 y1 + B2 y2) then runs on two lanes (I and Q), 64
+// steps out of LDS.  ~2 ms per call; called for a few decisions in 10^4 (the ones within the margin of the stream's error).
+// ======================================================================
+constexpr int kRefPieces = 6;              // stretches of raw input a feed can reach back into: the feed's own block + the history ring (it may wrap)
+constexpr int kRefCache = 32;              // stretches of a channel already made exact (a speculative walker and the stitcher come by the same places)
+struct RefPiece { const void *p; int64_t s0, n; };   // raw samples with absolute index s0 <= s < s0 + n, contiguous at p
+struct RefChan {
+	cf32 *y; uint32_t cap, mask;           // the decimated rings, [nchan][cap]
+	const uint32_t *dphi;                  // NCO step per channel
+	const uint8_t *mix;                    // per channel: offset_tuning (src/demod.c:386: centerfreq != freq)
+	const Lut4 *lut;
+	float A0, A1, A2, B1, B2;              // src/demod.c:55
+	int32_t os, fmt, npiece, kinds;        // kinds: bit k set = requests of kind k (REF_CANDIDATE ...) are served
+	RefPiece piece[kRefPieces];            // oldest first, contiguous; the last one is this feed's block
+	int64_t warm;                          // input samples the scan starts before the stretch
+	unsigned long long *done;              // [nchan][kRefCache] stretches made exact (see ref_exact_window_dev)
+	uint32_t *done_n;                      // [nchan] entries written so far
+	unsigned long long *dbg; int32_t dbg_chan, dbg_pad;   // development aid (-DVDL2_REF_DEBUG): event log of one channel, dbg[0] = entries written
+	uint32_t *stats;                       // [0] scans run, [1] requests answered from the list, [2] requests refused (input no longer held), [3] scans with a shortened run-up, [4 + kind] scans by who asked
+};
+
+// one raw sample as process_buf_short() / process_buf_uchar() convert it (src/demod.c:349-365)
+__device__ __forceinline__ bool ref_raw_sample(const RefChan &r, int64_t s, float &re, float &im) {
+	for(int j = r.npiece - 1; j >= 0; j--) {
+		const RefPiece &pc = r.piece[j];
+		if(s >= pc.s0 && s < pc.s0 + pc.n) {
+			if(r.fmt == 1) { const uint32_t w = ((const uint32_t *)pc.p)[s - pc.s0]; re = (float)(int16_t)(w & 0xffff) / 32768.0f; im = (float)(int16_t)(w >> 16) / 32768.0f; }
+			else { const uint16_t w = ((const uint16_t *)pc.p)[s - pc.s0]; re = ((float)(w & 0xff) - 127.5f) / 127.5f; im = ((float)(w >> 8) - 127.5f) / 127.5f; }
+			return true;
+		}
+	}
+	re = 0.f; im = 0.f;
+	return false;
+}
+
+__device__ __forceinline__ float dpp_wave_shr1(float v);
+#if VDL2_DEVICE_PASS
+// (no LDS, no memory traffic inside the recursion: the 64 feed-forward values of a block stay in the lanes that made them and are
+// handed to the recursion with v_readlane; the recursion itself is uniform - every lane does the same packed (I, Q) arithmetic.
+// The raw samples and NCO table entries of block k + 1 are fetched while block k's recursion runs.)
+typedef __attribute__((address_space(1))) const uint32_t ref_gu32;
+typedef __attribute__((address_space(1))) const uint16_t ref_gu16;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const v4f ref_gf4;
+__device__ __forceinline__ float ref_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ bool ref_exact_window_dev(const ChanView &v, int64_t n_lo, int64_t n_hi, int kind) {
+	#pragma clang fp contract(off)
+	RefChan *rp = v.ref;
+	if(!rp) return false;
+	const int lane = threadIdx.x & 63, c = v.ref_chan;
+	// the hook's scalars, once (wave-uniform: they live in SGPRs from here on; nothing below reads the hook again)
+	const int os = rp->os, fmt = rp->fmt, npiece = rp->npiece;
+	const uint32_t mask = rp->mask, cap = rp->cap;
+	const int64_t warm = rp->warm;
+	int64_t ps0[kRefPieces], pn[kRefPieces]; const void *pp[kRefPieces];
+	#pragma unroll
+	for(int j = 0; j < kRefPieces; j++) { ps0[j] = j < npiece ? rp->piece[j].s0 : 0; pn[j] = j < npiece ? rp->piece[j].n : 0; pp[j] = j < npiece ? rp->piece[j].p : nullptr; }
+	const float A0 = rp->A0, A1 = rp->A1, A2 = rp->A2;
+	const v2f B1 = v2f{rp->B1, rp->B1}, B2 = v2f{rp->B2, rp->B2};
+	const uint32_t dphi = rp->dphi[c];
+	const bool mix = rp->mix[c] != 0;
+	ref_gf4 *lut = (ref_gf4 *)rp->lut;
+	unsigned long long *done = rp->done + (size_t)c * kRefCache;
+	uint32_t *done_n = rp->done_n + c, *stats = rp->stats;
+	__attribute__((address_space(1))) float *yout = (__attribute__((address_space(1))) float *)(rp->y + (size_t)c * cap);
+	if(n_lo < 0) n_lo = 0;
+	if(n_hi < n_lo) return true;
+	const int64_t in_end = ps0[npiece - 1 < 0 ? 0 : npiece - 1] + pn[npiece - 1 < 0 ? 0 : npiece - 1];    // one past the newest raw sample held
+	// (whole blocks of 256 samples, as far as the input reaches: the candidates of one preamble ask for overlapping stretches)
+	{
+		const int64_t last = in_end / os - 1;
+		n_lo &= ~255ll;
+		if((n_hi | 255) <= last) n_hi |= 255; else if(n_hi < last) n_hi = last;
+	}
+	// done before?
+	{
+		const uint32_t ndv = *done_n, nd = ndv < (uint32_t)kRefCache ? ndv : (uint32_t)kRefCache;
+		bool hit = false;
+		if((uint32_t)lane < nd) {
+			// (lo / 256 : 32 bits, length / 256 : 16, launch : 16.  A stretch done by another wavefront of THIS launch does not count:
+			// its samples may still sit in another XCD's L2; from the next launch on they are everybody's)
+			const unsigned long long e = __hip_atomic_load(done + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const int64_t lo = (int64_t)(e >> 32) << 8, hi = lo + ((int64_t)((e >> 16) & 0xffffull) << 8) + 255;
+			hit = lo <= n_lo && n_hi <= hi && (uint32_t)(e & 0xffffull) != (v.ref_launch & 0xffffu);
+		}
+		if(__any(hit)) { if(lane == 0) atomicAdd(stats + 1, 1u); return true; }
+	}
+	const int64_t s_end = (int64_t)os * (n_hi + 1);            // decimated sample k is the filter's output after input sample os (k + 1) - 1
+	int64_t s_beg = (int64_t)os * n_lo - warm;
+	bool shortened = false;
+	if(s_beg < 0) s_beg = 0;                                     // the stream's own start: the reference's state there is zero, exactly
+	else {
+		if(ps0[0] > s_beg) { shortened = true; s_beg = ps0[0]; }
+		if(s_beg > 0 && (int64_t)os * n_lo - s_beg < warm / 4) { if(lane == 0) atomicAdd(stats + 2, 1u); return false; }
+	}
+	if(npiece <= 0 || in_end < s_end) { if(lane == 0) atomicAdd(stats + 2, 1u); return false; }
+	__builtin_amdgcn_s_setprio(3);
+
+	// raw sample s (this lane's of a block) as a 32-bit word, and its NCO table entry
+	auto fetch = [&](int64_t s, uint32_t &w, v4f &e) {
+		w = 0u;
+		#pragma unroll
+		for(int j = 0; j < kRefPieces; j++) {
+			if(j < npiece && s >= ps0[j] && s < ps0[j] + pn[j] && s < s_end) {
+				if(fmt == 1) w = ((ref_gu32 *)pp[j])[s - ps0[j]];
+				else w = ((ref_gu16 *)pp[j])[s - ps0[j]];
+			}
+		}
+		const uint32_t phi = ((uint32_t)s * dphi) & 0xffffffu;      // applied, then advanced, from 0 at sample 0 (demod.c:313-316); only the low 24 bits count
+		e = mix ? lut[phi >> 16] : v4f{0.f, 1.f, 0.f, 0.f};
+	};
+	// The scan starts on a decimation boundary and goes in blocks of G * os input samples (G = 64 / os decimated outputs: 60 samples
+	// at oversample 20), so that inside a block every step and every output is at a fixed place: the recursion is straight-line code,
+	// G x os steps of two v_readlane + four packed operations, no branch (a taken branch per step cost more than the arithmetic).
+	s_beg -= s_beg % os;
+	int64_t k_out = s_beg / os;                                  // the decimated sample the next output is
+	v2f y1 = v2f{0.f, 0.f}, y2 = v2f{0.f, 0.f};                 // (yr[1], yi[1]), (yr[2], yi[2]) of demod.c:289-298
+	float xm1r = 0.f, xm1i = 0.f, xm2r = 0.f, xm2i = 0.f;       // the mixed samples before the block (uniform)
+	const int G = 64 / os, blk = G * os;                        // (os <= kMaxOversample = 32)
+	uint32_t w_next; v4f e_next;
+	fetch(s_beg + (lane < blk ? lane : 0), w_next, e_next);
+	for(int64_t sb = s_beg; sb < s_end; sb += blk) {
+		const uint32_t w = w_next; const v4f e = e_next;
+		fetch(sb + blk + (lane < blk ? lane : 0), w_next, e_next);    // in flight during this block's recursion
+		// ---- this lane's sample: conversion (demod.c:349-365), NCO (:58-72), mixer (:200-203) ----
+		float re, im;
+		if(fmt == 1) { re = (float)(int16_t)(w & 0xffff) / 32768.0f; im = (float)(int16_t)(w >> 16) / 32768.0f; }
+		else { re = ((float)(w & 0xff) - 127.5f) / 127.5f; im = ((float)((w >> 8) & 0xff) - 127.5f) / 127.5f; }
+		if(mix) {
+			const uint32_t phi = ((uint32_t)(sb + lane) * dphi) & 0xffffffu;
+			const float F = (float)(phi & 0xffffu);
+			const float sn = e.x + e.z * F, cs = e.y + e.w * F;   // v1 + (v2 - v1) * fract (Lut4 = {s, c, ds, dc}: the differences pre-scaled by 2^-16, exactly)
+			const float mr = re * cs - im * sn, mi = im * cs + re * sn;
+			re = mr; im = mi;
+		}
+		// in[1], in[2]: the mixed samples of the two lanes before (lanes 0, 1: of the block before)
+		float x1r = dpp_wave_shr1(re), x1i = dpp_wave_shr1(im);
+		if(lane == 0) { x1r = xm1r; x1i = xm1i; }
+		float x2r = dpp_wave_shr1(x1r), x2i = dpp_wave_shr1(x1i);
+		if(lane == 0) { x2r = xm2r; x2i = xm2i; }
+		xm2r = ref_lane(re, blk - 2); xm2i = ref_lane(im, blk - 2);
+		xm1r = ref_lane(re, blk - 1); xm1i = ref_lane(im, blk - 1);
+		float fa = A0 * re; fa += A1 * x1r + A2 * x2r;              // r = A0 in0; r += A1 in1 + A2 in2   (demod.c:75-76)
+		float fb = A0 * im; fb += A1 * x1i + A2 * x2i;
+		// ---- the recursion over the block: r += B1 out1 + B2 out2 (demod.c:77), I and Q as one packed operation; every os-th value is an output ----
+		auto run = [&](auto OSC) {
+			constexpr int OS = decltype(OSC)::value;
+			constexpr int GG = 64 / OS;
+			#pragma unroll
+			for(int g = 0; g < GG; g++) {
+				#pragma unroll
+				for(int j = 0; j < OS; j++) {
+					const v2f r0 = v2f{ref_lane(fa, g * OS + j), ref_lane(fb, g * OS + j)};
+					const v2f yv = r0 + (B1 * y1 + B2 * y2);
+					y2 = y1; y1 = yv;
+				}
+				if(k_out >= n_lo && k_out <= n_hi && lane < 2) yout[2 * ((uint32_t)k_out & mask) + lane] = lane == 0 ? y1.x : y1.y;
+				k_out++;
+			}
+		};
+		if(os == 20) run(std::integral_constant<int, 20>());
+		else if(os == 10) run(std::integral_constant<int, 10>());
+		else if(os == 13) run(std::integral_constant<int, 13>());
+		else {
+			for(int g = 0; g < G; g++) {
+				for(int j = 0; j < os; j++) {
+					const v2f r0 = v2f{ref_lane(fa, g * os + j), ref_lane(fb, g * os + j)};
+					const v2f yv = r0 + (B1 * y1 + B2 * y2);
+					y2 = y1; y1 = yv;
+				}
+				if(k_out >= n_lo && k_out <= n_hi && lane < 2) yout[2 * ((uint32_t)k_out & mask) + lane] = lane == 0 ? y1.x : y1.y;
+				k_out++;
+			}
+		}
+	}
+	__builtin_amdgcn_s_setprio(0);
+	// The new samples are read back by the lanes of THIS wavefront: its stores must have landed (vmcnt(0)) and its CU's vector L1 and
+	// scalar cache - neither ever holds dirty data - must not answer with what they held before.  Nothing wider: __threadfence() (an
+	// agent-scope release) writes back the whole L2, and an agent-scope INVALIDATE (buffer_inv sc1) drops L2 lines, dirty ones included -
+	// the walker's own burst list and state went missing that way.  Other wavefronts see the samples from the next kernel on.
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_inv sc0\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (both invalidates are complete before anything is loaded again)
+	if(lane == 0) {
+		const uint32_t i = atomicAdd(done_n, 1u);
+		int64_t len = (n_hi - n_lo) >> 8; if(len > 0xffff) len = 0xffff;     // (whole blocks of 256: n_lo is aligned, n_hi ends a block or the input)
+		if(((n_hi + 1) & 255) != 0) len -= 1;                                 // a last, partial block is not promised
+		if(len >= 0) __hip_atomic_store(done + (i % (uint32_t)kRefCache), ((unsigned long long)(n_lo >> 8) << 32) | ((unsigned long long)len << 16) | (unsigned long long)(v.ref_launch & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		atomicAdd(stats + 0, 1u); atomicAdd(stats + 4 + kind, 1u);
+		if(shortened) atomicAdd(stats + 3, 1u);
+	}
+	return true;
+}
+#endif
+
+VDL2_HD void ref_debug_log(const ChanView &v, int tag, int64_t a, float b, float c, float d) {
+#if VDL2_DEVICE_PASS && defined(VDL2_REF_DEBUG)
+	RefChan *r = v.ref;
+	if(!r || !r->dbg || v.ref_chan != r->dbg_chan) return;
+	const unsigned long long i = atomicAdd(r->dbg, 1ull);
+	if(i < 1000) { unsigned long long *e = r->dbg + 1 + 4 * i; e[0] = ((unsigned long long)tag << 56) | (unsigned long long)(a & 0xffffffffffffffll); e[1] = __float_as_uint(b); e[2] = __float_as_uint(c); e[3] = __float_as_uint(d); }
+#else
+	(void)v; (void)tag; (void)a; (void)b; (void)c; (void)d;
+#endif
+}
+
+// the referee's raw-input history: `n` samples (sb bytes each) from src go to the ring at sample position pos (modulo cap samples)
+__global__ void k_ref_hist(const uint8_t *src, uint64_t n, uint8_t *ring, uint64_t pos, uint64_t cap, int sb) {
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	const uint64_t d = (pos + i) % cap;
+	if(sb == 4) reinterpret_cast<uint32_t *>(ring)[d] = reinterpret_cast<const uint32_t *>(src)[i];
+	else reinterpret_cast<uint16_t *>(ring)[d] = reinterpret_cast<const uint16_t *>(src)[i];
+}
+
+VDL2_HD __attribute__((always_inline)) bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void *scratch, int kind);
+// test hook: one wavefront makes [n_lo, n_hi] of channel `chan` exact; out[0] = 1 if it could
+// (block b of several: channel (chan + b) mod nchan, the stretch moved on by `stride` samples per block)
+__global__ __launch_bounds__(64) void k_ref_probe(RefChan *ref, int chan, int nchan, int64_t n_lo, int64_t n_hi, int64_t stride, int *out) {
+	__shared__ __align__(16) unsigned char scratch[2048];
+	const int c = (chan + (int)blockIdx.x) % nchan;
+	const int64_t off = stride * (int64_t)blockIdx.x;
+	ChanView v{ ref->y + (size_t)c * ref->cap, nullptr, nullptr, ref->mask, ref, c, 0xffffu };
+	const bool ok = ref_exact_window(v, n_lo + off, n_hi + off, scratch, REF_CANDIDATE);
+	if(threadIdx.x == 0) out[blockIdx.x] = ok ? 1 : 0;
+}
+
+VDL2_HD __attribute__((always_inline)) bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void *scratch, int kind) {
+#if VDL2_DEVICE_PASS
+	if(v.ref && !((v.ref->kinds >> kind) & 1)) return false;
+	(void)scratch;
+	return ref_exact_window_dev(v, n_lo, n_hi, kind);
+#else
+	(void)v; (void)n_lo; (void)n_hi; (void)scratch; (void)kind;
+	return false;
+#endif
+}
 
 // the slice of BlockForm K1 needs, passed by value so that it lives in the kernarg segment
 // (constant address space -> scalar loads into SGPRs)
@@ -640,6 +890,8 @@ struct K3Args {
 	uint32_t cap, mask;
 	int32_t wpl;              // exact tier: flag words scanned per lane (1..kK3bWordsPerLane)
 	OutCtl *ctl; uint32_t k5_waves;   // the feed's output control block, reset here (the last kernel of the front, so that no copy has to do it)
+	// referee (nullptr: off): the feed's hook - written here from `refv`, for the same reason - and what the candidate verdict needs
+	RefChan *ref; RefChan refv; float max_ppm; const float *ppm_thr; int32_t ref_on;      // (ref != nullptr, ref_on == 0: the hook is written, the verdicts are the plain ones)
 };
 
 // K3: got_sync() metric (contiguous ring) + the candidate bitmap, in two tiers and two kernels.
@@ -723,109 +975,7 @@ __global__ __launch_bounds__(kK3Threads) void k_sync_screen(K3Args a) {
 	}
 }
 
-__device__ __forceinline__ void k3_exact(const cf32 *y, uint32_t mask, int64_t n, int64_t k1, const Tables &T, float &p, float &f) {
-	cf32 yv[kPreamble];
-	#pragma unroll
-	for(int i = 0; i < kPreamble; i++) {            // all 16 loads first: one memory round trip, not 16
-		const int64_t t = n - 150 + 10 * i;
-		yv[i] = (t < 0 || t >= k1) ? cf32{0.f, 0.f} : y[(uint32_t)t & mask];
-	}
-	float ph[kPreamble];
-	#pragma unroll
-	for(int i = 0; i < kPreamble; i++) ph[i] = phase_of(yv[i]);   // unrolled: a rolled loop would index yv/ph dynamically, i.e. through scratch
-	sync_metric(ph, T, p, f);
-}
-
-// A wavefront scans 256 consecutive 64-sample words (four per lane) and lists the ones that hold work; those are then taken
-// four at a time, 16 lanes each: a word with work has a cluster of ~5-10 flagged samples plus three either side, so a quarter
-// wavefront per word keeps most lanes busy, and 256 words (16 384 samples) hold enough such words to fill the quarters (one
-// word per pass with all 64 lanes: 0.63 ms at 256 channels with 160 000 preamble-like events per 16 s block; four per pass
-// out of 64 words: 0.43; out of 256: see DESIGN 6).  Metric values go through LDS - exact where computed, "big" elsewhere -
-// and the 16 lanes of a quarter then form the word's 64 candidate bits, four per lane.
-// (launch bound 256 threads with 4 waves per SIMD = the 128-register budget: a wave of this kernel then fits into the slot a
-// channeliser wave leaves behind; see k_walk_stitch)
 constexpr int kK3bWordsPerLane = 4;      // at most; fewer when that leaves the chip short of wavefronts (few channels)
-__global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
-	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) reset_out_ctl(a.ctl, a.k5_waves);
-	__shared__ float psh[4][4][64 + 3];                  // [wave][quarter][3 + bit]: metric of sample word*64 + bit, entries 0..2 = the three samples before the word
-	__shared__ uint64_t s_need[4][64 * kK3bWordsPerLane];
-	__shared__ uint8_t s_fprev[4][64 * kK3bWordsPerLane];
-	__shared__ uint16_t s_list[4][64 * kK3bWordsPerLane];
-	const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const cf32 *y = a.y + (size_t)c * a.cap;
-	const uint64_t *flag = a.flag + (size_t)c * (a.cap >> 6);
-	uint64_t *cand = a.cand + (size_t)c * (a.cap >> 6);
-	const uint32_t wmask = a.mask >> 6;
-	const Tables &T = *a.tab;
-	const int64_t w0 = a.nbase >> 6, w1 = (a.k1 + 63) >> 6;
-	const int64_t wb = w0 + ((int64_t)blockIdx.x * 4 + wave) * (64 * a.wpl);   // first word of this wavefront
-	int nwork = 0;
-	for(int g = 0; g < a.wpl; g++) {
-		const int64_t w = wb + 64 * g + lane;
-		uint64_t need = 0, fprev = 0;
-		if(w < w1) {
-			const uint64_t f0 = flag[(uint32_t)w & wmask];
-			fprev = w > 0 ? flag[(uint32_t)(w - 1) & wmask] : 0ull;      // words before nbase hold the previous feed's flags
-			const uint64_t fnext = w + 1 < w1 ? flag[(uint32_t)(w + 1) & wmask] : 0ull;
-			need = f0 | (f0 << 3) | (f0 >> 3) | (fprev >> 61) | (fnext << 61);
-			const int64_t base = w << 6;
-			if(a.k1 - 3 < base + 64) {                                      // right neighbour n+3 not there yet
-				const int64_t lo = a.k1 - 3 - base;
-				need |= lo <= 0 ? ~0ull : (~0ull << lo);
-			}
-			if(a.k1 < base + 64) need &= (a.k1 - base <= 0) ? 0ull : (~0ull >> (64 - (a.k1 - base)));   // samples that exist
-			if(need == 0) cand[(uint32_t)w & wmask] = 0;
-		}
-		s_need[wave][64 * g + lane] = need; s_fprev[wave][64 * g + lane] = (uint8_t)(fprev >> 61);
-		const unsigned long long busy = __ballot(need != 0);
-		if(need != 0) s_list[wave][nwork + __builtin_popcountll(busy & ((1ull << lane) - 1ull))] = (uint16_t)(64 * g + lane);
-		nwork += __builtin_popcountll(busy);
-	}
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-	const int q = lane >> 4, r = lane & 15;
-	float *ps = psh[wave][q];
-	for(int it = 0; it < nwork; it += 4) {
-		// quarter q takes entry it + q of the list (idx < 0: this quarter idles)
-		const int idx = it + q < nwork ? (int)s_list[wave][it + q] : -1;
-		const uint64_t needj = idx >= 0 ? s_need[wave][idx] : 0ull;
-		const uint32_t fprevj = idx >= 0 ? s_fprev[wave][idx] : 0u;       // flags of the three samples before the word
-		const int64_t wj = wb + (idx >= 0 ? idx : 0);
-		for(int k = r; k < 67; k += 16) ps[k] = kPherrBig;
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-		// the r-th, (r+16)-th, ... set bit of the word's work mask is this lane's
-		uint64_t left = needj;
-		for(int skip = 0; skip < r && left; skip++) left &= left - 1;
-		while(__any(left != 0)) {
-			if(left) {
-				const int bit = __builtin_ctzll(left);
-				const int64_t n = (wj << 6) + bit;
-				float p, f;
-				k3_exact(y, a.mask, n, a.k1, T, p, f);
-				a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = cf32{p, f};
-				ps[3 + bit] = p;
-				for(int skip = 0; skip < 16 && left; skip++) left &= left - 1;
-			}
-		}
-		if(idx >= 0 && r < 3) {                                             // the three samples before the word
-			const int64_t m = (wj << 6) - 3 + r;
-			float pm = kPherrBig, fm;
-			if(m >= 0 && ((fprevj >> r) & 1u)) k3_exact(y, a.mask, m, a.k1, T, pm, fm);
-			ps[r] = pm;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-		uint64_t bits = 0;
-		for(int k = 0; k < 4; k++) {
-			const int bit = r + 16 * k;
-			const int64_t n = (wj << 6) + bit;
-			if(idx >= 0 && n >= 3 && n < a.k1 && is_candidate(ps[bit], ps[3 + bit])) bits |= 1ull << bit;
-		}
-		#pragma unroll
-		for(int d = 1; d < 16; d <<= 1) bits |= __shfl_xor(bits, d);         // OR over the quarter's 16 lanes (every lane takes part)
-		if(idx >= 0 && r == 0) cand[(uint32_t)wj & wmask] = bits;
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-	}
-}
-
 // The exact tier with FOUR lanes per sample: a word with work is taken by the whole wavefront, 16 of its samples at a time - lane
 // 4 s + part works out the phases of taps 4 part .. 4 part + 3 of sample s (4 loads, 4 atan2 in double instead of 16 per lane), the
 // phases meet in LDS and the lane with part 0 runs the reference's metric on them.  Same loads, same atan2, same metric, same
@@ -833,10 +983,13 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact(K3Args a) {
 // kernel is latency-bound: its arithmetic is a quarter of its run time) and how many lanes have work (a cluster around a preamble
 // is ~13 samples: 13 of 64 lanes busy in the 16-lanes-per-word form, 52 of 64 here).
 __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
-	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) reset_out_ctl(a.ctl, a.k5_waves);
-	__shared__ float psh[4][64 + 3];                     // [wave][3 + bit]: metric of sample word*64 + bit, entries 0..2 = the three samples before the word
+	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { reset_out_ctl(a.ctl, a.k5_waves); if(a.ref) *a.ref = a.refv; }
+	// [wave][6 + bit]: metric of sample word*64 + bit (entries 0..5 = the six samples before the word), its slope, and - for the
+	// referee - its error figure E and its value with the one discontinuity taken the other way (vdl2_core.h: sync_metric_ref)
+	__shared__ float psh[4][64 + 6], fsh[4][64 + 6], esh[4][64 + 6], ash[4][64 + 6];
 	__shared__ float phs[4][16][kPreamble + 1];          // [wave][sample slot][tap]: exact phases (floats, as the reference keeps them)
-	__shared__ uint8_t items[4][64 + 3];                 // [wave][e]: bit number of the e-th sample to work out (64..66: the three before the word)
+	__shared__ float eps[4][16][kPreamble + 1];          // ... and the squared bounds on their errors (ref_eps2)
+	__shared__ uint8_t items[4][64 + 6];                 // [wave][e]: bit number of the e-th sample to work out (64..69: the six before the word)
 	__shared__ uint64_t s_need[4][64 * kK3bWordsPerLane];
 	__shared__ uint8_t s_fprev[4][64 * kK3bWordsPerLane];
 	__shared__ uint16_t s_list[4][64 * kK3bWordsPerLane];
@@ -846,15 +999,19 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
 	uint64_t *cand = a.cand + (size_t)c * (a.cap >> 6);
 	const uint32_t wmask = a.mask >> 6;
 	const Tables &T = *a.tab;
+	const bool ref_on = a.ref != nullptr && a.ref_on != 0;
+	const float ppm_thr = ref_on ? a.ppm_thr[c] : 0.f;
+	const ChanView cv{ y, nullptr, nullptr, a.mask };
 	const int64_t w0 = a.nbase >> 6, w1 = (a.k1 + 63) >> 6;
 	const int64_t wb = w0 + ((int64_t)blockIdx.x * 4 + wave) * (64 * a.wpl);   // first word of this wavefront
 	int nwork = 0;
 	for(int g = 0; g < a.wpl; g++) {
 		const int64_t w = wb + 64 * g + lane;
-		uint64_t need = 0, fprev = 0;
+		uint64_t need = 0, fprev = 0, fpp = 0, f0 = 0;
 		if(w < w1) {
-			const uint64_t f0 = flag[(uint32_t)w & wmask];
+			f0 = flag[(uint32_t)w & wmask];
 			fprev = w > 0 ? flag[(uint32_t)(w - 1) & wmask] : 0ull;      // words before nbase hold the previous feed's flags
+			fpp = w > 1 ? flag[(uint32_t)(w - 2) & wmask] : 0ull;
 			const uint64_t fnext = w + 1 < w1 ? flag[(uint32_t)(w + 1) & wmask] : 0ull;
 			need = f0 | (f0 << 3) | (f0 >> 3) | (fprev >> 61) | (fnext << 61);
 			const int64_t base = w << 6;
@@ -865,56 +1022,76 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
 			if(a.k1 < base + 64) need &= (a.k1 - base <= 0) ? 0ull : (~0ull >> (64 - (a.k1 - base)));   // samples that exist
 			if(need == 0) cand[(uint32_t)w & wmask] = 0;
 		}
-		s_need[wave][64 * g + lane] = need; s_fprev[wave][64 * g + lane] = (uint8_t)(fprev >> 61);
+		// which of the six samples before the word have a tabulated metric: the last six bits of the previous word's work mask
+		const uint64_t need_prev = fprev | (fprev << 3) | (fprev >> 3) | (fpp >> 61) | (f0 << 61);
+		s_need[wave][64 * g + lane] = need; s_fprev[wave][64 * g + lane] = (uint8_t)(need_prev >> 58);
 		const unsigned long long busy = __ballot(need != 0);
 		if(need != 0) s_list[wave][nwork + __builtin_popcountll(busy & ((1ull << lane) - 1ull))] = (uint16_t)(64 * g + lane);
 		nwork += __builtin_popcountll(busy);
 	}
 	WAVE_SYNC();
 	const int slot = lane >> 2, part = lane & 3;
-	float *ps = psh[wave];
+	float *ps = psh[wave], *fs = fsh[wave], *es = esh[wave], *as = ash[wave];
 	#pragma unroll 1
 	for(int it = 0; it < nwork; it++) {
 		const int idx = (int)s_list[wave][it];
 		const uint64_t needj = s_need[wave][idx];
-		const uint32_t fprevj = s_fprev[wave][idx] & 7u;                  // flags of the three samples before the word
+		const uint32_t fprevj = s_fprev[wave][idx] & 63u;                 // which of the six samples before the word are tabulated (bit k: sample -6 + k)
 		const int64_t wj = wb + idx;
-		ps[lane] = kPherrBig; if(lane < 3) ps[64 + lane] = kPherrBig;
+		ps[6 + lane] = kPherrBig; if(lane < 6) ps[lane] = kPherrBig;
 		const int cnt = __builtin_popcountll(needj);
 		if((needj >> lane) & 1ull) items[wave][__builtin_popcountll(needj & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-		if(lane < 3 && ((fprevj >> lane) & 1u)) items[wave][cnt + __builtin_popcount(fprevj & ((1u << lane) - 1u))] = (uint8_t)(64 + lane);
+		if(lane < 6 && ((fprevj >> lane) & 1u)) items[wave][cnt + __builtin_popcount(fprevj & ((1u << lane) - 1u))] = (uint8_t)(64 + lane);
 		const int total = cnt + __builtin_popcount(fprevj);
 		WAVE_SYNC();
 		#pragma unroll 1
 		for(int r0 = 0; r0 < total; r0 += 16) {
 			const bool active = r0 + slot < total;
 			const int item = active ? (int)items[wave][r0 + slot] : 0;
-			const int bit = item < 64 ? item : item - 67;                 // 64..66 -> -3..-1
+			const int bit = item < 64 ? item : item - 70;                 // 64..69 -> -6..-1
 			const int64_t n = (wj << 6) + bit;
-			if(active) {
+			if(active && n >= 0) {
 				cf32 yv[4];
 				#pragma unroll
 				for(int k = 0; k < 4; k++) {                                 // all four loads first
 					const int64_t t = n - 150 + 10 * (4 * part + k);
 					yv[k] = (t < 0 || t >= a.k1) ? cf32{0.f, 0.f} : y[(uint32_t)t & a.mask];
 				}
+				if(ref_on) {
+					#pragma unroll
+					for(int k = 0; k < 4; k++) { const int64_t t = n - 150 + 10 * (4 * part + k); eps[wave][slot][4 * part + k] = t >= a.k1 ? 0.f : ref_eps2(cv, t); }
+				}
 				#pragma unroll
 				for(int k = 0; k < 4; k++) phs[wave][slot][4 * part + k] = phase_of(yv[k]);
 			}
 			WAVE_SYNC();
-			if(active && part == 0) {
+			if(active && part == 0 && n >= 0) {
 				float ph[kPreamble];
 				#pragma unroll
 				for(int i = 0; i < kPreamble; i++) ph[i] = phs[wave][slot][i];
-				float p, f;
-				sync_metric(ph, T, p, f);
-				if(bit >= 0) a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = cf32{p, f};
-				ps[3 + bit] = p;
+				float p, f, E = 0.f, pa;
+				if(ref_on) {
+					float e2[kPreamble];
+					#pragma unroll
+					for(int i = 0; i < kPreamble; i++) e2[i] = eps[wave][slot][i];
+					sync_metric_ref(ph, e2, T, p, f, E, pa);
+				} else { sync_metric(ph, T, p, f); pa = p; }
+				ps[6 + bit] = p; fs[6 + bit] = f; es[6 + bit] = E; as[6 + bit] = pa;
 			}
 			WAVE_SYNC();
 		}
+		// the verdict of every sample of the word as a candidate: got_sync() may fire there (bitmap) / some decision of the fire is
+		// within the margin of the stream's error (sign of the tabulated metric: the walker has the samples made exact first)
 		const int64_t n = (wj << 6) + lane;
-		const unsigned long long bits = __ballot(n >= 3 && n < a.k1 && is_candidate(ps[lane], ps[3 + lane]));
+		const float p0 = ps[6 + lane], p3 = ps[3 + lane], p6 = ps[lane];
+		int vd = 0;
+		if(n >= 3 && n < a.k1) {
+			if(!ref_on) vd = is_candidate(p3, p0) ? 1 : 0;
+			else vd = ref_candidate_verdict(ref_pherr_range(p0, as[6 + lane], es[6 + lane]), ref_pherr_range(p3, as[3 + lane], es[3 + lane]), fs[3 + lane], es[3 + lane],
+			                                ref_pherr_range(p6, as[lane], es[lane]), a.max_ppm, ppm_thr);
+		}
+		if((needj >> lane) & 1ull) a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = cf32{ (vd & 2) ? -p0 : p0, fs[6 + lane] };
+		const unsigned long long bits = __ballot((vd & 1) != 0);
 		if(lane == 0) cand[(uint32_t)wj & wmask] = bits;
 		WAVE_SYNC();
 	}
@@ -926,12 +1103,14 @@ struct K4Args {
 	EvalChunk *log; uint32_t *nlog; uint32_t cap_log;
 	int64_t k_end; float max_ppm; uint32_t cap, mask; int32_t chan_first, nchan;
 	const float *ppm_thr;      // per channel: ppm_gate_threshold(freq, max_ppm)
+	RefChan *ref;              // referee hook of this feed (nullptr: off)
+	uint32_t ref_launch;       // ... and a number that tells this launch from the others (k_walk_stitch: + 1)
 };
 
 __global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
 	__shared__ WalkShared sh;
 	const int c = blockIdx.x;
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	walk_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh);
@@ -952,12 +1131,9 @@ __global__ __launch_bounds__(64 * kWalkWaves, 4) void k_walk_spec(K4sArgs s) {
 	const int c = blockIdx.y, x = blockIdx.x * kWalkWaves + wave;
 	if(x >= 1 + 3 * (s.nseg - 1)) return;
 	WalkShared &sh = shw[wave];
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
-	if(x == 0) {
-		EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
-		walk_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], s.k0 + s.seglen, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
-		             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh);
-	} else {
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch };
+	if(x == 0) return;         // (segment 0 is walked from the real state by the stitcher)
+	{
 		const int seg = 1 + (x - 1) / 3, r = (x - 1) % 3;
 		const int64_t b = s.k0 + (int64_t)seg * s.seglen, kn = seg + 1 < s.nseg ? b + s.seglen : a.k_end;
 		spec_walk(c, a.freq[c], a.max_ppm, a.ppm_thr[c], b, r, kn, *a.tab, v, s.spec + (size_t)c * s.spec_stride + (x - 1), sh);
@@ -977,7 +1153,7 @@ __global__ __launch_bounds__(256, 4) void k_walk_stitch(K4sArgs s) {
 	const int wave = threadIdx.x >> 6, c = blockIdx.x * kStitchWaves + wave;      // a channel per wavefront
 	if(c >= a.nchan) return;
 	StitchLds &lds = reinterpret_cast<StitchLds *>(k4_lds)[wave];
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + 1u };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	stitch_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	               a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg,
@@ -1056,6 +1232,8 @@ struct K5Args {
 	const Burst *bursts; const uint32_t *nb_chan; uint32_t cap_bursts_chan; int32_t nchan;   // nb_chan[c]: bursts the walker has listed for channel c (its own list: no atomics on its critical path)
 	OutFrame *frames; uint8_t *pool; OutCtl *ctl; const uint32_t *freq;
 	uint32_t cap, mask;
+	RefChan *ref;              // referee hook of this feed (nullptr: off)
+	uint32_t ref_launch;
 };
 
 // Two bursts per workgroup, one per wavefront (they share nothing; four would need more LDS than a channeliser workgroup
@@ -1100,8 +1278,8 @@ __device__ __forceinline__ void burst_body(const K5Args &a, unsigned char *k5_ld
 		while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(bb[mid] <= g) lo = mid; else hi = mid; }
 		const int c = lo;
 		const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - bb[c])];
-		ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask };
-		decode_burst(b, 0u, *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
+		ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask, a.ref, c, a.ref_launch };
+		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
 		WAVE_SYNC();
 	}
 	burst_reserve_done(a.frames, sh);

@@ -165,6 +165,11 @@ struct Tables {
 struct cf32 { float re, im; };
 VDL2_HD float phase_of(cf32 y);
 
+// The referee (see "Referee" below): what a kernel needs to turn a stretch of one channel's decimated stream into the reference's
+// own samples, bit for bit.  Defined by the build: kernels.h for the device (raw input + the sequential scan of demod.c:302-329),
+// tests/hostsim for the CPU tests (a trace of exact samples).  nullptr: the samples are taken as they are.
+struct RefChan;
+
 // One channel's decimated-rate streams, ring-addressed by absolute sample index.  There is no stored phase stream: the
 // reference's atan2 (double, narrowed to float: demod.c:232,256) is evaluated where a decision reads a phase - the exact
 // tier of the sync kernel, the walker, the burst decoder - which is a few percent of the samples; the sync kernel's
@@ -174,6 +179,9 @@ struct ChanView {
 	const cf32     *pf;                // {pherr[0], freq_err} of got_sync() evaluated at n (contiguous ring) - valid where a preamble is near
 	const uint64_t *cand;              // bit n: pf[n-3].p < 4 && pf[n].p > pf[n-3].p
 	uint32_t        mask;              // capacity - 1 (capacity is a power of two)
+	RefChan        *ref = nullptr;     // referee hook of this channel (nullptr: none)
+	int32_t         ref_chan = 0;      // ... and the channel's index there (device build: one hook per feed, shared by the channels)
+	uint32_t        ref_launch = 0;    // ... and which kernel launch this is (device build: see ref_exact_window_dev)
 	VDL2_HD cf32  Y(int64_t n) const { return y[(uint32_t)n & mask]; }
 	VDL2_HD float Phi(int64_t n) const { return n < 0 ? 0.f : phase_of(y[(uint32_t)n & mask]); }   // atan2(lp_im, lp_re); 0 before the stream starts
 	VDL2_HD cf32  PF(int64_t n) const { return pf[(uint32_t)n & mask]; }
@@ -185,7 +193,9 @@ struct Burst {
 	int32_t  chan, nsym;
 	int64_t  t_first;                  // sample of the first symbol after the unique word
 	int64_t  sync_sample, end_sample, ord;
-	float    prev_phi0, vdphi, ppm, pad_;
+	float    prev_phi0, vdphi, ppm;
+	float    vdphi_err;                // referee: bound on |vdphi - the reference's| (0: taken on the reference's own samples; < 0: unknown and not recomputable)
+	int64_t  prev_n;                   // sample whose phase is prev_phi0 (-1: before the stream, phase 0; -2: unknown)
 	uint32_t tl_bits, syndrome;        // syndrome: bits 0-4 the header syndrome, bits 8.. the weight of the pattern it corrects (metadata->synd_weight)
 	int64_t  nf_upd;                   // number of mag_nf updates that preceded the sync (v->mag_nf at decode_frame())
 	int64_t  sync_evals;               // got_sync() evaluations executed up to and including the one that fired (nf_upd = sync_evals / 1000)
@@ -528,6 +538,160 @@ VDL2_HD Geometry header_to_geometry(uint32_t hdr, const uint32_t *tH, const uint
 }
 
 // ======================================================================
+// Referee.  The channeliser evaluates the reference's filter in block form; its output is what exact arithmetic gives, and
+// differs from the reference's own fp32 scan (demod.c:302-329) by that scan's rounding noise: <= 1.4e-4 of the largest
+// sample within the last 8 (measured over 1e7 samples of the fuzz and bench workloads; rms 1e-5).  Every decision the
+// reference takes on those samples - candidate test, parabola vertex, --max-ppm gate, symbol slicer - is therefore taken
+// here WITH A MARGIN: when the decision could come out differently for some stream within that distance, the wavefront asks
+// ref_exact_window() for the reference's own samples of the stretch the decision reads (the scan re-run sequentially in the
+// reference's operation order from kRefWarm input samples back: two such scans started from different states are
+// bit-identical after 1.5e4 samples on average, after kRefWarm with probability 1 - 1e-7) and takes the decision again on those.
+// A decision is then either robust against the stream's error or taken on the reference's samples: the reference's decision.
+// ======================================================================
+constexpr float kRefKappa = 3.0e-4f;       // bound used for |y - y_ref| / (largest |y| among the samples a decision reads): 2x the worst seen
+constexpr float kRefBig = 1.0e30f;
+constexpr int   kRefPre = 156, kRefPost = 96;   // a marginal candidate at n: evaluations n-6, n-3, n read n-156..n; sync point + 9 header symbols end before n+96
+
+// the stretch [n_lo, n_hi] of the channel's decimated stream becomes the reference's own; wave-uniform call, `scratch`: >= 2 KiB of
+// LDS the caller can spare.  false: not possible (no referee, or the raw input is no longer held) - the caller keeps its decision.
+VDL2_HD void ref_debug_log(const ChanView &v, int tag, int64_t a, float b, float c, float d);   // development aid (a no-op unless the build provides one)
+enum { REF_CANDIDATE = 0, REF_HEADER = 1, REF_SYMBOLS = 2 };   // who asks (statistics; a test hook can switch a kind off)
+VDL2_HD bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void *scratch, int kind);
+
+// squared bound on the phase error of decimated sample n: the stream's error there is at most kRefKappa x the largest of the
+// sample and its three predecessors (the scan's rounding noise is an exponentially weighted average of |y| over ~2 decimated
+// samples; measured: <= 1.5e-4 of that maximum, rms 1e-5), hence its phase's kRefKappa * max / |y|.  0 outside the stream
+// (phase exactly the reference's), kRefBig for a sample that is exactly zero inside it.
+VDL2_HD float ref_eps2_of(float m2_0, float m2_1, float m2_2, float m2_3) {
+	const float a = fmaxf(fmaxf(m2_0, m2_1), fmaxf(m2_2, m2_3));
+	return m2_0 > 0.f ? kRefKappa * kRefKappa * a / m2_0 : kRefBig;
+}
+VDL2_HD float ref_eps2(const ChanView &v, int64_t n) {
+	if(n < 0) return 0.f;
+	float m2[4] = {0.f, 0.f, 0.f, 0.f};
+	cf32 q[4];
+	for(int k = 0; k < 4; k++) q[k] = n - k >= 0 ? v.Y(n - k) : cf32{0.f, 0.f};     // loads first
+	for(int k = 0; k < 4; k++) m2[k] = q[k].re * q[k].re + q[k].im * q[k].im;
+	return ref_eps2_of(m2[0], m2[1], m2[2], m2[3]);
+}
+// how far a got_sync() metric value can be from the reference's: |dp| <= 2 sqrt(p) E + E^2 when the 16 phases move by a vector of
+// length E (mean and slope removal are projections), E = kappa A sqrt(sum 1/|y_i|^2), A = the largest tap
+// E sums the taps' WORST-CASE bounds as if all sixteen errors were at their maximum and lined up with the residual; they are
+// independent, and mostly thirty times smaller: over 25 000 preamble-like windows of the fuzz and bench captures the metric moved by
+// at most 0.040 of that figure (rms 0.006), the slope by at most 0.034 (dev/ref_margin_calibration.py).  kRefSum = 3x the worst seen.
+constexpr float kRefSum = 0.125f;
+VDL2_HD float ref_pherr_margin(float p, float E) { const float e = kRefSum * E; return 2.0f * sqrtf(p) * e + e * e + 4e-6f * p + 1e-6f; }
+// ... and the slope: |df| <= E sqrt(sum lrx^2) / lr_den = E / sqrt(340)
+VDL2_HD float ref_slope_margin(float E) { return 0.0543f * kRefSum * E + 1e-7f; }
+
+// could -roundf(calc_para_vertex()) come out differently for y1, y2, y3 anywhere in their boxes?  (the vertex is a ratio of two
+// forms linear in each y: over a box its extremes are at corners unless the denominator changes sign, which the corners show too)
+struct RefRange { float lo, hi; };
+VDL2_HD bool ref_vertex_marginal(RefRange y1, RefRange y2, RefRange y3) {
+	float lo = kRefBig, hi = -kRefBig;
+	for(int c = 0; c < 8; c++) {
+		const float v = parabola_vertex((c & 1) ? y1.hi : y1.lo, (c & 2) ? y2.hi : y2.lo, (c & 4) ? y3.hi : y3.lo);
+		if(!(v == v) || fabsf(v) > 1.0e6f) return true;
+		lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+	}
+	return roundf(lo - 1e-5f) != roundf(hi + 1e-5f);
+}
+
+// the values the reference's metric can have where this path's is p: [p - m, p + m], widened to the value with one unwrap decision
+// taken the other way (palt, see sync_metric_ref) where such a decision hangs on the stream's error
+VDL2_HD RefRange ref_pherr_range(float p, float palt, float E) {
+	if(!(p < kPherrBig)) return RefRange{ kPherrBig, kPherrBig };       // not tabulated / not part of the run: exactly PHERR_MAX
+	if(E >= kRefBig) return RefRange{ 0.f, kRefBig };
+	const float a = p < palt ? p : palt, b = p < palt ? palt : p;
+	return RefRange{ a - ref_pherr_margin(a, E), b + ref_pherr_margin(b, E) };
+}
+
+// got_sync()'s verdict at a candidate, given what K3's exact tier knows there: the metric at n, n-3 (with its slope f3 and error
+// figure E3) and n-6 (kPherrBig when that evaluation is not part of the run, or was not tabulated: then the walker does not use it either).
+// bit 0: the candidate may fire; bit 1: some decision of the fire (candidate test, vertex with either y1, gate) is within the margin
+VDL2_HD int ref_candidate_verdict(RefRange r0, RefRange r3, float f3, float E3, RefRange r6, float max_ppm, float ppm_thr) {
+	if(!(r3.lo < kPherrBig) || !(r0.lo < kPherrBig)) return 0;
+	const bool possibly = r3.lo < kSyncThr && r0.hi > r3.lo;
+	if(!possibly) return 0;
+	const bool surely = r3.hi < kSyncThr && r0.lo > r3.hi;
+	bool marg = !surely;
+	if(!marg) {
+		marg = ref_vertex_marginal(RefRange{ kPherrBig, kPherrBig }, r3, r0) || (r6.lo < kPherrBig && ref_vertex_marginal(r6, r3, r0));
+		if(!marg && max_ppm != 0.f) marg = fabsf(fabsf(f3) - ppm_thr) <= ref_slope_margin(E3);
+	}
+	return 1 | (marg ? 2 : 0);
+}
+
+// sync_metric() with the unwrap decision at tap `flip` taken the other way (the value the reference gets when that decision,
+// which hangs on a phase difference within the stream's error of +-pi, goes the other way on its samples; flip < 0: as it is)
+VDL2_HD float sync_metric_flipped(const float *ph, const Tables &T, int flip) {
+	float e[kPreamble];
+	float mean = 0.f, unwrap = 0.f;
+	float prev = mean = e[0] = ph[0] - T.pr_phase[0];
+	for(int i = 1; i < kPreamble; i++) {
+		float cur = ph[i] - T.pr_phase[i];
+		float diff = cur - prev;
+		prev = cur;
+		double step = diff > kPiBelow ? -(2.0f * M_PI) : (diff < -kPiBelow ? (2.0f * M_PI) : 0.0);
+		if(i == flip) step = step != 0.0 ? 0.0 : (diff > 0.f ? -(2.0f * M_PI) : (2.0f * M_PI));
+		unwrap = (float)((double)unwrap + step);
+		e[i] = cur + unwrap;
+		mean += e[i];
+	}
+	mean /= kPreamble;
+	for(int i = 0; i < kPreamble; i++) e[i] -= mean;
+	float slope = 0.f;
+	for(int i = 0; i < kPreamble; i++) slope += T.lrx[i] * e[i];
+	slope /= T.lr_den;
+	float acc = 0.f;
+	for(int i = 0; i < kPreamble; i++) { float r = e[i] - slope * T.lrx[i]; acc += r * r; }
+	return acc;
+}
+
+// sync_metric() plus what the referee needs: E (see ref_pherr_margin) and palt - the value the reference gets when the ONE
+// discontinuity within the stream's error goes the other way on its samples: an unwrap decision (a phase difference within the
+// margin of +-pi), or a tap whose phase is within the margin of atan2()'s branch cut (it then reads +pi for -pi: with the
+// reference's single unwrap step per tap the metric is not continuous there).  palt = pherr when there is none; with several, or
+// a tap that is exactly zero, E = kRefBig: "cannot tell".  eps2[i]: ref_eps2() of tap i
+VDL2_HD void sync_metric_ref(const float *ph, const float *eps2, const Tables &T, float &pherr, float &slope_out, float &E_out, float &palt) {
+	sync_metric(ph, T, pherr, slope_out);
+	float s = 0.f; bool big = false; int nev = 0, flip = -1, cut = -1;
+	float eprev = sqrtf(eps2[0]), cprev = ph[0] - T.pr_phase[0];
+	for(int i = 0; i < kPreamble; i++) {
+		s += eps2[i]; big = big || eps2[i] >= kRefBig;
+		if(kPiBelow - fabsf(ph[i]) <= sqrtf(eps2[i]) + 1e-6f && eps2[i] > 0.f) { nev++; cut = i; }
+	}
+	for(int i = 1; i < kPreamble; i++) {
+		const float cur = ph[i] - T.pr_phase[i], diff = cur - cprev, e = sqrtf(eps2[i]);
+		if(fabsf(fabsf(diff) - kPiBelow) <= e + eprev + 4e-6f) { nev++; flip = i; }
+		cprev = cur; eprev = e;
+	}
+	palt = pherr;
+	if(nev == 1 && !big) {
+		if(cut >= 0) {
+			float q[kPreamble];
+			for(int i = 0; i < kPreamble; i++) q[i] = i == cut ? -ph[i] : ph[i];
+			palt = sync_metric_flipped(q, T, -1);
+		} else palt = sync_metric_flipped(ph, T, flip);
+	}
+	E_out = (big || nev > 1) ? kRefBig : sqrtf(s);
+}
+
+// One D8PSK decision with its margin: the distance (radians) of slice_symbol()'s argument from the nearest decision boundary ...
+VDL2_HD float ref_symbol_dist(float phi, float prev_phi, float vdphi) {
+	float dphi = phi - prev_phi - vdphi;
+	if(dphi < 0) dphi = (float)((double)dphi + 2.0f * M_PI);
+	else if((double)dphi > 2.0f * M_PI) dphi = (float)((double)dphi - 2.0f * M_PI);
+	dphi = (float)((double)dphi / M_PI_4);
+	const float fr = dphi - floorf(dphi);                       // decision boundaries at k + 0.5
+	return fabsf(fr - 0.5f) * (float)M_PI_4;
+}
+// 1 / |y|^2 of a symbol's sample (the burst decoder bounds the stream's error there by kRefKappa x the larger of the decision's two
+// samples and twice the burst's rms instead of looking at the sample's predecessors: it reads thousands of symbols)
+VDL2_HD float ref_inv_mag2(cf32 y) { const float m2 = y.re * y.re + y.im * y.im; return m2 > 0.f ? 1.0f / m2 : kRefBig; }
+// ... and whether the decision could come out differently when the two phases and the carrier slope move by e_sum in all
+VDL2_HD bool ref_symbol_marginal(float phi, float prev_phi, float vdphi, float e_sum) { return ref_symbol_dist(phi, prev_phi, vdphi) <= e_sum + 2e-6f; }
+// ======================================================================
 // Walker: the per-channel sequential FSM of demod()/got_sync(), hopping
 // between the sparse places where something can happen.
 // ======================================================================
@@ -557,6 +721,11 @@ struct WalkShared {
 	uint64_t nzw[kCandWin / 64];       // bit i: cw[i] != 0 (a lane owns the byte of its eight words): one lane finds the next word worth a look without reading the empty ones
 	float wre[64], wim[64]; int64_t wbase;
 	int32_t u_fire; int64_t u_n;
+	// referee: the candidate whose metric values have been redone on the reference's own samples, and those values (evaluations x_n,
+	// x_n - 3, x_n - 6); x_hdr: sync sample of the burst whose header symbols have been; u_verr: bound on the error of u_prevd
+	int64_t x_n, x_hdr; float x_p0, x_p3, x_f3, x_p6, u_verr; int32_t x_ok;
+	float hph[16], him2[16];           // header: phases and 1/|y|^2 of the sync point and the nine symbols
+	int64_t x_lo, x_hi;                // the stretch this wavefront has had made exact last (the candidates of one preamble ask for overlapping ones)
 };
 
 // lowest lane whose flag is set, or -1.  Call from wave-uniform code after a WAVE_END.
@@ -673,6 +842,7 @@ VDL2_HD void walk_load(const WalkState *gstate, const EvalLog &lg, const uint32_
 		sh.spec_n = -1; sh.vring_a = -1; sh.nb = resume ? *nbursts_out : 0;
 		sh.first_fire = INT64_MAX;
 		sh.cw0 = 0; sh.cw_end = 0; sh.wbase = 0; sh.u_fire = 0; sh.u_n = 0;
+		sh.x_n = -1; sh.x_hdr = -1; sh.u_verr = 0.f; sh.x_ok = 0; sh.x_lo = 0; sh.x_hi = -1;
 	LANE0_END
 	WAVE_FOR(l)
 		if(l < kHdrParBits) sh.t_H[l] = T.hdr_H[l];
@@ -706,8 +876,10 @@ VDL2_HD bool walk_clean(const WalkState &st) { return st.mode == 0 && st.e >= st
 
 // Advance the FSM held in sh.st up to (not including) decimated sample k_end.  With `stop_clean` the walk also stops as
 // soon as the state is "clean" (walk_clean()).  Stopping anywhere is exact: it is what a feed boundary does.
+// `spec`: a speculative walk (spec_walk()) - it does not call the referee: at a decision within the margin it gives up (its result is
+// marked unusable, the stitcher walks that segment for real), so that a scan is run once, by the walk that counts, not by three hypotheses.
 VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, bool stop_clean, const Tables &T,
-		const ChanView &v, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
+		const ChanView &v, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh, bool spec = false) {
 	K4_BEGIN();
 	LANE0
 		// a speculative gather left by an earlier call was bounded by that call's k_end (phases beyond it read as zero): the
@@ -768,6 +940,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 						sh.u_y2 = jf >= 1 ? sh.p[jf - 1] : st.pherr1;
 						sh.u_y1 = jf >= 2 ? sh.p[jf - 2] : (jf == 1 ? st.pherr1 : st.pherr2);
 						sh.u_prevd = jf >= 1 ? sh.f[jf - 1] : st.prev_dphi;
+						sh.u_verr = -1.f;               // (taps through the interval history: the burst decoder cannot redo this slope)
 					} else {
 						const float o1 = st.pherr1;
 						st.pherr1 = sh.p[nb - 1];
@@ -852,9 +1025,20 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 						int64_t e0 = st.e0, evals = st.evals, lgf = sh.lg_first, lgc = sh.lg_count;
 						uint32_t lgn = sh.lg_n, nrej = 0;
 						const uint32_t cap_log = sh.cap_log;
-						int pending = 0;
+						int pending = 0; bool moved = false;
 						if(sh.first_fire == INT64_MAX) sh.first_fire = n;
 						for(;;) {
+							// Referee: the sign of the tabulated pherr marks a candidate some decision of which - the candidate test itself, the
+							// vertex, the gate - is within the margin of the stream's error (K3's exact tier: ref_candidate_verdict()); it is
+							// redone on the reference's own samples before anything is decided (below: sh.u_fire == 2), and comes by here again
+							const bool exact_here = sh.x_n == n;
+							if(v.ref && !exact_here && sh.wre[n - wbase] < 0.f) { pending = 2; break; }
+#ifdef VDL2_REF_DEBUG
+							ref_debug_log(v, exact_here ? 2 : 1, n, sh.wre[n - wbase], exact_here ? sh.x_p3 : sh.wre[n - 3 - wbase], (float)(e0 % 3));
+#endif
+							float y1, y2, y3, prevd;
+							if(exact_here) { y1 = (n - 6 >= e0) ? sh.x_p6 : kPherrBig; y2 = sh.x_p3; y3 = sh.x_p0; prevd = sh.x_f3; }
+							else { y1 = (n - 6 >= e0) ? fabsf(sh.wre[n - 6 - wbase]) : kPherrBig; y2 = fabsf(sh.wre[n - 3 - wbase]); y3 = fabsf(sh.wre[n - wbase]); prevd = sh.wim[n - 3 - wbase]; }
 							{   // log_evals_lane0() on the register copies: evaluations e_cur, e_cur + 3, ..., n
 								const int64_t count = (n - e_cur) / 3 + 1;
 								if(lgc > 0 && lgf + 3 * lgc == e_cur) lgc += count;
@@ -867,23 +1051,29 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 								}
 								evals += count;
 							}
-							const float y1 = (n - 6 >= e0) ? sh.wre[n - 6 - wbase] : kPherrBig, y2 = sh.wre[n - 3 - wbase], y3 = sh.wre[n - wbase];
-							const float prevd = sh.wim[n - 3 - wbase];
-							if(!(max_ppm != 0.f && fabsf(prevd) > ppm_thr)) {      // = fabsf(ppm_of(prevd, freq)) > max_ppm (ppm_gate_threshold())
-								sh.u_y1 = y1; sh.u_y2 = y2; sh.u_y3 = y3; sh.u_prevd = prevd;
-								pending = 1;
-								break;
+							moved = true;
+							int64_t e2;
+							if(exact_here && !is_candidate(y2, y3)) {
+								// on the reference's samples this evaluation does not fire (the bitmap holds "may fire"): the run goes on
+								e2 = n + 3; e_cur = e2;
+							} else {
+								if(!(max_ppm != 0.f && fabsf(prevd) > ppm_thr)) {      // = fabsf(ppm_of(prevd, freq)) > max_ppm (ppm_gate_threshold())
+									sh.u_y1 = y1; sh.u_y2 = y2; sh.u_y3 = y3; sh.u_prevd = prevd;
+									sh.u_verr = (exact_here && sh.x_ok) ? 0.f : 1.f;      // 1: bound worked out from the taps of n - 3 (below)
+									pending = 1;
+									break;
+								}
+								// demod.c:190-192: dropped by the gate; v->sclk keeps the vertex value, which shifts the evaluation grid (demod.c:179,233)
+								const int sclk = (int)(-roundf(parabola_vertex(y1, y2, y3)));
+								nrej++;
+								int64_t step = 3 - sclk; if(step < 1) step = 1;
+								e2 = n + step;
+								e0 = e2; e_cur = e2;
 							}
-							// demod.c:190-192: dropped by the gate; v->sclk keeps the vertex value, which shifts the evaluation grid (demod.c:179,233)
-							const int sclk = (int)(-roundf(parabola_vertex(y1, y2, y3)));
-							nrej++;
-							int64_t step = 3 - sclk; if(step < 1) step = 1;
-							const int64_t e2 = n + step;
-							e0 = e2; e_cur = e2;
-							// the next candidate on the new grid, if the words in LDS reach it
+							// the next candidate on the (new) grid, if the words in LDS reach it
 							kl = k_end;
-							if(stop_clean) { int64_t c = clean_at; if(c < e2 + 6) c = e2 + 6; if(c < kl) kl = c; }
-							const int64_t s2 = e2 + 3;
+							if(stop_clean) { int64_t c = clean_at; if(c < e0 + 6) c = e0 + 6; if(c < kl) kl = c; }
+							const int64_t s2 = e2 > e0 + 3 ? e2 : e0 + 3;      // the first evaluation of a run cannot fire
 							int64_t n2 = -1;
 							for(int64_t i = (s2 >> 6) - cw0; i >= 0 && i < ncw; ) {
 								const uint64_t nzm = sh.nzw[i >> 6] >> (i & 63);       // non-zero words from word i to the end of its group of 64
@@ -901,7 +1091,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 								i++;
 							}
 							if(n2 < 0) break;
-							if(n2 > whi) {
+							if(n2 > whi || n2 - 6 < wbase) {
 								// beyond the window of metric values, but its word is in LDS: this lane fetches the three values the next fire
 								// needs by itself - cheaper than sending the whole wavefront round the search again
 								const cf32 p1 = v.PF(n2 - 6), p2 = v.PF(n2 - 3), p3 = v.PF(n2);
@@ -914,10 +1104,42 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 						if(nrej) {
 							VDL2_CNT_ADD(cnt, CNT_PPM_REJECT, nrej);
 							st.pherr1 = st.pherr2 = kPherrBig;
-							st.e = st.e0 = e0;
+							st.e0 = e0;
 						}
+						if(moved && pending != 1) st.e = e_cur;
 						sh.u_fire = pending; sh.u_n = n;
 					LANE0_END
+					if(sh.u_fire == 2) {
+						// ---- referee: the candidate at u_n on the reference's own samples ----
+						if(spec) { LANE0 ctl->overflow = 1; LANE0_END break; }
+						const int64_t n = sh.u_n;
+						int64_t lo = (n - kRefPre) & ~255ll, hi = (n + kRefPost) | 255; if(lo < 0) lo = 0; if(hi > k_end - 1) hi = k_end - 1;   // (whole blocks of 256)
+						bool ok = sh.x_lo <= lo && hi <= sh.x_hi;
+						if(!ok) {
+							ok = ref_exact_window(v, lo, hi, sh.cw, REF_CANDIDATE);      // (the word cache is the scratch: reloaded when the search comes by again)
+							LANE0
+								if(ok) { sh.x_lo = lo; sh.x_hi = hi; }
+								sh.cw0 = 0; sh.cw_end = 0;
+							LANE0_END
+						}
+						WAVE_FOR(l)
+							if(l < 48) sh.spec[l] = v.Phi(n - 3 * (l >> 4) - 150 + 10 * (l & 15));
+						WAVE_END
+						WAVE_FOR(l)
+							if(l < 3) sync_metric(&sh.spec[16 * l], T, sh.p[l], sh.f[l]);
+						WAVE_END
+#ifdef VDL2_REF_DEBUG
+						LANE0
+							ref_debug_log(v, 3, n, sh.p[0], sh.p[1], sh.p[2]);
+							ref_debug_log(v, 4, n, sh.spec[0], sh.spec[15], sh.spec[47]);
+						LANE0_END
+#endif
+						LANE0
+							sh.spec_n = -1;
+							sh.x_n = n; sh.x_p0 = sh.p[0]; sh.x_p3 = sh.p[1]; sh.x_f3 = sh.f[1]; sh.x_p6 = sh.p[2]; sh.x_ok = ok ? 1 : 0;
+						LANE0_END
+						continue;       // the search resumes at st.e and finds this candidate again, now decided on those values
+					}
 					fired = sh.u_fire;
 					fire_n = sh.u_n;
 					K4_MARK(2);
@@ -930,9 +1152,15 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 							if(l < 4) val = v.Phi(n - 2 - l);
 							else if(l < 40) { const int sc = 2 + (l - 4) / 9, m = (l - 4) % 9; const int64_t t = n + kSpsDec - sc + (int64_t)kSpsDec * m; if(t < k_end) val = v.Phi(t); }
 							if(l < 40) sh.spec[l] = val;
+							else if(l < 56 && v.ref) sh.him2[l - 40] = ref_eps2(v, n - 3 - 150 + 10 * (l - 40));   // referee: the taps of evaluation n - 3, whose slope becomes the burst's carrier offset
 						WAVE_END
 						LANE0
 							sh.spec_n = n;
+							if(v.ref && sh.u_verr == 1.f) {
+								float si = 0.f;
+								for(int i = 0; i < kPreamble; i++) si += sh.him2[i];
+								sh.u_verr = ref_slope_margin(sqrtf(si));
+							}
 						LANE0_END
 					}
 				} else {
@@ -970,6 +1198,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 					if(sh.first_fire == INT64_MAX) sh.first_fire = n;
 					float vx = parabola_vertex(sh.u_y1, sh.u_y2, sh.u_y3);
 					int sclk = (int)(-roundf(vx));
+					const int64_t prev_n = sclk >= 0 ? seq_index(st, n, sclk) : -2;
 					float prev_phi0;
 					if(sh.spec_n == n && sclk >= 2 && sclk <= 5) prev_phi0 = sh.spec[sclk - 2];
 					else if(sh.vring_a == st.a && sclk >= 0 && 160 + (n - st.a) - sclk >= 0 && 160 + (n - st.a) - sclk < 320) prev_phi0 = sh.vring[160 + (n - st.a) - sclk];
@@ -987,7 +1216,8 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 						st.pb.chan = chan; st.pb.nsym = 0;
 						st.pb.t_first = n + (kSpsDec - sclk);
 						st.pb.sync_sample = n; st.pb.end_sample = 0; st.pb.ord = st.bursts++;
-						st.pb.prev_phi0 = prev_phi0; st.pb.vdphi = vdphi; st.pb.ppm = ppm; st.pb.pad_ = 0.f; st.pb.nf_upd = st.evals / 1000; st.pb.sync_evals = st.evals;
+						st.pb.prev_phi0 = prev_phi0; st.pb.vdphi = vdphi; st.pb.ppm = ppm; st.pb.nf_upd = st.evals / 1000; st.pb.sync_evals = st.evals;
+						st.pb.vdphi_err = v.ref ? sh.u_verr : 0.f; st.pb.prev_n = prev_n;
 						st.pb.tl_bits = 0; st.pb.syndrome = 0;
 						st.mode = 1;
 					}
@@ -998,16 +1228,55 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 			// ---- header: 9 symbols = 27 bits, of which 25 are the header (decode.c:198-258) ----
 			const int64_t t8 = sh.st.pb.t_first + 8 * kSpsDec;
 			if(t8 >= k_end) break;
-			const int sclk_pb = (int)(sh.st.pb.sync_sample + kSpsDec - sh.st.pb.t_first);
-			const bool have_spec = sh.spec_n == sh.st.pb.sync_sample && sclk_pb >= 2 && sclk_pb <= 5;
+			// phases (and, for the referee, magnitudes) of the sync point and the nine symbols, from the stream as it stands now
+			const int64_t ns = sh.st.pb.sync_sample;
+			WAVE_FOR(l)
+				if(l < 10) {
+					const int64_t t = l ? sh.st.pb.t_first + (int64_t)(l - 1) * kSpsDec : sh.st.pb.prev_n;
+					sh.hph[l] = t < 0 ? (t == -1 ? 0.f : sh.st.pb.prev_phi0) : v.Phi(t);
+					sh.him2[l] = !v.ref ? 0.f : t == -2 ? kRefBig : ref_eps2(v, t);
+				}
+			WAVE_END
+			if(v.ref && sh.x_hdr != ns) {
+				// referee: a header symbol within the margin of a decision boundary (demod.c:256-264) is sliced on the reference's own samples
+				WAVE_FOR(l)
+					int fl = 0;
+					if(l < 9) {
+						const float ev = sh.st.pb.vdphi_err < 0.f ? 0.f : sh.st.pb.vdphi_err;
+						fl = ref_symbol_marginal(sh.hph[l + 1], sh.hph[l], sh.st.pb.vdphi, sqrtf(sh.him2[l]) + sqrtf(sh.him2[l + 1]) + ev);
+					}
+					sh.flag[l] = fl;
+				WAVE_END
+				if(wave_first_flag(sh.flag) >= 0) {
+					if(spec) { LANE0 ctl->overflow = 1; LANE0_END break; }
+					int64_t lo = ns - kRefPre; if(sh.st.pb.prev_n >= 0 && sh.st.pb.prev_n < lo) lo = sh.st.pb.prev_n;
+					const bool ok = ref_exact_window(v, lo, t8, sh.cw, REF_HEADER);
+					const bool redo_slope = ok && sh.st.pb.vdphi_err > 0.f;          // a fire on a contiguous ring: the slope of evaluation ns - 3 again
+					if(redo_slope) {
+						WAVE_FOR(l)
+							if(l < 16) sh.spec[l] = v.Phi(ns - 3 - 150 + 10 * l);
+						WAVE_END
+					}
+					LANE0
+						sh.cw0 = 0; sh.cw_end = 0; sh.spec_n = -1; sh.x_hdr = ns;
+						if(redo_slope) {
+							float p_, f_;
+							sync_metric(sh.spec, T, p_, f_);
+							sh.st.pb.vdphi = f_; sh.st.pb.ppm = ppm_of(f_, freq); sh.st.pb.vdphi_err = 0.f;
+						}
+					LANE0_END
+					continue;                     // the symbols are read and sliced again
+				}
+			}
+#if !VDL2_DEVICE_PASS && defined(VDL2_HOST_DEBUG)
+			if(getenv("HOSTSIM_DEBUG_HDR")) { fprintf(stderr, "hdr chan %d sync %lld t_first %lld vdphi %.9g verr %g x_hdr %lld:", chan, (long long)ns, (long long)sh.st.pb.t_first, sh.st.pb.vdphi, sh.st.pb.vdphi_err, (long long)sh.x_hdr);
+				for(int l = 0; l < 9; l++) fprintf(stderr, " [%.6f d=%.2e e=%.2e]", sh.hph[l + 1], ref_symbol_dist(sh.hph[l + 1], sh.hph[l], sh.st.pb.vdphi), sqrtf(sh.him2[l]) + sqrtf(sh.him2[l + 1]));
+				fprintf(stderr, "\n"); }
+#endif
 			WAVE_FOR(l)
 				if(l < 9) {
-					int64_t t = sh.st.pb.t_first + (int64_t)l * kSpsDec;
-					float cur, prev;
-					if(have_spec) { cur = sh.spec[4 + 9 * (sclk_pb - 2) + l]; prev = l ? sh.spec[4 + 9 * (sclk_pb - 2) + l - 1] : sh.st.pb.prev_phi0; }
-					else { cur = v.Phi(t); prev = l ? v.Phi(t - kSpsDec) : sh.st.pb.prev_phi0; }
 					int neg = 0;
-					sh.sym[l] = sh.t_gray[slice_symbol(cur, prev, sh.st.pb.vdphi, neg)];
+					sh.sym[l] = sh.t_gray[slice_symbol(sh.hph[l + 1], sh.hph[l], sh.st.pb.vdphi, neg)];
 					sh.neg[l] = neg;
 				}
 			WAVE_END
@@ -1121,7 +1390,7 @@ VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, float ppm_thr, in
 	WAVE_SYNC_GLOBAL();                    // lane 0's counter atomics below must find the zeros the other lanes have just stored
 	uint32_t nb_dummy = 0;
 	walk_load(&o->st, lg, &nb_dummy, false, T, &o->ctl, sh);
-	walk_run(chan, freq, max_ppm, ppm_thr, k_end, false, T, v, o->cnt, o->bursts, kSpecBursts, &o->ctl, lg, sh);
+	walk_run(chan, freq, max_ppm, ppm_thr, k_end, false, T, v, o->cnt, o->bursts, kSpecBursts, &o->ctl, lg, sh, true);
 	walk_flush_log(sh, lg, &o->ctl);
 	LANE0
 		const WalkState &st = sh.st;
@@ -1218,12 +1487,14 @@ VDL2_HD void stitch_materialize(const SpecOut *spec, WalkShared &sh, StitchShare
 	}
 }
 
-// The feed [k0, k_end) of one channel in nseg segments of seglen samples; segment 0 has already been walked from the real
-// state (walk_channel() with k_end = k0 + seglen) and spec[(s-1)*3 + r] holds the speculative walks of segments 1..nseg-1.
+// The feed [k0, k_end) of one channel in nseg segments of seglen samples; spec[(s-1)*3 + r] holds the speculative walks of
+// segments 1..nseg-1.  Segment 0 is walked from the real state right here (the walk that may call the referee is this one
+// wavefront per channel, in this kernel, and no other).
 VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k0, int64_t seglen, int nseg, int64_t k_end, const Tables &T,
 		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
 		OutCtl *ctl, const EvalLog &lg, const SpecOut *spec, WalkShared &sh, StitchShared &ss, uint32_t *seg_stats) {
-	walk_load(gstate, lg, nbursts_out, true, T, ctl, sh);
+	walk_load(gstate, lg, nbursts_out, false, T, ctl, sh);
+	walk_run(chan, freq, max_ppm, ppm_thr, k0 + seglen < k_end ? k0 + seglen : k_end, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
 	LANE0
 		ss.njobs = 0; ss.hist_src = -1; ss.pb_src = -1; ss.accepted = 0; ss.walked = 0; ss.cap_log = ctl->cap_log;
 	LANE0_END
@@ -1601,6 +1872,7 @@ struct BurstShared {
 	uint8_t gf_exp[512], gf_log[256];  // LDS copies of the field tables
 	uint8_t gam[2][8];                 // erasure locators of short blocks: the missing parity octets sit at fixed places, [0]: two of them, [1]: four
 	float   pw[64];
+	float   qmin[64];                  // referee: per lane, the smallest (distance from a decision boundary) / (1/|y_cur| + 1/|y_prev|) among its symbols
 	int32_t neg[64];
 	int32_t u_ret, u_kind, u_ok;
 	uint32_t u_k, u_sprev, u_lastend, u_S, u_L, u_off, u_capf, u_capp;
@@ -1837,25 +2109,44 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 
 	// 1. slice every symbol (demod.c:252-274); decisions are independent because prev_phi is the raw phase.  A lane takes
 	//    a run of consecutive symbols, so that the phase of a symbol (one double-precision atan2, evaluated here: there is no
-	//    stored phase stream) also serves as the next symbol's prev_phi
+	//    stored phase stream) also serves as the next symbol's prev_phi.
+	//    Referee: a symbol whose decision is within the margin of the stream's error is marked (bit 7 of its entry) and sliced
+	//    again below, on the reference's own samples.
 	const int per_lane = (nsym + 63) / 64;
+	const bool ref_on = v.ref != nullptr;
+	float vdphi = b.vdphi, ppm = b.ppm;
+	const float verr = b.vdphi_err > 0.f ? b.vdphi_err : 0.f;
 	WAVE_FOR(l)
-		float pw = 0.f; int neg = 0;
+		float pw = 0.f; int neg = 0; float qmin = kRefBig;
 		const int m0 = l * per_lane, m1 = m0 + per_lane < nsym ? m0 + per_lane : nsym;
-		float prev = b.prev_phi0;
-		if(m0 > 0 && m0 < nsym) prev = v.Phi(b.t_first + (int64_t)(m0 - 1) * kSpsDec);
+		float prev = b.prev_phi0, pim2 = 0.f, pm2 = 0.f;              // phase, 1/|y|^2 and |y|^2 of the previous symbol's sample
+		if(m0 < nsym) {
+			const int64_t tp = m0 > 0 ? b.t_first + (int64_t)(m0 - 1) * kSpsDec : b.prev_n;
+			if(tp >= 0) { const cf32 yp = v.Y(tp); if(m0 > 0) prev = phase_of(yp); pim2 = ref_inv_mag2(yp); pm2 = yp.re * yp.re + yp.im * yp.im; }
+			else if(tp == -2) pim2 = kRefBig;
+		}
 		for(int mb = m0; mb < m1; mb += 4) {
 			cf32 yv[4];
 			for(int q = 0; q < 4; q++) yv[q] = mb + q < m1 ? v.Y(b.t_first + (int64_t)(mb + q) * kSpsDec) : cf32{0.f, 0.f};   // loads first
 			for(int q = 0; q < 4 && mb + q < m1; q++) {
 				const float cur = phase_of(yv[q]);
-				const int idx = slice_symbol(cur, prev, b.vdphi, neg);
-				sh.sym[mb + q] = (uint8_t)(idx ^ (idx >> 1));          // graycode[] of demod.c:223 (= Tables::gray, tests/test_design.py), without the table
+				const int idx = slice_symbol(cur, prev, vdphi, neg);
+				uint8_t sy = (uint8_t)(idx ^ (idx >> 1));                 // graycode[] of demod.c:223 (= Tables::gray, tests/test_design.py), without the table
+				const float m2 = yv[q].re * yv[q].re + yv[q].im * yv[q].im;
+				if(ref_on) {
+					const float im2 = ref_inv_mag2(yv[q]), a2 = fmaxf(m2, pm2);
+					const float d = ref_symbol_dist(cur, prev, vdphi) - verr - 2e-6f, w = sqrtf(im2) + sqrtf(pim2);
+					if(d <= kRefKappa * sqrtf(a2) * w) sy |= 0x80;
+					const float qv = w > 0.f ? d / w : kRefBig;
+					qmin = qv < qmin ? qv : qmin;
+					pim2 = im2; pm2 = m2;
+				}
+				sh.sym[mb + q] = sy;
 				prev = cur;
-				pw += yv[q].re * yv[q].re + yv[q].im * yv[q].im;
+				pw += m2;
 			}
 		}
-		sh.pw[l] = pw; sh.neg[l] = neg;
+		sh.pw[l] = pw; sh.neg[l] = neg; sh.qmin[l] = qmin;
 	WAVE_END
 	LANE0
 		// frame_pwr: the reference keeps a running mean updated per symbol (demod.c:266-268); the mean
@@ -1865,6 +2156,69 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		sh.u_pwr = (float)(s / (double)nsym);
 		if(negs) VDL2_CNT_ADD(cnt, CNT_SLICER_NEG_IDX, negs);
 	LANE0_END
+	if(ref_on) {
+		// the error bound scales with the signal around the sample: the two samples of the decision (above) or the burst's rms -
+		// a lane one of whose symbols could be within THAT bound looks at its run again; then the first and last marked symbol
+		const float athr = kRefKappa * 2.0f * sqrtf(sh.u_pwr);
+		WAVE_FOR(l)
+			const int m0 = l * per_lane, m1 = m0 + per_lane < nsym ? m0 + per_lane : nsym;
+			uint32_t first = 0xffffffffu, last = 0u;
+			if(m0 < nsym) {
+				const bool again = sh.qmin[l] <= athr;
+				float prev = b.prev_phi0, pim2 = 0.f;
+				if(again) {
+					const int64_t tp = m0 > 0 ? b.t_first + (int64_t)(m0 - 1) * kSpsDec : b.prev_n;
+					if(tp >= 0) { const cf32 yp = v.Y(tp); if(m0 > 0) prev = phase_of(yp); pim2 = ref_inv_mag2(yp); }
+					else if(tp == -2) pim2 = kRefBig;
+				}
+				for(int m = m0; m < m1; m++) {
+					if(again) {
+						const cf32 y = v.Y(b.t_first + (int64_t)m * kSpsDec);
+						const float cur = phase_of(y), im2 = ref_inv_mag2(y);
+						if(ref_symbol_dist(cur, prev, vdphi) - verr - 2e-6f <= athr * (sqrtf(im2) + sqrtf(pim2))) sh.sym[m] |= 0x80;
+						prev = cur; pim2 = im2;
+					}
+					if(sh.sym[m] & 0x80) { if(first == 0xffffffffu) first = (uint32_t)m; last = (uint32_t)m; }
+				}
+			}
+			sh.lanek[l] = first; sh.lanet[l] = ~last;
+		WAVE_END
+		const uint32_t mfirst = wave_min64(sh.lanek), mlast = ~wave_min64(sh.lanet);
+		WAVE_SYNC();
+		if(mfirst != 0xffffffffu) {
+			// ---- referee: symbols mfirst .. mlast (and, if it is not the reference's yet, the carrier slope) on the reference's own samples ----
+			const bool redo_slope = b.vdphi_err > 0.f;
+			const int64_t t_lo = mfirst > 0 ? b.t_first + (int64_t)(mfirst - 1) * kSpsDec : (b.prev_n >= 0 ? b.prev_n : b.t_first);
+			int64_t lo = redo_slope ? b.sync_sample - kRefPre : t_lo; if(t_lo < lo) lo = t_lo;
+			const int64_t hi = b.t_first + (int64_t)mlast * kSpsDec;
+			const bool ok = ref_exact_window(v, lo, hi, sh.xw, REF_SYMBOLS);
+			if(ok && redo_slope) {
+				float *phs = reinterpret_cast<float *>(sh.keptw);
+				WAVE_FOR(l)
+					if(l < 16) phs[l] = v.Phi(b.sync_sample - 3 - 150 + 10 * l);
+				WAVE_END
+				LANE0
+					float p_, f_;
+					sync_metric(phs, T, p_, f_);
+					sh.u_pwr_db = f_;                                  // (a scalar slot that is free until the frames are written)
+				LANE0_END
+				vdphi = sh.u_pwr_db; ppm = ppm_of(vdphi, freq);
+				WAVE_SYNC();
+			}
+			WAVE_FOR(l)
+				for(uint32_t m = mfirst + (uint32_t)l; m <= mlast; m += 64) {
+					if(!(sh.sym[m] & 0x80)) continue;
+					const int64_t t = b.t_first + (int64_t)m * kSpsDec;
+					const float cur = v.Phi(t);
+					const float prev = m > 0 ? v.Phi(t - kSpsDec) : (b.prev_n >= 0 ? v.Phi(b.prev_n) : b.prev_phi0);
+					int neg = 0;
+					const int idx = slice_symbol(cur, prev, vdphi, neg);
+					sh.sym[m] = (uint8_t)(idx ^ (idx >> 1));
+					(void)neg;
+				}
+			WAVE_END
+		}
+	}
 
 	K5_MARK(0);
 	// 2. descramble + pack data and FEC octets LSB-first (bitstream.c:70-81,94-107): the scrambling sequence comes an octet at a time
@@ -2075,7 +2429,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 						f.num_fec_corrections = fec_fixed;
 						f.frame_pwr_dbfs = sh.u_pwr_db;
 						f.nf_pwr_dbfs = 0.f; f.nf_upd = b.nf_upd;            // filled in by stamp_noise_floor()
-						f.ppm_error = b.ppm;
+						f.ppm_error = ppm;
 						f.burst_ord = b.ord; f.sync_sample = b.sync_sample; f.end_sample = b.end_sample;
 					} else {
 						ctl->overflow = 1;
@@ -2119,7 +2473,6 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		if(sh.u_pwr > 1.0f) VDL2_CNT_ADD(cnt, CNT_MSG_GOOD_LOUD, 1);
 	LANE0_END
 	K5_END();
-	(void)freq;
 }
 
 }  // namespace vdl2

@@ -97,10 +97,18 @@ struct vdl2hip_ctx {
 	// sync_on: 0 = both sync kernels on the front stream (the product); 1 = the exact tier in front of the walk on the walk stream;
 	// 2 = both on a stream of their own (stream_sync), beside the channeliser of the next feed.  tiles_force / k3b_wpl: K1 tiles per
 	// workgroup segment / K3b words per lane instead of the values chosen from the channel count.
-	int k3b_form = 4;                      // lanes per sample in the exact tier of the sync metric: 4 = k_sync_exact4, 16 = k_sync_exact (test hook "k3b_form")
 	int sync_on = 0; hipStream_t stream_sync = nullptr; int k3b_wpl = 0, tiles_force = 0; bool show_gaps = false; int ablate = 0;
 	OutCtl ctl_template{};                 // the capacities of a feed's output buffers (the counters are reset on the device: reset_out_ctl)
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
+	// Referee (kernels.h): decisions within the margin of the channeliser's distance from the reference's fp32 scan are taken on the
+	// reference's own samples, recomputed from the raw input.  The input of a feed stays where it is (d_in / the caller's device
+	// buffer) while its back end runs; what lies before it - up to ref_T samples: the run-up of the scan + the longest burst - is kept
+	// in a ring (ref_hist), appended to by every feed (its last min(n, ref_T) samples).  ref_pieces: what of the stream the ring holds,
+	// contiguously, newest last: {first absolute sample, count, ring position of the first}.
+	bool referee = true; int ref_kinds = 7; int64_t ref_warm = 1 << 17, ref_T = 0; uint8_t *d_refhist = nullptr; uint64_t ref_cap = 0, ref_wp = 0;
+	struct HistPiece { int64_t s0, n; uint64_t pos; }; std::vector<HistPiece> ref_pieces;
+	unsigned long long *d_refdbg = nullptr; int ref_dbg_chan = -1;
+	RefChan *d_ref[kSlots] = {}; unsigned long long *d_refdone = nullptr; uint32_t *d_refdonen = nullptr, *d_refstats = nullptr; uint8_t *d_mix = nullptr;
 	bool defer_back = false;               // VDL2HIP_BACKEND=deferred: the back end of feed i is queued behind the channeliser of feed i+1 (launch_back)
 	std::vector<uint64_t> statsd_prev;
 	std::vector<HostFrame> queue;
@@ -308,6 +316,45 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 	}
 	if(nrem) hipLaunchKernelGGL(k_carry, dim3(1), dim3(64), 0, st, a, (void *)c->d_carry[c->carry_sel ^ 1], nrem);
 	c->carry_sel ^= 1; c->ncarry = nrem;
+	// Referee: this feed's hook - the raw input it may read (what the history ring holds of the stream before this block, then the
+	// block where it lies) - and the block's tail appended to the ring for the feeds that follow.
+	RefChan refv{}; RefChan *ref_dst = nullptr;
+	if(c->d_refhist) {
+		ref_dst = c->d_ref[c->feed_no % kSlots];
+		refv.y = c->d_y; refv.cap = c->cap; refv.mask = c->cap - 1; refv.dphi = c->d_dphi; refv.mix = c->d_mix; refv.lut = c->d_lut;
+		refv.A0 = c->lpf.A[0]; refv.A1 = c->lpf.A[1]; refv.A2 = c->lpf.A[2]; refv.B1 = c->lpf.B[1]; refv.B2 = c->lpf.B[2];
+		refv.os = c->os; refv.fmt = c->fmt; refv.warm = c->ref_warm; refv.kinds = c->ref_kinds;
+		refv.done = c->d_refdone; refv.done_n = c->d_refdonen; refv.stats = c->d_refstats; refv.dbg = c->d_refdbg; refv.dbg_chan = c->ref_dbg_chan;
+		int np = 0;
+		const int64_t blk_s0 = (int64_t)c->n_total, want0 = blk_s0 - c->ref_T;
+		// (at most the two newest pieces matter - an older one ends more than ref_T samples back - and each may wrap once)
+		for(size_t i = c->ref_pieces.size() > 2 ? c->ref_pieces.size() - 2 : 0; i < c->ref_pieces.size(); i++) {
+			vdl2hip_ctx::HistPiece hp = c->ref_pieces[i];
+			if(hp.s0 + hp.n <= want0) continue;
+			if(hp.s0 < want0) { hp.pos = (hp.pos + (uint64_t)(want0 - hp.s0)) % c->ref_cap; hp.n -= want0 - hp.s0; hp.s0 = want0; }
+			const uint64_t first = std::min<uint64_t>((uint64_t)hp.n, c->ref_cap - hp.pos);
+			refv.piece[np++] = RefPiece{ c->d_refhist + hp.pos * sb, hp.s0, (int64_t)first };
+			if(first < (uint64_t)hp.n) refv.piece[np++] = RefPiece{ c->d_refhist, hp.s0 + (int64_t)first, hp.n - (int64_t)first };
+		}
+		refv.piece[np++] = RefPiece{ dev_in, blk_s0, (int64_t)nnew };
+		refv.npiece = np;
+		// the pieces must be contiguous (a gap = a block longer than ref_T whose head was not kept): drop what lies before the last gap
+		int firstp = 0;
+		for(int i = 1; i < np; i++) if(refv.piece[i - 1].s0 + refv.piece[i - 1].n != refv.piece[i].s0) firstp = i;
+		if(firstp) { for(int i = firstp; i < np; i++) refv.piece[i - firstp] = refv.piece[i]; refv.npiece = np - firstp; }
+		if(nnew) {
+			const uint64_t w = std::min<uint64_t>(nnew, (uint64_t)c->ref_T);
+			hipLaunchKernelGGL(k_ref_hist, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, st, (const uint8_t *)dev_in + (nnew - w) * sb, w, c->d_refhist, c->ref_wp, c->ref_cap, (int)sb);
+			if(w < nnew) c->ref_pieces.clear();                          // the head of this block is not kept: nothing before it can be reached any more
+			if(!c->ref_pieces.empty() && c->ref_pieces.back().s0 + c->ref_pieces.back().n == blk_s0 + (int64_t)(nnew - w)) c->ref_pieces.back().n += (int64_t)w;
+			else c->ref_pieces.push_back(vdl2hip_ctx::HistPiece{ blk_s0 + (int64_t)(nnew - w), (int64_t)w, c->ref_wp });
+			c->ref_wp = (c->ref_wp + w) % c->ref_cap;
+			// forget what the ring has overwritten (a piece never needs to be longer than the ring is)
+			auto &bp = c->ref_pieces.back();
+			if((uint64_t)bp.n > c->ref_cap / 2) { const int64_t cut = bp.n - (int64_t)(c->ref_cap / 2); bp.s0 += cut; bp.pos = (bp.pos + (uint64_t)cut) % c->ref_cap; bp.n -= cut; }
+			while(c->ref_pieces.size() > 2) c->ref_pieces.erase(c->ref_pieces.begin());
+		}
+	}
 	// deferred mode: the back end of the feed before this one is queued now, behind this feed's channeliser
 	if(c->feed_no > 0) {
 		OutSlot &pv = c->slot[(c->feed_no - 1) % kSlots];
@@ -323,7 +370,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		// wavefronts of this feed's burst decoder: each owns kResSlots frame records of the output from the start, so a short block gets few
 		sl.k5_waves = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(16, (D * (int64_t)c->C) >> 14));
 		sl.k5_waves = (sl.k5_waves + kBurstWaves - 1) / kBurstWaves * kBurstWaves;
-		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves };
+		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0 };
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
 		// on the front stream than a separate hipEventRecord.  (VDL2HIP_SYNC_ON=walk puts the exact tier in front of the walk on
 		// the walk stream, VDL2HIP_SYNC_ON=own both sync kernels on a stream of their own, so that the front stream goes on
@@ -340,8 +387,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		for(int wpl = kK3bWordsPerLane; wpl >= 1; wpl >>= 1) { k3.wpl = wpl; if(((nwords + 256 * wpl - 1) / (256 * wpl)) * c->C >= 2048 || wpl == 1) break; }
 		if(c->k3b_wpl) k3.wpl = c->k3b_wpl;                                   // experiments only (VDL2HIP_K3B_WPL)
 		const int64_t wpb = 256 * k3.wpl;                                      // words per block
-		if(c->k3b_form == 16) LAUNCH_EV(k_sync_exact, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
-		else LAUNCH_EV(k_sync_exact4, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
+		LAUNCH_EV(k_sync_exact4, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
 	}
 	if(D <= 0) HIPCHK(hipEventRecord(sl.ev_front, st));
 	if(D > 0) { sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0; if(sl.k1_timed) c->stats.chan_samples += (uint64_t)D * c->os * c->C; } else sl.k1_timed = false;
@@ -389,7 +435,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	if(D > 0) {
 		const int64_t k1 = k0 + D;
 		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
-		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr };
+		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(3 * sl.seq + 1) };
 		if(nseg >= 2) {
 			const int64_t seglen = (D + nseg - 1) / nseg;
 			nseg = (int)((D + seglen - 1) / seglen);
@@ -422,7 +468,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			HIPCHK(hipEventRecord(sl.ev_nf, sn_));
 		}
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, c->C,
-		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1 };
+		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(3 * sl.seq + 3) };
 		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: no bursts to decode)
 		const unsigned k5_lds = (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves);
 		if(small) hipExtLaunchKernelGGL(k_nf_burst, dim3(nf_grid + sl.k5_waves / kBurstWaves), dim3(64 * kNfWaves), std::max(nf_lds, k5_lds), s5_, EV(8), EV(11), 0, k4b, k5, (uint32_t)nf_grid);
@@ -492,6 +538,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 		for(int i = 0; i < kNumEv; i++) if(sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
 	}
 	if(c->h_stage) (void)hipHostFree(c->h_stage);
+	{ void *q[] = { c->d_refhist, c->d_ref[0], c->d_ref[1], c->d_ref[2], c->d_refdone, c->d_refdonen, c->d_refstats, c->d_mix, c->d_refdbg }; for(void *p : q) if(p) (void)hipFree(p); }
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
 	for(auto &e : c->cold.ev) if(e) (void)hipEventDestroy(e);
 	if(c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
@@ -556,7 +603,6 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		if(getenv("VDL2HIP_NO_PRIO")) prio_low = prio_high = 0;
 		if(getenv("VDL2HIP_LOW_PRIO")) lowp = getenv("VDL2HIP_LOW_PRIO");          // list of nf,burst,walk
 		if(const char *e = getenv("VDL2HIP_SYNC_ON")) c->sync_on = strcmp(e, "walk") == 0 ? 1 : strncmp(e, "own", 3) == 0 ? 2 : 0;   // front | walk | own | own-high
-		if(const char *e = getenv("VDL2HIP_K3B")) c->k3b_form = atoi(e) == 16 ? 16 : 4;
 		if(const char *e = getenv("VDL2HIP_K3B_WPL")) { int v = atoi(e); if(v == 1 || v == 2 || v == 4) c->k3b_wpl = v; }
 		if(const char *e = getenv("VDL2HIP_K1_TILES")) { long v = atol(e); if(v >= 1 && v <= 64) c->tiles_force = (int)v; }
 		if(const char *e = getenv("VDL2HIP_ABLATE")) c->ablate = (strstr(e, "walk") ? 1 : 0) | (strstr(e, "nf") ? 2 : 0) | (strstr(e, "burst") ? 4 : 0);
@@ -651,6 +697,20 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipHostMalloc((void **)&sl.h_mail, sizeof(OutMail), hipHostMallocDefault));
 		memset(sl.h_mail, 0, sizeof(OutMail));
 		DEV_CHK(hipMemset(sl.d_nbchan, 0, count * 4));
+	}
+
+	if(const char *e = getenv("VDL2HIP_REFEREE")) c->referee = atoi(e) != 0;
+	if(const char *e = getenv("VDL2HIP_REF_WARM")) { const long long v = atoll(e); if(v >= 1024 && v <= (1ll << 24)) c->ref_warm = v; }
+	if(c->referee) {
+		c->ref_T = c->ref_warm + (int64_t)(kHistory + 256) * c->os + 4096;      // run-up + the longest burst (its symbols are sliced when its last one has arrived)
+		c->ref_cap = 1; while(c->ref_cap < (uint64_t)(kSlots + 2) * (uint64_t)c->ref_T) c->ref_cap <<= 1;
+		DEV_ALLOC(c->d_refhist, c->ref_cap * sb);
+		for(int k = 0; k < kSlots; k++) { DEV_ALLOC(c->d_ref[k], sizeof(RefChan)); DEV_CHK(hipMemset(c->d_ref[k], 0, sizeof(RefChan))); }
+		DEV_ALLOC(c->d_refdone, (size_t)count * kRefCache * 8); DEV_ALLOC(c->d_refdonen, (size_t)count * 4); DEV_ALLOC(c->d_refstats, 32); DEV_ALLOC(c->d_mix, count);
+		DEV_CHK(hipMemset(c->d_refdone, 0, (size_t)count * kRefCache * 8)); DEV_CHK(hipMemset(c->d_refdonen, 0, (size_t)count * 4)); DEV_CHK(hipMemset(c->d_refstats, 0, 32));
+		std::vector<uint8_t> mix(count);
+		for(uint32_t i = 0; i < count; i++) mix[i] = cfg->centerfreq != c->freqs[i];       // v->offset_tuning, demod.c:386
+		DEV_CHK(hipMemcpy(c->d_mix, mix.data(), count, hipMemcpyHostToDevice));
 	}
 
 	Lut4 lut[256]; build_nco_lut(lut);                            // sincosf_lut_init()
@@ -934,7 +994,7 @@ int vdl2hip_set_profiling(vdl2hip_ctx *c, int on) {
 	return r == VDL2HIP_E_OVERFLOW ? VDL2HIP_OK : r;
 }
 
-int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) {
+int vdl2hip_get_stats_sized(vdl2hip_ctx *c, vdl2hip_stats *out, size_t size) {
 	if(!c || !out) return VDL2HIP_E_INVAL;
 	OnDevice dev_guard(c);
 	int r = collect_pending(c);
@@ -947,9 +1007,16 @@ int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) {
 		c->stats.front_sync_timeouts = tmo;
 		for(int i = 0; i < c->C; i++) { c->stats.seg_adopted += ss[2 * i]; c->stats.seg_walked += ss[2 * i + 1]; }
 	}
-	*out = c->stats;
+	if(c->d_refstats) {
+		uint32_t rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		if(hipMemcpy(rs, c->d_refstats, sizeof rs, hipMemcpyDeviceToHost) != hipSuccess) return VDL2HIP_E_DEVICE;
+		c->stats.referee_scans = rs[0]; c->stats.referee_cached = rs[1]; c->stats.referee_refused = rs[2]; c->stats.referee_short = rs[3];
+		c->stats.referee_candidate_scans = rs[4]; c->stats.referee_header_scans = rs[5]; c->stats.referee_symbol_scans = rs[6];
+	}
+	memcpy(out, &c->stats, std::min(size, sizeof c->stats));
 	return (r == VDL2HIP_E_OVERFLOW || c->failed) ? VDL2HIP_OK : r;
 }
+int vdl2hip_get_stats(vdl2hip_ctx *c, vdl2hip_stats *out) { return vdl2hip_get_stats_sized(c, out, sizeof(vdl2hip_stats)); }
 
 void *vdl2hip_stream(vdl2hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
@@ -969,9 +1036,40 @@ int vdl2hip_debug_option(vdl2hip_ctx *c, const char *name, long value) {
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	if(strcmp(name, "no_fuse") == 0) { c->fuse_k2 = value == 0; return VDL2HIP_OK; }
 	if(strcmp(name, "force_timeout") == 0) { c->debug_force_timeout = value != 0; return VDL2HIP_OK; }
-	if(strcmp(name, "k3b_form") == 0) { c->k3b_form = value == 16 ? 16 : 4; return VDL2HIP_OK; }
+	if(strcmp(name, "referee") == 0) { if(value && !c->d_refhist) return VDL2HIP_E_INVAL; c->referee = value != 0; return VDL2HIP_OK; }   // (on only where it was on at create: the history ring)
+	if(strcmp(name, "ref_debug_chan") == 0) {
+		if(!c->d_refdbg) { if(hipMalloc((void **)&c->d_refdbg, 8 * 4001) != hipSuccess) return VDL2HIP_E_NOMEM; }
+		if(hipMemset(c->d_refdbg, 0, 8 * 4001) != hipSuccess) return VDL2HIP_E_DEVICE;
+		c->ref_dbg_chan = (int)value; return VDL2HIP_OK;
+	}
+	if(strcmp(name, "ref_kinds") == 0) { c->ref_kinds = (int)value & 7; return VDL2HIP_OK; }
+	if(strcmp(name, "ref_warm") == 0) { if(value < 0 || value > c->ref_T - 4096) return VDL2HIP_E_INVAL; c->ref_warm = value; return VDL2HIP_OK; }
 	return VDL2HIP_E_INVAL;
 }
+
+// test hook (not declared in vdl2hip.h): the referee's scan on [n_lo, n_hi] of one channel, with the raw input the most recent feed could
+// reach - the decimated stream there is then the reference's own, to be read back with vdl2hip_read_decimated().  1: done, 0: refused
+int vdl2hip_debug_exact_window_many(vdl2hip_ctx *c, uint32_t chan, int64_t n_lo, int64_t n_hi, uint32_t count, int64_t stride, float *ms) {
+	if(!c || !c->d_refhist || chan >= (uint32_t)c->C || c->feed_no == 0 || count == 0 || count > 65536) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	int *d_out = nullptr; std::vector<int> h(count, 0);
+	if(hipMalloc((void **)&d_out, 4 * (size_t)count) != hipSuccess) return VDL2HIP_E_NOMEM;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+	if(ok) hipExtLaunchKernelGGL(k_ref_probe, dim3(count), dim3(64), 0, c->stream, e0, e1, 0, c->d_ref[(c->feed_no - 1) % kSlots], (int)chan, c->C, n_lo, n_hi, stride, d_out);
+	ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(h.data(), d_out, 4 * (size_t)count, hipMemcpyDeviceToHost) == hipSuccess;
+	float t = 0.f;
+	if(ok && ms) { (void)hipEventElapsedTime(&t, e0, e1); *ms = t; }
+	if(e0) (void)hipEventDestroy(e0);
+	if(e1) (void)hipEventDestroy(e1);
+	(void)hipFree(d_out);
+	if(!ok) return VDL2HIP_E_DEVICE;
+	int n = 0; for(int v : h) n += v;
+	return n;            // stretches done (of `count`)
+}
+int vdl2hip_debug_exact_window(vdl2hip_ctx *c, uint32_t chan, int64_t n_lo, int64_t n_hi) { return vdl2hip_debug_exact_window_many(c, chan, n_lo, n_hi, 1, 0, nullptr); }
 
 // test hook (not declared in vdl2hip.h): what the DPP controls the channeliser's scan relies on do on this device
 int vdl2hip_debug_dpp_probe(const float in[64], float out[256]) {
@@ -1046,6 +1144,44 @@ int vdl2hip_read_decimated(vdl2hip_ctx *c, uint32_t chan, int64_t first, float *
 		uint32_t slot = (uint32_t)(first + (int64_t)done) & (c->cap - 1);
 		size_t m = std::min<size_t>(n - done, c->cap - slot);
 		HIPCHK(hipMemcpy(dst + 2 * done, base + slot, m * sizeof(cf32), hipMemcpyDeviceToHost));
+		done += m;
+	}
+	return (int)n;
+}
+
+// development aid: the referee's event log (ref_debug_log) of the channel chosen with debug option "ref_debug_chan": out[4 * i ..] per entry
+int vdl2hip_debug_ref_log(vdl2hip_ctx *c, unsigned long long *out, size_t cap_entries) {
+	if(!c || !c->d_refdbg) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
+	(void)collect_pending(c);
+	unsigned long long n = 0;
+	HIPCHK(hipMemcpy(&n, c->d_refdbg, 8, hipMemcpyDeviceToHost));
+	if(n > 1000) n = 1000;
+	if(n > cap_entries) n = cap_entries;
+	if(n) HIPCHK(hipMemcpy(out, c->d_refdbg + 1, 32 * n, hipMemcpyDeviceToHost));
+	return (int)n;
+}
+
+// test hook (not declared in vdl2hip.h): what the sync kernels left for decimated samples first .. first+count-1 of one channel - the tabulated
+// metric {pherr (its sign: the referee's mark), slope} and the candidate bit, one byte per sample
+int vdl2hip_debug_read_sync(vdl2hip_ctx *c, uint32_t chan, int64_t first, size_t count, float *pf, uint8_t *cand) {
+	if(!c || !pf || !cand || chan < (uint32_t)c->chan_first || chan >= (uint32_t)(c->chan_first + c->C)) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	if(first < 0 || first > c->k_total || c->k_total - first > (int64_t)c->cap) return VDL2HIP_E_INVAL;
+	const size_t n = std::min<size_t>(count, (size_t)(c->k_total - first)), ch = chan - c->chan_first;
+	std::vector<uint64_t> words(c->cap >> 6);
+	HIPCHK(hipMemcpy(words.data(), c->d_cand + ch * (c->cap >> 6), words.size() * 8, hipMemcpyDeviceToHost));
+	for(size_t i = 0; i < n; i++) {
+		const uint32_t slot = (uint32_t)(first + (int64_t)i) & (c->cap - 1);
+		cand[i] = (uint8_t)((words[slot >> 6] >> (slot & 63)) & 1u);
+	}
+	size_t done = 0;
+	while(done < n) {
+		const uint32_t slot = (uint32_t)(first + (int64_t)done) & (c->cap - 1);
+		const size_t m = std::min<size_t>(n - done, c->cap - slot);
+		HIPCHK(hipMemcpy(pf + 2 * done, c->d_pf + ch * c->cap + slot, m * sizeof(cf32), hipMemcpyDeviceToHost));
 		done += m;
 	}
 	return (int)n;

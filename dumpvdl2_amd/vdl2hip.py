@@ -33,10 +33,11 @@ AVLC_COUNTER_NAMES = [
 ]
 NUM_AVLC_COUNTERS = len(AVLC_COUNTER_NAMES)
 AVLC_OK, AVLC_TOO_SHORT, AVLC_BAD_FCS = 0, 1, 2
+ABI_VERSION = 5
 EXPORTS = [
     "vdl2hip_abi_version", "vdl2hip_strerror", "vdl2hip_create", "vdl2hip_destroy", "vdl2hip_feed",
     "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
-    "vdl2hip_drain_packed", "vdl2hip_pack_raw_frame", "vdl2hip_get_stats", "vdl2hip_stream", "vdl2hip_set_drain_lag", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
+    "vdl2hip_drain_packed", "vdl2hip_pack_raw_frame", "vdl2hip_get_stats", "vdl2hip_get_stats_sized", "vdl2hip_stream", "vdl2hip_set_drain_lag", "vdl2hip_get_lpf", "vdl2hip_get_nco_step", "vdl2hip_read_decimated",
     "vdl2hip_avlc_counters", "vdl2hip_set_avlc_filter", "vdl2hip_statsd_lines", "vdl2hip_feed_pinned",
     "vdl2hip_group_create", "vdl2hip_group_destroy", "vdl2hip_group_feed", "vdl2hip_group_feed_pinned", "vdl2hip_group_sync", "vdl2hip_group_drain",
     "vdl2hip_group_set_drain_lag", "vdl2hip_group_counters", "vdl2hip_group_avlc_counters", "vdl2hip_group_size", "vdl2hip_group_ctx",
@@ -65,7 +66,9 @@ class Stats(C.Structure):
                 ("sync_ms", C.c_double), ("walk_ms", C.c_double), ("burst_ms", C.c_double), ("nf_ms", C.c_double),
                 ("bursts", C.c_uint64), ("frames", C.c_uint64),
                 ("seg_adopted", C.c_uint64), ("seg_walked", C.c_uint64), ("front_sync_timeouts", C.c_uint64),
-                ("overflow_feeds", C.c_uint64), ("cold_start_feeds", C.c_uint64)]
+                ("overflow_feeds", C.c_uint64), ("cold_start_feeds", C.c_uint64),
+                ("referee_scans", C.c_uint64), ("referee_cached", C.c_uint64), ("referee_refused", C.c_uint64), ("referee_short", C.c_uint64),
+                ("referee_candidate_scans", C.c_uint64), ("referee_header_scans", C.c_uint64), ("referee_symbol_scans", C.c_uint64)]
 
 
 class PackedFrame(C.Structure):
@@ -93,6 +96,8 @@ def load_library(path: str = None):
         raise RuntimeError(f"{path} is missing - build it with dumpvdl2_amd.build.build(); there is no CPU fallback")
     L = C.CDLL(path)
     L.vdl2hip_abi_version.restype = C.c_int
+    if L.vdl2hip_abi_version() != ABI_VERSION:      # (the structures below are this version's: a library of another would be read or written out of bounds)
+        raise RuntimeError(f"{path} has ABI version {L.vdl2hip_abi_version()}, this binding is for {ABI_VERSION}")
     L.vdl2hip_strerror.restype = C.c_char_p
     L.vdl2hip_strerror.argtypes = [C.c_int]
     L.vdl2hip_create.argtypes = [C.POINTER(Cfg), C.POINTER(C.c_void_p)]
@@ -282,6 +287,27 @@ class Receiver:
         f = self.L.vdl2hip_debug_option
         f.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         self._chk(f(self.h, name.encode(), value), "vdl2hip_debug_option")
+
+    def exact_window(self, chan: int, n_lo: int, n_hi: int) -> bool:
+        """test hook: the referee's scan over decimated samples n_lo..n_hi of one channel (True: done; read them with read_decimated)"""
+        f = self.L.vdl2hip_debug_exact_window
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_int64]
+        return bool(self._chk(f(self.h, chan, n_lo, n_hi), "vdl2hip_debug_exact_window"))
+
+    def exact_window_many(self, chan: int, n_lo: int, n_hi: int, count: int, stride: int):
+        """test hook: `count` wavefronts scan at once (channel chan + b, the stretch moved on by stride * b) -> (stretches done, kernel ms)"""
+        f = self.L.vdl2hip_debug_exact_window_many
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_int64, C.c_uint32, C.c_int64, C.POINTER(C.c_float)]
+        ms = C.c_float(0)
+        return self._chk(f(self.h, chan, n_lo, n_hi, count, stride, C.byref(ms)), "vdl2hip_debug_exact_window_many"), ms.value
+
+    def read_sync(self, chan: int, first: int, count: int):
+        """test hook: (pf [count, 2] = tabulated {pherr with the referee's mark as its sign, slope}, cand [count] candidate bits) of one channel"""
+        f = self.L.vdl2hip_debug_read_sync
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_size_t, C.c_void_p, C.c_void_p]
+        pf = np.zeros((count, 2), dtype=np.float32); cand = np.zeros(count, dtype=np.uint8)
+        n = self._chk(f(self.h, chan, first, count, pf.ctypes.data, cand.ctypes.data), "vdl2hip_debug_read_sync")
+        return pf[:n], cand[:n]
 
     def set_profiling(self, level) -> None:
         """0/False off, 1/True: time the channeliser kernel only, 2: every stage (a few percent slower)"""

@@ -24,11 +24,15 @@
 extern "C" {
 #endif
 
-#define VDL2HIP_ABI_VERSION 4   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added
+#define VDL2HIP_ABI_VERSION 5   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added
                                  * 3: vdl2hip_feed_pinned(); vdl2hip_stats.overflow_feeds; vdl2hip_group_*: one receiver over several
                                  *    GPUs from C (a channeliser look-back that gives up is no longer an error: it falls back)
                                  * 4: vdl2hip_group_set_exchange() / vdl2hip_group_exchange(): striped ingest + all-gather is the group's
-                                 *    default exchange, broadcast stays selectable; RCCL is opt-in (VDL2HIP_USE_RCCL=1) */
+                                 *    default exchange, broadcast stays selectable; RCCL is opt-in (VDL2HIP_USE_RCCL=1)
+                                 * 5: the referee (decisions within the margin of the channeliser's distance from the reference's fp32 scan are
+                                 *    taken on the reference's own samples): vdl2hip_stats grew by referee_*; vdl2hip_get_stats_sized() for callers
+                                 *    built against an older vdl2hip_stats.  (Since ABI 4 chanfir_ms / chanfir_launches / chan_samples cover only
+                                 *    the TIMED channeliser launches - profiling on, cold-start feeds excluded - not every launch.) */
 
 /* enum sample_formats, src/dumpvdl2.h:319 */
 #define VDL2HIP_FMT_U8     0
@@ -146,6 +150,16 @@ typedef struct {
 	                             * vdl2hip_sync() returns VDL2HIP_E_OVERFLOW for those, the drain calls only count here */
 	uint64_t cold_start_feeds;  /* large page-locked blocks fed to an idle receiver: copied and channelised in pieces (vdl2hip_feed_pinned);
 	                             * their channeliser launches are not in chanfir_ms / chanfir_launches */
+	/* The referee.  The channeliser's samples are what exact arithmetic gives; the reference's own fp32 scan (src/demod.c:302-329) differs
+	 * from that by its rounding noise (<= 1.5e-4 of the local amplitude).  A decision of the reference that could come out differently
+	 * within that distance - candidate test, parabola vertex, --max-ppm gate (src/demod.c:173-192), a symbol at a slicer boundary
+	 * (:256-264) - is taken on the reference's own samples, recomputed by running its scan sequentially over the raw input: */
+	uint64_t referee_scans;     /* such scans run (one wavefront, ~2 ms each) */
+	uint64_t referee_cached;    /* requests for a stretch that had been made exact already */
+	uint64_t referee_refused;   /* requests that could not be served (the raw input was no longer held): the decision stayed as it was */
+	uint64_t referee_short;     /* scans whose run-up was shorter than configured (early in a stream of short blocks) */
+	uint64_t referee_candidate_scans, referee_header_scans, referee_symbol_scans;   /* referee_scans by the decision that asked: a preamble candidate
+	                             * (candidate test / vertex / gate), a header symbol, the symbols of a burst */
 } vdl2hip_stats;
 
 int  vdl2hip_abi_version(void);
@@ -214,6 +228,7 @@ int  vdl2hip_statsd_lines(vdl2hip_ctx *ctx, const char *ns, char *out, size_t ca
 int  vdl2hip_set_profiling(vdl2hip_ctx *ctx, int level); /* 0 off; 1 time the channeliser kernel (start/stop events attached to
                                                           * its launch); 2 time every stage the same way (costs ~5 % throughput) */
 int  vdl2hip_get_stats(vdl2hip_ctx *ctx, vdl2hip_stats *out);
+int  vdl2hip_get_stats_sized(vdl2hip_ctx *ctx, vdl2hip_stats *out, size_t size);   /* writes at most `size` bytes: for a caller built against an older header */
 void *vdl2hip_stream(vdl2hip_ctx *ctx);                 /* the hipStream_t all work is queued on */
 
 /* ---- One receiver over several GPUs of this process (src/dumpvdl2.c:117-135: one worker per channel over a shared block;

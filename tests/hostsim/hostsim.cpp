@@ -12,7 +12,28 @@
 #include "../../dumpvdl2_amd/csrc/tables.h"
 #include "../../dumpvdl2_amd/csrc/design.h"
 
+// The referee's hook of the CPU build: the "reference's own samples" come from a trace the test supplies (the oracle's decimated
+// stream); the device build works them out from the raw input (kernels.h).
+namespace vdl2 {
+struct RefChan { const float *exact; int64_t n_exact; cf32 *y; uint32_t mask; int64_t calls, samples; };
+inline void ref_debug_log(const ChanView &, int tag, int64_t a, float b, float c, float d) { if(getenv("HOSTSIM_REF_LOG")) fprintf(stderr, "reflog %d %lld %.9g %.9g %.9g\n", tag, (long long)a, b, c, d); }
+inline bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void *, int) {
+	RefChan *r = v.ref;
+	if(!r || !r->exact) return false;
+	r->calls++;
+	for(int64_t n = n_lo < 0 ? 0 : n_lo; n <= n_hi && n < r->n_exact; n++) { r->y[(uint32_t)n & r->mask] = cf32{ r->exact[2 * n], r->exact[2 * n + 1] }; r->samples++; }
+	return true;
+}
+}
+
 using namespace vdl2;
+
+// metric_contiguous() plus the referee's error figure E (vdl2_core.h: sync_metric_ref)
+static void metric_contiguous_ref(const ChanView &v, int64_t n, const Tables &T, float &p, float &f, float &E, float &palt) {
+	float ph[kPreamble], e2[kPreamble];
+	for(int i = 0; i < kPreamble; i++) { const int64_t t = n - 150 + 10 * i; ph[i] = v.Phi(t); e2[i] = ref_eps2(v, t); }
+	sync_metric_ref(ph, e2, T, p, f, E, palt);
+}
 
 struct Sim {
 	int nchan; uint32_t cap, mask; float max_ppm;
@@ -29,6 +50,10 @@ struct Sim {
 	int64_t seg_min = 0; int seg_max = 1;          // segmented walk (off by default)
 	bool two_tier = false; int64_t n_exact = 0, n_total = 0;   // K3's screening rule instead of the exact metric everywhere
 	std::vector<SpecOut> spec; uint32_t seg_stats[2] = {0, 0};
+	// referee: exact samples [nchan][exact_D] and the per-channel hooks; marg: candidates K3 marked as within the margin
+	std::vector<float> exact; int64_t exact_D = 0; std::vector<RefChan> rc; int64_t n_marg = 0, n_cand = 0, n_walk_windows = 0;
+	std::vector<float> pe, pa;
+	std::vector<Burst> all_bursts;   // every burst descriptor the walker has emitted (debugging aid)
 };
 
 extern "C" {
@@ -54,6 +79,18 @@ void hostsim_destroy(Sim *s) { delete s; }
 // walk feeds of at least 2*seg_min decimated samples in up to seg_max speculative segments (0 = plain sequential walk)
 void hostsim_set_segments(Sim *s, int64_t seg_min, int seg_max) { s->seg_min = seg_min; s->seg_max = seg_max < 1 ? 1 : seg_max > kMaxSeg ? kMaxSeg : seg_max; }
 void hostsim_set_two_tier(Sim *s, int on) { s->two_tier = on != 0; }
+// referee on: decisions within the margin of the stream's error are taken on `exact` ([nchan][D] complex, the oracle's trace)
+void hostsim_set_exact(Sim *s, const float *exact, int64_t D) {
+	s->exact.assign(exact, exact + (size_t)s->nchan * D * 2); s->exact_D = D;
+	s->rc.resize(s->nchan);
+	for(int c = 0; c < s->nchan; c++) s->rc[c] = RefChan{ s->exact.data() + (size_t)c * D * 2, D, &s->y[(size_t)c * s->cap], s->mask, 0, 0 };
+	s->pe.assign((size_t)s->nchan * s->cap, 0.f); s->pa.assign((size_t)s->nchan * s->cap, 0.f);
+}
+// [0] candidates K3 marked, [1] candidate bits set, [2] exact windows served, [3] samples replaced, [4] windows asked for by the walkers (one feed)
+void hostsim_referee_stats(Sim *s, int64_t out[5]) {
+	out[0] = s->n_marg; out[1] = s->n_cand; out[2] = out[3] = 0; out[4] = s->n_walk_windows;
+	for(auto &r : s->rc) { out[2] += r.calls; out[3] += r.samples; }
+}
 void hostsim_two_tier_stats(Sim *s, int64_t out[2]) { out[0] = s->n_exact; out[1] = s->n_total; }
 void hostsim_segment_stats(Sim *s, uint32_t out[2]) { out[0] = s->seg_stats[0]; out[1] = s->seg_stats[1]; }
 
@@ -67,11 +104,14 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 			cf32 v{ yin[((size_t)c * D + (k - k0)) * 2], yin[((size_t)c * D + (k - k0)) * 2 + 1] };
 			y[(uint32_t)k & s->mask] = v;
 		}
-		const ChanView cv{ y, pf, cand, s->mask };
+		ChanView cv{ y, pf, cand, s->mask };
+		const bool ref_on = !s->rc.empty();
+		float *pe = ref_on ? &s->pe[(size_t)c * s->cap] : nullptr, *pa = ref_on ? &s->pa[(size_t)c * s->cap] : nullptr;
 		// sync kernel: whole 64-aligned words covering [k0, k1)
 		if(!s->two_tier) {
 			for(int64_t n = k0 & ~63ll; n < ((k1 + 63) & ~63ll); n++) {
 				cf32 r = (n < k1) ? metric_contiguous(cv, n, s->T) : cf32{kPherrBig, 0.f};
+				if(ref_on && n < k1) { float p_, f_, E_, a_; metric_contiguous_ref(cv, n, s->T, p_, f_, E_, a_); pe[(uint32_t)n & s->mask] = E_; pa[(uint32_t)n & s->mask] = a_; }
 				pf[(uint32_t)n & s->mask] = r;
 			}
 		} else {
@@ -100,6 +140,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 					// the kernel stores a metric value only where it computed the exact one; everywhere else the ring keeps whatever
 					// an earlier lap left there, which the walker must never look at: the simulation puts poison there
 					r = need ? metric_contiguous(cv, n, s->T) : cf32{12345.f, 54321.f};
+					if(ref_on && need) { float p_, f_, E_, a_; metric_contiguous_ref(cv, n, s->T, p_, f_, E_, a_); pe[(uint32_t)n & s->mask] = E_; pa[(uint32_t)n & s->mask] = a_; }
 					s->n_exact += need; s->n_total++;
 				}
 				pf[(uint32_t)n & s->mask] = r;
@@ -110,7 +151,27 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 			for(int b = 0; b < 64; b++) {
 				int64_t n = (w << 6) + b;
 				if(n >= k1 || n < 3) continue;
-				if(is_candidate(pf[(uint32_t)(n - 3) & s->mask].re, pf[(uint32_t)n & s->mask].re)) bits |= 1ull << b;
+				if(!ref_on) { if(is_candidate(pf[(uint32_t)(n - 3) & s->mask].re, pf[(uint32_t)n & s->mask].re)) bits |= 1ull << b; continue; }
+				// referee (the device's K3 exact tier does the same, kernels.h): "may fire" in the bitmap, "within the margin" as the sign of pf[n].p
+				auto R = [&](int64_t m) -> RefRange {
+					if(m < 0) return RefRange{ kPherrBig, kPherrBig };
+					const float p = fabsf(pf[(uint32_t)m & s->mask].re);
+					return p > 999.f ? RefRange{ kPherrBig, kPherrBig } : ref_pherr_range(p, pa[(uint32_t)m & s->mask], pe[(uint32_t)m & s->mask]);
+				};
+				const int vd = ref_candidate_verdict(R(n), R(n - 3), pf[(uint32_t)(n - 3) & s->mask].im, pe[(uint32_t)(n - 3) & s->mask], R(n - 6), s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm));
+				if(getenv("HOSTSIM_DEBUG_AT") && c == atoi(getenv("HOSTSIM_DEBUG_CH")) && llabs(n - atoll(getenv("HOSTSIM_DEBUG_AT"))) <= 9) {
+					const RefRange a0 = R(n), a3 = R(n - 3), a6 = R(n - 6);
+					fprintf(stderr, "at c=%d n=%lld vd=%d p0=%.6f r6=[%g,%g] r3=[%g,%g] r0=[%g,%g] f3=%g E0=%g palt0=%g\n", c, (long long)n, vd, pf[(uint32_t)n & s->mask].re, a6.lo, a6.hi, a3.lo, a3.hi, a0.lo, a0.hi,
+						pf[(uint32_t)(n - 3) & s->mask].im, pe[(uint32_t)n & s->mask], pa[(uint32_t)n & s->mask]);
+				}
+				if((vd & 2) && getenv("HOSTSIM_DEBUG_REF")) {
+					static int shown = 0;
+					const RefRange a0 = R(n), a3 = R(n - 3), a6 = R(n - 6);
+					if(n > 3000 && shown++ < 40) fprintf(stderr, "marg c=%d n=%lld r6=[%g,%g] r3=[%g,%g] r0=[%g,%g] f3=%g E3=%g\n", c, (long long)n, a6.lo, a6.hi, a3.lo, a3.hi, a0.lo, a0.hi,
+						pf[(uint32_t)(n - 3) & s->mask].im, pe[(uint32_t)(n - 3) & s->mask]);
+				}
+				if(vd & 1) { bits |= 1ull << b; s->n_cand++; }
+				if(vd & 2) { cf32 &q = pf[(uint32_t)n & s->mask]; q.re = -fabsf(q.re); s->n_marg++; }
 			}
 			cand[(uint32_t)w & (s->mask >> 6)] = bits;
 		}
@@ -121,6 +182,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 	static WalkShared wsh;
 	for(int c = 0; c < s->nchan; c++) {
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
+		if(!s->rc.empty()) v.ref = &s->rc[c];
 		EvalLog lg{ &s->log[(size_t)c * s->cap_log], &s->nlog[c] };
 		uint32_t nbc = 0;
 		int nseg = s->seg_min > 0 ? (int)std::min<int64_t>(s->seg_max, D / s->seg_min) : 1;
@@ -129,7 +191,6 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 			const int64_t seglen = (D + nseg - 1) / nseg;
 			nseg = (int)((D + seglen - 1) / seglen);
 			Burst *bdst = s->bursts.data() + s->ctl.nbursts; const uint32_t bcap = (uint32_t)s->bursts.size() - s->ctl.nbursts;
-			walk_channel(c, s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k0 + seglen, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], bdst, bcap, &nbc, &s->ctl, lg, wsh);
 			s->spec.resize((size_t)3 * (nseg - 1));
 			for(int x = 0; x < 3 * (nseg - 1); x++) {
 				const int seg = 1 + x / 3, r = x % 3;
@@ -150,14 +211,17 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		for(int64_t g = 0; fd.u0 + 1 + kNfGroup * g <= fd.u1; g++) nf_replay_group(v, sc, fd, g, &s->lpbuf[(size_t)c * s->cap_hist], s->cap_hist, nsh);
 		nf_finish(&s->nf[c], sc, fd, &s->lpbuf[(size_t)c * s->cap_hist], &s->ring[(size_t)c * s->nf_ring], s->nf_ring - 1, s->cap_hist, nsh);
 	}
+	for(auto &r : s->rc) s->n_walk_windows += r.calls;      // (cumulative below: calls made by the walkers so far)
 	static BurstShared bsh;
 	s->ctl.nframes = burst_reserve_initial_frames(1); s->ctl.pool_used = burst_reserve_initial_pool(1);   // one "wavefront" decodes everything
 	burst_shared_init(s->T, 0, &s->ctl, bsh);
 	uint32_t nb = s->ctl.nbursts;
+	s->all_bursts.insert(s->all_bursts.end(), s->bursts.begin(), s->bursts.begin() + nb);
 	for(uint32_t i = 0; i < nb; i++) {
 		const Burst &b = s->bursts[i];
 		int c = b.chan;
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
+		if(!s->rc.empty()) v.ref = &s->rc[c];
 		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl, bsh);
 	}
 	burst_reserve_done(s->frames.data(), bsh);
@@ -180,6 +244,21 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 	return s->ctl.overflow ? -1 : (int)nf;
 }
 
+// debugging aid: (chan, sync_sample, t_first, nsym, tl_bits, syndrome, vdphi_err * 1e6, prev_n) of every burst descriptor so far
+int64_t hostsim_bursts(Sim *s, int64_t *out, int64_t cap) {
+	int64_t n = 0;
+	for(const Burst &b : s->all_bursts) { if(n >= cap) break; int64_t *o = out + 8 * n++; o[0] = b.chan; o[1] = b.sync_sample; o[2] = b.t_first; o[3] = b.nsym; o[4] = b.tl_bits; o[5] = b.syndrome; o[6] = (int64_t)(b.vdphi_err * 1e6f); o[7] = b.prev_n; }
+	return n;
+}
+// what the sync stage left for samples first .. first+count-1 of one channel: {pherr (sign: the referee's mark), slope}, candidate bit
+void hostsim_read_sync(Sim *s, int chan, int64_t first, int64_t count, float *pf, uint8_t *cand) {
+	for(int64_t i = 0; i < count; i++) {
+		const uint32_t slot = (uint32_t)(first + i) & s->mask;
+		const cf32 q = s->pf[(size_t)chan * s->cap + slot];
+		pf[2 * i] = q.re; pf[2 * i + 1] = q.im;
+		cand[i] = (uint8_t)((s->cand[(size_t)chan * (s->cap / 64) + (slot >> 6)] >> (slot & 63)) & 1u);
+	}
+}
 int64_t hostsim_num_frames(Sim *s) { return (int64_t)s->all_frames.size(); }
 const OutFrame *hostsim_frames(Sim *s) { return s->all_frames.data(); }
 const uint8_t *hostsim_pool(Sim *s) { return s->all_pool.data(); }

@@ -73,6 +73,34 @@ class HostSim:
                             avlc_status=f.avlc_status, dst_addr=f.dst_addr, src_addr=f.src_addr))
         return out
 
+    def set_exact(self, y_exact):
+        """referee on: y_exact float32 [nchan, D, 2] = the reference's own decimated samples (the oracle's trace) of the whole capture"""
+        y = np.ascontiguousarray(y_exact, dtype=np.float32)
+        assert y.shape[0] == self.n and y.shape[2] == 2
+        self.L.hostsim_set_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        self.L.hostsim_set_exact(self.h, y.ctypes.data, y.shape[1])
+
+    def referee_stats(self):
+        a = (C.c_int64 * 5)()
+        self.L.hostsim_referee_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        self.L.hostsim_referee_stats(self.h, a)
+        return {"marked_candidates": a[0], "candidate_bits": a[1], "exact_windows": a[2], "exact_samples": a[3], "walker_windows_first_feed": a[4]}
+
+    def bursts(self):
+        """debugging aid: every burst descriptor the walker has emitted, as (chan, sync_sample, t_first, nsym, tl_bits, syndrome, vdphi_err*1e6, prev_n)"""
+        a = (C.c_int64 * (8 * 65536))()
+        self.L.hostsim_bursts.restype = C.c_int64
+        self.L.hostsim_bursts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int64]
+        n = self.L.hostsim_bursts(self.h, a, 65536)
+        return [tuple(a[8 * i:8 * i + 8]) for i in range(n)]
+
+    def read_sync(self, chan, first, count):
+        """(pf [count, 2], cand [count]) as the sync stage left them (cf. vdl2hip.Receiver.read_sync)"""
+        pf = np.zeros((count, 2), dtype=np.float32); cand = np.zeros(count, dtype=np.uint8)
+        self.L.hostsim_read_sync.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        self.L.hostsim_read_sync(self.h, chan, first, count, pf.ctypes.data, cand.ctypes.data)
+        return pf, cand
+
     def set_segments(self, seg_min, seg_max=32):
         """walk long feeds in speculative segments, as k_walk_spec / k_walk_stitch do on the device"""
         self.L.hostsim_set_segments(self.h, seg_min, seg_max)

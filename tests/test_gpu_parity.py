@@ -608,20 +608,24 @@ def test_separate_fixup_kernel_gives_the_same_answer(vh, name):
 
 
 @pytest.mark.parametrize("name", ["config2_1s", "os10_noisy_1s", "config4_0p4s", "config5_0p4s"])
-def test_both_forms_of_the_exact_sync_tier_agree(vh, name):
-    """The exact tier of the sync metric runs with four lanes per sample (k_sync_exact4: 4 taps' phases per lane, the metric on the
-    lane that collects them); the test hook "k3b_form" = 16 selects the older one-lane-per-sample form (k_sync_exact).  Same loads,
-    same atan2 in double, same metric in the reference's operation order: everything downstream - frames, timing, every float of the
-    metadata, the counters - is bit-identical, for whole and for chunked feeds."""
+def test_with_and_without_the_referee_on_the_golden_captures(vh, name):
+    """The golden captures hold no decision within the margin of the channeliser's distance from the reference's scan that comes out
+    differently (they are compared with the committed oracle answers elsewhere): with the referee (the default) and without it
+    (test hook "referee" = 0) frames, timing, integer metadata and counters are the same, for whole and for chunked feeds; the floats
+    within SURVEY 8.5 (a stretch the referee has made exact carries the reference's own samples, the rest the channeliser's)."""
     cfg, iq, bursts, gold = cases.load(name)
     key = lambda f: (f["chan"], f["burst_ord"], f["idx"])
-    out = []
-    for dbg in (None, {"k3b_form": 16}):
+    out, flt = [], []
+    for dbg in ({"referee": 0}, {"referee": 1}):
         for kw in ({}, dict(chunks=(3000, 200000), max_block=800000)):
             rx, fr, cnt = gpu_decode(vh, cfg, iq, debug=dbg, **kw)
-            out.append(([(key(f), f["octets"], f["sync_sample"], f["end_sample"], f["ppm_error"], f["frame_pwr_dbfs"], f["nf_pwr_dbfs"]) for f in sorted(fr, key=key)], cnt))
+            out.append(([(key(f), f["octets"], f["sync_sample"], f["end_sample"], f["synd_weight"], f["num_fec_corrections"]) for f in sorted(fr, key=key)], [c[:18] for c in cnt]))
+            flt.append([(f["ppm_error"], f["frame_pwr_dbfs"], f["nf_pwr_dbfs"]) for f in sorted(fr, key=key)])
+            cases.check_against_golden(fr, cnt, gold, label=f"{name} {dbg} {kw}", exact_diagnostics=False)
             rx.close()
-    assert out[0] == out[2] and out[1] == out[3]          # (whole and chunked feeds differ from each other in float rounding)
+    assert out[0] == out[1] == out[2] == out[3]
+    for a, b in zip(flt[0], flt[2]):
+        assert abs(a[0] - b[0]) <= 0.01 and abs(a[1] - b[1]) <= 0.05 and abs(a[2] - b[2]) <= 0.05
 
 
 @pytest.mark.parametrize("name", ["config2_1s", "config4_0p4s"])

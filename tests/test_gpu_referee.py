@@ -1,0 +1,102 @@
+"""The referee: decisions within the margin of the channeliser's distance from the reference's fp32 scan are taken on the
+reference's own samples, which one wavefront recomputes from the raw input by running the reference's arithmetic sequentially
+(kernels.h: ref_exact_window_dev; src/demod.c:302-329).
+
+1. the scan itself: a stretch made exact on the device is BIT-identical to the oracle's decimated stream - s16 and u8, offset-tuned and
+   on-centre channels, whole-block and 320 000-byte feeds (the run-up then comes out of the history ring), at the stream's start
+   (zero state, exactly) and far into it (run-up from a zero state 2^18 samples back);
+2. the decisions: random captures that differ from the oracle in a frame or a counter without the referee (tests/fuzz_gpu.py's seeds
+   175, 274, 1014: a symbol at a slicer boundary, a header bit, a preamble whose metric hangs on atan2()'s branch cut) are identical to
+   it with the referee - frames, timing, the reference's 18 counters - strictly, no tie allowances."""
+import numpy as np
+import pytest
+
+import cases
+from util import assert_frames_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vh():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from dumpvdl2_amd import vdl2hip
+    vdl2hip.load_library()
+    return vdl2hip
+
+
+def _oracle_trace(oracle_mod, cfg, raw, fmt, D):
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, sample_fmt=fmt, max_ppm=cfg.rx_max_ppm)
+    tr = o.trace_all(D + 4)
+    o.process(raw, block_bytes=1 << 24, nthreads=8)
+    return o, tr[:, :D, :]
+
+
+@pytest.mark.parametrize("fmt,block", [(1, None), (1, 320000), (0, 262144)])
+def test_scan_is_bit_exact(vh, oracle_mod, fmt, block):
+    cfg, iq, _, _ = cases.load("config2_1s")
+    raw = iq.view(np.uint8) if fmt == 1 else np.clip(np.rint(iq.astype(np.float64) / 256.0 + 127.5), 0, 255).astype(np.uint8)
+    sb = 4 if fmt == 1 else 2
+    D = raw.size // sb // cfg.oversample
+    o, tr = _oracle_trace(oracle_mod, cfg, raw, fmt, D)
+    rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, fmt, cfg.rx_max_ppm, max_block_bytes=raw.size)
+    rx.debug_option("referee", 0)                    # the stream as the channeliser leaves it ...
+    step = block or raw.size
+    for k in range(0, raw.size, step):
+        rx.feed(raw[k:k + step])
+    rx.drain()
+    nch = len(cfg.freqs)
+    rng = np.random.default_rng(5)
+    # ... is close to the oracle's but not it; the stretches the scan has been over are it, bit for bit
+    checked = 0
+    for c in range(nch):
+        # (with short feeds: what the LAST feed can reach - its own block and the history ring, 2^18 samples of run-up + the longest burst)
+        for lo in ((0, 17, int(rng.integers(20000, D - 6000)), D - 400) if not block else (int(rng.integers(D - 40000, D - 6000)), D - 3000, D - 400)):
+            hi = min(D - 1, lo + int(rng.integers(40, 700)) + (9000 if c % 3 == 1 else 0))       # (every third channel: a stretch as long as a burst)
+            before = rx.read_decimated(c, lo, hi - lo + 1)
+            assert rx.exact_window(c, lo, hi), f"scan refused for channel {c} [{lo}, {hi}]"
+            after = rx.read_decimated(c, lo, hi - lo + 1)
+            want = tr[c, lo:hi + 1]
+            assert after.tobytes() == want.tobytes(), f"channel {c} [{lo}, {hi}]: scan differs from the oracle's stream (max {np.abs(after - want).max():.3e})"
+            if lo > 1000:
+                assert before.tobytes() != want.tobytes()      # (the channeliser's own samples are not bit-identical: otherwise this test shows nothing)
+            checked += 1
+    assert checked >= 2 * nch
+    s = rx.stats()
+    assert s["referee_scans"] + s["referee_cached"] == checked and s["referee_scans"] >= nch and s["referee_refused"] == 0, s   # (a scan covers whole blocks of 256 samples: some stretches had been done)
+    rx.close(); o.close()
+
+
+@pytest.mark.parametrize("seed,profile", [(175, "plain"), (274, "plain"), (1014, "extreme")])
+def test_decisions_that_hang_on_the_references_rounding(vh, oracle_mod, seed, profile):
+    import fuzz_gpu
+    from dumpvdl2_amd import synth
+    cfg, _ = fuzz_gpu.make_cfg(seed, profile)
+    iq, _ = synth.synthesize(cfg)
+    raw = iq.view(np.uint8)
+    nch = len(cfg.freqs)
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+    o.process(raw, block_bytes=1 << 24, nthreads=8)
+    fo = o.frames()
+    co = [list(o.counters(c).values())[:18] for c in range(nch)]
+    out = {}
+    for referee in (0, 1):
+        rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, 1, cfg.rx_max_ppm, max_block_bytes=raw.size)
+        rx.debug_option("referee", referee)
+        for k in range(0, raw.size, 1 << 20):
+            rx.feed(raw[k:k + (1 << 20)])
+        fr = rx.drain()
+        cg = [list(rx.counters(c).values())[:18] for c in range(nch)]
+        try:
+            assert_frames_equal(fo, fr, exact_samples=True, label=f"seed {seed}")
+            assert cg == co, "counters"
+            out[referee] = "identical"
+        except AssertionError as e:
+            out[referee] = str(e)[:160]
+        if referee:
+            s = rx.stats()
+            assert s["referee_scans"] > 0 and s["referee_refused"] == 0, s
+        rx.close()
+    assert out[1] == "identical", out
+    assert out[0] != "identical", "this capture no longer differs without the referee: pick another seed"
