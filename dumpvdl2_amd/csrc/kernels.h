@@ -64,7 +64,7 @@ struct RefChan {
 	unsigned long long *done;              // [nchan][kRefCache] stretches made exact (see ref_exact_window_dev)
 	uint32_t *done_n;                      // [nchan] entries written so far
 	unsigned long long *dbg; int32_t dbg_chan, dbg_pad;   // development aid (-DVDL2_REF_DEBUG): event log of one channel, dbg[0] = entries written
-	uint32_t *stats;                       // [0] scans run, [1] requests answered from the list, [2] requests refused (input no longer held), [3] scans with a shortened run-up, [4 + kind] scans by who asked
+	uint32_t *stats;                       // [0] scans run, [1] requests answered from the list, [2] requests refused (input no longer held), [3] scans with a shortened run-up, [4 + kind] scans by who asked, [7] channels walked again
 };
 
 // one raw sample as process_buf_short() / process_buf_uchar() convert it (src/demod.c:349-365)
@@ -891,7 +891,7 @@ struct K3Args {
 	int32_t wpl;              // exact tier: flag words scanned per lane (1..kK3bWordsPerLane)
 	OutCtl *ctl; uint32_t k5_waves;   // the feed's output control block, reset here (the last kernel of the front, so that no copy has to do it)
 	// referee (nullptr: off): the feed's hook - written here from `refv`, for the same reason - and what the candidate verdict needs
-	RefChan *ref; RefChan refv; float max_ppm; const float *ppm_thr; int32_t ref_on;      // (ref != nullptr, ref_on == 0: the hook is written, the verdicts are the plain ones)
+	RefChan *ref; RefChan refv; float max_ppm; const float *ppm_thr; int32_t ref_on; uint32_t *rq_n, *rq_flag;      // rq_n, rq_flag: the feed's list of decisions to check / its "walk again" flags, reset here;      // (ref != nullptr, ref_on == 0: the hook is written, the verdicts are the plain ones)
 };
 
 // K3: got_sync() metric (contiguous ring) + the candidate bitmap, in two tiers and two kernels.
@@ -976,20 +976,20 @@ __global__ __launch_bounds__(kK3Threads) void k_sync_screen(K3Args a) {
 }
 
 constexpr int kK3bWordsPerLane = 4;      // at most; fewer when that leaves the chip short of wavefronts (few channels)
-// The exact tier with FOUR lanes per sample: a word with work is taken by the whole wavefront, 16 of its samples at a time - lane
-// 4 s + part works out the phases of taps 4 part .. 4 part + 3 of sample s (4 loads, 4 atan2 in double instead of 16 per lane), the
-// phases meet in LDS and the lane with part 0 runs the reference's metric on them.  Same loads, same atan2, same metric, same
-// operation order as k3_exact(): bit-identical values; what changes is the length of the dependent chain a wavefront sits on (the
-// kernel is latency-bound: its arithmetic is a quarter of its run time) and how many lanes have work (a cluster around a preamble
-// is ~13 samples: 13 of 64 lanes busy in the 16-lanes-per-word form, 52 of 64 here).
+// The exact tier, a word at a time.  A word with work is taken by the whole wavefront: the 224 samples its evaluations can read (the
+// word and 160 before it) are loaded once, coalesced, and turned into exact phases (atan2 in double, four per lane) - and, for the
+// referee, into the bounds on their errors (ref_eps2_of: a sample and its three predecessors) - in LDS; then every sample that has
+// work is ONE lane's: sixteen phases out of LDS, the reference's metric on them in its own operation order (sync_metric), the
+// referee's error figure beside it.  Same atan2, same metric, bit-identical values as the four-lanes-per-sample form it replaces
+// (which read every tap from memory - five loads per tap with the referee - and kept three lanes in four idle during the metric).
 __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
-	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { reset_out_ctl(a.ctl, a.k5_waves); if(a.ref) *a.ref = a.refv; }
+	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { reset_out_ctl(a.ctl, a.k5_waves); if(a.ref) *a.ref = a.refv; if(a.rq_n) *a.rq_n = 0u; }
+	if(blockIdx.x == 0 && threadIdx.x == 0 && a.rq_flag) a.rq_flag[blockIdx.y] = 0u;
+	constexpr int kBack = 160, kSpan = kBack + 64;        // staged samples: base - 160 .. base + 63
 	// [wave][6 + bit]: metric of sample word*64 + bit (entries 0..5 = the six samples before the word), its slope, and - for the
 	// referee - its error figure E and its value with the one discontinuity taken the other way (vdl2_core.h: sync_metric_ref)
-	__shared__ float psh[4][64 + 6], fsh[4][64 + 6], esh[4][64 + 6], ash[4][64 + 6];
-	__shared__ float phs[4][16][kPreamble + 1];          // [wave][sample slot][tap]: exact phases (floats, as the reference keeps them)
-	__shared__ float eps[4][16][kPreamble + 1];          // ... and the squared bounds on their errors (ref_eps2)
-	__shared__ uint8_t items[4][64 + 6];                 // [wave][e]: bit number of the e-th sample to work out (64..69: the six before the word)
+	__shared__ float psh[4][64 + 6], fsh[4][64 + 6], esh[4][64 + 6], ash[4][64 + 6], bsh[4][64 + 6];
+	__shared__ float phs[4][kSpan], e2s[4][kSpan];
 	__shared__ uint64_t s_need[4][64 * kK3bWordsPerLane];
 	__shared__ uint8_t s_fprev[4][64 * kK3bWordsPerLane];
 	__shared__ uint16_t s_list[4][64 * kK3bWordsPerLane];
@@ -1001,7 +1001,6 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
 	const Tables &T = *a.tab;
 	const bool ref_on = a.ref != nullptr && a.ref_on != 0;
 	const float ppm_thr = ref_on ? a.ppm_thr[c] : 0.f;
-	const ChanView cv{ y, nullptr, nullptr, a.mask };
 	const int64_t w0 = a.nbase >> 6, w1 = (a.k1 + 63) >> 6;
 	const int64_t wb = w0 + ((int64_t)blockIdx.x * 4 + wave) * (64 * a.wpl);   // first word of this wavefront
 	int nwork = 0;
@@ -1030,65 +1029,73 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
 		nwork += __builtin_popcountll(busy);
 	}
 	WAVE_SYNC();
-	const int slot = lane >> 2, part = lane & 3;
-	float *ps = psh[wave], *fs = fsh[wave], *es = esh[wave], *as = ash[wave];
+	float *ps = psh[wave], *fs = fsh[wave], *es = esh[wave], *as = ash[wave], *bs = bsh[wave], *ph = phs[wave], *e2 = e2s[wave];
 	#pragma unroll 1
 	for(int it = 0; it < nwork; it++) {
 		const int idx = (int)s_list[wave][it];
 		const uint64_t needj = s_need[wave][idx];
 		const uint32_t fprevj = s_fprev[wave][idx] & 63u;                 // which of the six samples before the word are tabulated (bit k: sample -6 + k)
-		const int64_t wj = wb + idx;
+		const int64_t wj = wb + idx, r0 = (wj << 6) - kBack;
+		// ---- stage: phases (and |y|^2, for the error bounds) of samples r0 .. r0 + 223, four per lane, all loads first ----
+		{
+			cf32 yv[4]; bool in[4];
+			#pragma unroll
+			for(int k = 0; k < 4; k++) {
+				const int64_t t = r0 + lane + 64 * k;
+				in[k] = 64 * k + lane < kSpan && t >= 0 && t < a.k1;
+				yv[k] = in[k] ? y[(uint32_t)t & a.mask] : cf32{0.f, 0.f};
+			}
+			#pragma unroll
+			for(int k = 0; k < 4; k++) if(64 * k + lane < kSpan) {
+				ph[64 * k + lane] = in[k] ? phase_of(yv[k]) : 0.f;
+				e2[64 * k + lane] = in[k] ? yv[k].re * yv[k].re + yv[k].im * yv[k].im : -1.f;     // (-1: outside the stream - its phase is exactly the reference's)
+			}
+		}
 		ps[6 + lane] = kPherrBig; if(lane < 6) ps[lane] = kPherrBig;
-		const int cnt = __builtin_popcountll(needj);
-		if((needj >> lane) & 1ull) items[wave][__builtin_popcountll(needj & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-		if(lane < 6 && ((fprevj >> lane) & 1u)) items[wave][cnt + __builtin_popcount(fprevj & ((1u << lane) - 1u))] = (uint8_t)(64 + lane);
-		const int total = cnt + __builtin_popcount(fprevj);
 		WAVE_SYNC();
-		#pragma unroll 1
-		for(int r0 = 0; r0 < total; r0 += 16) {
-			const bool active = r0 + slot < total;
-			const int item = active ? (int)items[wave][r0 + slot] : 0;
-			const int bit = item < 64 ? item : item - 70;                 // 64..69 -> -6..-1
-			const int64_t n = (wj << 6) + bit;
-			if(active && n >= 0) {
-				cf32 yv[4];
-				#pragma unroll
-				for(int k = 0; k < 4; k++) {                                 // all four loads first
-					const int64_t t = n - 150 + 10 * (4 * part + k);
-					yv[k] = (t < 0 || t >= a.k1) ? cf32{0.f, 0.f} : y[(uint32_t)t & a.mask];
+		if(ref_on) {
+			// |y|^2 -> the squared bound on the phase error (ref_eps2_of), in place: every lane reads its four and their predecessors first
+			float ev[4];
+			#pragma unroll
+			for(int k = 0; k < 4; k++) {
+				const int i = 64 * k + lane;
+				ev[k] = 0.f;
+				if(i >= 3 && i < kSpan) {
+					const float m0 = e2[i], m1 = e2[i - 1], m2 = e2[i - 2], m3 = e2[i - 3];
+					ev[k] = m0 < 0.f ? 0.f : ref_eps2_of(m0, fmaxf(m1, 0.f), fmaxf(m2, 0.f), fmaxf(m3, 0.f));
 				}
-				if(ref_on) {
-					#pragma unroll
-					for(int k = 0; k < 4; k++) { const int64_t t = n - 150 + 10 * (4 * part + k); eps[wave][slot][4 * part + k] = t >= a.k1 ? 0.f : ref_eps2(cv, t); }
-				}
-				#pragma unroll
-				for(int k = 0; k < 4; k++) phs[wave][slot][4 * part + k] = phase_of(yv[k]);
 			}
 			WAVE_SYNC();
-			if(active && part == 0 && n >= 0) {
-				float ph[kPreamble];
-				#pragma unroll
-				for(int i = 0; i < kPreamble; i++) ph[i] = phs[wave][slot][i];
-				float p, f, E = 0.f, pa;
-				if(ref_on) {
-					float e2[kPreamble];
-					#pragma unroll
-					for(int i = 0; i < kPreamble; i++) e2[i] = eps[wave][slot][i];
-					sync_metric_ref(ph, e2, T, p, f, E, pa);
-				} else { sync_metric(ph, T, p, f); pa = p; }
-				ps[6 + bit] = p; fs[6 + bit] = f; es[6 + bit] = E; as[6 + bit] = pa;
-			}
+			#pragma unroll
+			for(int k = 0; k < 4; k++) if(64 * k + lane < kSpan) e2[64 * k + lane] = ev[k];
 			WAVE_SYNC();
 		}
+		// ---- one lane per sample with work: the word's own (bit = lane), then the six before it (lanes 0..5) ----
+		#pragma unroll 1
+		for(int round = 0; round < 2; round++) {
+			const int bit = round == 0 ? lane : lane - 6;
+			const bool todo = round == 0 ? ((needj >> lane) & 1ull) != 0 : (lane < 6 && ((fprevj >> lane) & 1u) && (wj << 6) + bit >= 0);
+			if(todo) {
+				const int i0 = bit + kBack - 150;                            // staged index of tap 0
+				float p[kPreamble];
+				#pragma unroll
+				for(int i = 0; i < kPreamble; i++) p[i] = ph[i0 + 10 * i];
+				float pv, fv, E = 0.f, pa, pb;
+				if(ref_on) sync_metric_ref(p, e2 + i0, 10, T, pv, fv, E, pa, pb);
+				else { sync_metric(p, T, pv, fv); pa = pb = pv; }
+				ps[6 + bit] = pv; fs[6 + bit] = fv; es[6 + bit] = E; as[6 + bit] = pa; bs[6 + bit] = pb;
+			}
+		}
+		WAVE_SYNC();
 		// the verdict of every sample of the word as a candidate: got_sync() may fire there (bitmap) / some decision of the fire is
-		// within the margin of the stream's error (sign of the tabulated metric: the walker has the samples made exact first)
+		// within the margin of the stream's error (sign of the tabulated metric: the walker has it checked on the reference's samples)
 		const int64_t n = (wj << 6) + lane;
 		const float p0 = ps[6 + lane], p3 = ps[3 + lane], p6 = ps[lane];
 		int vd = 0;
 		if(n >= 3 && n < a.k1) {
 			if(!ref_on) vd = is_candidate(p3, p0) ? 1 : 0;
-			else vd = ref_candidate_verdict(ref_pherr_range(p0, as[6 + lane], es[6 + lane]), ref_pherr_range(p3, as[3 + lane], es[3 + lane]), fs[3 + lane], es[3 + lane],
-			                                ref_pherr_range(p6, as[lane], es[lane]), a.max_ppm, ppm_thr);
+			else vd = ref_candidate_verdict(ref_pherr_range(p0, as[6 + lane], bs[6 + lane], es[6 + lane]), ref_pherr_range(p3, as[3 + lane], bs[3 + lane], es[3 + lane]), fs[3 + lane], es[3 + lane],
+			                                ref_pherr_range(p6, as[lane], bs[lane], es[lane]), a.max_ppm, ppm_thr);
 		}
 		if((needj >> lane) & 1ull) a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = cf32{ (vd & 2) ? -p0 : p0, fs[6 + lane] };
 		const unsigned long long bits = __ballot((vd & 1) != 0);
@@ -1104,21 +1111,50 @@ struct K4Args {
 	int64_t k_end; float max_ppm; uint32_t cap, mask; int32_t chan_first, nchan;
 	const float *ppm_thr;      // per channel: ppm_gate_threshold(freq, max_ppm)
 	RefChan *ref;              // referee hook of this feed (nullptr: off)
-	uint32_t ref_launch;       // ... and a number that tells this launch from the others (k_walk_stitch: + 1)
+	uint32_t ref_launch;       // ... and a number that tells this launch from the others (k_walk_stitch: + 1, k_ref_verify: + 2, k_walk_again: + 3)
+	// optimistic mode (rq != nullptr; vdl2_core.h: ref_verify): the feed's list of decisions to check, the "walk again" flag per channel,
+	// and where the state and counters a channel's walk starts from are kept
+	RefReq *rq; uint32_t *rq_n; uint32_t rq_cap; uint32_t *rq_flag; WalkState *ws_snap; unsigned long long *cnt_snap;
 };
 
 __global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
 	__shared__ WalkShared sh;
 	const int c = blockIdx.x;
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch, a.rq, a.rq_n, a.rq_cap, a.rq_flag };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	walk_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
-	             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh);
+	             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh, WalkSnap{ a.rq ? a.ws_snap : nullptr, a.cnt_snap });
+}
+
+// Referee, optimistic mode (vdl2_core.h: ref_verify): the decisions the walk noted are checked on the reference's own samples, a
+// wavefront each, all at once - a scan takes ~3 ms, and the walk does not wait for it ...
+__global__ __launch_bounds__(64, 4) void k_ref_verify(K4Args a) {
+	__shared__ float lds[64];
+	const uint32_t nreq = *a.rq_n < a.rq_cap ? *a.rq_n : a.rq_cap;
+	for(uint32_t i = blockIdx.x; i < nreq; i += gridDim.x) {
+		const RefReq r = a.rq[i];
+		const int c = r.chan;
+		ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + 2u };
+		if(!ref_verify(r, a.freq[c], a.max_ppm, a.ppm_thr[c], a.k_end, *a.tab, v, lds) && threadIdx.x == 0) a.rq_flag[c] = 1u;
+		WAVE_SYNC();
+	}
+}
+// ... and a channel one of whose decisions did not stand is walked again, from the state the feed started with
+__global__ __launch_bounds__(64, 4) void k_walk_again(K4Args a) {
+	__shared__ WalkShared sh;
+	const int c = blockIdx.x;
+	if(!a.rq_flag[c]) return;
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + 3u };
+	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
+	walk_again(c, a.freq[c], a.max_ppm, a.ppm_thr[c], a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
+	           a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh, WalkSnap{ a.ws_snap, a.cnt_snap });
+	if(threadIdx.x == 0) atomicAdd(a.ref->stats + 7, 1u);
 }
 
 // K4 in segments (vdl2_core.h "Speculative segments"): grid.x = 1 + 3*(nseg-1) walks per channel, then one stitcher per channel
 struct K4sArgs {
 	K4Args k; SpecOut *spec; uint32_t spec_stride; int32_t nseg; int64_t k0, seglen; uint32_t *seg_stats;
+	int32_t again;             // k_walk_stitch, second launch (referee, optimistic mode): only the channels flagged "walk again" (vdl2_core.h: stitch_channel)
 };
 
 // Four walks per workgroup, one per wavefront (they share nothing): see k_nf_replay for why the back-end kernels that run
@@ -1131,7 +1167,7 @@ __global__ __launch_bounds__(64 * kWalkWaves, 4) void k_walk_spec(K4sArgs s) {
 	const int c = blockIdx.y, x = blockIdx.x * kWalkWaves + wave;
 	if(x >= 1 + 3 * (s.nseg - 1)) return;
 	WalkShared &sh = shw[wave];
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch, a.rq, a.rq_n, a.rq_cap, a.rq_flag };
 	if(x == 0) return;         // (segment 0 is walked from the real state by the stitcher)
 	{
 		const int seg = 1 + (x - 1) / 3, r = (x - 1) % 3;
@@ -1152,12 +1188,14 @@ __global__ __launch_bounds__(256, 4) void k_walk_stitch(K4sArgs s) {
 	const K4Args &a = s.k;
 	const int wave = threadIdx.x >> 6, c = blockIdx.x * kStitchWaves + wave;      // a channel per wavefront
 	if(c >= a.nchan) return;
+	if(s.again && !a.rq_flag[c]) return;
 	StitchLds &lds = reinterpret_cast<StitchLds *>(k4_lds)[wave];
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + 1u };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + (s.again ? 3u : 1u), s.again ? nullptr : a.rq, a.rq_n, a.rq_cap, a.rq_flag };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	stitch_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	               a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg,
-	               s.spec + (size_t)c * s.spec_stride, lds.sh, lds.ss, s.seg_stats + 2 * c);
+	               s.spec + (size_t)c * s.spec_stride, lds.sh, lds.ss, s.seg_stats + 2 * c, WalkSnap{ a.rq ? a.ws_snap : nullptr, a.cnt_snap }, s.again != 0);
+	if(s.again && (threadIdx.x & 63) == 0) atomicAdd(a.ref->stats + 7, 1u);
 }
 
 struct K4bArgs {

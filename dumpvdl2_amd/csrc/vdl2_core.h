@@ -134,6 +134,7 @@ constexpr int kCleanAfter = 320;          // search state this far into an inter
 constexpr int kSpecBack = 4096;           // a speculative walker pretends its DM_INIT interval started this far before its segment
 constexpr int kSpecBursts = 48;           // per speculative segment; more than that and the segment is simply walked for real
 constexpr int kSpecLog = 128;
+constexpr int kSpecReq = 8;              // decisions within the margin a speculative segment may note (more: it gives up)
 constexpr int kMaxSeg = 32;
 constexpr int kCandWin = 512;             // candidate-bitmap words (64 samples each) a walker loads per pass and keeps in LDS
 
@@ -182,6 +183,10 @@ struct ChanView {
 	RefChan        *ref = nullptr;     // referee hook of this channel (nullptr: none)
 	int32_t         ref_chan = 0;      // ... and the channel's index there (device build: one hook per feed, shared by the channels)
 	uint32_t        ref_launch = 0;    // ... and which kernel launch this is (device build: see ref_exact_window_dev)
+	// optimistic mode (rq != nullptr): a decision within the margin is TAKEN on the samples as they are and noted here, to be checked on
+	// the reference's own afterwards by all the wavefronts it takes at once (ref_verify); a channel one of whose decisions does not
+	// stand is walked again from the feed's start.  rq_flag: per channel, "walk again" (nullptr: a speculative walk - it gives up instead)
+	struct RefReq  *rq = nullptr; uint32_t *rq_n = nullptr; uint32_t rq_cap = 0; uint32_t *rq_flag = nullptr;
 	VDL2_HD cf32  Y(int64_t n) const { return y[(uint32_t)n & mask]; }
 	VDL2_HD float Phi(int64_t n) const { return n < 0 ? 0.f : phase_of(y[(uint32_t)n & mask]); }   // atan2(lp_im, lp_re); 0 before the stream starts
 	VDL2_HD cf32  PF(int64_t n) const { return pf[(uint32_t)n & mask]; }
@@ -556,6 +561,32 @@ constexpr int   kRefPre = 156, kRefPost = 96;   // a marginal candidate at n: ev
 // LDS the caller can spare.  false: not possible (no referee, or the raw input is no longer held) - the caller keeps its decision.
 VDL2_HD void ref_debug_log(const ChanView &v, int tag, int64_t a, float b, float c, float d);   // development aid (a no-op unless the build provides one)
 enum { REF_CANDIDATE = 0, REF_HEADER = 1, REF_SYMBOLS = 2 };   // who asks (statistics; a test hook can switch a kind off)
+// a decision taken on the channeliser's samples although it lies within the margin (optimistic mode)
+struct RefReq {
+	int32_t  chan, kind;               // REF_CANDIDATE / REF_HEADER
+	int64_t  n;                        // the candidate / the sync sample
+	int64_t  t_first, prev_n;          // header: the first symbol's sample, the sample whose phase is prev_phi0
+	float    vdphi, vdphi_err, prev_phi0, pad_;
+	uint32_t code, pad2_;              // what was decided.  Candidate: ref_candidate_code().  Header: the nine symbols, three bits each
+};
+// got_sync()'s outcome at a candidate: bit 0 it fires (demod.c:173), bit 1 it passes the --max-ppm gate (:190), bits 8-15 sclk + 64 (:179)
+VDL2_HD uint32_t ref_candidate_code(float y1, float y2, float y3, float prevd, float max_ppm, float ppm_thr) {
+	if(!is_candidate(y2, y3)) return 0u;
+	const int sclk = (int)(-roundf(parabola_vertex(y1, y2, y3)));
+	const uint32_t pass = !(max_ppm != 0.f && fabsf(prevd) > ppm_thr) ? 2u : 0u;
+	return 1u | pass | ((uint32_t)((sclk + 64) & 0xff) << 8);
+}
+// one lane (inside a LANE0 section).  false: the list is full
+VDL2_HD bool ref_log_request(const ChanView &v, const RefReq &r) {
+#if VDL2_DEVICE_PASS
+	const uint32_t i = atomicAdd(v.rq_n, 1u);
+#else
+	const uint32_t i = (*v.rq_n)++;
+#endif
+	if(i >= v.rq_cap) return false;
+	v.rq[i] = r;
+	return true;
+}
 VDL2_HD bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void *scratch, int kind);
 
 // squared bound on the phase error of decimated sample n: the stream's error there is at most kRefKappa x the largest of the
@@ -578,8 +609,8 @@ VDL2_HD float ref_eps2(const ChanView &v, int64_t n) {
 // length E (mean and slope removal are projections), E = kappa A sqrt(sum 1/|y_i|^2), A = the largest tap
 // E sums the taps' WORST-CASE bounds as if all sixteen errors were at their maximum and lined up with the residual; they are
 // independent, and mostly thirty times smaller: over 25 000 preamble-like windows of the fuzz and bench captures the metric moved by
-// at most 0.040 of that figure (rms 0.006), the slope by at most 0.034 (dev/ref_margin_calibration.py).  kRefSum = 3x the worst seen.
-constexpr float kRefSum = 0.125f;
+// at most 0.040 of that figure (rms 0.006), the slope by at most 0.034 (dev/ref_margin_calibration.py).  kRefSum = 2x the worst seen.
+constexpr float kRefSum = 0.085f;
 VDL2_HD float ref_pherr_margin(float p, float E) { const float e = kRefSum * E; return 2.0f * sqrtf(p) * e + e * e + 4e-6f * p + 1e-6f; }
 // ... and the slope: |df| <= E sqrt(sum lrx^2) / lr_den = E / sqrt(340)
 VDL2_HD float ref_slope_margin(float E) { return 0.0543f * kRefSum * E + 1e-7f; }
@@ -588,21 +619,30 @@ VDL2_HD float ref_slope_margin(float E) { return 0.0543f * kRefSum * E + 1e-7f; 
 // forms linear in each y: over a box its extremes are at corners unless the denominator changes sign, which the corners show too)
 struct RefRange { float lo, hi; };
 VDL2_HD bool ref_vertex_marginal(RefRange y1, RefRange y2, RefRange y3) {
-	float lo = kRefBig, hi = -kRefBig;
-	for(int c = 0; c < 8; c++) {
-		const float v = parabola_vertex((c & 1) ? y1.hi : y1.lo, (c & 2) ? y2.hi : y2.lo, (c & 4) ? y3.hi : y3.lo);
-		if(!(v == v) || fabsf(v) > 1.0e6f) return true;
-		lo = v < lo ? v : lo; hi = v > hi ? v : hi;
+	// (the three values' errors are independent: the vertex moves by the root of the sum of the squares of what each alone does, taken
+	// from its own end points; a value that "cannot be told" - [0, big] - or a vertex that runs away decides it outright)
+	const float c1 = 0.5f * (y1.lo + y1.hi), c2 = 0.5f * (y2.lo + y2.hi), c3 = 0.5f * (y3.lo + y3.hi);
+	if(y1.hi - y1.lo > 100.f || y2.hi - y2.lo > 100.f || y3.hi - y3.lo > 100.f) return true;
+	const float v0 = parabola_vertex(c1, c2, c3);
+	float d2 = 0.f;
+	for(int k = 0; k < 3; k++) {
+		const float a = parabola_vertex(k == 0 ? y1.lo : c1, k == 1 ? y2.lo : c2, k == 2 ? y3.lo : c3);
+		const float b = parabola_vertex(k == 0 ? y1.hi : c1, k == 1 ? y2.hi : c2, k == 2 ? y3.hi : c3);
+		if(!(a == a) || !(b == b) || fabsf(a) > 1.0e6f || fabsf(b) > 1.0e6f) return true;
+		const float d = fmaxf(fabsf(a - v0), fabsf(b - v0));
+		d2 += d * d;
 	}
-	return roundf(lo - 1e-5f) != roundf(hi + 1e-5f);
+	if(!(v0 == v0)) return true;
+	const float d = sqrtf(d2) + 1e-5f;
+	return roundf(v0 - d) != roundf(v0 + d);
 }
 
 // the values the reference's metric can have where this path's is p: [p - m, p + m], widened to the value with one unwrap decision
 // taken the other way (palt, see sync_metric_ref) where such a decision hangs on the stream's error
-VDL2_HD RefRange ref_pherr_range(float p, float palt, float E) {
+VDL2_HD RefRange ref_pherr_range(float p, float alo, float ahi, float E) {
 	if(!(p < kPherrBig)) return RefRange{ kPherrBig, kPherrBig };       // not tabulated / not part of the run: exactly PHERR_MAX
 	if(E >= kRefBig) return RefRange{ 0.f, kRefBig };
-	const float a = p < palt ? p : palt, b = p < palt ? palt : p;
+	const float a = p < alo ? p : alo, b = p > ahi ? p : ahi;
 	return RefRange{ a - ref_pherr_margin(a, E), b + ref_pherr_margin(b, E) };
 }
 
@@ -624,12 +664,12 @@ VDL2_HD int ref_candidate_verdict(RefRange r0, RefRange r3, float f3, float E3, 
 
 // sync_metric() with the unwrap decision at tap `flip` taken the other way (the value the reference gets when that decision,
 // which hangs on a phase difference within the stream's error of +-pi, goes the other way on its samples; flip < 0: as it is)
-VDL2_HD float sync_metric_flipped(const float *ph, const Tables &T, int flip) {
+VDL2_HD float sync_metric_flipped(const float *ph, const Tables &T, int flip, int cut = -1) {      // cut: the tap that reads -phase (atan2's branch cut)
 	float e[kPreamble];
 	float mean = 0.f, unwrap = 0.f;
-	float prev = mean = e[0] = ph[0] - T.pr_phase[0];
+	float prev = mean = e[0] = (cut == 0 ? -ph[0] : ph[0]) - T.pr_phase[0];
 	for(int i = 1; i < kPreamble; i++) {
-		float cur = ph[i] - T.pr_phase[i];
+		float cur = (i == cut ? -ph[i] : ph[i]) - T.pr_phase[i];
 		float diff = cur - prev;
 		prev = cur;
 		double step = diff > kPiBelow ? -(2.0f * M_PI) : (diff < -kPiBelow ? (2.0f * M_PI) : 0.0);
@@ -648,33 +688,46 @@ VDL2_HD float sync_metric_flipped(const float *ph, const Tables &T, int flip) {
 	return acc;
 }
 
+VDL2_HD void sync_metric_two(const float *ph, const Tables &T, const int *ev, const int *kind, float pherr, float &lo, float &hi);
 // sync_metric() plus what the referee needs: E (see ref_pherr_margin) and palt - the value the reference gets when the ONE
 // discontinuity within the stream's error goes the other way on its samples: an unwrap decision (a phase difference within the
 // margin of +-pi), or a tap whose phase is within the margin of atan2()'s branch cut (it then reads +pi for -pi: with the
 // reference's single unwrap step per tap the metric is not continuous there).  palt = pherr when there is none; with several, or
 // a tap that is exactly zero, E = kRefBig: "cannot tell".  eps2[i]: ref_eps2() of tap i
-VDL2_HD void sync_metric_ref(const float *ph, const float *eps2, const Tables &T, float &pherr, float &slope_out, float &E_out, float &palt) {
+VDL2_HD void sync_metric_ref(const float *ph, const float *eps2, int estride, const Tables &T, float &pherr, float &slope_out, float &E_out, float &alo, float &ahi) {      // eps2[i * estride]; [alo, ahi]: the alternatives' values
 	sync_metric(ph, T, pherr, slope_out);
-	float s = 0.f; bool big = false; int nev = 0, flip = -1, cut = -1;
+	float s = 0.f; bool big = false; int nev = 0, flip = -1, cut = -1; int ev[2] = {0, 0}, kind[2] = {0, 0};
 	float eprev = sqrtf(eps2[0]), cprev = ph[0] - T.pr_phase[0];
 	for(int i = 0; i < kPreamble; i++) {
-		s += eps2[i]; big = big || eps2[i] >= kRefBig;
-		if(kPiBelow - fabsf(ph[i]) <= sqrtf(eps2[i]) + 1e-6f && eps2[i] > 0.f) { nev++; cut = i; }
+		const float q = eps2[i * estride];
+		s += q; big = big || q >= kRefBig;
+		if(kPiBelow - fabsf(ph[i]) <= sqrtf(q) + 1e-6f && q > 0.f) { if(nev < 2) { ev[nev] = i; kind[nev] = 1; } nev++; cut = i; }
 	}
 	for(int i = 1; i < kPreamble; i++) {
-		const float cur = ph[i] - T.pr_phase[i], diff = cur - cprev, e = sqrtf(eps2[i]);
-		if(fabsf(fabsf(diff) - kPiBelow) <= e + eprev + 4e-6f) { nev++; flip = i; }
+		const float cur = ph[i] - T.pr_phase[i], diff = cur - cprev, e = sqrtf(eps2[i * estride]);
+		if(fabsf(fabsf(diff) - kPiBelow) <= e + eprev + 4e-6f) { if(nev < 2) { ev[nev] = i; kind[nev] = 0; } nev++; flip = i; }
 		cprev = cur; eprev = e;
 	}
-	palt = pherr;
-	if(nev == 1 && !big) {
-		if(cut >= 0) {
-			float q[kPreamble];
-			for(int i = 0; i < kPreamble; i++) q[i] = i == cut ? -ph[i] : ph[i];
-			palt = sync_metric_flipped(q, T, -1);
-		} else palt = sync_metric_flipped(ph, T, flip);
+	alo = ahi = pherr;
+	if(nev == 1 && !big) alo = ahi = sync_metric_flipped(ph, T, flip, cut);
+	else if(nev == 2 && !big) { sync_metric_two(ph, T, ev, kind, pherr, alo, ahi); if(ahi >= kRefBig) big = true; }
+	E_out = (big || nev > 2) ? kRefBig : sqrtf(s);
+}
+// ... with TWO discontinuities within the margin (noise windows with a faded tap or two: half of what "cannot be told" on the bench
+// workloads): the smallest and the largest of the four values the reference can get.  (ev[k]: tap, kind[k]: 0 unwrap decision, 1 branch cut)
+VDL2_HD void sync_metric_two(const float *ph, const Tables &T, const int *ev, const int *kind, float pherr, float &lo, float &hi) {
+	lo = hi = pherr;
+	for(int c = 1; c < 4; c++) {
+		float q[kPreamble];
+		for(int i = 0; i < kPreamble; i++) q[i] = ph[i];
+		int flip = -1;
+		for(int k = 0; k < 2; k++) if((c >> k) & 1) { if(kind[k]) q[ev[k]] = -q[ev[k]]; else flip = ev[k]; }
+		// (two unwrap decisions cannot both go through sync_metric_flipped(): the second is applied by hand on top of the first)
+		float v;
+		if((c == 3) && !kind[0] && !kind[1]) { lo = 0.f; hi = kRefBig; return; }
+		v = sync_metric_flipped(q, T, flip, -1);
+		lo = v < lo ? v : lo; hi = v > hi ? v : hi;
 	}
-	E_out = (big || nev > 1) ? kRefBig : sqrtf(s);
 }
 
 // One D8PSK decision with its margin: the distance (radians) of slice_symbol()'s argument from the nearest decision boundary ...
@@ -1032,7 +1085,8 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 							// vertex, the gate - is within the margin of the stream's error (K3's exact tier: ref_candidate_verdict()); it is
 							// redone on the reference's own samples before anything is decided (below: sh.u_fire == 2), and comes by here again
 							const bool exact_here = sh.x_n == n;
-							if(v.ref && !exact_here && sh.wre[n - wbase] < 0.f) { pending = 2; break; }
+							const bool marked = v.ref && !exact_here && sh.wre[n - wbase] < 0.f;
+							if(marked && !v.rq) { pending = 2; break; }
 #ifdef VDL2_REF_DEBUG
 							ref_debug_log(v, exact_here ? 2 : 1, n, sh.wre[n - wbase], exact_here ? sh.x_p3 : sh.wre[n - 3 - wbase], (float)(e0 % 3));
 #endif
@@ -1053,8 +1107,15 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 							}
 							moved = true;
 							int64_t e2;
-							if(exact_here && !is_candidate(y2, y3)) {
-								// on the reference's samples this evaluation does not fire (the bitmap holds "may fire"): the run goes on
+							if(marked) {
+								// optimistic mode: decided on the samples as they are, noted for the check on the reference's own
+								RefReq rq{};
+								rq.chan = chan; rq.kind = REF_CANDIDATE; rq.n = n;
+								rq.code = ref_candidate_code(y1, y2, y3, prevd, max_ppm, ppm_thr) | ((n - 6 >= e0) ? 0u : 0x10000u);
+								if(!ref_log_request(v, rq)) { if(v.rq_flag) v.rq_flag[chan] = 1u; else ctl->overflow = 1; }
+							}
+							if((exact_here || marked) && !is_candidate(y2, y3)) {
+								// on these samples the evaluation does not fire (the bitmap holds "may fire"): the run goes on
 								e2 = n + 3; e_cur = e2;
 							} else {
 								if(!(max_ppm != 0.f && fabsf(prevd) > ppm_thr)) {      // = fabsf(ppm_of(prevd, freq)) > max_ppm (ppm_gate_threshold())
@@ -1247,7 +1308,19 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 					}
 					sh.flag[l] = fl;
 				WAVE_END
-				if(wave_first_flag(sh.flag) >= 0) {
+				const bool hdr_marginal = wave_first_flag(sh.flag) >= 0;
+				if(hdr_marginal && v.rq) {
+					LANE0
+						// optimistic mode: sliced on the samples as they are (below), noted for the check on the reference's own
+						int neg_ = 0; uint32_t code = 0;
+						for(int l = 0; l < 9; l++) code |= (uint32_t)slice_symbol(sh.hph[l + 1], sh.hph[l], sh.st.pb.vdphi, neg_) << (3 * l);
+						RefReq rq{};
+						rq.chan = chan; rq.kind = REF_HEADER; rq.n = ns; rq.t_first = sh.st.pb.t_first; rq.prev_n = sh.st.pb.prev_n;
+						rq.vdphi = sh.st.pb.vdphi; rq.vdphi_err = sh.st.pb.vdphi_err; rq.prev_phi0 = sh.st.pb.prev_phi0; rq.code = code;
+						if(!ref_log_request(v, rq)) { if(v.rq_flag) v.rq_flag[chan] = 1u; else ctl->overflow = 1; }
+						sh.x_hdr = ns;
+					LANE0_END
+				} else if(hdr_marginal) {
 					if(spec) { LANE0 ctl->overflow = 1; LANE0_END break; }
 					int64_t lo = ns - kRefPre; if(sh.st.pb.prev_n >= 0 && sh.st.pb.prev_n < lo) lo = sh.st.pb.prev_n;
 					const bool ok = ref_exact_window(v, lo, t8, sh.cw, REF_HEADER);
@@ -1318,9 +1391,21 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 }
 
 // Process one channel up to (not including) decimated sample k_end.
+// what a channel's walk of one feed starts from, kept so that the walk can be done again (optimistic mode: ref_verify / walk_again)
+struct WalkSnap { WalkState *ws; unsigned long long *cnt; };
+VDL2_HD void walk_snapshot(const WalkSnap &snap, int chan, const WalkState *gstate, const unsigned long long *cnt) {
+	if(!snap.ws) return;
+	LANE0
+		snap.ws[chan] = *gstate;
+	LANE0_END
+	WAVE_FOR(l)
+		if(l < kNumCounters) snap.cnt[(size_t)chan * kNumCounters + l] = cnt[l];
+	WAVE_END
+}
 VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T,
 		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
-		OutCtl *ctl, const EvalLog &lg, WalkShared &sh) {
+		OutCtl *ctl, const EvalLog &lg, WalkShared &sh, WalkSnap snap = WalkSnap{nullptr, nullptr}) {
+	walk_snapshot(snap, chan, gstate, cnt);
 	walk_load(gstate, lg, nbursts_out, false, T, ctl, sh);
 	walk_run(chan, freq, max_ppm, ppm_thr, k_end, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
 	walk_store(sh, gstate, lg, ctl, nbursts_out);
@@ -1346,6 +1431,7 @@ struct SpecHead {                      // what the stitcher needs to decide and 
 	float   pherr1, pherr2, prev_dphi;
 	int32_t mode, niv;
 	uint32_t nb, nlog, ok;
+	uint32_t nreq, pad_;               // decisions within the margin taken along the way (optimistic mode): SpecOut::req
 	EvalChunk c_first, c_last;         // first and last chunk of the evaluation log
 };
 
@@ -1357,6 +1443,7 @@ struct SpecOut {
 	uint32_t nlog, pad_;
 	Burst bursts[kSpecBursts];
 	EvalChunk chunks[kSpecLog];
+	RefReq req[kSpecReq]; uint32_t nreq, pad2_;
 };
 
 struct StitchShared {
@@ -1378,7 +1465,7 @@ VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, float ppm_thr, in
 		const ChanView &v, SpecOut *o, WalkShared &sh) {
 	EvalLog lg{ o->chunks, &o->nlog };
 	LANE0
-		o->nlog = 0;
+		o->nlog = 0; o->nreq = 0;
 		o->ctl.nbursts = o->ctl.nframes = o->ctl.pool_used = o->ctl.overflow = 0;
 		o->ctl.cap_bursts = kSpecBursts; o->ctl.cap_frames = 0; o->ctl.cap_pool = 0; o->ctl.cap_log = kSpecLog;
 		walk_state_init(o->st);
@@ -1390,7 +1477,9 @@ VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, float ppm_thr, in
 	WAVE_SYNC_GLOBAL();                    // lane 0's counter atomics below must find the zeros the other lanes have just stored
 	uint32_t nb_dummy = 0;
 	walk_load(&o->st, lg, &nb_dummy, false, T, &o->ctl, sh);
-	walk_run(chan, freq, max_ppm, ppm_thr, k_end, false, T, v, o->cnt, o->bursts, kSpecBursts, &o->ctl, lg, sh, true);
+	ChanView vs = v;                       // (optimistic mode: what the walk notes goes to the segment's own list; the stitcher passes it on if it adopts the walk)
+	if(v.rq) { vs.rq = o->req; vs.rq_n = &o->nreq; vs.rq_cap = kSpecReq; vs.rq_flag = nullptr; }
+	walk_run(chan, freq, max_ppm, ppm_thr, k_end, false, T, vs, o->cnt, o->bursts, kSpecBursts, &o->ctl, lg, sh, true);
 	walk_flush_log(sh, lg, &o->ctl);
 	LANE0
 		const WalkState &st = sh.st;
@@ -1401,6 +1490,7 @@ VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, float ppm_thr, in
 		h.pherr1 = st.pherr1; h.pherr2 = st.pherr2; h.prev_dphi = st.prev_dphi;
 		h.mode = st.mode; h.niv = st.niv;
 		h.nb = sh.nb; h.nlog = sh.lg_n; h.ok = o->ctl.overflow ? 0u : 1u;
+		h.nreq = o->nreq < (uint32_t)kSpecReq ? o->nreq : (uint32_t)kSpecReq; h.pad_ = 0;
 		h.c_first.first = h.c_first.count = 0; h.c_last = h.c_first;
 		if(sh.lg_n > 0) { h.c_first = o->chunks[0]; h.c_last = o->chunks[sh.lg_n - 1]; }
 		o->h = h;
@@ -1408,7 +1498,7 @@ VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, float ppm_thr, in
 }
 
 // adopt speculative segment `idx` (boundary b, grid phase r) if the real state in sh.st allows it
-VDL2_HD bool stitch_try_accept(int64_t b, int64_t kn, int seg, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh, StitchShared &ss) {
+VDL2_HD bool stitch_try_accept(int64_t b, int64_t kn, int seg, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh, StitchShared &ss, bool no_req = false) {
 	LANE0
 		ss.u_ok = 0;
 		WalkState &st = sh.st;
@@ -1417,7 +1507,7 @@ VDL2_HD bool stitch_try_accept(int64_t b, int64_t kn, int seg, uint32_t cap_burs
 			const int idx = (seg - 1) * 3 + r;
 			const SpecHead &H = ss.head[idx];
 			const int64_t pre = (st.e - (b + r)) / 3;          // evaluations of the speculative walk that precede the join
-			if(H.ok && H.n_first >= st.e && ss.njobs < kMaxSeg && (H.nlog == 0 || H.c_first.count > pre)) {
+			if(H.ok && !(no_req && H.nreq) && H.n_first >= st.e && ss.njobs < kMaxSeg && (H.nlog == 0 || H.c_first.count > pre)) {
 				const int64_t base_e = st.evals - pre, base_b = st.bursts;
 				const int64_t sent_a = b - kSpecBack;
 				const int j = ss.njobs++;
@@ -1492,7 +1582,21 @@ VDL2_HD void stitch_materialize(const SpecOut *spec, WalkShared &sh, StitchShare
 // wavefront per channel, in this kernel, and no other).
 VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k0, int64_t seglen, int nseg, int64_t k_end, const Tables &T,
 		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
-		OutCtl *ctl, const EvalLog &lg, const SpecOut *spec, WalkShared &sh, StitchShared &ss, uint32_t *seg_stats) {
+		OutCtl *ctl, const EvalLog &lg, const SpecOut *spec, WalkShared &sh, StitchShared &ss, uint32_t *seg_stats, WalkSnap snap = WalkSnap{nullptr, nullptr}, bool again = false) {
+	// `again` (optimistic mode, after the check): a channel one of whose noted decisions did not stand - its state and counters go
+	// back to what the feed started from (snap) and the feed is stitched once more, the referee asked on the spot (v.rq == nullptr); a
+	// speculative walk that noted decisions of its own is not adopted (it is walked for real: what it asks for has been made exact by the
+	// check), the others still are - they took no decision within the margin
+	if(again) {
+		LANE0
+			*gstate = snap.ws[chan];
+		LANE0_END
+		WAVE_FOR(l)
+			if(l < kNumCounters) cnt[l] = snap.cnt[(size_t)chan * kNumCounters + l];
+		WAVE_END
+		WAVE_SYNC_GLOBAL();
+	} else
+	walk_snapshot(snap, chan, gstate, cnt);
 	walk_load(gstate, lg, nbursts_out, false, T, ctl, sh);
 	walk_run(chan, freq, max_ppm, ppm_thr, k0 + seglen < k_end ? k0 + seglen : k_end, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
 	LANE0
@@ -1505,10 +1609,10 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_th
 	for(int s = 1; s < nseg; s++) {
 		const int64_t b = k0 + (int64_t)s * seglen;
 		const int64_t kn = s + 1 < nseg ? b + seglen : k_end;
-		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss)) continue;
+		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss, again)) continue;
 		stitch_materialize(spec, sh, ss);
 		walk_run(chan, freq, max_ppm, ppm_thr, kn, true, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
-		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss)) continue;
+		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss, again)) continue;
 		walk_run(chan, freq, max_ppm, ppm_thr, kn, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
 		LANE0
 			ss.walked++;
@@ -1540,11 +1644,74 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_th
 			for(int j = 0; j < nj; j++) acc += spec[ss.job_src[j]].cnt[l];
 			if(acc) VDL2_CNT_ADD(cnt, l, acc);
 		}
+		if(v.rq && l < kSpecReq) {
+			// the decisions within the margin the adopted walks took: onto the feed's list, to be checked
+			for(int j = 0; j < nj; j++)
+				if((uint32_t)l < ss.head[ss.job_src[j]].nreq && !ref_log_request(v, spec[ss.job_src[j]].req[l])) v.rq_flag[chan] = 1u;
+		}
 	WAVE_END
 	walk_store(sh, gstate, lg, ctl, nbursts_out);
 	LANE0
 		if(seg_stats) { seg_stats[0] += (uint32_t)ss.accepted; seg_stats[1] += (uint32_t)ss.walked; }
 	LANE0_END
+}
+
+// ======================================================================
+// Referee, optimistic mode: the check.  One wavefront per noted decision: the stretch the decision reads becomes the reference's
+// own (ref_exact_window), the decision is taken again on it - the reference's - and compared with what the walk did.  They agree
+// all but once in a hundred (the margin is wide, the stream's error small): then nothing else happens; otherwise the channel is
+// walked again from the feed's start (walk_again), in the synchronous mode, over samples that are by then exact where it matters.
+// `lds`: >= 64 floats.  true: the decision stands (or cannot be checked: the raw input is no longer held).
+// ======================================================================
+VDL2_HD bool ref_verify(const RefReq &r, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T, const ChanView &v, float *lds) {
+	if(r.kind == REF_CANDIDATE) {
+		const int64_t n = r.n;
+		int64_t lo = (n - kRefPre) & ~255ll, hi = (n + kRefPost) | 255; if(lo < 0) lo = 0; if(hi > k_end - 1) hi = k_end - 1;
+		if(!ref_exact_window(v, lo, hi, nullptr, REF_CANDIDATE)) return true;
+		WAVE_FOR(l)
+			if(l < 48) lds[l] = v.Phi(n - 3 * (l >> 4) - 150 + 10 * (l & 15));
+		WAVE_END
+		WAVE_FOR(l)
+			if(l < 3) sync_metric(&lds[16 * l], T, lds[48 + l], lds[52 + l]);
+		WAVE_END
+		LANE0
+			const float y1 = (r.code & 0x10000u) ? kPherrBig : lds[50];
+			lds[56] = ((ref_candidate_code(y1, lds[49], lds[48], lds[53], max_ppm, ppm_thr) ^ r.code) & 0xffffu) == 0u ? 1.f : 0.f;
+		LANE0_END
+		return lds[56] != 0.f;
+	}
+	// header: sync point + nine symbols, and the carrier slope they are sliced with
+	const int64_t ns = r.n, t8 = r.t_first + 8 * kSpsDec;
+	int64_t lo = ns - kRefPre; if(r.prev_n >= 0 && r.prev_n < lo) lo = r.prev_n;
+	if(!ref_exact_window(v, lo, t8, nullptr, REF_HEADER)) return true;
+	WAVE_FOR(l)
+		if(l < 10) { const int64_t t = l ? r.t_first + (int64_t)(l - 1) * kSpsDec : r.prev_n; lds[l] = t < 0 ? (t == -1 ? 0.f : r.prev_phi0) : v.Phi(t); }
+		else if(l >= 16 && l < 32) lds[l] = v.Phi(ns - 3 - 150 + 10 * (l - 16));
+	WAVE_END
+	LANE0
+		float vd = r.vdphi;
+		if(r.vdphi_err > 0.f) { float p_; sync_metric(&lds[16], T, p_, vd); }      // (a fire on a contiguous ring: the slope of evaluation ns - 3 again)
+		int neg_ = 0; uint32_t code = 0;
+		for(int l = 0; l < 9; l++) code |= (uint32_t)slice_symbol(lds[l + 1], lds[l], vd, neg_) << (3 * l);
+		lds[56] = code == r.code ? 1.f : 0.f;
+	LANE0_END
+	(void)freq;
+	return lds[56] != 0.f;
+}
+
+// a channel whose walk took a decision that does not stand: its state and counters back to what the feed started from, then the
+// whole feed again, sequentially, with the referee asked on the spot (most of what it asks for has been made exact by the check)
+VDL2_HD void walk_again(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T, const ChanView &v, WalkState *gstate,
+		unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out, OutCtl *ctl, const EvalLog &lg, WalkShared &sh, const WalkSnap &snap) {
+	LANE0
+		*gstate = snap.ws[chan];
+	LANE0_END
+	WAVE_FOR(l)
+		if(l < kNumCounters) cnt[l] = snap.cnt[(size_t)chan * kNumCounters + l];
+	WAVE_END
+	WAVE_SYNC_GLOBAL();
+	ChanView vs = v; vs.rq = nullptr; vs.rq_n = nullptr; vs.rq_cap = 0; vs.rq_flag = nullptr;
+	walk_channel(chan, freq, max_ppm, ppm_thr, k_end, T, vs, gstate, cnt, bursts, cap_bursts, nbursts_out, ctl, lg, sh);
 }
 
 // ======================================================================
@@ -2189,9 +2356,13 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 			// ---- referee: symbols mfirst .. mlast (and, if it is not the reference's yet, the carrier slope) on the reference's own samples ----
 			const bool redo_slope = b.vdphi_err > 0.f;
 			const int64_t t_lo = mfirst > 0 ? b.t_first + (int64_t)(mfirst - 1) * kSpsDec : (b.prev_n >= 0 ? b.prev_n : b.t_first);
-			int64_t lo = redo_slope ? b.sync_sample - kRefPre : t_lo; if(t_lo < lo) lo = t_lo;
 			const int64_t hi = b.t_first + (int64_t)mlast * kSpsDec;
-			const bool ok = ref_exact_window(v, lo, hi, sh.xw, REF_SYMBOLS);
+			// (the taps of the slope lie before the burst, the symbols anywhere in it: one scan over both when they are close, two otherwise -
+			// a scan costs its run-up, 2^17 input samples, plus the stretch)
+			const bool split = redo_slope && t_lo - b.sync_sample > 4096;
+			int64_t lo = redo_slope && !split ? b.sync_sample - kRefPre : t_lo; if(t_lo < lo) lo = t_lo;
+			bool ok = ref_exact_window(v, lo, hi, sh.xw, REF_SYMBOLS);
+			if(ok && split) ok = ref_exact_window(v, b.sync_sample - kRefPre, b.sync_sample, sh.xw, REF_SYMBOLS);
 			if(ok && redo_slope) {
 				float *phs = reinterpret_cast<float *>(sh.keptw);
 				WAVE_FOR(l)

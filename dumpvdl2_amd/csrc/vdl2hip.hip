@@ -48,6 +48,7 @@ struct OutSlot {
 	OutMail *d_mail = nullptr; OutCtl *d_ctl = nullptr;   // control block + the first few delivered frames, contiguous (d_ctl = &d_mail->ctl): one small copy brings both
 	OutFrame *d_frames_out = nullptr; uint8_t *d_pool_out = nullptr;    // what k_frame_finish delivers (no tombstones, no holes): what the host copies
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
+	RefReq *d_rq = nullptr; uint32_t *d_rqn = nullptr, *d_rqflag = nullptr;   // referee, optimistic mode: this feed's decisions to check, its "walk again" flags
 	OutMail *h_mail = nullptr;             // pinned
 	hipEvent_t done = nullptr, ev_front = nullptr, ev_chan = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
 	bool pending = false, ev_valid = false, fused = false; int ev_level = 0;
@@ -92,7 +93,7 @@ struct vdl2hip_ctx {
 	SpecOut *d_spec = nullptr; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
-	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst = nullptr;
+	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst[kSlots] = {};   // (a burst stream per feed in flight: a burst decoder that waits for the referee - a scan over a whole burst takes milliseconds - does not hold up the next feed's)
 	// Experiment switches (only read in builds with -DVDL2_EXPERIMENTS, dev/gpu_run.sh; the measured outcomes are in DESIGN 6).
 	// sync_on: 0 = both sync kernels on the front stream (the product); 1 = the exact tier in front of the walk on the walk stream;
 	// 2 = both on a stream of their own (stream_sync), beside the channeliser of the next feed.  tiles_force / k3b_wpl: K1 tiles per
@@ -108,6 +109,7 @@ struct vdl2hip_ctx {
 	bool referee = true; int ref_kinds = 7; int64_t ref_warm = 1 << 17, ref_T = 0; uint8_t *d_refhist = nullptr; uint64_t ref_cap = 0, ref_wp = 0;
 	struct HistPiece { int64_t s0, n; uint64_t pos; }; std::vector<HistPiece> ref_pieces;
 	unsigned long long *d_refdbg = nullptr; int ref_dbg_chan = -1;
+	WalkState *d_ws_snap = nullptr; unsigned long long *d_cnt_snap = nullptr; uint32_t rq_cap = 8192; bool ref_optimistic = true;
 	RefChan *d_ref[kSlots] = {}; unsigned long long *d_refdone = nullptr; uint32_t *d_refdonen = nullptr, *d_refstats = nullptr; uint8_t *d_mix = nullptr;
 	bool defer_back = false;               // VDL2HIP_BACKEND=deferred: the back end of feed i is queued behind the channeliser of feed i+1 (launch_back)
 	std::vector<uint64_t> statsd_prev;
@@ -370,7 +372,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		// wavefronts of this feed's burst decoder: each owns kResSlots frame records of the output from the start, so a short block gets few
 		sl.k5_waves = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(16, (D * (int64_t)c->C) >> 14));
 		sl.k5_waves = (sl.k5_waves + kBurstWaves - 1) / kBurstWaves * kBurstWaves;
-		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0 };
+		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0, sl.d_rqn, sl.d_rqflag };
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
 		// on the front stream than a separate hipEventRecord.  (VDL2HIP_SYNC_ON=walk puts the exact tier in front of the walk on
 		// the walk stream, VDL2HIP_SYNC_ON=own both sync kernels on a stream of their own, so that the front stream goes on
@@ -419,7 +421,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	// microseconds: its whole back end goes onto the FRONT stream, behind its own sync kernels - no event hand-offs between streams -
 	// with the three noise-floor passes as one kernel.  Whoever follows on the front stream is then behind it anyway.
 	const bool small = D > 0 && D < 2 * c->seg_min && nseg < 2 && !c->defer_back;
-	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst;
+	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst[sl.seq % kSlots];
 	hipEvent_t *ev = sl.ev;
 	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
 	sl.back_queued = false; sl.small = small;
@@ -435,17 +437,28 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	if(D > 0) {
 		const int64_t k1 = k0 + D;
 		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
-		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(3 * sl.seq + 1) };
+		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(5 * sl.seq + 1),
+		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
+		int64_t seglen = D;
 		if(nseg >= 2) {
-			const int64_t seglen = (D + nseg - 1) / nseg;
+			seglen = (D + nseg - 1) / nseg;
 			nseg = (int)((D + seglen - 1) / seglen);
-			K4sArgs k4s{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, k0, seglen, c->d_segstats };
+			K4sArgs k4s{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, k0, seglen, c->d_segstats, 0 };
 			if(!(c->ablate & 1))
 			LAUNCH_EV(k_walk_spec, dim3((unsigned)((1 + 3 * (nseg - 1) + kWalkWaves - 1) / kWalkWaves), (unsigned)c->C), dim3(64 * kWalkWaves), sb_, EV(6), (hipEvent_t) nullptr, k4s);
 			if(!(c->ablate & 1))
 			hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, EV(7), 0, k4s);
 		} else {
 			LAUNCH_EV(k_walk, dim3((unsigned)c->C), dim3(64), sb_, EV(6), EV(7), k4);
+		}
+		if(k4.rq) {
+			// referee, optimistic mode (long feeds): the decisions within the margin that the walk took are checked now, all at once, and
+			// the (rare) channel one of whose decisions does not stand is stitched again
+			hipLaunchKernelGGL(k_ref_verify, dim3(1024), dim3(64), 0, sb_, k4);
+			if(nseg >= 2) {
+				K4sArgs k4a{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, k0, seglen, c->d_segstats, 1 };
+				hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0, k4a);
+			} else hipLaunchKernelGGL(k_walk_again, dim3((unsigned)c->C), dim3(64), 0, sb_, k4);
 		}
 	}
 	if(!small) {
@@ -468,7 +481,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			HIPCHK(hipEventRecord(sl.ev_nf, sn_));
 		}
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, c->C,
-		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(3 * sl.seq + 3) };
+		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(5 * sl.seq + 5) };
 		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: no bursts to decode)
 		const unsigned k5_lds = (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves);
 		if(small) hipExtLaunchKernelGGL(k_nf_burst, dim3(nf_grid + sl.k5_waves / kBurstWaves), dim3(64 * kNfWaves), std::max(nf_lds, k5_lds), s5_, EV(8), EV(11), 0, k4b, k5, (uint32_t)nf_grid);
@@ -526,7 +539,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
 	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
-		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog };
+		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag };
 		for(void *p : q) if(p) (void)hipFree(p);
 		if(sl.h_mail) (void)hipHostFree(sl.h_mail);
 		if(sl.done) (void)hipEventDestroy(sl.done);
@@ -538,7 +551,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 		for(int i = 0; i < kNumEv; i++) if(sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
 	}
 	if(c->h_stage) (void)hipHostFree(c->h_stage);
-	{ void *q[] = { c->d_refhist, c->d_ref[0], c->d_ref[1], c->d_ref[2], c->d_refdone, c->d_refdonen, c->d_refstats, c->d_mix, c->d_refdbg }; for(void *p : q) if(p) (void)hipFree(p); }
+	{ void *q[] = { c->d_refhist, c->d_ref[0], c->d_ref[1], c->d_ref[2], c->d_refdone, c->d_refdonen, c->d_refstats, c->d_mix, c->d_refdbg, c->d_ws_snap, c->d_cnt_snap }; for(void *p : q) if(p) (void)hipFree(p); }
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
 	for(auto &e : c->cold.ev) if(e) (void)hipEventDestroy(e);
 	if(c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
@@ -546,7 +559,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(c->stream_sync) { (void)hipStreamSynchronize(c->stream_sync); (void)hipStreamDestroy(c->stream_sync); }
 	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
 	if(c->stream_nf) { (void)hipStreamSynchronize(c->stream_nf); (void)hipStreamDestroy(c->stream_nf); }
-	if(c->stream_burst) { (void)hipStreamSynchronize(c->stream_burst); (void)hipStreamDestroy(c->stream_burst); }
+	for(auto &sb5 : c->stream_burst) if(sb5) { (void)hipStreamSynchronize(sb5); (void)hipStreamDestroy(sb5); }
 	for(void *p : ptrs) if(p) (void)hipFree(p);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
@@ -622,7 +635,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		auto prio_of = [&](const char *name) { return strstr(lowp, name) ? prio_low : prio_high; };
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_back, hipStreamNonBlocking, prio_of("walk")));
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_nf, hipStreamNonBlocking, prio_of("nf")));
-		DEV_CHK(hipStreamCreateWithPriority(&c->stream_burst, hipStreamNonBlocking, prio_of("burst")));
+		for(auto &sb5 : c->stream_burst) DEV_CHK(hipStreamCreateWithPriority(&sb5, hipStreamNonBlocking, prio_of("burst")));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
 #ifdef VDL2_EXPERIMENTS
@@ -706,11 +719,18 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		c->ref_cap = 1; while(c->ref_cap < (uint64_t)(kSlots + 2) * (uint64_t)c->ref_T) c->ref_cap <<= 1;
 		DEV_ALLOC(c->d_refhist, c->ref_cap * sb);
 		for(int k = 0; k < kSlots; k++) { DEV_ALLOC(c->d_ref[k], sizeof(RefChan)); DEV_CHK(hipMemset(c->d_ref[k], 0, sizeof(RefChan))); }
-		DEV_ALLOC(c->d_refdone, (size_t)count * kRefCache * 8); DEV_ALLOC(c->d_refdonen, (size_t)count * 4); DEV_ALLOC(c->d_refstats, 32); DEV_ALLOC(c->d_mix, count);
-		DEV_CHK(hipMemset(c->d_refdone, 0, (size_t)count * kRefCache * 8)); DEV_CHK(hipMemset(c->d_refdonen, 0, (size_t)count * 4)); DEV_CHK(hipMemset(c->d_refstats, 0, 32));
+		DEV_ALLOC(c->d_refdone, (size_t)count * kRefCache * 8); DEV_ALLOC(c->d_refdonen, (size_t)count * 4); DEV_ALLOC(c->d_refstats, 64); DEV_ALLOC(c->d_mix, count);
+		DEV_CHK(hipMemset(c->d_refdone, 0, (size_t)count * kRefCache * 8)); DEV_CHK(hipMemset(c->d_refdonen, 0, (size_t)count * 4)); DEV_CHK(hipMemset(c->d_refstats, 0, 64));
 		std::vector<uint8_t> mix(count);
 		for(uint32_t i = 0; i < count; i++) mix[i] = cfg->centerfreq != c->freqs[i];       // v->offset_tuning, demod.c:386
 		DEV_CHK(hipMemcpy(c->d_mix, mix.data(), count, hipMemcpyHostToDevice));
+		if(const char *e = getenv("VDL2HIP_REF_MODE")) c->ref_optimistic = strcmp(e, "sync") != 0;        // optimistic (default) | sync
+		if(const char *e = getenv("VDL2HIP_REF_KINDS")) c->ref_kinds = atoi(e) & 7;                          // (development: 1 candidates, 2 headers, 4 symbols)
+		DEV_ALLOC(c->d_ws_snap, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt_snap, (size_t)count * kNumCounters * 8);
+		for(auto &sl : c->slot) {
+			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 4); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
+			DEV_CHK(hipMemset(sl.d_rqn, 0, 4)); DEV_CHK(hipMemset(sl.d_rqflag, 0, (size_t)count * 4));
+		}
 	}
 
 	Lut4 lut[256]; build_nco_lut(lut);                            // sincosf_lut_init()
@@ -1011,7 +1031,7 @@ int vdl2hip_get_stats_sized(vdl2hip_ctx *c, vdl2hip_stats *out, size_t size) {
 		uint32_t rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 		if(hipMemcpy(rs, c->d_refstats, sizeof rs, hipMemcpyDeviceToHost) != hipSuccess) return VDL2HIP_E_DEVICE;
 		c->stats.referee_scans = rs[0]; c->stats.referee_cached = rs[1]; c->stats.referee_refused = rs[2]; c->stats.referee_short = rs[3];
-		c->stats.referee_candidate_scans = rs[4]; c->stats.referee_header_scans = rs[5]; c->stats.referee_symbol_scans = rs[6];
+		c->stats.referee_candidate_scans = rs[4]; c->stats.referee_header_scans = rs[5]; c->stats.referee_symbol_scans = rs[6]; c->stats.referee_rewalks = rs[7];
 	}
 	memcpy(out, &c->stats, std::min(size, sizeof c->stats));
 	return (r == VDL2HIP_E_OVERFLOW || c->failed) ? VDL2HIP_OK : r;

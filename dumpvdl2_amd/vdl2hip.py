@@ -67,7 +67,7 @@ class Stats(C.Structure):
                 ("bursts", C.c_uint64), ("frames", C.c_uint64),
                 ("seg_adopted", C.c_uint64), ("seg_walked", C.c_uint64), ("front_sync_timeouts", C.c_uint64),
                 ("overflow_feeds", C.c_uint64), ("cold_start_feeds", C.c_uint64),
-                ("referee_scans", C.c_uint64), ("referee_cached", C.c_uint64), ("referee_refused", C.c_uint64), ("referee_short", C.c_uint64),
+                ("referee_scans", C.c_uint64), ("referee_cached", C.c_uint64), ("referee_refused", C.c_uint64), ("referee_short", C.c_uint64), ("referee_rewalks", C.c_uint64),
                 ("referee_candidate_scans", C.c_uint64), ("referee_header_scans", C.c_uint64), ("referee_symbol_scans", C.c_uint64)]
 
 

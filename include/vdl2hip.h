@@ -158,6 +158,7 @@ typedef struct {
 	uint64_t referee_cached;    /* requests for a stretch that had been made exact already */
 	uint64_t referee_refused;   /* requests that could not be served (the raw input was no longer held): the decision stayed as it was */
 	uint64_t referee_short;     /* scans whose run-up was shorter than configured (early in a stream of short blocks) */
+	uint64_t referee_rewalks;   /* channels walked again because a decision taken on the channeliser's samples did not stand on the reference's */
 	uint64_t referee_candidate_scans, referee_header_scans, referee_symbol_scans;   /* referee_scans by the decision that asked: a preamble candidate
 	                             * (candidate test / vertex / gate), a header symbol, the symbols of a burst */
 } vdl2hip_stats;

@@ -29,10 +29,10 @@ inline bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void
 using namespace vdl2;
 
 // metric_contiguous() plus the referee's error figure E (vdl2_core.h: sync_metric_ref)
-static void metric_contiguous_ref(const ChanView &v, int64_t n, const Tables &T, float &p, float &f, float &E, float &palt) {
+static void metric_contiguous_ref(const ChanView &v, int64_t n, const Tables &T, float &p, float &f, float &E, float &alo, float &ahi) {
 	float ph[kPreamble], e2[kPreamble];
 	for(int i = 0; i < kPreamble; i++) { const int64_t t = n - 150 + 10 * i; ph[i] = v.Phi(t); e2[i] = ref_eps2(v, t); }
-	sync_metric_ref(ph, e2, T, p, f, E, palt);
+	sync_metric_ref(ph, e2, 1, T, p, f, E, alo, ahi);
 }
 
 struct Sim {
@@ -52,7 +52,8 @@ struct Sim {
 	std::vector<SpecOut> spec; uint32_t seg_stats[2] = {0, 0};
 	// referee: exact samples [nchan][exact_D] and the per-channel hooks; marg: candidates K3 marked as within the margin
 	std::vector<float> exact; int64_t exact_D = 0; std::vector<RefChan> rc; int64_t n_marg = 0, n_cand = 0, n_walk_windows = 0;
-	std::vector<float> pe, pa;
+	std::vector<float> pe, pa, pb;
+	bool optimistic = true; std::vector<RefReq> rq; uint32_t rq_n = 0; std::vector<uint32_t> rq_flag; std::vector<WalkState> ws_snap; std::vector<unsigned long long> cnt_snap; int64_t n_rewalk = 0, n_requests = 0;
 	std::vector<Burst> all_bursts;   // every burst descriptor the walker has emitted (debugging aid)
 };
 
@@ -79,16 +80,17 @@ void hostsim_destroy(Sim *s) { delete s; }
 // walk feeds of at least 2*seg_min decimated samples in up to seg_max speculative segments (0 = plain sequential walk)
 void hostsim_set_segments(Sim *s, int64_t seg_min, int seg_max) { s->seg_min = seg_min; s->seg_max = seg_max < 1 ? 1 : seg_max > kMaxSeg ? kMaxSeg : seg_max; }
 void hostsim_set_two_tier(Sim *s, int on) { s->two_tier = on != 0; }
+void hostsim_set_optimistic(Sim *s, int on) { s->optimistic = on != 0; }
 // referee on: decisions within the margin of the stream's error are taken on `exact` ([nchan][D] complex, the oracle's trace)
 void hostsim_set_exact(Sim *s, const float *exact, int64_t D) {
 	s->exact.assign(exact, exact + (size_t)s->nchan * D * 2); s->exact_D = D;
 	s->rc.resize(s->nchan);
 	for(int c = 0; c < s->nchan; c++) s->rc[c] = RefChan{ s->exact.data() + (size_t)c * D * 2, D, &s->y[(size_t)c * s->cap], s->mask, 0, 0 };
-	s->pe.assign((size_t)s->nchan * s->cap, 0.f); s->pa.assign((size_t)s->nchan * s->cap, 0.f);
+	s->pe.assign((size_t)s->nchan * s->cap, 0.f); s->pa.assign((size_t)s->nchan * s->cap, 0.f); s->pb.assign((size_t)s->nchan * s->cap, 0.f);
 }
 // [0] candidates K3 marked, [1] candidate bits set, [2] exact windows served, [3] samples replaced, [4] windows asked for by the walkers (one feed)
-void hostsim_referee_stats(Sim *s, int64_t out[5]) {
-	out[0] = s->n_marg; out[1] = s->n_cand; out[2] = out[3] = 0; out[4] = s->n_walk_windows;
+void hostsim_referee_stats(Sim *s, int64_t out[7]) {
+	out[0] = s->n_marg; out[1] = s->n_cand; out[2] = out[3] = 0; out[4] = s->n_walk_windows; out[5] = s->n_requests; out[6] = s->n_rewalk;
 	for(auto &r : s->rc) { out[2] += r.calls; out[3] += r.samples; }
 }
 void hostsim_two_tier_stats(Sim *s, int64_t out[2]) { out[0] = s->n_exact; out[1] = s->n_total; }
@@ -106,12 +108,12 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		}
 		ChanView cv{ y, pf, cand, s->mask };
 		const bool ref_on = !s->rc.empty();
-		float *pe = ref_on ? &s->pe[(size_t)c * s->cap] : nullptr, *pa = ref_on ? &s->pa[(size_t)c * s->cap] : nullptr;
+		float *pe = ref_on ? &s->pe[(size_t)c * s->cap] : nullptr, *pa = ref_on ? &s->pa[(size_t)c * s->cap] : nullptr, *pb = ref_on ? &s->pb[(size_t)c * s->cap] : nullptr;
 		// sync kernel: whole 64-aligned words covering [k0, k1)
 		if(!s->two_tier) {
 			for(int64_t n = k0 & ~63ll; n < ((k1 + 63) & ~63ll); n++) {
 				cf32 r = (n < k1) ? metric_contiguous(cv, n, s->T) : cf32{kPherrBig, 0.f};
-				if(ref_on && n < k1) { float p_, f_, E_, a_; metric_contiguous_ref(cv, n, s->T, p_, f_, E_, a_); pe[(uint32_t)n & s->mask] = E_; pa[(uint32_t)n & s->mask] = a_; }
+				if(ref_on && n < k1) { float p_, f_, E_, a_, b_; metric_contiguous_ref(cv, n, s->T, p_, f_, E_, a_, b_); pe[(uint32_t)n & s->mask] = E_; pa[(uint32_t)n & s->mask] = a_; pb[(uint32_t)n & s->mask] = b_; }
 				pf[(uint32_t)n & s->mask] = r;
 			}
 		} else {
@@ -140,7 +142,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 					// the kernel stores a metric value only where it computed the exact one; everywhere else the ring keeps whatever
 					// an earlier lap left there, which the walker must never look at: the simulation puts poison there
 					r = need ? metric_contiguous(cv, n, s->T) : cf32{12345.f, 54321.f};
-					if(ref_on && need) { float p_, f_, E_, a_; metric_contiguous_ref(cv, n, s->T, p_, f_, E_, a_); pe[(uint32_t)n & s->mask] = E_; pa[(uint32_t)n & s->mask] = a_; }
+					if(ref_on && need) { float p_, f_, E_, a_, b_; metric_contiguous_ref(cv, n, s->T, p_, f_, E_, a_, b_); pe[(uint32_t)n & s->mask] = E_; pa[(uint32_t)n & s->mask] = a_; pb[(uint32_t)n & s->mask] = b_; }
 					s->n_exact += need; s->n_total++;
 				}
 				pf[(uint32_t)n & s->mask] = r;
@@ -156,7 +158,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 				auto R = [&](int64_t m) -> RefRange {
 					if(m < 0) return RefRange{ kPherrBig, kPherrBig };
 					const float p = fabsf(pf[(uint32_t)m & s->mask].re);
-					return p > 999.f ? RefRange{ kPherrBig, kPherrBig } : ref_pherr_range(p, pa[(uint32_t)m & s->mask], pe[(uint32_t)m & s->mask]);
+					return p > 999.f ? RefRange{ kPherrBig, kPherrBig } : ref_pherr_range(p, pa[(uint32_t)m & s->mask], pb[(uint32_t)m & s->mask], pe[(uint32_t)m & s->mask]);
 				};
 				const int vd = ref_candidate_verdict(R(n), R(n - 3), pf[(uint32_t)(n - 3) & s->mask].im, pe[(uint32_t)(n - 3) & s->mask], R(n - 6), s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm));
 				if(getenv("HOSTSIM_DEBUG_AT") && c == atoi(getenv("HOSTSIM_DEBUG_CH")) && llabs(n - atoll(getenv("HOSTSIM_DEBUG_AT"))) <= 9) {
@@ -170,6 +172,19 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 					if(n > 3000 && shown++ < 40) fprintf(stderr, "marg c=%d n=%lld r6=[%g,%g] r3=[%g,%g] r0=[%g,%g] f3=%g E3=%g\n", c, (long long)n, a6.lo, a6.hi, a3.lo, a3.hi, a0.lo, a0.hi,
 						pf[(uint32_t)(n - 3) & s->mask].im, pe[(uint32_t)(n - 3) & s->mask]);
 				}
+				if((vd & 2) && n > 3000 && getenv("HOSTSIM_REF_REASONS")) {
+					static long cnt[6]; static long tot;
+					const RefRange r0 = R(n), r3 = R(n - 3), r6 = R(n - 6);
+					const bool surely = r3.hi < kSyncThr && r0.lo > r3.hi;
+					int why = 0;
+					if(!surely) why = !(r3.hi < kSyncThr) ? 0 : 1;
+					else if(ref_vertex_marginal(RefRange{ kPherrBig, kPherrBig }, r3, r0)) why = 2;
+					else if(r6.lo < kPherrBig && ref_vertex_marginal(r6, r3, r0)) why = 3;
+					else why = 4;
+					if(r3.hi >= kRefBig || r0.hi >= kRefBig || (r6.lo < kPherrBig && r6.hi >= kRefBig)) why = 5;
+					cnt[why]++; tot++;
+					if(tot % 5 == 0) fprintf(stderr, "reasons: p3~4 %ld, p0~p3 %ld, vertex(y1 max) %ld, vertex(p6) %ld, gate %ld, cannot tell %ld\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5]);
+				}
 				if(vd & 1) { bits |= 1ull << b; s->n_cand++; }
 				if(vd & 2) { cf32 &q = pf[(uint32_t)n & s->mask]; q.re = -fabsf(q.re); s->n_marg++; }
 			}
@@ -180,15 +195,22 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 	memset(&s->ctl, 0, sizeof s->ctl);
 	s->ctl.cap_bursts = (uint32_t)s->bursts.size(); s->ctl.cap_frames = (uint32_t)s->frames.size(); s->ctl.cap_pool = (uint32_t)s->pool.size(); s->ctl.cap_log = s->cap_log;
 	static WalkShared wsh;
+	const bool opt = !s->rc.empty() && s->optimistic;
+	if(opt) { s->rq.resize(8192); s->rq_n = 0; s->rq_flag.assign(s->nchan, 0); s->ws_snap.resize(s->nchan); s->cnt_snap.resize((size_t)s->nchan * kNumCounters); }
+	const WalkSnap snap{ opt ? s->ws_snap.data() : nullptr, opt ? s->cnt_snap.data() : nullptr };
+	std::vector<uint32_t> nb_first(s->nchan, 0);
 	for(int c = 0; c < s->nchan; c++) {
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
 		if(!s->rc.empty()) v.ref = &s->rc[c];
+		if(opt) { v.rq = s->rq.data(); v.rq_n = &s->rq_n; v.rq_cap = (uint32_t)s->rq.size(); v.rq_flag = s->rq_flag.data(); }
+		nb_first[c] = s->ctl.nbursts;
 		EvalLog lg{ &s->log[(size_t)c * s->cap_log], &s->nlog[c] };
 		uint32_t nbc = 0;
 		int nseg = s->seg_min > 0 ? (int)std::min<int64_t>(s->seg_max, D / s->seg_min) : 1;
+		int64_t seglen = D;
 		if(nseg >= 2) {
 			// same three steps as k_walk_spec / k_walk_stitch
-			const int64_t seglen = (D + nseg - 1) / nseg;
+			seglen = (D + nseg - 1) / nseg;
 			nseg = (int)((D + seglen - 1) / seglen);
 			Burst *bdst = s->bursts.data() + s->ctl.nbursts; const uint32_t bcap = (uint32_t)s->bursts.size() - s->ctl.nbursts;
 			s->spec.resize((size_t)3 * (nseg - 1));
@@ -199,10 +221,29 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 			}
 			static StitchShared ssh;
 			stitch_channel(c, s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k0, seglen, nseg, k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], bdst, bcap, &nbc,
-			               &s->ctl, lg, s->spec.data(), wsh, ssh, s->seg_stats);
+			               &s->ctl, lg, s->spec.data(), wsh, ssh, s->seg_stats, snap);
 		} else
 		walk_channel(c, s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k1, s->T, v, &s->st[c], &s->cnt[(size_t)c * kNumCounters], s->bursts.data() + s->ctl.nbursts,
-		             (uint32_t)s->bursts.size() - s->ctl.nbursts, &nbc, &s->ctl, lg, wsh);
+		             (uint32_t)s->bursts.size() - s->ctl.nbursts, &nbc, &s->ctl, lg, wsh, snap);
+		if(opt) {
+			// the device checks a feed's noted decisions all at once after the walks and walks the (rare) channel again; here channel by channel
+			static float vlds[64];
+			ChanView vv = v; vv.rq = nullptr; vv.rq_n = nullptr; vv.rq_cap = 0; vv.rq_flag = nullptr;
+			const uint32_t nreq = s->rq_n < (uint32_t)s->rq.size() ? s->rq_n : (uint32_t)s->rq.size();
+			for(uint32_t i = 0; i < nreq; i++) { s->n_requests++; if(!ref_verify(s->rq[i], s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k1, s->T, vv, vlds)) s->rq_flag[c] = 1; }
+			s->rq_n = 0;
+			if(s->rq_flag[c] && nseg >= 2) {
+				s->n_rewalk++;
+				static StitchShared ssh2;
+				Burst *bdst = s->bursts.data() + s->ctl.nbursts; const uint32_t bcap = (uint32_t)s->bursts.size() - s->ctl.nbursts;
+				stitch_channel(c, s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k0, seglen, nseg, k1, s->T, vv, &s->st[c], &s->cnt[(size_t)c * kNumCounters], bdst, bcap, &nbc,
+				               &s->ctl, lg, s->spec.data(), wsh, ssh2, s->seg_stats, snap, true);
+			} else if(s->rq_flag[c]) {
+				s->n_rewalk++;
+				walk_again(c, s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k1, s->T, vv, &s->st[c], &s->cnt[(size_t)c * kNumCounters], s->bursts.data() + s->ctl.nbursts,
+				           (uint32_t)s->bursts.size() - s->ctl.nbursts, &nbc, &s->ctl, lg, wsh, snap);
+			}
+		}
 		s->ctl.nbursts += nbc;
 		static NfShared nsh;
 		NfScratch sc{ &s->scf[(size_t)c * (s->cap_comb + 1)], &s->scc[(size_t)c * (s->cap_comb + 1)] };

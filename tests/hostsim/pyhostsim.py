@@ -81,10 +81,17 @@ class HostSim:
         self.L.hostsim_set_exact(self.h, y.ctypes.data, y.shape[1])
 
     def referee_stats(self):
-        a = (C.c_int64 * 5)()
+        a = (C.c_int64 * 7)()
         self.L.hostsim_referee_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         self.L.hostsim_referee_stats(self.h, a)
-        return {"marked_candidates": a[0], "candidate_bits": a[1], "exact_windows": a[2], "exact_samples": a[3], "walker_windows_first_feed": a[4]}
+        return {"marked_candidates": a[0], "candidate_bits": a[1], "exact_windows": a[2], "exact_samples": a[3], "walker_windows_first_feed": a[4],
+                "decisions_checked": a[5], "channels_walked_again": a[6]}
+
+    def set_optimistic(self, on=True):
+        """referee mode: decisions within the margin are taken on the samples as they are and checked afterwards (the device's mode for long
+        feeds; default) / the referee is asked on the spot"""
+        self.L.hostsim_set_optimistic.argtypes = [C.c_void_p, C.c_int]
+        self.L.hostsim_set_optimistic(self.h, int(on))
 
     def bursts(self):
         """debugging aid: every burst descriptor the walker has emitted, as (chan, sync_sample, t_first, nsym, tl_bits, syndrome, vdphi_err*1e6, prev_n)"""
