@@ -163,7 +163,7 @@ class Case:
     def _timed_once(self, feeder, steps, dist):
         torch = self.torch
         self.rx.set_profiling(1)           # start/stop events on the channeliser launch only: its duration is the roofline figure
-        self.rx.set_drain_lag(2)
+        self.rx.set_drain_lag(self.vdl2hip.MAX_DRAIN_LAG)
         s0 = self.rx.stats()
         if self.world > 1:
             dist.barrier()
@@ -209,7 +209,7 @@ class Case:
     def stage_times(self, feeder, nstage=4):
         """per-stage kernel times (informational): a short untimed pass with every stage's launch timed"""
         self.rx.set_profiling(2)
-        self.rx.set_drain_lag(2)
+        self.rx.set_drain_lag(self.vdl2hip.MAX_DRAIN_LAG)
         sa = self.rx.stats()
         for _ in range(nstage):
             feeder.step()
@@ -458,11 +458,11 @@ def group_from_c(case, args, torch, local, members=8):
             fr = g.drain()
             want = sum(len(b.frames) for b in case.bursts if b.decodable)
             assert truth_is_subset(case.bursts, fr) == 0 and (len(fr) >= want if cfg.error_injection else len(fr) == want), f"group {form}: frames missing"
-            g.set_drain_lag(2)
+            g.set_drain_lag(vh.MAX_DRAIN_LAG)
             for _ in range(3):
                 g.feed_pinned(pin.data_ptr(), case.nbytes); g.drain_count()
             g.set_drain_lag(0); g.drain_count(); g.sync()
-            g.set_drain_lag(2)
+            g.set_drain_lag(vh.MAX_DRAIN_LAG)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             n = 0

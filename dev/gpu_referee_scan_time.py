@@ -11,7 +11,7 @@ raw = iq.view(np.uint8)
 rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=raw.size)
 rx.feed(raw); rx.drain()
 D = raw.size // 4 // cfg.oversample
-for warm in (1 << 16, 1 << 17, 1 << 18):
+for warm in (1 << 15, 1 << 16, 1 << 17):
     rx.debug_option("ref_warm", warm); rx.feed(raw[:4000]); rx.drain()   # (the run-up travels in the feed's hook)
     ts = []
     for i in range(12):
@@ -20,10 +20,17 @@ for warm in (1 << 16, 1 << 17, 1 << 18):
         assert ok
     print(f"run-up {warm}: {np.median(ts):.3f} ms per scan (min {min(ts):.3f}, max {max(ts):.3f}); {np.median(ts) * 1e6 / (warm + 5120):.2f} ns per input sample", flush=True)
 # many wavefronts at once (the device then runs at its working clock; one wavefront per SIMD up to 1024)
-for warm in (1 << 16, 1 << 18):
+for warm in (1 << 16,):
     rx.debug_option("ref_warm", warm); rx.feed(raw[:4000]); rx.drain()   # (the run-up travels in the feed's hook)
     for count in (64, 1024, 4096):
         base = 30000 + (warm >> 8) + 7 * count
         done, ms = rx.exact_window_many(0, base, base + 200, count, 256)
         print(f"run-up {warm}, {count} scans at once: {ms:.3f} ms for the kernel ({done} done); {ms * 1e6 / (warm + 5120):.2f} ns per input sample and wavefront", flush=True)
 print(rx.stats())
+# ... and side by side (k_ref_scan_multi: 32 requests per workgroup)
+rng = np.random.default_rng(3)
+rx.debug_option("ref_warm", 1 << 17); rx.feed(raw[:4000]); rx.drain()
+for count in (1, 32, 160, 1024):
+    chans = rng.integers(0, len(cfg.freqs), count); los = rng.integers(20000, D - 2000, count); his = los + 255
+    ran, ms = rx.scan_multi(chans, los, his)
+    print(f"side by side, run-up 131072: {count} requests ({ran} scans run) in {ms:.3f} ms", flush=True)

@@ -43,7 +43,7 @@ def run_rank(cfg, dev_block, nbytes, bursts, first, count, steps, repeats, check
     rx.set_profiling(1)
     times, k1 = [], []
     for _ in range(repeats):
-        rx.set_drain_lag(2)
+        rx.set_drain_lag(vdl2hip.MAX_DRAIN_LAG)
         s0 = rx.stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -60,7 +60,7 @@ def run_rank(cfg, dev_block, nbytes, bursts, first, count, steps, repeats, check
     out["ms_per_step"] = {"min": round(min(times), 4), "median": round(statistics.median(times), 4), "all": [round(t, 4) for t in times]}
     out["k_chanfir_ms"] = round(statistics.median(k1), 4)
     # per-stage kernel times, in the pipeline (every launch stamped: a few percent slower)
-    rx.set_profiling(2); rx.set_drain_lag(2)
+    rx.set_profiling(2); rx.set_drain_lag(vdl2hip.MAX_DRAIN_LAG)
     sa = rx.stats()
     n = 6
     for _ in range(n):

@@ -40,7 +40,7 @@ def measure(rx, torch, dev_block, nbytes, steps, repeats, stage_n=6):
     times, k1 = [], []
     rx.set_profiling(1)
     for _ in range(repeats):
-        rx.set_drain_lag(2)
+        rx.set_drain_lag(3)
         s0 = rx.stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -57,7 +57,7 @@ def measure(rx, torch, dev_block, nbytes, steps, repeats, stage_n=6):
     out["ms"] = round(statistics.median(times), 4)
     out["ms_all"] = [round(t, 4) for t in times]
     out["k1"] = round(statistics.median(k1), 4)
-    rx.set_profiling(2); rx.set_drain_lag(2)
+    rx.set_profiling(2); rx.set_drain_lag(3)
     sa = rx.stats()
     for _ in range(stage_n):
         rx.feed_device(dev_block.data_ptr(), nbytes); rx.drain_packed()

@@ -33,6 +33,7 @@ namespace vdl2 {
 
 constexpr int kK1Unroll = VDL2_K1_UNROLL;
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // ======================================================================
 // Referee (vdl2_core.h "Referee"): the reference's own samples of a stretch of one channel's decimated stream.
@@ -41,16 +42,25 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // chebyshev_lpf_2pole() (:74-79) on I and Q, every product and sum rounded to float in exactly that order.  Two such scans over
 // the same input started from different filter states become BIT-IDENTICAL after a while - the difference of two fp32
 // trajectories of a contracting recursion does not shrink below an ulp, it hits zero (measured on the bench workloads:
-// exponentially distributed, 1.5e4 input samples per component on average, never more than 1.2e5 in 1 100 trials;
-// dev/iir_state_coalescence.c).  So the reference's trajectory over [n_lo, n_hi] is obtained by running ITS arithmetic from
-// `warm` (default 2^18) input samples earlier with a zero state: wrong with probability ~2 exp(-warm / 1.5e4) = 1e-7.
+// exponentially distributed, 1.6e4 input samples on average per component; dev/iir_state_coalescence.c, dev/ref_short_runup.py -
+// which also shows that until they meet the two differ by as much as the channeliser's stream does from either, 1e-4 of the
+// signal: a short run-up buys nothing).  So the reference's trajectory over [n_lo, n_hi] is obtained by running ITS arithmetic
+// from `warm` (default 2^17) input samples earlier with a zero state: not yet the reference's with probability 2.5e-4 (measured on
+// the device with a second, witness scan from another state: 9 of 35 838 had not met; the witness costs 40% more time per sample
+// and is not kept - VDL2HIP_REF_WARM=262144 squares that probability for twice the time).
 //
 // One wavefront does it.  The part without a recursion - sample conversion, NCO, mixer, the three feed-forward taps - is done
-// for 64 input samples at a time by the 64 lanes; the recursion y = r0 + (B1 y1 + B2 y2) then runs on two lanes (I and Q), 64
-// steps out of LDS.  ~2 ms per call; called for a few decisions in 10^4 (the ones within the margin of the stream's error).
+// for 60-odd input samples at a time by the lanes; the recursion y = r0 + (B1 y1 + B2 y2) is uniform: every lane does the same
+// packed (I, Q) arithmetic on values handed over with v_readlane.  ~24 ns per input sample: 3.3 ms per scan.
 // ======================================================================
+#ifndef VDL2_REF_PRIO
+#define VDL2_REF_PRIO 3                   // the scan's wavefront among those of its SIMD (s_setprio)
+#endif
+#ifndef VDL2_K1_PRIO
+#define VDL2_K1_PRIO 0
+#endif
 constexpr int kRefPieces = 6;              // stretches of raw input a feed can reach back into: the feed's own block + the history ring (it may wrap)
-constexpr int kRefCache = 32;              // stretches of a channel already made exact (a speculative walker and the stitcher come by the same places)
+constexpr int kRefCache = 64;              // stretches of a channel already made exact (a speculative walker and the stitcher come by the same places)
 struct RefPiece { const void *p; int64_t s0, n; };   // raw samples with absolute index s0 <= s < s0 + n, contiguous at p
 struct RefChan {
 	cf32 *y; uint32_t cap, mask;           // the decimated rings, [nchan][cap]
@@ -88,7 +98,6 @@ __device__ __forceinline__ float dpp_wave_shr1(float v);
 // The raw samples and NCO table entries of block k + 1 are fetched while block k's recursion runs.)
 typedef __attribute__((address_space(1))) const uint32_t ref_gu32;
 typedef __attribute__((address_space(1))) const uint16_t ref_gu16;
-typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const v4f ref_gf4;
 __device__ __forceinline__ float ref_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 __device__ __forceinline__ bool ref_exact_window_dev(const ChanView &v, int64_t n_lo, int64_t n_hi, int kind) {
@@ -142,7 +151,7 @@ __device__ __forceinline__ bool ref_exact_window_dev(const ChanView &v, int64_t 
 		if(s_beg > 0 && (int64_t)os * n_lo - s_beg < warm / 4) { if(lane == 0) atomicAdd(stats + 2, 1u); return false; }
 	}
 	if(npiece <= 0 || in_end < s_end) { if(lane == 0) atomicAdd(stats + 2, 1u); return false; }
-	__builtin_amdgcn_s_setprio(3);
+	__builtin_amdgcn_s_setprio(VDL2_REF_PRIO);
 
 	// raw sample s (this lane's of a block) as a 32-bit word, and its NCO table entry
 	auto fetch = [&](int64_t s, uint32_t &w, v4f &e) {
@@ -419,6 +428,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	__shared__ __align__(16) float park[4 * 4 * 4 * 4];   // per wave: carried state and the end-of-feed state, [wave][4][CR][4]
 	__shared__ int fallback;                      // fused fix-up: some wave of this workgroup gave up waiting for the previous segment's state
 	extern __shared__ __align__(16) unsigned char smem[];
+	if(VDL2_K1_PRIO) __builtin_amdgcn_s_setprio(VDL2_K1_PRIO);
 	const int os = OS ? OS : a.os;
 	const int run = R * os;                       // input samples per lane and tile
 	float2 *tile = (float2 *)smem;                // [run][65]
@@ -983,7 +993,7 @@ constexpr int kK3bWordsPerLane = 4;      // at most; fewer when that leaves the 
 // referee's error figure beside it.  Same atan2, same metric, bit-identical values as the four-lanes-per-sample form it replaces
 // (which read every tap from memory - five loads per tap with the referee - and kept three lanes in four idle during the metric).
 __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
-	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { reset_out_ctl(a.ctl, a.k5_waves); if(a.ref) *a.ref = a.refv; if(a.rq_n) *a.rq_n = 0u; }
+	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { reset_out_ctl(a.ctl, a.k5_waves); if(a.ref) *a.ref = a.refv; if(a.rq_n) { a.rq_n[0] = 0u; a.rq_n[1] = 0u; a.rq_n[2] = 0u; } }   // (rq_n[1], [2]: the burst decoder's lists, BurstDefer)
 	if(blockIdx.x == 0 && threadIdx.x == 0 && a.rq_flag) a.rq_flag[blockIdx.y] = 0u;
 	constexpr int kBack = 160, kSpan = kBack + 64;        // staged samples: base - 160 .. base + 63
 	// [wave][6 + bit]: metric of sample word*64 + bit (entries 0..5 = the six samples before the word), its slope, and - for the
@@ -1272,7 +1282,254 @@ struct K5Args {
 	uint32_t cap, mask;
 	RefChan *ref;              // referee hook of this feed (nullptr: off)
 	uint32_t ref_launch;
+	BurstDefer df;             // pass 0: the referee's scans on the spot; 1: bursts that need one are listed; 2: the listed bursts
 };
+
+// ======================================================================
+// Many scans side by side.  ref_exact_window_dev() spends a whole wavefront on one recursion - 64 lanes doing the same packed
+// arithmetic, 60 % of a SIMD's issue slots for 3.3 ms: with a few hundred requests per feed that was 8 % (config4) to 28 %
+// (config4_bursty) of the channeliser's time.  Here a workgroup takes kScanLanes requests at once: two producer wavefronts do the part
+// without a recursion for one request and 64 input samples at a time (lane = sample), into LDS; one consumer wavefront runs the
+// recursions, lane = request, a step of all of them per turn.  Same arithmetic, operation for operation; ~45 clocks per input sample
+// for 32 requests instead of 58 for one.
+// ======================================================================
+constexpr int kScanLanes = 32, kScanProd = 4, kScanBlock = 64;
+struct ScanShared {
+	v2f buf[2][kScanBlock][kScanLanes + 1];      // [block parity][sample][request] feed-forward values {I, Q}
+	int64_t s_beg[kScanLanes], len[kScanLanes], n_lo[kScanLanes], n_hi[kScanLanes];
+	uint32_t dphi[kScanLanes]; int32_t chan[kScanLanes], kind[kScanLanes]; uint32_t flags[kScanLanes];   // flags: 1 mix, 2 shortened run-up
+	int64_t lmax, smin;
+	v4f lut[256];                                // the NCO table
+};
+template<int FMT>
+__global__ __launch_bounds__(64 * (1 + kScanProd)) void k_ref_scan_multi(RefChan *rp, uint32_t launch, const ScanReq *sq, const RefReq *rq, const uint32_t *n_ptr, uint32_t cap, int64_t k_end) {
+#if VDL2_DEVICE_PASS
+	#pragma clang fp contract(off)
+	__shared__ ScanShared sh;
+	const uint32_t ntot = *n_ptr < cap ? *n_ptr : cap;
+	const uint32_t base = blockIdx.x * (uint32_t)kScanLanes;
+	if(base >= ntot) return;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const int os = rp->os, npiece = rp->npiece;
+	const uint32_t mask = rp->mask, cap_y = rp->cap;
+	const int64_t warm = rp->warm;
+	int64_t ps0[kRefPieces], pn[kRefPieces]; const void *pp[kRefPieces];
+	#pragma unroll
+	for(int j = 0; j < kRefPieces; j++) { ps0[j] = j < npiece ? rp->piece[j].s0 : 0; pn[j] = j < npiece ? rp->piece[j].n : 0; pp[j] = j < npiece ? rp->piece[j].p : nullptr; }
+	const float A0 = rp->A0, A1 = rp->A1, A2 = rp->A2;
+	uint32_t *stats = rp->stats;
+	// ---- the requests of this workgroup: stretch, run-up, what has been done before (as ref_exact_window_dev) ----
+	if(threadIdx.x < kScanLanes) {
+		const int r = threadIdx.x;
+		int64_t n_lo = 0, n_hi = -1, s_beg = 0, len = 0; int c = 0, kind = 0; uint32_t fl = 0;
+		if(base + r < ntot && npiece > 0) {
+			if(sq) { const ScanReq q = sq[base + r]; c = q.chan; kind = q.kind; n_lo = q.lo; n_hi = q.hi; }
+			else { const RefReq q = rq[base + r]; c = q.chan; kind = q.kind; ref_request_window(q, k_end, n_lo, n_hi); }
+			const int64_t in_end = ps0[npiece - 1] + pn[npiece - 1];
+			if(n_lo < 0) n_lo = 0;
+			bool go = n_hi >= n_lo && ((rp->kinds >> kind) & 1);
+			if(go) {
+				const int64_t last = in_end / os - 1;
+				n_lo &= ~255ll;
+				if((n_hi | 255) <= last) n_hi |= 255; else if(n_hi < last) n_hi = last;
+				const unsigned long long *done = rp->done + (size_t)c * kRefCache;
+				const uint32_t ndv = rp->done_n[c], nd = ndv < (uint32_t)kRefCache ? ndv : (uint32_t)kRefCache;
+				bool hit = false;
+				for(uint32_t i = 0; i < nd; i++) {
+					const unsigned long long e = __hip_atomic_load(done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const int64_t lo = (int64_t)(e >> 32) << 8, hi = lo + ((int64_t)((e >> 16) & 0xffffull) << 8) + 255;
+					hit = hit || (lo <= n_lo && n_hi <= hi && (uint32_t)(e & 0xffffull) != (launch & 0xffffu));
+				}
+				if(hit) { atomicAdd(stats + 1, 1u); go = false; }
+			}
+			if(go) {
+				const int64_t s_end = (int64_t)os * (n_hi + 1);
+				s_beg = (int64_t)os * n_lo - warm;
+				bool refuse = in_end < s_end;
+				if(s_beg < 0) s_beg = 0;
+				else {
+					if(ps0[0] > s_beg) { fl |= 2u; s_beg = ps0[0]; }
+					if(s_beg > 0 && (int64_t)os * n_lo - s_beg < warm / 4) refuse = true;
+				}
+				if(refuse) { atomicAdd(stats + 2, 1u); go = false; }
+				else {
+					s_beg -= s_beg % os;
+					len = s_end - s_beg;
+					if(rp->mix[c]) fl |= 1u;
+				}
+			}
+			if(!go) len = 0;
+		}
+		sh.s_beg[r] = s_beg; sh.len[r] = len; sh.n_lo[r] = n_lo; sh.n_hi[r] = n_hi; sh.chan[r] = c; sh.kind[r] = kind; sh.flags[r] = fl;
+		sh.dphi[r] = len ? rp->dphi[c] : 0u;
+	}
+	__syncthreads();
+	if(threadIdx.x < kScanLanes) {
+		// the same stretch twice in one workgroup (the candidates of one preamble): once is enough
+		const int r = threadIdx.x;
+		bool dup = false;
+		for(int q = 0; q < r; q++) dup = dup || (sh.len[q] && sh.chan[q] == sh.chan[r] && sh.n_lo[q] == sh.n_lo[r] && sh.n_hi[q] >= sh.n_hi[r]);
+		if(dup && sh.len[r]) { atomicAdd(stats + 1, 1u); sh.len[r] = 0; }
+	}
+	__syncthreads();
+	if(threadIdx.x == 0) {
+		int64_t m = 0, lo = INT64_MAX;
+		for(int r = 0; r < kScanLanes; r++) { m = sh.len[r] > m ? sh.len[r] : m; if(sh.len[r] > 0 && sh.s_beg[r] < lo) lo = sh.s_beg[r]; }
+		sh.lmax = m; sh.smin = lo;
+		for(int r = 0; r < kScanLanes; r++) if(sh.len[r] <= 0) sh.s_beg[r] = lo;      // (idle lanes: any position in range)
+	}
+	__syncthreads();
+	const int64_t lmax = sh.lmax;
+	if(lmax <= 0) return;
+	__builtin_amdgcn_s_setprio(3);                               // (a few dozen wavefronts on the whole device, on the walk's critical path)
+	const int64_t nblk = (lmax + kScanBlock - 1) / kScanBlock;
+	for(int i = threadIdx.x; i < 256; i += blockDim.x) sh.lut[i] = ((ref_gf4 *)rp->lut)[i];
+	__syncthreads();
+
+	// a barrier that waits for LDS traffic only (the producers' raw-sample loads for the block after next stay in flight across it -
+	// __syncthreads() would wait for them)
+	auto uni64 = [](int64_t v) -> int64_t { return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v)); };
+	auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+	constexpr int NQ = kScanLanes / kScanProd;                     // requests per producer wavefront
+	const v2f B1 = v2f{rp->B1, rp->B1}, B2 = v2f{rp->B2, rp->B2};
+	if(wave > 0) {
+		// ---- a producer: requests wave - 1, wave - 1 + kScanProd, ...; what it needs of each in registers (uniform values: where the
+		// request's sample 0 would lie if the stretch of raw input it is in went on for ever, how far that stretch does go) ----
+		const uint8_t *q_ptr[NQ]; uint32_t q_pend[NQ], q_ph0[NQ], q_len[NQ], q_dphi[NQ]; uint32_t mixmask = 0u;
+		int64_t q_beg[NQ];
+		float pre[NQ], pim[NQ];                                       // a request's mixed samples of the block before (lanes 62, 63 are read)
+		uint32_t wq[NQ];
+		constexpr int SB = FMT == 1 ? 4 : 2;                          // bytes per raw sample
+		#pragma unroll
+		for(int q = 0; q < NQ; q++) {
+			const int r = wave - 1 + q * kScanProd;
+			q_beg[q] = uni64(sh.s_beg[r]);
+			q_ph0[q] = (uint32_t)q_beg[q];
+			q_len[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sh.len[r]);
+			q_dphi[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dphi[r]);
+			if(__builtin_amdgcn_readfirstlane((int)sh.flags[r]) & 1) mixmask |= 1u << q;
+			pre[q] = 0.f; pim[q] = 0.f; q_ptr[q] = nullptr; q_pend[q] = 0u;
+		}
+		// the stretch of raw input that holds sample p of request q (uniform; a handful of times per scan)
+		auto locate = [&](int q, uint32_t p) {
+			const int64_t s = q_beg[q] + p;
+			q_ptr[q] = nullptr; q_pend[q] = p;                           // (not held: zeros, one block at a time)
+			for(int j = 0; j < npiece; j++) {
+				const int64_t a0 = rp->piece[j].s0, an = rp->piece[j].n;
+				if(s >= a0 && s < a0 + an) {
+					q_ptr[q] = (const uint8_t *)rp->piece[j].p - (a0 - q_beg[q]) * SB;
+					const int64_t e = a0 + an - q_beg[q];
+					q_pend[q] = e > 0xffffffffll ? 0xffffffffu : (uint32_t)e;
+				}
+			}
+		};
+		// the raw sample of request q and block b for this lane (0 past the request's end)
+		auto fetch = [&](int q, uint32_t b) -> uint32_t {
+			const uint32_t p0 = b * (uint32_t)kScanBlock;
+			if(p0 >= q_len[q]) return 0u;                                // (uniform)
+			const uint32_t n = q_len[q] - p0 < (uint32_t)kScanBlock ? q_len[q] - p0 : (uint32_t)kScanBlock;
+			if(p0 + n > q_pend[q]) {
+				// the block reaches past the stretch: lane by lane (the scan's first block, and where two stretches meet)
+				uint32_t w = 0u;
+				for(uint32_t i = 0; i < n; i++) {
+					if(p0 + i >= q_pend[q]) locate(q, p0 + i);
+					if(q_ptr[q] && (uint32_t)lane == i) w = FMT == 1 ? *(ref_gu32 *)(q_ptr[q] + (size_t)(p0 + i) * SB) : (uint32_t)*(ref_gu16 *)(q_ptr[q] + (size_t)(p0 + i) * SB);
+					if(!q_ptr[q]) q_pend[q] = p0 + i + 1;
+				}
+				return w;
+			}
+			uint32_t w = 0u;
+			if((uint32_t)lane < n) w = FMT == 1 ? *(ref_gu32 *)(q_ptr[q] + (size_t)(p0 + (uint32_t)lane) * SB) : (uint32_t)*(ref_gu16 *)(q_ptr[q] + (size_t)(p0 + (uint32_t)lane) * SB);
+			return w;
+		};
+		// block b of all its requests (the raw samples are in wq): the NCO table entries first, all of them, then the arithmetic;
+		// the raw samples of block b + 1 are asked for before either
+		auto produce = [&](uint32_t b) {
+			uint32_t wn[NQ]; v4f eq[NQ]; uint32_t phq[NQ];
+			#pragma unroll
+			for(int q = 0; q < NQ; q++) wn[q] = fetch(q, b + 1);
+			#pragma unroll
+			for(int q = 0; q < NQ; q++) {
+				phq[q] = ((q_ph0[q] + b * (uint32_t)kScanBlock + (uint32_t)lane) * q_dphi[q]) & 0xffffffu;
+				eq[q] = sh.lut[phq[q] >> 16];
+			}
+			#pragma unroll
+			for(int q = 0; q < NQ; q++) {
+				if(b * (uint32_t)kScanBlock >= q_len[q]) continue;        // (uniform: the request is through)
+				const uint32_t w = wq[q];
+				float re, im;
+				if(FMT == 1) { re = (float)(int16_t)(w & 0xffff) / 32768.0f; im = (float)(int16_t)(w >> 16) / 32768.0f; }
+				else { re = ((float)(w & 0xff) - 127.5f) / 127.5f; im = ((float)((w >> 8) & 0xff) - 127.5f) / 127.5f; }
+				if((mixmask >> q) & 1u) {
+					const float F = (float)(phq[q] & 0xffffu);
+					const float sn = eq[q].x + eq[q].z * F, cs = eq[q].y + eq[q].w * F;
+					const float mr = re * cs - im * sn, mi = im * cs + re * sn;
+					re = mr; im = mi;
+				}
+				float x1r = dpp_wave_shr1(re), x1i = dpp_wave_shr1(im);
+				if(lane == 0) { x1r = ref_lane(pre[q], kScanBlock - 1); x1i = ref_lane(pim[q], kScanBlock - 1); }
+				float x2r = dpp_wave_shr1(x1r), x2i = dpp_wave_shr1(x1i);
+				if(lane == 0) { x2r = ref_lane(pre[q], kScanBlock - 2); x2i = ref_lane(pim[q], kScanBlock - 2); }
+				pre[q] = re; pim[q] = im;
+				float fa = A0 * re; fa += A1 * x1r + A2 * x2r;
+				float fb = A0 * im; fb += A1 * x1i + A2 * x2i;
+				sh.buf[b & 1][lane][wave - 1 + q * kScanProd] = v2f{fa, fb};
+			}
+			#pragma unroll
+			for(int q = 0; q < NQ; q++) wq[q] = wn[q];
+		};
+		#pragma unroll
+		for(int q = 0; q < NQ; q++) wq[q] = fetch(q, 0);
+		produce(0);
+		lds_barrier();
+		for(uint32_t b = 0; b < (uint32_t)nblk; b++) {
+			if(b + 1 < (uint32_t)nblk) produce(b + 1);
+			lds_barrier();
+		}
+		return;
+	}
+	// ---- the consumer: lane = request ----
+	lds_barrier();
+	const int r = lane < kScanLanes ? lane : 0;
+	v2f y1 = v2f{0.f, 0.f}, y2 = v2f{0.f, 0.f};
+	const int64_t my_lo = sh.n_lo[r], my_hi = (lane < kScanLanes && sh.len[r] > 0) ? sh.n_hi[r] : -1;
+	int64_t k_out = sh.s_beg[r] / os;                                // the decimated sample this lane's next output is
+	__attribute__((address_space(1))) float *yout = (__attribute__((address_space(1))) float *)(rp->y + (size_t)sh.chan[r] * cap_y);
+	int cnt = 0;                                                     // input samples since the last output (uniform: every request starts on a decimation boundary)
+	constexpr int kChunk = 16;
+	for(int64_t b = 0; b < nblk; b++) {
+		#pragma unroll 1
+		for(int j0 = 0; j0 < kScanBlock; j0 += kChunk) {
+			v2f r0v[kChunk];
+			#pragma unroll
+			for(int j = 0; j < kChunk; j++) r0v[j] = sh.buf[b & 1][j0 + j][r];      // (all asked for before the first is used)
+			#pragma unroll
+			for(int j = 0; j < kChunk; j++) {
+				const v2f yv = r0v[j] + (B1 * y1 + B2 * y2);
+				y2 = y1; y1 = yv;
+				if(__builtin_expect(++cnt == os, 0)) {
+					cnt = 0;
+					if(k_out >= my_lo && k_out <= my_hi) { yout[2 * ((uint32_t)k_out & mask)] = y1.x; yout[2 * ((uint32_t)k_out & mask) + 1] = y1.y; }
+					k_out++;
+				}
+			}
+		}
+		lds_barrier();
+	}
+	if(lane < kScanLanes && sh.len[r] > 0) {
+		const int c = sh.chan[r];
+		const int64_t n_lo = sh.n_lo[r], n_hi = sh.n_hi[r];
+		const uint32_t i = atomicAdd(rp->done_n + c, 1u);
+		int64_t len = (n_hi - n_lo) >> 8; if(len > 0xffff) len = 0xffff;
+		if(((n_hi + 1) & 255) != 0) len -= 1;
+		if(len >= 0) __hip_atomic_store(rp->done + (size_t)c * kRefCache + (i % (uint32_t)kRefCache), ((unsigned long long)(n_lo >> 8) << 32) | ((unsigned long long)len << 16) | (unsigned long long)(launch & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		atomicAdd(stats + 0, 1u); atomicAdd(stats + 4 + sh.kind[r], 1u);
+		if(sh.flags[r] & 2u) atomicAdd(stats + 3, 1u);
+	}
+#else
+	(void)rp; (void)launch; (void)sq; (void)rq; (void)n_ptr; (void)cap; (void)k_end;
+#endif
+}
 
 // Two bursts per workgroup, one per wavefront (they share nothing; four would need more LDS than a channeliser workgroup
 // leaves on a CU): see k_nf_replay.
@@ -1302,8 +1559,26 @@ __device__ __forceinline__ void burst_body(const K5Args &a, unsigned char *k5_ld
 		if(c0 + lane < a.nchan) bb[c0 + lane] = total + inc - v;
 		total += __shfl(inc, 63);
 	}
-	if(lane == 0) { bb[a.nchan] = total; if(wave_id == 0) a.ctl->nbursts = total; }
+	if(lane == 0) { bb[a.nchan] = total; if(wave_id == 0 && a.df.pass != 2) a.ctl->nbursts = total; }
 	WAVE_SYNC();
+	if(a.df.pass == 2) {
+		// the bursts the first pass has listed; its wavefronts own the initial shares of the output, this pass's go to the counters
+		const uint32_t nd = *a.df.dq_n < a.df.dq_cap ? *a.df.dq_n : a.df.dq_cap;
+		if(wave_id >= nd) return;
+		burst_shared_init(*a.tab, wave_id, a.ctl, sh, true);
+		for(uint32_t i = wave_id; i < nd; i += nblocks * kBurstWaves) {
+			const uint32_t g = a.df.dq[i];
+			int lo = 0, hi = a.nchan;
+			while(hi - lo > 1) { const int mid = (lo + hi) >> 1; if(bb[mid] <= g) lo = mid; else hi = mid; }
+			const int c = lo;
+			const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - bb[c])];
+			ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask, a.ref, c, a.ref_launch };
+			decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh, &a.df, g);
+			WAVE_SYNC();
+		}
+		burst_reserve_done(a.frames, sh);
+		return;
+	}
 	if(wave_id >= total) {
 		// nothing to decode: this wavefront's share of the output (vdl2_core.h: burst_reserve_*) stays empty
 		const uint32_t slot = wave_id * (uint32_t)kResSlots + (uint32_t)lane;
@@ -1317,7 +1592,7 @@ __device__ __forceinline__ void burst_body(const K5Args &a, unsigned char *k5_ld
 		const int c = lo;
 		const Burst b = a.bursts[(size_t)c * a.cap_bursts_chan + (g - bb[c])];
 		ChanView v{ a.y + (size_t)c * a.cap, nullptr, nullptr, a.mask, a.ref, c, a.ref_launch };
-		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh);
+		decode_burst(b, a.freq[c], *a.tab, v, a.cnt + (size_t)c * kNumCounters, a.frames, a.pool, a.ctl, sh, a.df.pass ? &a.df : nullptr, g);
 		WAVE_SYNC();
 	}
 	burst_reserve_done(a.frames, sh);

@@ -1663,10 +1663,20 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_th
 // walked again from the feed's start (walk_again), in the synchronous mode, over samples that are by then exact where it matters.
 // `lds`: >= 64 floats.  true: the decision stands (or cannot be checked: the raw input is no longer held).
 // ======================================================================
+// the stretch a noted decision reads
+VDL2_HD void ref_request_window(const RefReq &r, int64_t k_end, int64_t &lo, int64_t &hi) {
+	if(r.kind == REF_CANDIDATE) {
+		lo = (r.n - kRefPre) & ~255ll; hi = (r.n + kRefPost) | 255; if(lo < 0) lo = 0; if(hi > k_end - 1) hi = k_end - 1;
+	} else {                                                        // header: sync point + nine symbols, and the carrier slope they are sliced with
+		lo = r.n - kRefPre; if(r.prev_n >= 0 && r.prev_n < lo) lo = r.prev_n;
+		hi = r.t_first + 8 * kSpsDec;
+	}
+}
 VDL2_HD bool ref_verify(const RefReq &r, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T, const ChanView &v, float *lds) {
+	int64_t lo, hi;
+	ref_request_window(r, k_end, lo, hi);
 	if(r.kind == REF_CANDIDATE) {
 		const int64_t n = r.n;
-		int64_t lo = (n - kRefPre) & ~255ll, hi = (n + kRefPost) | 255; if(lo < 0) lo = 0; if(hi > k_end - 1) hi = k_end - 1;
 		if(!ref_exact_window(v, lo, hi, nullptr, REF_CANDIDATE)) return true;
 		WAVE_FOR(l)
 			if(l < 48) lds[l] = v.Phi(n - 3 * (l >> 4) - 150 + 10 * (l & 15));
@@ -1681,9 +1691,8 @@ VDL2_HD bool ref_verify(const RefReq &r, uint32_t freq, float max_ppm, float ppm
 		return lds[56] != 0.f;
 	}
 	// header: sync point + nine symbols, and the carrier slope they are sliced with
-	const int64_t ns = r.n, t8 = r.t_first + 8 * kSpsDec;
-	int64_t lo = ns - kRefPre; if(r.prev_n >= 0 && r.prev_n < lo) lo = r.prev_n;
-	if(!ref_exact_window(v, lo, t8, nullptr, REF_HEADER)) return true;
+	const int64_t ns = r.n;
+	if(!ref_exact_window(v, lo, hi, nullptr, REF_HEADER)) return true;
 	WAVE_FOR(l)
 		if(l < 10) { const int64_t t = l ? r.t_first + (int64_t)(l - 1) * kSpsDec : r.prev_n; lds[l] = t < 0 ? (t == -1 ? 0.f : r.prev_phi0) : v.Phi(t); }
 		else if(l >= 16 && l < 32) lds[l] = v.Phi(ns - 3 - 150 + 10 * (l - 16));
@@ -2041,7 +2050,8 @@ struct BurstShared {
 	float   pw[64];
 	float   qmin[64];                  // referee: per lane, the smallest (distance from a decision boundary) / (1/|y_cur| + 1/|y_prev|) among its symbols
 	int32_t neg[64];
-	int32_t u_ret, u_kind, u_ok;
+	int32_t u_ret, u_kind, u_ok, u_negs, u_defer;
+	uint32_t u_pm[4];                  // referee: the pieces of the burst that hold a marked symbol's samples
 	uint32_t u_k, u_sprev, u_lastend, u_S, u_L, u_off, u_capf, u_capp;
 	float u_pwr, u_pwr_db;
 	uint32_t res_slot, res_nslot, res_off, res_npool, res_capf, res_capp;   // the wavefront's reserve of frame records and octet space (burst_reserve_*)
@@ -2233,7 +2243,7 @@ VDL2_HD void burst_reserve_done(OutFrame *frames, BurstShared &sh) {
 
 // once per wavefront (`wave` of the launch's wavefronts): LDS copies of the field tables (they do not change from burst to burst), the
 // erasure locators of short blocks, the wavefront's own share of the output
-VDL2_HD void burst_shared_init(const Tables &T, uint32_t wave, const OutCtl *ctl, BurstShared &sh) {
+VDL2_HD void burst_shared_init(const Tables &T, uint32_t wave, const OutCtl *ctl, BurstShared &sh, bool no_reserve = false) {
 	WAVE_FOR(l)
 		for(int i = l; i < 512; i += 64) sh.gf_exp[i] = T.gf_exp[i];
 		for(int i = l; i < 256; i += 64) sh.gf_log[i] = T.gf_log[i];
@@ -2255,14 +2265,23 @@ VDL2_HD void burst_shared_init(const Tables &T, uint32_t wave, const OutCtl *ctl
 		}
 		if(l == 0) {
 			sh.res_slot = wave * (uint32_t)kResSlots; sh.res_nslot = (uint32_t)kResSlots; sh.res_off = wave * (uint32_t)kResPool; sh.res_npool = (uint32_t)kResPool;
+			if(no_reserve) { sh.res_nslot = 0; sh.res_npool = 0; }        // (the second pass over deferred bursts: those shares are the first pass's)
 			sh.res_capf = ctl->cap_frames; sh.res_capp = ctl->cap_pool;
 		}
 	WAVE_END
 }
 
+// Referee, long feeds: a burst some of whose symbols have to be sliced on the reference's own samples is not held up for the
+// scans (milliseconds each, one after the other) - the first pass lists it and the stretches it needs (pass 1), k_ref_scan makes
+// them all at once, a wavefront each, and a second pass decodes the listed bursts (pass 2: every stretch it asks for is then done).
+constexpr int kRefPieceBits = 12;           // a burst's stretches are asked for in pieces of 2^12 decimated samples, each scanned on its own
+struct ScanReq { int32_t chan, kind; int64_t lo, hi; };
+struct BurstDefer { uint32_t *dq, *dq_n; uint32_t dq_cap; ScanReq *sq; uint32_t *sq_n; uint32_t sq_cap; int32_t pass; };
+
 // decode_vdl2_burst() DEC_DATA branch + decode_frame(): decode.c:259-380, 173-194.  burst_shared_init() first.
+// (df, tag: see BurstDefer - tag is what pass 1 lists the burst as)
 VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const ChanView &v, unsigned long long *cnt,
-		OutFrame *frames, uint8_t *pool, OutCtl *ctl, BurstShared &sh) {
+		OutFrame *frames, uint8_t *pool, OutCtl *ctl, BurstShared &sh, const BurstDefer *df = nullptr, uint32_t tag = 0) {
 	// geometry again from TL (decode.c:233-256)
 	const uint32_t octets = b.tl_bits / 8 + (b.tl_bits % 8 != 0);
 	uint32_t nblk = octets / kRsK, last = octets % kRsK;
@@ -2297,8 +2316,10 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 			for(int q = 0; q < 4; q++) yv[q] = mb + q < m1 ? v.Y(b.t_first + (int64_t)(mb + q) * kSpsDec) : cf32{0.f, 0.f};   // loads first
 			for(int q = 0; q < 4 && mb + q < m1; q++) {
 				const float cur = phase_of(yv[q]);
-				const int idx = slice_symbol(cur, prev, vdphi, neg);
-				uint8_t sy = (uint8_t)(idx ^ (idx >> 1));                 // graycode[] of demod.c:223 (= Tables::gray, tests/test_design.py), without the table
+				int neg1 = 0;
+				const int idx = slice_symbol(cur, prev, vdphi, neg1);
+				uint8_t sy = (uint8_t)((idx ^ (idx >> 1)) | (neg1 << 6));   // graycode[] of demod.c:223 (= Tables::gray, tests/test_design.py), without the table; bit 6: counted in `neg`
+				neg += neg1;
 				const float m2 = yv[q].re * yv[q].re + yv[q].im * yv[q].im;
 				if(ref_on) {
 					const float im2 = ref_inv_mag2(yv[q]), a2 = fmaxf(m2, pm2);
@@ -2321,7 +2342,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		double s = 0.0; int negs = 0;
 		for(int l = 0; l < 64; l++) { s += (double)sh.pw[l]; negs += sh.neg[l]; }
 		sh.u_pwr = (float)(s / (double)nsym);
-		if(negs) VDL2_CNT_ADD(cnt, CNT_SLICER_NEG_IDX, negs);
+		sh.u_negs = negs;
 	LANE0_END
 	if(ref_on) {
 		// the error bound scales with the signal around the sample: the two samples of the decision (above) or the burst's rms -
@@ -2353,16 +2374,76 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 		const uint32_t mfirst = wave_min64(sh.lanek), mlast = ~wave_min64(sh.lanet);
 		WAVE_SYNC();
 		if(mfirst != 0xffffffffu) {
-			// ---- referee: symbols mfirst .. mlast (and, if it is not the reference's yet, the carrier slope) on the reference's own samples ----
+			// ---- referee: the marked symbols (and, if it is not the reference's yet, the carrier slope) on the reference's own samples ----
+			// A scan costs its run-up (2^17 input samples) plus the stretch, so not the whole burst is asked for but the pieces of it
+			// that hold a marked symbol's two samples or the slope's taps (which lie before the burst).
 			const bool redo_slope = b.vdphi_err > 0.f;
 			const int64_t t_lo = mfirst > 0 ? b.t_first + (int64_t)(mfirst - 1) * kSpsDec : (b.prev_n >= 0 ? b.prev_n : b.t_first);
 			const int64_t hi = b.t_first + (int64_t)mlast * kSpsDec;
-			// (the taps of the slope lie before the burst, the symbols anywhere in it: one scan over both when they are close, two otherwise -
-			// a scan costs its run-up, 2^17 input samples, plus the stretch)
-			const bool split = redo_slope && t_lo - b.sync_sample > 4096;
-			int64_t lo = redo_slope && !split ? b.sync_sample - kRefPre : t_lo; if(t_lo < lo) lo = t_lo;
-			bool ok = ref_exact_window(v, lo, hi, sh.xw, REF_SYMBOLS);
-			if(ok && split) ok = ref_exact_window(v, b.sync_sample - kRefPre, b.sync_sample, sh.xw, REF_SYMBOLS);
+			const int64_t s_lo = b.sync_sample - kRefPre;
+			const int64_t w_lo = (redo_slope && s_lo < t_lo) ? (s_lo < 0 ? 0 : s_lo) : t_lo;
+			const int64_t P0 = w_lo >> kRefPieceBits;
+			const bool wide = (hi >> kRefPieceBits) - P0 >= 128;             // (longer than any burst of the bench workloads: one stretch then)
+			const int pass = df ? df->pass : 0;
+			LANE0
+				uint32_t pm[4] = { 0u, 0u, 0u, 0u };
+				if(wide) pm[0] = 1u;
+				else {
+					if(redo_slope) for(int64_t q = ((s_lo < 0 ? 0 : s_lo) >> kRefPieceBits) - P0; q <= (b.sync_sample >> kRefPieceBits) - P0; q++) if(q >= 0 && q < 128) pm[q >> 5] |= 1u << (q & 31);
+					for(int l = 0; l < 64; l++) {
+						const uint32_t first = sh.lanek[l], last = ~sh.lanet[l];
+						if(first == 0xffffffffu) continue;
+						const int64_t a_ = first > 0 ? b.t_first + (int64_t)(first - 1) * kSpsDec : (b.prev_n >= 0 ? b.prev_n : b.t_first);
+						const int64_t b_ = b.t_first + (int64_t)last * kSpsDec;
+						for(int64_t q = (a_ >> kRefPieceBits) - P0; q <= (b_ >> kRefPieceBits) - P0; q++) if(q >= 0 && q < 128) pm[q >> 5] |= 1u << (q & 31);
+					}
+				}
+				for(int i = 0; i < 4; i++) sh.u_pm[i] = pm[i];
+				sh.u_defer = 0;
+				if(pass == 1) {
+					// list the burst and its pieces; a burst that does not get on the list is done here and now
+#if VDL2_DEVICE_PASS
+					const uint32_t i = atomicAdd(df->dq_n, 1u);
+#else
+					const uint32_t i = (*df->dq_n)++;
+#endif
+					if(i < df->dq_cap) {
+						df->dq[i] = tag; sh.u_defer = 1;
+						uint32_t np = 0;
+						for(int q = 0; q < 4; q++) np += (uint32_t)popc32(pm[q]);
+#if VDL2_DEVICE_PASS
+						uint32_t j = atomicAdd(df->sq_n, np);
+#else
+						uint32_t j = *df->sq_n; *df->sq_n += np;
+#endif
+						for(int q = 0; q < 128; q++) {
+							if(!((pm[q >> 5] >> (q & 31)) & 1u)) continue;
+							int64_t lo_ = (P0 + q) << kRefPieceBits, hi_ = ((P0 + q + 1) << kRefPieceBits) - 1;
+							if(wide) { lo_ = w_lo; hi_ = hi; }
+							if(lo_ < w_lo) lo_ = w_lo;
+							if(hi_ > hi) hi_ = hi;                                   // (the slope's taps lie before the burst's first symbol: below hi)
+							if(j < df->sq_cap) df->sq[j] = ScanReq{ v.ref_chan, REF_SYMBOLS, lo_, hi_ };      // (a piece that finds no room is scanned by pass 2 itself)
+							j++;
+						}
+					}
+				}
+			LANE0_END
+			if(sh.u_defer) { K5_END(); return; }
+			bool ok = true;
+			{
+				// runs of pieces: one stretch each (pass 2: piece by piece, as they were made)
+				for(int q = 0; q < 128 && ok; ) {
+					if(!((sh.u_pm[q >> 5] >> (q & 31)) & 1u)) { q++; continue; }
+					int q1 = q;
+					if(pass != 2) while(q1 + 1 < 128 && ((sh.u_pm[(q1 + 1) >> 5] >> ((q1 + 1) & 31)) & 1u)) q1++;
+					int64_t lo_ = (P0 + q) << kRefPieceBits, hi_ = ((P0 + q1 + 1) << kRefPieceBits) - 1;
+					if(wide) { lo_ = w_lo; hi_ = hi; }
+					if(lo_ < w_lo) lo_ = w_lo;
+					if(hi_ > hi) hi_ = hi;
+					ok = ref_exact_window(v, lo_, hi_, sh.xw, REF_SYMBOLS);
+					q = q1 + 1;
+				}
+			}
 			if(ok && redo_slope) {
 				float *phs = reinterpret_cast<float *>(sh.keptw);
 				WAVE_FOR(l)
@@ -2377,19 +2458,29 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 				WAVE_SYNC();
 			}
 			WAVE_FOR(l)
-				for(uint32_t m = mfirst + (uint32_t)l; m <= mlast; m += 64) {
+				int negd = 0;
+				if(ok) for(uint32_t m = mfirst + (uint32_t)l; m <= mlast; m += 64) {
 					if(!(sh.sym[m] & 0x80)) continue;
 					const int64_t t = b.t_first + (int64_t)m * kSpsDec;
 					const float cur = v.Phi(t);
 					const float prev = m > 0 ? v.Phi(t - kSpsDec) : (b.prev_n >= 0 ? v.Phi(b.prev_n) : b.prev_phi0);
 					int neg = 0;
 					const int idx = slice_symbol(cur, prev, vdphi, neg);
+					negd += neg - (int)((sh.sym[m] >> 6) & 1);
 					sh.sym[m] = (uint8_t)(idx ^ (idx >> 1));
-					(void)neg;
 				}
+				sh.neg[l] = negd;
 			WAVE_END
+			LANE0
+				int d = 0;
+				for(int l = 0; l < 64; l++) d += sh.neg[l];
+				sh.u_negs += d;
+			LANE0_END
 		}
 	}
+	LANE0
+		if(sh.u_negs > 0) VDL2_CNT_ADD(cnt, CNT_SLICER_NEG_IDX, sh.u_negs);
+	LANE0_END
 
 	K5_MARK(0);
 	// 2. descramble + pack data and FEC octets LSB-first (bitstream.c:70-81,94-107): the scrambling sequence comes an octet at a time

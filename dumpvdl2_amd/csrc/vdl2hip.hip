@@ -38,7 +38,8 @@ constexpr int kHistory = 65536;          // decimated samples kept behind the ne
 constexpr int kNumEv = 12;            // profiling: {start, stop} of K1, K2, K3, K4, K4b, K5
 constexpr int kColdParts = 4;         // pieces a cold-start block is copied and channelised in
 constexpr size_t kColdMinBytes = 8u << 20;
-constexpr int kSlots = 3;             // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered)
+constexpr uint32_t kDeferBursts = 256, kDeferScans = 512;   // referee: bursts of one feed that may wait for their scans, stretches they may wait for (what does not fit is scanned on the spot)
+constexpr int kSlots = VDL2HIP_MAX_DRAIN_LAG + 1;   // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered).  Four: with the referee a feed's way through the device - front, walk + check, bursts + their scans - is three fronts long
 
 }  // namespace
 
@@ -48,6 +49,7 @@ struct OutSlot {
 	OutMail *d_mail = nullptr; OutCtl *d_ctl = nullptr;   // control block + the first few delivered frames, contiguous (d_ctl = &d_mail->ctl): one small copy brings both
 	OutFrame *d_frames_out = nullptr; uint8_t *d_pool_out = nullptr;    // what k_frame_finish delivers (no tombstones, no holes): what the host copies
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
+	uint32_t *d_dq = nullptr; ScanReq *d_sq = nullptr;      // referee, long feeds: the bursts that wait for a scan, the stretches they wait for (counts: d_rqn[1], d_rqn[2])
 	RefReq *d_rq = nullptr; uint32_t *d_rqn = nullptr, *d_rqflag = nullptr;   // referee, optimistic mode: this feed's decisions to check, its "walk again" flags
 	OutMail *h_mail = nullptr;             // pinned
 	hipEvent_t done = nullptr, ev_front = nullptr, ev_chan = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
@@ -413,6 +415,8 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 // well, so that these latency-bound kernels run beside the sync screening (few registers: they fit in beside it) instead of taking
 // workgroup slots from a channeliser (whose four waves per SIMD own the whole register file: every back-end workgroup keeps one
 // channeliser workgroup off its CU for as long as it lives).
+// (the kernel is compiled per sample format)
+#define LAUNCH_SCAN_MULTI(how, ...) do { if(c->fmt == 1) how(k_ref_scan_multi<1>, __VA_ARGS__); else how(k_ref_scan_multi<0>, __VA_ARGS__); } while(0)
 static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	const int64_t D = sl.back_D, k0 = sl.back_k0;
 	// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
@@ -437,7 +441,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	if(D > 0) {
 		const int64_t k1 = k0 + D;
 		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
-		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(5 * sl.seq + 1),
+		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(8 * sl.seq + 1),
 		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
 		int64_t seglen = D;
 		if(nseg >= 2) {
@@ -454,6 +458,8 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		if(k4.rq) {
 			// referee, optimistic mode (long feeds): the decisions within the margin that the walk took are checked now, all at once, and
 			// the (rare) channel one of whose decisions does not stand is stitched again
+			// (the stretches first, many side by side - k_ref_scan_multi - then the decisions on them, a wavefront each)
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(c->rq_cap / kScanLanes), dim3(64 * (1 + kScanProd)), 0, sb_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, c->rq_cap, k1);
 			hipLaunchKernelGGL(k_ref_verify, dim3(1024), dim3(64), 0, sb_, k4);
 			if(nseg >= 2) {
 				K4sArgs k4a{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, k0, seglen, c->d_segstats, 1 };
@@ -481,11 +487,20 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			HIPCHK(hipEventRecord(sl.ev_nf, sn_));
 		}
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, c->C,
-		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(5 * sl.seq + 5) };
+		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(8 * sl.seq + 5), BurstDefer{} };
+		// referee, long feeds: a burst that needs a scan is listed by the first pass, the scans run side by side, a second pass decodes the listed bursts
+		const bool defer5 = c->referee && c->ref_optimistic && !small && ((c->ref_kinds >> REF_SYMBOLS) & 1);
+		if(defer5) k5.df = BurstDefer{ sl.d_dq, sl.d_rqn + 1, kDeferBursts, sl.d_sq, sl.d_rqn + 2, kDeferScans, 1 };
 		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: no bursts to decode)
 		const unsigned k5_lds = (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves);
 		if(small) hipExtLaunchKernelGGL(k_nf_burst, dim3(nf_grid + sl.k5_waves / kBurstWaves), dim3(64 * kNfWaves), std::max(nf_lds, k5_lds), s5_, EV(8), EV(11), 0, k4b, k5, (uint32_t)nf_grid);
-		else hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), EV(11), 0, k5);
+		else if(!defer5) hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), EV(11), 0, k5);
+		else {
+			hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), (hipEvent_t) nullptr, 0, k5);
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kDeferScans / kScanLanes), dim3(64 * (1 + kScanProd)), 0, s5_, k5.ref, (uint32_t)(8 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), (uint32_t)kDeferScans, (int64_t)(k0 + D));
+			K5Args k5b = k5; k5b.df.pass = 2; k5b.ref_launch = (uint32_t)(8 * sl.seq + 7);
+			hipExtLaunchKernelGGL(k_burst, dim3(kDeferBursts / kBurstWaves / 4), dim3(64 * kBurstWaves), k5_lds, s5_, (hipEvent_t) nullptr, EV(11), 0, k5b);
+		}
 		if(!small) HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
 		// record chunks of kFrameChunk: enough workgroups for the records the burst decoder's wavefronts own, at most 256
 		const unsigned ff_grid = std::min(256u, (sl.k5_waves * (unsigned)kResSlots * 2 / kFrameChunk + kFrameWaves - 1) / kFrameWaves);
@@ -536,10 +551,10 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(!c) return;
 	OnDevice dev_guard(c);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
-	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_in[0], c->d_in[1], c->d_in[2], c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
+	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
 	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
-		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag };
+		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag, sl.d_dq, sl.d_sq };
 		for(void *p : q) if(p) (void)hipFree(p);
 		if(sl.h_mail) (void)hipHostFree(sl.h_mail);
 		if(sl.done) (void)hipEventDestroy(sl.done);
@@ -551,7 +566,9 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 		for(int i = 0; i < kNumEv; i++) if(sl.ev[i]) (void)hipEventDestroy(sl.ev[i]);
 	}
 	if(c->h_stage) (void)hipHostFree(c->h_stage);
-	{ void *q[] = { c->d_refhist, c->d_ref[0], c->d_ref[1], c->d_ref[2], c->d_refdone, c->d_refdonen, c->d_refstats, c->d_mix, c->d_refdbg, c->d_ws_snap, c->d_cnt_snap }; for(void *p : q) if(p) (void)hipFree(p); }
+	for(auto &p : c->d_in) if(p) (void)hipFree(p);
+	for(auto &p : c->d_ref) if(p) (void)hipFree(p);
+	{ void *q[] = { c->d_refhist, c->d_refdone, c->d_refdonen, c->d_refstats, c->d_mix, c->d_refdbg, c->d_ws_snap, c->d_cnt_snap }; for(void *p : q) if(p) (void)hipFree(p); }
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
 	for(auto &e : c->cold.ev) if(e) (void)hipEventDestroy(e);
 	if(c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
@@ -649,7 +666,6 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	}
 	DEV_ALLOC(c->d_bf, sizeof(BlockForm)); DEV_ALLOC(c->d_lut, sizeof(Lut4) * 256); DEV_ALLOC(c->d_tab, sizeof(Tables));
 	DEV_ALLOC(c->d_dphi, 4 * count); DEV_ALLOC(c->d_freq, 4 * count); DEV_ALLOC(c->d_ppmthr, 4 * count);
-	static_assert(kSlots == 3, "vdl2hip_destroy() lists the input buffers one by one");
 	DEV_ALLOC(c->d_carry[0], 4 * kMaxOversample); DEV_ALLOC(c->d_carry[1], 4 * kMaxOversample);
 	const size_t nring = (size_t)count * cap;
 	DEV_ALLOC(c->d_y, nring * sizeof(cf32)); DEV_ALLOC(c->d_pf, nring * sizeof(cf32));
@@ -728,8 +744,9 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		if(const char *e = getenv("VDL2HIP_REF_KINDS")) c->ref_kinds = atoi(e) & 7;                          // (development: 1 candidates, 2 headers, 4 symbols)
 		DEV_ALLOC(c->d_ws_snap, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt_snap, (size_t)count * kNumCounters * 8);
 		for(auto &sl : c->slot) {
-			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 4); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
-			DEV_CHK(hipMemset(sl.d_rqn, 0, 4)); DEV_CHK(hipMemset(sl.d_rqflag, 0, (size_t)count * 4));
+			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 16); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
+			DEV_ALLOC(sl.d_dq, (size_t)kDeferBursts * 4); DEV_ALLOC(sl.d_sq, (size_t)kDeferScans * sizeof(ScanReq));
+			DEV_CHK(hipMemset(sl.d_rqn, 0, 16)); DEV_CHK(hipMemset(sl.d_rqflag, 0, (size_t)count * 4));
 		}
 	}
 
@@ -1089,6 +1106,32 @@ int vdl2hip_debug_exact_window_many(vdl2hip_ctx *c, uint32_t chan, int64_t n_lo,
 	int n = 0; for(int v : h) n += v;
 	return n;            // stretches done (of `count`)
 }
+// test hook (not declared in vdl2hip.h): the same through k_ref_scan_multi - `count` stretches (chan[i], lo[i], hi[i]) side by side;
+// returns the number of scans run, *ms = the kernel's time
+int vdl2hip_debug_scan_multi(vdl2hip_ctx *c, const int32_t *chan, const int64_t *lo, const int64_t *hi, uint32_t count, float *ms) {
+	if(!c || !c->d_refhist || c->feed_no == 0 || count == 0 || count > 65536 || !chan || !lo || !hi) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	std::vector<ScanReq> h(count);
+	for(uint32_t i = 0; i < count; i++) { if(chan[i] < 0 || chan[i] >= c->C) return VDL2HIP_E_INVAL; h[i] = ScanReq{ chan[i], REF_CANDIDATE, lo[i], hi[i] }; }
+	ScanReq *d_sq = nullptr; uint32_t *d_n = nullptr;
+	if(hipMalloc((void **)&d_sq, sizeof(ScanReq) * (size_t)count) != hipSuccess || hipMalloc((void **)&d_n, 4) != hipSuccess) { if(d_sq) (void)hipFree(d_sq); return VDL2HIP_E_NOMEM; }
+	uint32_t before[8] = {0}, after[8] = {0};
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess
+		&& hipMemcpy(d_sq, h.data(), sizeof(ScanReq) * (size_t)count, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_n, &count, 4, hipMemcpyHostToDevice) == hipSuccess
+		&& hipMemcpy(before, c->d_refstats, sizeof before, hipMemcpyDeviceToHost) == hipSuccess;
+	if(ok) LAUNCH_SCAN_MULTI(hipExtLaunchKernelGGL, dim3((count + kScanLanes - 1) / kScanLanes), dim3(64 * (1 + kScanProd)), 0, c->stream, e0, e1, 0, c->d_ref[(c->feed_no - 1) % kSlots], 0xfffeu,
+	                             (const ScanReq *)d_sq, (const RefReq *) nullptr, (const uint32_t *)d_n, count, (int64_t)c->k_total);
+	ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(after, c->d_refstats, sizeof after, hipMemcpyDeviceToHost) == hipSuccess;
+	float t = 0.f;
+	if(ok && ms) { (void)hipEventElapsedTime(&t, e0, e1); *ms = t; }
+	if(e0) (void)hipEventDestroy(e0);
+	if(e1) (void)hipEventDestroy(e1);
+	(void)hipFree(d_sq); (void)hipFree(d_n);
+	return ok ? (int)(after[0] - before[0]) : VDL2HIP_E_DEVICE;
+}
 int vdl2hip_debug_exact_window(vdl2hip_ctx *c, uint32_t chan, int64_t n_lo, int64_t n_hi) { return vdl2hip_debug_exact_window_many(c, chan, n_lo, n_hi, 1, 0, nullptr); }
 
 // test hook (not declared in vdl2hip.h): what the DPP controls the channeliser's scan relies on do on this device
@@ -1179,6 +1222,24 @@ int vdl2hip_debug_ref_log(vdl2hip_ctx *c, unsigned long long *out, size_t cap_en
 	if(n > 1000) n = 1000;
 	if(n > cap_entries) n = cap_entries;
 	if(n) HIPCHK(hipMemcpy(out, c->d_refdbg + 1, 32 * n, hipMemcpyDeviceToHost));
+	return (int)n;
+}
+
+// test hook (not declared in vdl2hip.h): the decisions the walk of the LAST feed has asked the referee to check (optimistic mode), as
+// (chan, kind, n, k0 of the feed) quadruples of int64; returns how many there were
+int vdl2hip_debug_read_requests(vdl2hip_ctx *c, int64_t *out, size_t cap) {
+	if(!c || !out) return VDL2HIP_E_INVAL;
+	OnDevice dev_guard(c);
+	int r = collect_pending(c);
+	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	if(c->feed_no == 0 || !c->referee) return 0;
+	OutSlot &sl = c->slot[(c->feed_no - 1) % kSlots];
+	uint32_t n = 0;
+	HIPCHK(hipMemcpy(&n, sl.d_rqn, 4, hipMemcpyDeviceToHost));
+	const uint32_t m = std::min<uint32_t>(n, c->rq_cap);
+	std::vector<RefReq> rq(m);
+	if(m) HIPCHK(hipMemcpy(rq.data(), sl.d_rq, (size_t)m * sizeof(RefReq), hipMemcpyDeviceToHost));
+	for(uint32_t i = 0; i < m && i < cap; i++) { out[4 * i] = rq[i].chan; out[4 * i + 1] = rq[i].kind; out[4 * i + 2] = rq[i].n; out[4 * i + 3] = sl.back_k0; }
 	return (int)n;
 }
 

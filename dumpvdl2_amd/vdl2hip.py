@@ -34,6 +34,7 @@ AVLC_COUNTER_NAMES = [
 NUM_AVLC_COUNTERS = len(AVLC_COUNTER_NAMES)
 AVLC_OK, AVLC_TOO_SHORT, AVLC_BAD_FCS = 0, 1, 2
 ABI_VERSION = 5
+MAX_DRAIN_LAG = 3                     # include/vdl2hip.h: VDL2HIP_MAX_DRAIN_LAG
 EXPORTS = [
     "vdl2hip_abi_version", "vdl2hip_strerror", "vdl2hip_create", "vdl2hip_destroy", "vdl2hip_feed",
     "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
@@ -300,6 +301,14 @@ class Receiver:
         f.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_int64, C.c_uint32, C.c_int64, C.POINTER(C.c_float)]
         ms = C.c_float(0)
         return self._chk(f(self.h, chan, n_lo, n_hi, count, stride, C.byref(ms)), "vdl2hip_debug_exact_window_many"), ms.value
+
+    def scan_multi(self, chans, los, his):
+        """test hook: the stretches (chans[i], los[i] .. his[i]) made exact side by side (k_ref_scan_multi) -> (scans run, kernel ms)"""
+        f = self.L.vdl2hip_debug_scan_multi
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+        ch = np.ascontiguousarray(chans, dtype=np.int32); lo = np.ascontiguousarray(los, dtype=np.int64); hi = np.ascontiguousarray(his, dtype=np.int64)
+        ms = C.c_float(0)
+        return self._chk(f(self.h, ch.ctypes.data, lo.ctypes.data, hi.ctypes.data, len(ch), C.byref(ms)), "vdl2hip_debug_scan_multi"), ms.value
 
     def read_sync(self, chan: int, first: int, count: int):
         """test hook: (pf [count, 2] = tabulated {pherr with the referee's mark as its sign, slope}, cand [count] candidate bits) of one channel"""

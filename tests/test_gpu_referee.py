@@ -49,7 +49,7 @@ def test_scan_is_bit_exact(vh, oracle_mod, fmt, block):
     nch = len(cfg.freqs)
     rng = np.random.default_rng(5)
     # ... is close to the oracle's but not it; the stretches the scan has been over are it, bit for bit
-    checked = 0
+    checked = differed = 0
     for c in range(nch):
         # (with short feeds: what the LAST feed can reach - its own block and the history ring, 2^18 samples of run-up + the longest burst)
         for lo in ((0, 17, int(rng.integers(20000, D - 6000)), D - 400) if not block else (int(rng.integers(D - 40000, D - 6000)), D - 3000, D - 400)):
@@ -59,12 +59,49 @@ def test_scan_is_bit_exact(vh, oracle_mod, fmt, block):
             after = rx.read_decimated(c, lo, hi - lo + 1)
             want = tr[c, lo:hi + 1]
             assert after.tobytes() == want.tobytes(), f"channel {c} [{lo}, {hi}]: scan differs from the oracle's stream (max {np.abs(after - want).max():.3e})"
-            if lo > 1000:
-                assert before.tobytes() != want.tobytes()      # (the channeliser's own samples are not bit-identical: otherwise this test shows nothing)
+            differed += before.tobytes() != want.tobytes()      # (a stretch an earlier scan went over is the oracle's already)
             checked += 1
     assert checked >= 2 * nch
+    assert differed >= nch, "the channeliser's own samples were bit-identical to the oracle's: this test shows nothing"
     s = rx.stats()
     assert s["referee_scans"] + s["referee_cached"] == checked and s["referee_scans"] >= nch and s["referee_refused"] == 0, s   # (a scan covers whole blocks of 256 samples: some stretches had been done)
+    rx.close(); o.close()
+
+
+@pytest.mark.parametrize("fmt,block", [(1, None), (0, 262144)])
+def test_many_scans_side_by_side_are_bit_exact(vh, oracle_mod, fmt, block):
+    """k_ref_scan_multi: a workgroup runs 32 recursions at once (lane = request), two wavefronts feed it - the same arithmetic"""
+    cfg, iq, _, _ = cases.load("config2_1s")
+    raw = iq.view(np.uint8) if fmt == 1 else np.clip(np.rint(iq.astype(np.float64) / 256.0 + 127.5), 0, 255).astype(np.uint8)
+    sb = 4 if fmt == 1 else 2
+    D = raw.size // sb // cfg.oversample
+    o, tr = _oracle_trace(oracle_mod, cfg, raw, fmt, D)
+    rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, fmt, cfg.rx_max_ppm, max_block_bytes=raw.size)
+    rx.debug_option("referee", 0)
+    step = block or raw.size
+    for k in range(0, raw.size, step):
+        rx.feed(raw[k:k + step])
+    rx.drain()
+    nch = len(cfg.freqs)
+    rng = np.random.default_rng(11)
+    n = 75                                           # three workgroups, the last one partly filled
+    lo_min = 0 if not block else D - 30000           # (short feeds: what the last feed can reach)
+    chans = rng.integers(0, nch, n); los = rng.integers(lo_min, D - 6000, n); his = los + rng.integers(20, 900, n)
+    his[::7] += 5000                                 # unequal lengths: the longest decides how long the workgroup runs
+    chans[40], los[40], his[40] = chans[39], los[39], his[39]      # the same stretch twice in one workgroup
+    if not block:
+        los[3], his[3] = 0, 300                      # the stream's own start: zero state, exactly
+    his = np.minimum(his, D - 1)
+    before = [rx.read_decimated(int(c), int(a), int(b - a + 1)) for c, a, b in zip(chans, los, his)]
+    ran, ms = rx.scan_multi(chans, los, his)
+    assert 0 < ran <= n - 1, ran
+    differed = 0
+    for c, a, b, bf in zip(chans, los, his, before):
+        got = rx.read_decimated(int(c), int(a), int(b - a + 1)); want = tr[int(c), int(a):int(b) + 1]
+        assert got.tobytes() == want.tobytes(), f"channel {c} [{a}, {b}]: differs from the oracle's stream (max {np.abs(got - want).max():.3e})"
+        differed += bf.tobytes() != want.tobytes()
+    assert differed >= n // 2
+    assert rx.stats()["referee_refused"] == 0
     rx.close(); o.close()
 
 
