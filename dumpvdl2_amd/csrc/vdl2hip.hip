@@ -424,7 +424,9 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	// A short feed (fewer than two walk segments' worth of samples; the reference's own 320 000-byte blocks are 4 000) is a chain of kernels that each run for
 	// microseconds: its whole back end goes onto the FRONT stream, behind its own sync kernels - no event hand-offs between streams -
 	// with the three noise-floor passes as one kernel.  Whoever follows on the front stream is then behind it anyway.
-	const bool small = D > 0 && D < 2 * c->seg_min && nseg < 2 && !c->defer_back;
+	// (... and only when both sync kernels ARE on the front stream - sync_on 0, the product; the experiment builds' other placements hand the
+	// candidate bitmap over with an event the short cut does not wait for)
+	const bool small = D > 0 && D < 2 * c->seg_min && nseg < 2 && !c->defer_back && c->sync_on == 0;
 	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst[sl.seq % kSlots];
 	hipEvent_t *ev = sl.ev;
 	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
@@ -831,6 +833,10 @@ static int feed_host(vdl2hip_ctx *c, const void *buf, size_t nbytes, bool wait_c
 		// vdl2hip_feed(): `buf` is only ours during the call, so the copy is the blocking one - and a copy the host has waited for
 		// needs no event for the front stream to wait on (0.190 -> 0.174-0.181 ms per 320 000-byte block against the asynchronous copy
 		// + event + wait it replaces; profiles/r04_dropin_feed_path_ab.txt)
+		// RELIES ON: ROCm's hipMemcpy() returns when the data is in device memory, for pageable and page-locked sources alike (the
+		// front stream is hipStreamNonBlocking - no implicit ordering with the null stream the copy runs on - and nothing else makes
+		// it wait).  CUDA only promises that much for page-locked sources; on a HIP back end without it, use the asynchronous branch
+		// below (copy stream + event).  The call also waits for whatever else the process has on the legacy default stream.
 		HIPCHK(hipMemcpy(c->d_in[k], buf, nbytes, hipMemcpyHostToDevice));
 	} else {
 		HIPCHK(hipMemcpyAsync(c->d_in[k], buf, nbytes, hipMemcpyHostToDevice, c->stream_copy));

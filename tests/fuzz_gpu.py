@@ -7,17 +7,19 @@ per-wavefront output shares and the compaction behind them.
 usage: python tests/fuzz_gpu.py [seconds] [seed0] [plain|extreme|rejects|all]      one line per seed, a summary at the end;
 exit status 1 if any seed fails (see below).
 
-Per seed: frames (octets, integer metadata) identical, floats within SURVEY 8.5's tolerances, burst timing identical except for
-counted ties (tests/util.compare_at_full_size), the reference's 18 counters identical except for the failure bookkeeping of bursts
-that deliver nothing (util.compare_reference_counters, not strict) - both exceptions are tallied in the summary.
+Per seed: frames (octets, integer metadata), burst timing and the reference's 18 counters IDENTICAL to the oracle's on every channel,
+floats within SURVEY 8.5's tolerances (tests/util.compare_at_full_size / compare_reference_counters, strict).  Any seed that differs
+fails the run.
 
 These captures are harsher than the bench workloads on purpose (noise up to the decoding threshold, injected symbol errors, bursts
 cut off by the next one): they are full of decisions that hinge on one symbol, and the channeliser's samples differ from the
-reference's by ~1e-5, so a seed in fifty or so differs from the oracle in a frame or a counter.  Such a seed is then
-decided, not shrugged off: the decimated stream is read back from the GPU and run through the HOST build of the device logic
-(tests/hostsim, bit-exact with the oracle on the oracle's samples); if that reproduces the GPU's frames, timing and counters
-exactly, everything behind the channeliser did on the GPU what the reference does with those samples ("explained by the samples");
-if not, it is a defect and the run fails.  Every fourth agreeing seed gets the same check."""
+reference's by the reference's own rounding noise (~1e-5 rms).  Those decisions are the referee's: it takes them on the
+reference's own samples.  With VDL2HIP_REFEREE=0 in the environment the run shows what it is there for: a seed in fifty or so then
+differs from the oracle in a frame or a counter; the comparison then allows counted ties and the failure bookkeeping of bursts that
+deliver nothing, and a seed that differs is decided, not shrugged off - the decimated stream is read back from the GPU and run
+through the HOST build of the device logic (tests/hostsim, bit-exact with the oracle on the oracle's samples); if that reproduces
+the GPU's frames, timing and counters exactly, everything behind the channeliser did on the GPU what the reference does with those
+samples ("explained by the samples"); if not, it is a defect and the run fails.  Every fourth agreeing seed gets the same check."""
 import os
 import sys
 import time
@@ -29,6 +31,7 @@ from dumpvdl2_amd import synth, vdl2hip
 from oracle import pyoracle as po
 from util import compare_at_full_size, compare_reference_counters
 
+STRICT = os.environ.get("VDL2HIP_REFEREE", "1") != "0"
 EXACT = ("chan", "burst_ord", "idx", "octets", "synd_weight", "datalen_octets", "num_fec_corrections", "sync_sample", "end_sample")
 
 
@@ -88,7 +91,8 @@ def make_cfg(seed, profile):
     return cfg, rng
 
 
-def run_seed(seed, profile, always_check=False):
+def run_seed(seed, profile, always_check=False, strict=None):
+    strict = STRICT if strict is None else strict
     cfg, rng = make_cfg(seed, profile)
     iq, _ = synth.synthesize(cfg)
     raw = iq.view(np.uint8)
@@ -151,8 +155,8 @@ def run_seed(seed, profile, always_check=False):
     assert s["overflow_feeds"] == 0, f"{label}: overflow"
     D = o.decimated_count(0)
     try:
-        st = compare_at_full_size(fo, got, label=label, max_tie_frac=0.02)
-        which, nbad = compare_reference_counters(names, co, cg, label=label, strict=False, max_channels=max(1, nch // 4))
+        st = compare_at_full_size(fo, got, label=label, max_tie_frac=0.0 if strict else 0.02)
+        which, nbad = compare_reference_counters(names, co, cg, label=label, strict=strict, max_channels=max(1, nch // 4))
     except AssertionError as e:
         ok, why, y = device_logic_on_device_samples(rx, cfg, D, got, cg)
         tr = o2_trace(cfg, raw, D, fmt)
@@ -168,7 +172,7 @@ def run_seed(seed, profile, always_check=False):
     rx.close()
     return {"frames": len(fo), "ties": st["timing_ties"], "nf_ties": st["nf_update_ties"], "bookkeeping_channels": nbad, "feeds": nfeeds,
             "short_feeds": int(nsmall), "lag": lag, "nch": nch, "os": cfg.oversample, "fallbacks": s["front_sync_timeouts"], "host_build_check": check,
-            "fmt": "u8" if fmt == vdl2hip.FMT_U8 else "s16", "receiver": "one context" if ndev == 1 else f"group of {ndev}, {form}"}
+            "fmt": "u8" if fmt == vdl2hip.FMT_U8 else "s16", "referee_scans": s.get("referee_scans", 0), "referee_refused": s.get("referee_refused", 0), "receiver": "one context" if ndev == 1 else f"group of {ndev}, {form}"}
 
 
 def o2_trace(cfg, raw, D, fmt):
@@ -186,7 +190,7 @@ def main():
     profiles = ["plain", "extreme", "rejects"] if which == "all" else [which]
     t0 = time.time()
     tot = {"seeds": 0, "frames": 0, "ties": 0, "nf_ties": 0, "bookkeeping_channels": 0, "feeds": 0, "short_feeds": 0, "failed": 0,
-           "differ_from_oracle": 0, "of_those_explained_by_the_samples": 0, "host_build_checks": 0}
+           "differ_from_oracle": 0, "of_those_explained_by_the_samples": 0, "host_build_checks": 0, "referee_scans": 0, "referee_refused": 0, "strict": STRICT}
     i = 0
     while time.time() - t0 < budget:
         seed, profile = seed0 + i, profiles[i % len(profiles)]
@@ -195,7 +199,7 @@ def main():
             r = run_seed(seed, profile)
         except Differs as e:
             tot["seeds"] += 1; tot["differ_from_oracle"] += 1; tot["of_those_explained_by_the_samples"] += bool(e.from_samples)
-            tot["failed"] += not e.from_samples
+            tot["failed"] += (not e.from_samples) or STRICT
             print(f"seed {seed} {profile}: DIFFERS from the oracle ({'device logic == its host build on the device samples' if e.from_samples else 'DEVICE LOGIC DEFECT'}; "
                   f"samples differ from the oracle's by {e.rel:.2e} rms relative): {str(e)[:500]}", flush=True)
             continue
@@ -204,7 +208,7 @@ def main():
             print(f"seed {seed} {profile}: FAILED: {str(e)[:500]}", flush=True)
             continue
         tot["seeds"] += 1; tot["host_build_checks"] += bool(r.get("host_build_check"))
-        for k in ("frames", "ties", "nf_ties", "bookkeeping_channels", "feeds", "short_feeds"):
+        for k in ("frames", "ties", "nf_ties", "bookkeeping_channels", "feeds", "short_feeds", "referee_scans", "referee_refused"):
             tot[k] += r[k]
         print(f"seed {seed} {profile}: ok {r}", flush=True)
     print(f"SUMMARY ({time.time() - t0:.0f} s): {tot}", flush=True)

@@ -362,9 +362,8 @@ def test_many_channel_configs_vs_oracle(vh, oracle_mod, which, secs):
 
 def test_burst_dense_block_vs_oracle(vh, oracle_mod):
     """The lock-dense secondary workload of bench.py (config4_bursty: 4x the bursts and ~4.6x the gate-dropped locks of config4) at 3 s
-    against the oracle on all 256 channels: frames, timing and integer metadata identical; the reference's 18 counters identical on
-    every channel, or - the one exception DESIGN 5 describes, asserted in its SHAPE by util.compare_reference_counters - the failure
-    bookkeeping of bursts that deliver nothing differing by <= 2 on <= 1 % of the channels."""
+    against the oracle on all 256 channels: frames, timing and integer metadata identical, the reference's 18 counters identical on
+    every channel (the referee, DESIGN 5: no tie allowances, no bookkeeping exception)."""
     import os
     from dumpvdl2_amd import workloads, synth
     from util import compare_reference_counters, compare_at_full_size
@@ -378,9 +377,12 @@ def test_burst_dense_block_vs_oracle(vh, oracle_mod):
     cmp = compare_at_full_size(fo, fg, label="config4_bursty 3 s")
     names = list(o.counters(0).keys())
     co = [list(o.counters(c).values()) for c in range(len(cfg.freqs))]
-    which, nbad = compare_reference_counters(names, co, cnt, label="config4_bursty 3 s", strict=False)
+    which, nbad = compare_reference_counters(names, co, cnt, label="config4_bursty 3 s", strict=True)
+    assert cmp["timing_ties"] == 0 and cmp["nf_update_ties"] == 0 and nbad == 0
     assert sum(c[18] for c in co) > 10000                                # demod.ppm_reject: the gate really is busy
-    print("config4_bursty 3 s:", cmp, "bookkeeping differences:", which, "on", nbad, "channels")
+    s = rx.stats()
+    assert s["referee_scans"] > 0 and s["referee_refused"] == 0, s
+    print("config4_bursty 3 s:", cmp, "referee:", {k: v for k, v in s.items() if k.startswith("referee_")})
     rx.close()
 
 
@@ -752,6 +754,39 @@ def test_group_of_virtual_shards_from_c(vh, devices):
     g.close()
 
 
+@pytest.mark.parametrize("name", ["config3", "config4"])
+def test_group_of_eight_on_the_bench_configs_vs_oracle(vh, oracle_mod, name):
+    """BASELINE.json's configs[3] (32 channels) and configs[4] (256 channels) at 3 s through an 8-member vdl2hip_group - the channels
+    sharded 8 ways, here on one GPU - in both exchange forms, against the oracle: frames, burst timing and the reference's 18 counters
+    identical on every channel."""
+    import os
+    from dumpvdl2_amd import workloads, synth
+    from util import compare_reference_counters, compare_at_full_size
+    cfg = getattr(workloads, name)(3.0)
+    iq, bursts = synth.synthesize(cfg)
+    raw = iq.view(np.uint8)
+    nch = len(cfg.freqs)
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=cfg.oversample, max_ppm=cfg.rx_max_ppm)
+    o.process(raw, block_bytes=1 << 24, nthreads=min(nch, os.cpu_count() or 8))
+    fo = o.frames(); names = list(o.counters(0).keys()); co = [list(o.counters(c).values()) for c in range(nch)]
+    assert len(fo) > 100
+    for form in ("allgather", "broadcast"):
+        g = vh.ReceiverGroup(cfg.centerfreq, list(cfg.freqs), [0] * 8, cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=8_000_000)
+        g.set_exchange(form); g.set_drain_lag(vh.MAX_DRAIN_LAG)
+        got = []
+        for k in range(0, raw.size, 8_000_000):
+            g.feed(raw[k:k + 8_000_000]); got += g.drain()
+        g.set_drain_lag(0); got += g.drain()
+        assert g.exchange().startswith(form)
+        cnt = [list(g.counters(c).values()) for c in range(nch)]
+        assert truth_is_subset(bursts, got) == 0
+        cmp = compare_at_full_size(fo, got, label=f"{name} 3 s, group of 8, {form}")
+        which, nbad = compare_reference_counters(names, co, cnt, label=f"{name} 3 s, group of 8, {form}", strict=True)
+        assert cmp["timing_ties"] == 0 and cmp["nf_update_ties"] == 0 and nbad == 0
+        g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("devices", [[0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0]])
 def test_group_exchange_forms_agree(vh, devices):
     """The two ways vdl2hip_group_feed() puts a block on every member - stripes over each member's own host link + all-gather
@@ -940,18 +975,25 @@ def test_dpp_primitives_behave_as_the_scan_assumes(vh):
 
 
 @pytest.mark.parametrize("seed,profile", [(55, "plain"), (145, "plain"), (104, "extreme"), (4, "plain"), (8, "extreme"), (12, "rejects"),
-                                          (17, "extreme"), (20, "extreme"), (31, "plain"), (41, "extreme"), (9, "rejects")])
+                                          (17, "extreme"), (20, "extreme"), (31, "plain"), (41, "extreme"), (9, "rejects"),
+                                          (175, "plain"), (274, "plain"), (1014, "extreme"), (2274, "plain")])
 def test_random_capture_in_random_pieces(vh, seed, profile):
     """tests/fuzz_gpu.py's seeds as a test: a random capture fed in random pieces (long feeds with the speculative walk and the back
-    end on its own streams, short ones with everything on the front stream, in one stream; random drain lag).  Either the answer is
-    the oracle's (within util.compare_at_full_size / compare_reference_counters), or - seeds 55, 145, 104 were such cases in the 300 s run of
-    profiles/r04_gpu_fuzz.txt, before the channeliser's state went into normal form; they agree now - a frame or counter differs and the difference is *decided*: the decimated stream is
-    read back from the GPU and run through the host build of the device logic, which must reproduce the GPU's frames, burst timing
-    and 18 counters exactly (then the ~1e-5 by which the samples differ - the reference's own rounding - is the cause).  In both cases the host-build check is made."""
+    end on its own streams, short ones with everything on the front stream, in one stream; random drain lag).  The answer is the
+    oracle's - frames, burst timing, the reference's 18 counters on every channel, strictly.  (Seeds 55, 145, 104 differed in
+    profiles/r04_gpu_fuzz.txt, 175, 274, 1014 in round 4's CPU prediction over 2000 captures: decisions that hang on the reference's
+    own rounding - the referee takes them on the reference's own samples now.)  The host build of the device logic, run on the
+    decimated stream read back from the GPU, must give the GPU's answer as well."""
     import fuzz_gpu
-    try:
-        r = fuzz_gpu.run_seed(seed, profile, always_check=True)
-        assert r["host_build_check"] is True and r["frames"] > 0
-    except fuzz_gpu.Differs as e:
-        assert e.from_samples, str(e)
-        assert e.rel < 5e-5, f"the decimated stream differs from the oracle's by {e.rel:.2e} rms"
+    r = fuzz_gpu.run_seed(seed, profile, always_check=True, strict=True)
+    assert r["host_build_check"] is True and r["frames"] > 0 and r["ties"] == 0 and r["nf_ties"] == 0 and r["bookkeeping_channels"] == 0, r
+    assert r["referee_refused"] == 0, r
+
+
+@pytest.mark.xfail(strict=True, reason="without the referee a symbol at a slicer boundary is decided on the channeliser's samples: num_fec_corrections 1, the reference's 2 (DESIGN 5)")
+def test_random_capture_without_the_referee(vh, monkeypatch):
+    """what the referee is for: seed 175 with VDL2HIP_REFEREE=0 is NOT the oracle's answer (if this ever passes, the channeliser has
+    become the reference's scan bit for bit and the referee can go)"""
+    import fuzz_gpu
+    monkeypatch.setenv("VDL2HIP_REFEREE", "0")
+    fuzz_gpu.run_seed(175, "plain", always_check=False, strict=True)

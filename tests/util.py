@@ -2,8 +2,8 @@
 import numpy as np
 
 EXACT_KEYS = ("chan", "idx", "octets", "synd_weight", "datalen_octets", "num_fec_corrections", "burst_ord")
-# tolerances from SURVEY.md 8.5 (floats are compared, not bit-matched: the time-parallel
-# filter cannot reproduce the reference's rounding sequence)
+# tolerances from SURVEY.md 8.5 (floats are compared, not bit-matched: frame power and the noise floor are sums formed in another
+# order)
 TOL_DB = 0.05
 TOL_PPM = 0.01
 
@@ -28,14 +28,15 @@ def assert_frames_equal(ref, got, exact_samples=True, label=""):
         assert abs(a["ppm_error"] - b["ppm_error"]) <= TOL_PPM, f"{label}: ppm {a['ppm_error']} vs {b['ppm_error']}"
 
 
-def compare_at_full_size(ref, got, label="", max_tie_frac=5e-3):
-    """The parity gate of SURVEY 8.5 for runs with thousands of bursts: (channel, burst ordinal, idx, octets) and the integer
-    metadata identical, floats within tolerance.  Burst timing (sync_sample / end_sample - diagnostics of this repo, not
-    reference metadata) is required identical too, except for "ties": the time-parallel filter differs from the reference's
-    sequential one by ~1e-5 relative, and where calc_para_vertex lands within that of a rounding boundary the sync
-    point moves by one or two decimated samples (the evaluation grid has a stride of three; <= 2/10 of a symbol - the same
-    symbols are sliced, the same octets come out).  Such frames are counted, must stay under max_tie_frac of all frames, may
-    differ by at most 2 samples and get the looser ppm bound of a slope estimated a sample or two later.  Returns the statistics."""
+def compare_at_full_size(ref, got, label="", max_tie_frac=0.0):
+    """The parity gate of SURVEY 8.5 for runs with thousands of bursts: (channel, burst ordinal, idx, octets), the integer metadata
+    and the burst timing (sync_sample / end_sample - diagnostics of this repo, not reference metadata) identical, floats within
+    tolerance (0.01 ppm, 0.05 dB).  No exceptions: decisions that hang on the reference's own rounding are taken on the reference's
+    own samples (the referee).
+    max_tie_frac > 0 is for diagnosing a run WITHOUT the referee (dev/ scripts, VDL2HIP_REFEREE=0): the channeliser's stream
+    differs from the reference's sequential one by its rounding noise, and where calc_para_vertex lands within that of a rounding
+    boundary the sync point moves by one or two decimated samples (a "tie": <= 2 samples, looser ppm bound, and the noise-floor update
+    a frame sees may shift by one); such frames are counted and must stay under the fraction.  Returns the statistics."""
     ref = sorted(ref, key=frame_key)
     got = sorted(got, key=frame_key)
     assert len(ref) == len(got), f"{label}: frame count {len(got)} != reference {len(ref)}"
@@ -68,7 +69,7 @@ def compare_at_full_size(ref, got, label="", max_tie_frac=5e-3):
         if not tie:
             worst["ppm"] = max(worst["ppm"], abs(a["ppm_error"] - b["ppm_error"]))
         worst["frame_pwr_db"] = max(worst["frame_pwr_db"], abs(a["frame_pwr_dbfs"] - b["frame_pwr_dbfs"]))
-    lim = max(1, int(max_tie_frac * len(ref)))
+    lim = max(1, int(max_tie_frac * len(ref))) if max_tie_frac > 0 else 0
     assert ties <= lim and nf_ties <= lim, f"{label}: {ties} / {nf_ties} of {len(ref)} frames differ in burst timing / noise-floor update"
     return {"frames": len(ref), "timing_ties": ties, "nf_update_ties": nf_ties, "max_abs_diff": {k: round(v, 6) for k, v in worst.items()},
             "max_abs_diff_on_ties": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in on_ties.items()}}
