@@ -155,7 +155,7 @@ def test_drain_packed_equals_drain(vh):
     rx.close()
 
 
-@pytest.mark.parametrize("lag", [1, 2])
+@pytest.mark.parametrize("lag", [1, 2, 3])
 def test_pipelined_feeds_with_drain_lag(vh, lag):
     """Streaming mode (drain lag L): L+1 blocks in flight, frames arrive L blocks late, nothing is lost or reordered."""
     cfg, iq, _, gold = cases.load("config2_1s")
@@ -163,7 +163,7 @@ def test_pipelined_feeds_with_drain_lag(vh, lag):
     rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, max_block_bytes=1 << 20)
     rx.set_drain_lag(lag)
     with pytest.raises(vh.Vdl2HipError):
-        rx.set_drain_lag(3)
+        rx.set_drain_lag(vh.MAX_DRAIN_LAG + 1)
     got = []
     for k in range(0, raw.size, 1 << 20):
         rx.feed(raw[k:k + (1 << 20)])
