@@ -97,14 +97,20 @@ def run_seed(seed, profile, referee=False):
         return seed, profile, "differs", {"frames": len(fo), "why": str(e)[:200]}
 
 
+REFEREE = False
+
+
 def _job(a):
     try:
-        return run_seed(*a)
+        return run_seed(*a, referee=REFEREE)
     except Exception as e:  # noqa: BLE001
         return a[0], a[1], "error", {"why": f"{type(e).__name__}: {str(e)[:200]}"}
 
 
 def main():
+    global REFEREE
+    if "--referee" in sys.argv:          # the host build with its referee, compared strictly (what the device does by default)
+        REFEREE = True; sys.argv.remove("--referee")
     if sys.argv[1] == "--known":
         agree = 0
         for seed, profile in KNOWN:
@@ -119,13 +125,14 @@ def main():
     jobs = [(seed0 + i, PROFILES[i % 3]) for i in range(count)]
     import multiprocessing as mp
     t0 = time.time()
-    tot = {"seeds": 0, "frames": 0, "ties": 0, "nf_ties": 0, "bookkeeping_channels": 0, "differ": 0, "errors": 0}
+    tot = {"seeds": 0, "frames": 0, "ties": 0, "nf_ties": 0, "bookkeeping_channels": 0, "differ": 0, "errors": 0, "referee": REFEREE, "referee_windows": 0, "marked_candidates": 0}
     with mp.Pool(procs) as pool:
         for seed, profile, verdict, info in pool.imap(_job, jobs, chunksize=1):
             tot["seeds"] += 1
             if verdict == "ok":
                 for k in ("frames", "ties", "nf_ties", "bookkeeping_channels"):
                     tot[k] += info[k]
+                tot["referee_windows"] += info.get("referee", {}).get("exact_windows", 0); tot["marked_candidates"] += info.get("referee", {}).get("marked_candidates", 0)
             elif verdict == "differs":
                 tot["differ"] += 1; tot["frames"] += info.get("frames", 0)
                 print(f"seed {seed} {profile}: predicted to differ: {info['why']}", flush=True)
