@@ -199,7 +199,7 @@ struct Burst {
 	int64_t  t_first;                  // sample of the first symbol after the unique word
 	int64_t  sync_sample, end_sample, ord;
 	float    prev_phi0, vdphi, ppm;
-	float    vdphi_err;                // referee: bound on |vdphi - the reference's| (0: taken on the reference's own samples; < 0: unknown and not recomputable)
+	float    vdphi_err;                // referee: bound on |vdphi - the reference's| (0: taken on the reference's own samples; < 0: minus the bound, and the slope cannot be worked out again - its taps reach through the interval history)
 	int64_t  prev_n;                   // sample whose phase is prev_phi0 (-1: before the stream, phase 0; -2: unknown)
 	uint32_t tl_bits, syndrome;        // syndrome: bits 0-4 the header syndrome, bits 8.. the weight of the pattern it corrects (metadata->synd_weight)
 	int64_t  nf_upd;                   // number of mag_nf updates that preceded the sync (v->mag_nf at decode_frame())
@@ -705,10 +705,11 @@ VDL2_HD void sync_metric_ref(const float *ph, const float *eps2, int estride, co
 	}
 	for(int i = 1; i < kPreamble; i++) {
 		const float cur = ph[i] - T.pr_phase[i], diff = cur - cprev, e = sqrtf(eps2[i * estride]);
-		if(fabsf(fabsf(diff) - kPiBelow) <= e + eprev + 4e-6f) { if(nev < 2) { ev[nev] = i; kind[nev] = 0; } nev++; flip = i; }
+		if(e + eprev > 0.f && fabsf(fabsf(diff) - kPiBelow) <= e + eprev + 4e-6f) { if(nev < 2) { ev[nev] = i; kind[nev] = 0; } nev++; flip = i; }   // (two taps that are the reference's own: its decision, exactly)
 		cprev = cur; eprev = e;
 	}
 	alo = ahi = pherr;
+	if(s == 0.f && !big) { E_out = 0.f; return; }                 // (every tap is the reference's own)
 	if(nev == 1 && !big) alo = ahi = sync_metric_flipped(ph, T, flip, cut);
 	else if(nev == 2 && !big) { sync_metric_two(ph, T, ev, kind, pherr, alo, ahi); if(ahi >= kRefBig) big = true; }
 	E_out = (big || nev > 2) ? kRefBig : sqrtf(s);
@@ -779,6 +780,11 @@ struct WalkShared {
 	int64_t x_n, x_hdr; float x_p0, x_p3, x_f3, x_p6, u_verr; int32_t x_ok;
 	float hph[16], him2[16];           // header: phases and 1/|y|^2 of the sync point and the nine symbols
 	int64_t x_lo, x_hi;                // the stretch this wavefront has had made exact last (the candidates of one preamble ask for overlapping ones)
+	// referee, evaluations near an interval start (their taps reach through the interval history): squared phase bounds of the staged
+	// ring, the evaluations' values / ranges / error figures (two before the pass + 64), which of them are within the margin, and the
+	// interval start whose ring has been made exact (up to sample xs_hi)
+	// (they live in the candidate-word cache `cw`, which such a pass gives up: StaleRef)
+	int64_t xs_a, xs_hi;
 };
 
 // lowest lane whose flag is set, or -1.  Call from wave-uniform code after a WAVE_END.
@@ -834,6 +840,7 @@ VDL2_HD uint32_t wave_min64(const uint32_t *a) {
 }
 #endif
 
+struct StaleRef { float veps[320]; float sp[66], sf[66], slo[66], shi[66], sE[66]; int32_t smarg[64]; };
 // absolute index of the DM_INIT sample d steps before n (n inside the current interval); -1 = before the stream
 VDL2_HD int64_t seq_index(const WalkState &st, int64_t n, int d) {
 	if((int64_t)d <= n - st.a) return n - d;
@@ -895,7 +902,7 @@ VDL2_HD void walk_load(const WalkState *gstate, const EvalLog &lg, const uint32_
 		sh.spec_n = -1; sh.vring_a = -1; sh.nb = resume ? *nbursts_out : 0;
 		sh.first_fire = INT64_MAX;
 		sh.cw0 = 0; sh.cw_end = 0; sh.wbase = 0; sh.u_fire = 0; sh.u_n = 0;
-		sh.x_n = -1; sh.x_hdr = -1; sh.u_verr = 0.f; sh.x_ok = 0; sh.x_lo = 0; sh.x_hi = -1;
+		sh.x_n = -1; sh.x_hdr = -1; sh.u_verr = 0.f; sh.x_ok = 0; sh.x_lo = 0; sh.x_hi = -1; sh.xs_a = -1; sh.xs_hi = -1;
 	LANE0_END
 	WAVE_FOR(l)
 		if(l < kHdrParBits) sh.t_H[l] = T.hdr_H[l];
@@ -960,30 +967,126 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 				// stage the reference's phase ring as it stands around this interval start: vring[160+t] = sample a+t,
 				// vring[159-r] = the (r+1)-th DM_INIT sample before a (through the interval history)
 				const int64_t a0 = sh.st.a;
+				// Referee: these evaluations are not tabulated (K3 knows contiguous windows only), so their margins are worked out here,
+				// from the phase bounds of the staged samples; when the first evaluation that may fire is within its margin the ring is
+				// made the reference's own (the stretches it reads, through the interval history) and the pass is done again
+				const int64_t fwd_hi = (a0 + 159 < k_end - 1) ? a0 + 159 : k_end - 1;
+				const bool ref_here = v.ref != nullptr;
+				const bool exact_ring = ref_here && sh.xs_a == a0 && sh.xs_hi >= fwd_hi;      // (made the reference's own by an earlier turn of this loop)
+				StaleRef &sr = *reinterpret_cast<StaleRef *>(sh.cw);
+				static_assert(sizeof(StaleRef) <= sizeof(sh.cw), "the referee's scratch of a pass near an interval start fits the candidate-word cache");
+				if(ref_here) {
+					LANE0
+						sh.cw0 = 0; sh.cw_end = 0;                 // (the cached words are gone)
+					LANE0_END
+				}
 				WAVE_FOR(l)
-					cf32 yv[5]; bool ok[5];
+					cf32 yv[5]; bool ok[5]; int64_t nn[5];
 					for(int q = 0; q < 5; q++) {                  // the five loads of a lane first, then the five phases
 						const int j = l + 64 * q;
 						int64_t n;
 						if(j >= 160) { n = a0 + (j - 160); ok[q] = n < k_end; }
 						else { n = seq_index(sh.st, a0, 160 - j); ok[q] = n >= 0; }
+						nn[q] = n;
 						yv[q] = ok[q] ? v.Y(n) : cf32{0.f, 0.f};
 					}
 					for(int q = 0; q < 5; q++) sh.vring[l + 64 * q] = ok[q] ? phase_of(yv[q]) : 0.f;
+					if(ref_here && !exact_ring) for(int q = 0; q < 5; q++) sr.veps[l + 64 * q] = ok[q] ? ref_eps2(v, nn[q]) : 0.f;
 					if(l == 0) sh.vring_a = a0;
 				WAVE_END
-				WAVE_FOR(l)
-					if(l < nb) {
-						const int t = (int)(e + 3 * l - a0);
-						float ph[kPreamble];
-						for(int i = 0; i < kPreamble; i++) ph[i] = sh.vring[160 + t - 150 + 10 * i];
-						sync_metric(ph, T, sh.p[l], sh.f[l]);
+				if(!ref_here) {
+					WAVE_FOR(l)
+						if(l < nb) {
+							const int t = (int)(e + 3 * l - a0);
+							float ph[kPreamble];
+							for(int i = 0; i < kPreamble; i++) ph[i] = sh.vring[160 + t - 150 + 10 * i];
+							sync_metric(ph, T, sh.p[l], sh.f[l]);
+						}
+					WAVE_END
+					WAVE_FOR(l)
+						const float pm1 = l ? sh.p[l - 1] : sh.st.pherr1;
+						sh.flag[l] = (l < nb && pm1 < kSyncThr && sh.p[l] > pm1) ? 1 : 0;
+					WAVE_END
+				} else {
+					// evaluations e - 6, e - 3 (as far as they belong to this run: else PHERR_MAX, exactly) and the nb of the pass
+					const int64_t e0r = sh.st.e0;
+					for(int base = 0; base < (int)nb + 2; base += 64) {
+						WAVE_FOR(l)
+							const int i = base + l;
+							if(i < (int)nb + 2) {
+								const int64_t pos = e + 3 * (int64_t)(i - 2);
+								if(pos >= e0r && pos >= a0) {
+									const int t = (int)(pos - a0);
+									float ph[kPreamble], e2[kPreamble];
+									for(int k = 0; k < kPreamble; k++) { ph[k] = sh.vring[160 + t - 150 + 10 * k]; e2[k] = exact_ring ? 0.f : sr.veps[160 + t - 150 + 10 * k]; }
+									float pv, fv, E = 0.f, alo, ahi;
+									RefRange r;
+									if(exact_ring) { sync_metric(ph, T, pv, fv); r = RefRange{ pv, pv }; }
+									else { sync_metric_ref(ph, e2, 1, T, pv, fv, E, alo, ahi); r = ref_pherr_range(pv, alo, ahi, E); }
+									sr.sp[i] = pv; sr.sf[i] = fv; sr.sE[i] = E; sr.slo[i] = r.lo; sr.shi[i] = r.hi;
+								} else { sr.sp[i] = kPherrBig; sr.sf[i] = 0.f; sr.sE[i] = 0.f; sr.slo[i] = kPherrBig; sr.shi[i] = kPherrBig; }
+							}
+						WAVE_END
 					}
-				WAVE_END
-				WAVE_FOR(l)
-					const float pm1 = l ? sh.p[l - 1] : sh.st.pherr1;
-					sh.flag[l] = (l < nb && pm1 < kSyncThr && sh.p[l] > pm1) ? 1 : 0;
-				WAVE_END
+					WAVE_FOR(l)
+						int fl = 0, mg = 0;
+						if(l < nb) {
+							const int i = l + 2;
+							if(exact_ring) fl = (sr.sp[i - 1] < kSyncThr && sr.sp[i] > sr.sp[i - 1]) ? 1 : 0;
+							else {
+								const int vd = ref_candidate_verdict(RefRange{ sr.slo[i], sr.shi[i] }, RefRange{ sr.slo[i - 1], sr.shi[i - 1] }, sr.sf[i - 1], sr.sE[i - 1],
+								                                     RefRange{ sr.slo[i - 2], sr.shi[i - 2] }, max_ppm, ppm_thr);
+								fl = vd & 1; mg = (vd >> 1) & 1;
+							}
+							sh.p[l] = sr.sp[i]; sh.f[l] = sr.sf[i];
+						}
+						sh.flag[l] = fl; sr.smarg[l] = mg;
+					WAVE_END
+					LANE0
+						// (pherr[1], pherr[2] and prev_dphi as this run's evaluations before the pass left them: the same values by definition,
+						// worked out on the ring as it is now)
+						sh.st.pherr1 = sr.sp[1]; sh.st.pherr2 = sr.sp[0];
+						if(sr.sp[1] < kPherrBig) sh.st.prev_dphi = sr.sf[1];
+					LANE0_END
+					const int jm = wave_first_flag(sh.flag);
+					if(jm >= 0 && sr.smarg[jm]) {
+						// the first evaluation that may fire hangs on the reference's rounding
+#if !VDL2_DEVICE_PASS && defined(VDL2_HOST_DEBUG)
+						if(getenv("HOSTSIM_DEBUG_STALE")) fprintf(stderr, "stale chan %d a0 %lld e %lld jm %d spec %d: r6=[%g,%g] r3=[%g,%g] r0=[%g,%g] f3=%g E3=%g E0=%g\n", chan, (long long)a0, (long long)e, jm, (int)spec,
+							sr.slo[jm], sr.shi[jm], sr.slo[jm + 1], sr.shi[jm + 1], sr.slo[jm + 2], sr.shi[jm + 2], sr.sf[jm + 1], sr.sE[jm + 1], sr.sE[jm + 2]);
+#endif
+						if(spec) { LANE0 ctl->overflow = 1; LANE0_END break; }
+						bool ok = false;
+						if(v.rq) {
+							// optimistic mode: the channel is walked again, asking on the spot; this walk goes on with the samples as they are
+							LANE0
+								v.rq_flag[chan] = 1u;
+							LANE0_END
+						} else {
+							// the stretches the ring reads: the current interval's part, then the history's (runs of DM_INIT samples between bursts)
+							ok = ref_exact_window(v, a0, fwd_hi, sh.cw, REF_CANDIDATE);
+							int64_t run_hi = -1, run_lo = -1;
+							for(int r = 1; r <= 160 && ok; r++) {
+								const int64_t n = seq_index(sh.st, a0, r);
+								if(n < 0) break;
+								if(run_hi < 0) { run_hi = n; run_lo = n; }
+								else if(n >= run_lo - 512) run_lo = n;                    // (the same stretch, or near enough to be one scan)
+								else { ok = ref_exact_window(v, run_lo, run_hi, sh.cw, REF_CANDIDATE); run_hi = n; run_lo = n; }
+							}
+							if(ok && run_hi >= 0) ok = ref_exact_window(v, run_lo, run_hi, sh.cw, REF_CANDIDATE);
+							LANE0
+								sh.cw0 = 0; sh.cw_end = 0;
+								if(ok) { sh.xs_a = a0; sh.xs_hi = fwd_hi; }
+							LANE0_END
+						}
+						if(ok) continue;                            // the same pass again, on the reference's own samples
+						// (not made exact: the plain test on the values as they are)
+						WAVE_FOR(l)
+							const float pm1 = l ? sh.p[l - 1] : sr.sp[1];
+							sh.flag[l] = (l < nb && pm1 < kSyncThr && sh.p[l] > pm1) ? 1 : 0;
+						WAVE_END
+					}
+				}
 				const int jf = wave_first_flag(sh.flag);
 				const int64_t nexec = jf >= 0 ? jf + 1 : nb;
 				LANE0
@@ -993,7 +1096,9 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 						sh.u_y2 = jf >= 1 ? sh.p[jf - 1] : st.pherr1;
 						sh.u_y1 = jf >= 2 ? sh.p[jf - 2] : (jf == 1 ? st.pherr1 : st.pherr2);
 						sh.u_prevd = jf >= 1 ? sh.f[jf - 1] : st.prev_dphi;
-						sh.u_verr = -1.f;               // (taps through the interval history: the burst decoder cannot redo this slope)
+						// (taps through the interval history: the burst decoder cannot redo this slope - 0 when the ring is the reference's own,
+						// else minus the bound)
+						sh.u_verr = exact_ring ? 0.f : (ref_here ? -ref_slope_margin(sr.sE[jf + 1]) : -1.f);
 					} else {
 						const float o1 = st.pherr1;
 						st.pherr1 = sh.p[nb - 1];
@@ -1303,7 +1408,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 				WAVE_FOR(l)
 					int fl = 0;
 					if(l < 9) {
-						const float ev = sh.st.pb.vdphi_err < 0.f ? 0.f : sh.st.pb.vdphi_err;
+						const float ev = fabsf(sh.st.pb.vdphi_err);
 						fl = ref_symbol_marginal(sh.hph[l + 1], sh.hph[l], sh.st.pb.vdphi, sqrtf(sh.him2[l]) + sqrtf(sh.him2[l + 1]) + ev);
 					}
 					sh.flag[l] = fl;
@@ -2301,7 +2406,7 @@ VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const 
 	const int per_lane = (nsym + 63) / 64;
 	const bool ref_on = v.ref != nullptr;
 	float vdphi = b.vdphi, ppm = b.ppm;
-	const float verr = b.vdphi_err > 0.f ? b.vdphi_err : 0.f;
+	const float verr = fabsf(b.vdphi_err);
 	WAVE_FOR(l)
 		float pw = 0.f; int neg = 0; float qmin = kRefBig;
 		const int m0 = l * per_lane, m1 = m0 + per_lane < nsym ? m0 + per_lane : nsym;
