@@ -901,7 +901,7 @@ struct K3Args {
 	int32_t wpl;              // exact tier: flag words scanned per lane (1..kK3bWordsPerLane)
 	OutCtl *ctl; uint32_t k5_waves;   // the feed's output control block, reset here (the last kernel of the front, so that no copy has to do it)
 	// referee (nullptr: off): the feed's hook - written here from `refv`, for the same reason - and what the candidate verdict needs
-	RefChan *ref; RefChan refv; float max_ppm; const float *ppm_thr; int32_t ref_on; uint32_t *rq_n, *rq_flag;      // rq_n, rq_flag: the feed's list of decisions to check / its "walk again" flags, reset here;      // (ref != nullptr, ref_on == 0: the hook is written, the verdicts are the plain ones)
+	RefChan *ref; RefChan refv; float max_ppm; const float *ppm_thr; int32_t ref_on; uint32_t *rq_n, *rq_flag; RefBad *rq_bad;      // rq_n, rq_flag, rq_bad: the feed's list of decisions to check / its "walk again" flags / the decisions that fell, reset here;      // (ref != nullptr, ref_on == 0: the hook is written, the verdicts are the plain ones)
 };
 
 // K3: got_sync() metric (contiguous ring) + the candidate bitmap, in two tiers and two kernels.
@@ -994,7 +994,7 @@ constexpr int kK3bWordsPerLane = 4;      // at most; fewer when that leaves the 
 // (which read every tap from memory - five loads per tap with the referee - and kept three lanes in four idle during the metric).
 __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
 	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { reset_out_ctl(a.ctl, a.k5_waves); if(a.ref) *a.ref = a.refv; if(a.rq_n) { a.rq_n[0] = 0u; a.rq_n[1] = 0u; a.rq_n[2] = 0u; } }   // (rq_n[1], [2]: the burst decoder's lists, BurstDefer)
-	if(blockIdx.x == 0 && threadIdx.x == 0 && a.rq_flag) a.rq_flag[blockIdx.y] = 0u;
+	if(blockIdx.x == 0 && threadIdx.x == 0 && a.rq_flag) { a.rq_flag[blockIdx.y] = 0u; a.rq_bad[blockIdx.y].n = 0u; }
 	constexpr int kBack = 160, kSpan = kBack + 64;        // staged samples: base - 160 .. base + 63
 	// [wave][6 + bit]: metric of sample word*64 + bit (entries 0..5 = the six samples before the word), its slope, and - for the
 	// referee - its error figure E and its value with the one discontinuity taken the other way (vdl2_core.h: sync_metric_ref)
@@ -1124,13 +1124,13 @@ struct K4Args {
 	uint32_t ref_launch;       // ... and a number that tells this launch from the others (k_walk_stitch: + 1, k_ref_verify: + 2, k_walk_again: + 3)
 	// optimistic mode (rq != nullptr; vdl2_core.h: ref_verify): the feed's list of decisions to check, the "walk again" flag per channel,
 	// and where the state and counters a channel's walk starts from are kept
-	RefReq *rq; uint32_t *rq_n; uint32_t rq_cap; uint32_t *rq_flag; WalkState *ws_snap; unsigned long long *cnt_snap;
+	RefReq *rq; uint32_t *rq_n; uint32_t rq_cap; uint32_t *rq_flag; WalkState *ws_snap; unsigned long long *cnt_snap; RefBad *rq_bad;
 };
 
 __global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
 	__shared__ WalkShared sh;
 	const int c = blockIdx.x;
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch, a.rq, a.rq_n, a.rq_cap, a.rq_flag };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch, a.rq, a.rq_n, a.rq_cap, a.rq_flag, a.rq_bad ? a.rq_bad + c : nullptr };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	walk_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh, WalkSnap{ a.rq ? a.ws_snap : nullptr, a.cnt_snap });
@@ -1145,7 +1145,11 @@ __global__ __launch_bounds__(64, 4) void k_ref_verify(K4Args a) {
 		const RefReq r = a.rq[i];
 		const int c = r.chan;
 		ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + 2u };
-		if(!ref_verify(r, a.freq[c], a.max_ppm, a.ppm_thr[c], a.k_end, *a.tab, v, lds) && threadIdx.x == 0) a.rq_flag[c] = 1u;
+		if(!ref_verify(r, a.freq[c], a.max_ppm, a.ppm_thr[c], a.k_end, *a.tab, v, lds) && threadIdx.x == 0) {
+			a.rq_flag[c] = 1u;
+			const uint32_t k = atomicAdd(&a.rq_bad[c].n, 1u);
+			if(k < (uint32_t)kRefBad) a.rq_bad[c].at[k] = 4 * r.n + r.kind;
+		}
 		WAVE_SYNC();
 	}
 }
@@ -1177,7 +1181,7 @@ __global__ __launch_bounds__(64 * kWalkWaves, 4) void k_walk_spec(K4sArgs s) {
 	const int c = blockIdx.y, x = blockIdx.x * kWalkWaves + wave;
 	if(x >= 1 + 3 * (s.nseg - 1)) return;
 	WalkShared &sh = shw[wave];
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch, a.rq, a.rq_n, a.rq_cap, a.rq_flag };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch, a.rq, a.rq_n, a.rq_cap, a.rq_flag, a.rq_bad ? a.rq_bad + c : nullptr };
 	if(x == 0) return;         // (segment 0 is walked from the real state by the stitcher)
 	{
 		const int seg = 1 + (x - 1) / 3, r = (x - 1) % 3;
@@ -1200,7 +1204,7 @@ __global__ __launch_bounds__(256, 4) void k_walk_stitch(K4sArgs s) {
 	if(c >= a.nchan) return;
 	if(s.again && !a.rq_flag[c]) return;
 	StitchLds &lds = reinterpret_cast<StitchLds *>(k4_lds)[wave];
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + (s.again ? 3u : 1u), s.again ? nullptr : a.rq, a.rq_n, a.rq_cap, a.rq_flag };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + (s.again ? 3u : 1u), s.again ? nullptr : a.rq, a.rq_n, a.rq_cap, a.rq_flag, a.rq_bad ? a.rq_bad + c : nullptr };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	stitch_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	               a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg,
@@ -1327,6 +1331,7 @@ __global__ __launch_bounds__(64 * (1 + kScanProd)) void k_ref_scan_multi(RefChan
 			else { const RefReq q = rq[base + r]; c = q.chan; kind = q.kind; ref_request_window(q, k_end, n_lo, n_hi); }
 			const int64_t in_end = ps0[npiece - 1] + pn[npiece - 1];
 			if(n_lo < 0) n_lo = 0;
+			if(kind == REF_STALE) kind = REF_CANDIDATE;                  // (asked for by the candidate search: counted and switched with it)
 			bool go = n_hi >= n_lo && ((rp->kinds >> kind) & 1);
 			if(go) {
 				const int64_t last = in_end / os - 1;

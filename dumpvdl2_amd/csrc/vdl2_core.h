@@ -175,6 +175,9 @@ struct RefChan;
 // reference's atan2 (double, narrowed to float: demod.c:232,256) is evaluated where a decision reads a phase - the exact
 // tier of the sync kernel, the walker, the burst decoder - which is a few percent of the samples; the sync kernel's
 // screening tier works on a cheap single-precision phase of its own (phase_fast()).
+// the noted decisions of a channel and feed that did not stand: 4 n + kind each; n > kRefBad: more than the list holds, or some went unnoted
+constexpr int kRefBad = 6;
+struct RefBad { uint32_t n, pad_; int64_t at[kRefBad]; };
 struct ChanView {
 	const cf32     *y;                 // filtered + decimated samples (lp_re, lp_im)
 	const cf32     *pf;                // {pherr[0], freq_err} of got_sync() evaluated at n (contiguous ring) - valid where a preamble is near
@@ -187,6 +190,7 @@ struct ChanView {
 	// the reference's own afterwards by all the wavefronts it takes at once (ref_verify); a channel one of whose decisions does not
 	// stand is walked again from the feed's start.  rq_flag: per channel, "walk again" (nullptr: a speculative walk - it gives up instead)
 	struct RefReq  *rq = nullptr; uint32_t *rq_n = nullptr; uint32_t rq_cap = 0; uint32_t *rq_flag = nullptr;
+	struct RefBad  *rq_bad = nullptr;  // this channel's noted decisions that did NOT stand (written by the check, read when the channel is stitched again)
 	VDL2_HD cf32  Y(int64_t n) const { return y[(uint32_t)n & mask]; }
 	VDL2_HD float Phi(int64_t n) const { return n < 0 ? 0.f : phase_of(y[(uint32_t)n & mask]); }   // atan2(lp_im, lp_re); 0 before the stream starts
 	VDL2_HD cf32  PF(int64_t n) const { return pf[(uint32_t)n & mask]; }
@@ -560,7 +564,7 @@ constexpr int   kRefPre = 156, kRefPost = 96;   // a marginal candidate at n: ev
 // the stretch [n_lo, n_hi] of the channel's decimated stream becomes the reference's own; wave-uniform call, `scratch`: >= 2 KiB of
 // LDS the caller can spare.  false: not possible (no referee, or the raw input is no longer held) - the caller keeps its decision.
 VDL2_HD void ref_debug_log(const ChanView &v, int tag, int64_t a, float b, float c, float d);   // development aid (a no-op unless the build provides one)
-enum { REF_CANDIDATE = 0, REF_HEADER = 1, REF_SYMBOLS = 2 };   // who asks (statistics; a test hook can switch a kind off)
+enum { REF_CANDIDATE = 0, REF_HEADER = 1, REF_SYMBOLS = 2, REF_STALE = 3 };   // who asks (statistics; a test hook can switch a kind off)
 // a decision taken on the channeliser's samples although it lies within the margin (optimistic mode)
 struct RefReq {
 	int32_t  chan, kind;               // REF_CANDIDATE / REF_HEADER
@@ -938,7 +942,8 @@ VDL2_HD bool walk_clean(const WalkState &st) { return st.mode == 0 && st.e >= st
 // soon as the state is "clean" (walk_clean()).  Stopping anywhere is exact: it is what a feed boundary does.
 // `spec`: a speculative walk (spec_walk()) - it does not call the referee: at a decision within the margin it gives up (its result is
 // marked unusable, the stitcher walks that segment for real), so that a scan is run once, by the walk that counts, not by three hypotheses.
-VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, bool stop_clean, const Tables &T,
+// (always inlined: as a function of its own on the device - it has grown past the inliner's patience - the walker kernels fault)
+VDL2_HD __attribute__((always_inline)) void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, bool stop_clean, const Tables &T,
 		const ChanView &v, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh, bool spec = false) {
 	K4_BEGIN();
 	LANE0
@@ -1057,27 +1062,43 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 #endif
 						if(spec) { LANE0 ctl->overflow = 1; LANE0_END break; }
 						bool ok = false;
-						if(v.rq) {
-							// optimistic mode: the channel is walked again, asking on the spot; this walk goes on with the samples as they are
+						// the stretches the ring reads: the current interval's part, then the history's (runs of DM_INIT samples between bursts);
+						// optimistic mode: they are noted, the channel is flagged - it is walked again, asking on the spot, and finds them done -
+						// and this walk goes on with the samples as they are
+						const bool note = v.rq != nullptr;
+						if(note) {
 							LANE0
 								v.rq_flag[chan] = 1u;
 							LANE0_END
-						} else {
-							// the stretches the ring reads: the current interval's part, then the history's (runs of DM_INIT samples between bursts)
-							ok = ref_exact_window(v, a0, fwd_hi, sh.cw, REF_CANDIDATE);
+						}
+						{
+							int64_t wl[8], wh[8]; int nw = 1;
+							wl[0] = a0; wh[0] = fwd_hi;
 							int64_t run_hi = -1, run_lo = -1;
-							for(int r = 1; r <= 160 && ok; r++) {
+							for(int r = 1; r <= 160; r++) {
 								const int64_t n = seq_index(sh.st, a0, r);
 								if(n < 0) break;
 								if(run_hi < 0) { run_hi = n; run_lo = n; }
 								else if(n >= run_lo - 512) run_lo = n;                    // (the same stretch, or near enough to be one scan)
-								else { ok = ref_exact_window(v, run_lo, run_hi, sh.cw, REF_CANDIDATE); run_hi = n; run_lo = n; }
+								else { if(nw < 8) { wl[nw] = run_lo; wh[nw] = run_hi; nw++; } run_hi = n; run_lo = n; }
 							}
-							if(ok && run_hi >= 0) ok = ref_exact_window(v, run_lo, run_hi, sh.cw, REF_CANDIDATE);
-							LANE0
-								sh.cw0 = 0; sh.cw_end = 0;
-								if(ok) { sh.xs_a = a0; sh.xs_hi = fwd_hi; }
-							LANE0_END
+							if(run_hi >= 0 && nw < 8) { wl[nw] = run_lo; wh[nw] = run_hi; nw++; }
+							ok = !note;
+							for(int i = 0; i < nw; i++) {
+								if(note) {
+									LANE0
+										RefReq rq{};
+										rq.chan = chan; rq.kind = REF_STALE; rq.n = wl[i]; rq.t_first = wh[i];
+										(void)ref_log_request(v, rq);
+									LANE0_END
+								} else if(ok) ok = ref_exact_window(v, wl[i], wh[i], sh.cw, REF_CANDIDATE);
+							}
+							if(!note) {
+								LANE0
+									sh.cw0 = 0; sh.cw_end = 0;
+									if(ok) { sh.xs_a = a0; sh.xs_hi = fwd_hi; }
+								LANE0_END
+							}
 						}
 						if(ok) continue;                            // the same pass again, on the reference's own samples
 						// (not made exact: the plain test on the values as they are)
@@ -1217,7 +1238,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 								RefReq rq{};
 								rq.chan = chan; rq.kind = REF_CANDIDATE; rq.n = n;
 								rq.code = ref_candidate_code(y1, y2, y3, prevd, max_ppm, ppm_thr) | ((n - 6 >= e0) ? 0u : 0x10000u);
-								if(!ref_log_request(v, rq)) { if(v.rq_flag) v.rq_flag[chan] = 1u; else ctl->overflow = 1; }
+								if(!ref_log_request(v, rq)) { if(v.rq_flag) { v.rq_flag[chan] = 1u; if(v.rq_bad) v.rq_bad->n = (uint32_t)kRefBad + 1u; } else ctl->overflow = 1; }
 							}
 							if((exact_here || marked) && !is_candidate(y2, y3)) {
 								// on these samples the evaluation does not fire (the bitmap holds "may fire"): the run goes on
@@ -1422,7 +1443,7 @@ VDL2_HD void walk_run(int chan, uint32_t freq, float max_ppm, float ppm_thr, int
 						RefReq rq{};
 						rq.chan = chan; rq.kind = REF_HEADER; rq.n = ns; rq.t_first = sh.st.pb.t_first; rq.prev_n = sh.st.pb.prev_n;
 						rq.vdphi = sh.st.pb.vdphi; rq.vdphi_err = sh.st.pb.vdphi_err; rq.prev_phi0 = sh.st.pb.prev_phi0; rq.code = code;
-						if(!ref_log_request(v, rq)) { if(v.rq_flag) v.rq_flag[chan] = 1u; else ctl->overflow = 1; }
+						if(!ref_log_request(v, rq)) { if(v.rq_flag) { v.rq_flag[chan] = 1u; if(v.rq_bad) v.rq_bad->n = (uint32_t)kRefBad + 1u; } else ctl->overflow = 1; }
 						sh.x_hdr = ns;
 					LANE0_END
 				} else if(hdr_marginal) {
@@ -1507,7 +1528,7 @@ VDL2_HD void walk_snapshot(const WalkSnap &snap, int chan, const WalkState *gsta
 		if(l < kNumCounters) snap.cnt[(size_t)chan * kNumCounters + l] = cnt[l];
 	WAVE_END
 }
-VDL2_HD void walk_channel(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T,
+VDL2_HD __attribute__((always_inline)) void walk_channel(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T,
 		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
 		OutCtl *ctl, const EvalLog &lg, WalkShared &sh, WalkSnap snap = WalkSnap{nullptr, nullptr}) {
 	walk_snapshot(snap, chan, gstate, cnt);
@@ -1566,7 +1587,7 @@ struct StitchShared {
 };
 
 // one speculative walk: segment [b, k_end), evaluation grid phase r
-VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t b, int r, int64_t k_end, const Tables &T,
+VDL2_HD __attribute__((always_inline)) void spec_walk(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t b, int r, int64_t k_end, const Tables &T,
 		const ChanView &v, SpecOut *o, WalkShared &sh) {
 	EvalLog lg{ o->chunks, &o->nlog };
 	LANE0
@@ -1603,7 +1624,17 @@ VDL2_HD void spec_walk(int chan, uint32_t freq, float max_ppm, float ppm_thr, in
 }
 
 // adopt speculative segment `idx` (boundary b, grid phase r) if the real state in sh.st allows it
-VDL2_HD bool stitch_try_accept(int64_t b, int64_t kn, int seg, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh, StitchShared &ss, bool no_req = false) {
+// (again: the channel is stitched a second time because a noted decision did not stand - a walk that noted decisions is adopted
+// only if it was adopted the first time, so that they were checked, and none of them is on the channel's list of those that fell)
+VDL2_HD bool spec_requests_stand(const SpecOut &o, uint32_t checked, const RefBad *B) {
+	if(!B || !checked || B->n > (uint32_t)kRefBad) return false;
+	const uint32_t nr = o.nreq < (uint32_t)kSpecReq ? o.nreq : (uint32_t)kSpecReq;
+	for(uint32_t k = 0; k < nr; k++)
+		for(uint32_t i = 0; i < B->n; i++)
+			if(4 * o.req[k].n + o.req[k].kind == B->at[i]) return false;
+	return true;
+}
+VDL2_HD bool stitch_try_accept(int64_t b, int64_t kn, int seg, uint32_t cap_bursts, OutCtl *ctl, const EvalLog &lg, WalkShared &sh, StitchShared &ss, const SpecOut *again_spec = nullptr, const RefBad *bad = nullptr) {
 	LANE0
 		ss.u_ok = 0;
 		WalkState &st = sh.st;
@@ -1612,7 +1643,7 @@ VDL2_HD bool stitch_try_accept(int64_t b, int64_t kn, int seg, uint32_t cap_burs
 			const int idx = (seg - 1) * 3 + r;
 			const SpecHead &H = ss.head[idx];
 			const int64_t pre = (st.e - (b + r)) / 3;          // evaluations of the speculative walk that precede the join
-			if(H.ok && !(no_req && H.nreq) && H.n_first >= st.e && ss.njobs < kMaxSeg && (H.nlog == 0 || H.c_first.count > pre)) {
+			if(H.ok && !(again_spec && H.nreq && !spec_requests_stand(again_spec[idx], H.pad_, bad)) && H.n_first >= st.e && ss.njobs < kMaxSeg && (H.nlog == 0 || H.c_first.count > pre)) {
 				const int64_t base_e = st.evals - pre, base_b = st.bursts;
 				const int64_t sent_a = b - kSpecBack;
 				const int j = ss.njobs++;
@@ -1685,7 +1716,7 @@ VDL2_HD void stitch_materialize(const SpecOut *spec, WalkShared &sh, StitchShare
 // The feed [k0, k_end) of one channel in nseg segments of seglen samples; spec[(s-1)*3 + r] holds the speculative walks of
 // segments 1..nseg-1.  Segment 0 is walked from the real state right here (the walk that may call the referee is this one
 // wavefront per channel, in this kernel, and no other).
-VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k0, int64_t seglen, int nseg, int64_t k_end, const Tables &T,
+VDL2_HD __attribute__((always_inline)) void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k0, int64_t seglen, int nseg, int64_t k_end, const Tables &T,
 		const ChanView &v, WalkState *gstate, unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out,
 		OutCtl *ctl, const EvalLog &lg, const SpecOut *spec, WalkShared &sh, StitchShared &ss, uint32_t *seg_stats, WalkSnap snap = WalkSnap{nullptr, nullptr}, bool again = false) {
 	// `again` (optimistic mode, after the check): a channel one of whose noted decisions did not stand - its state and counters go
@@ -1714,10 +1745,10 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_th
 	for(int s = 1; s < nseg; s++) {
 		const int64_t b = k0 + (int64_t)s * seglen;
 		const int64_t kn = s + 1 < nseg ? b + seglen : k_end;
-		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss, again)) continue;
+		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss, again ? spec : nullptr, v.rq_bad)) continue;
 		stitch_materialize(spec, sh, ss);
 		walk_run(chan, freq, max_ppm, ppm_thr, kn, true, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
-		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss, again)) continue;
+		if(stitch_try_accept(b, kn, s, cap_bursts, ctl, lg, sh, ss, again ? spec : nullptr, v.rq_bad)) continue;
 		walk_run(chan, freq, max_ppm, ppm_thr, kn, false, T, v, cnt, bursts, cap_bursts, ctl, lg, sh);
 		LANE0
 			ss.walked++;
@@ -1752,11 +1783,14 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_th
 		if(v.rq && l < kSpecReq) {
 			// the decisions within the margin the adopted walks took: onto the feed's list, to be checked
 			for(int j = 0; j < nj; j++)
-				if((uint32_t)l < ss.head[ss.job_src[j]].nreq && !ref_log_request(v, spec[ss.job_src[j]].req[l])) v.rq_flag[chan] = 1u;
+				if((uint32_t)l < ss.head[ss.job_src[j]].nreq && !ref_log_request(v, spec[ss.job_src[j]].req[l])) { v.rq_flag[chan] = 1u; if(v.rq_bad) v.rq_bad->n = (uint32_t)kRefBad + 1u; }
 		}
 	WAVE_END
 	walk_store(sh, gstate, lg, ctl, nbursts_out);
 	LANE0
+		// (an adopted walk's noted decisions are on the feed's list now: if the channel is stitched again, the walk may be adopted again
+		// provided they all stood)
+		if(v.rq) for(int j = 0; j < nj; j++) if(ss.head[ss.job_src[j]].nreq) const_cast<SpecOut *>(spec)[ss.job_src[j]].h.pad_ = 1u;
 		if(seg_stats) { seg_stats[0] += (uint32_t)ss.accepted; seg_stats[1] += (uint32_t)ss.walked; }
 	LANE0_END
 }
@@ -1772,14 +1806,21 @@ VDL2_HD void stitch_channel(int chan, uint32_t freq, float max_ppm, float ppm_th
 VDL2_HD void ref_request_window(const RefReq &r, int64_t k_end, int64_t &lo, int64_t &hi) {
 	if(r.kind == REF_CANDIDATE) {
 		lo = (r.n - kRefPre) & ~255ll; hi = (r.n + kRefPost) | 255; if(lo < 0) lo = 0; if(hi > k_end - 1) hi = k_end - 1;
+	} else if(r.kind == REF_STALE) {                               // a stretch the ring of an interval start reads: [n, t_first], as the walk will ask for it
+		lo = r.n; hi = r.t_first;
 	} else {                                                        // header: sync point + nine symbols, and the carrier slope they are sliced with
 		lo = r.n - kRefPre; if(r.prev_n >= 0 && r.prev_n < lo) lo = r.prev_n;
 		hi = r.t_first + 8 * kSpsDec;
 	}
 }
-VDL2_HD bool ref_verify(const RefReq &r, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T, const ChanView &v, float *lds) {
+VDL2_HD __attribute__((always_inline)) bool ref_verify(const RefReq &r, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T, const ChanView &v, float *lds) {
 	int64_t lo, hi;
 	ref_request_window(r, k_end, lo, hi);
+	if(r.kind == REF_STALE) {
+		// nothing to compare: the walk has flagged the channel itself; the stretch is made exact for the walk-again to find
+		(void)ref_exact_window(v, lo, hi, nullptr, REF_CANDIDATE);
+		return true;
+	}
 	if(r.kind == REF_CANDIDATE) {
 		const int64_t n = r.n;
 		if(!ref_exact_window(v, lo, hi, nullptr, REF_CANDIDATE)) return true;
@@ -1815,7 +1856,7 @@ VDL2_HD bool ref_verify(const RefReq &r, uint32_t freq, float max_ppm, float ppm
 
 // a channel whose walk took a decision that does not stand: its state and counters back to what the feed started from, then the
 // whole feed again, sequentially, with the referee asked on the spot (most of what it asks for has been made exact by the check)
-VDL2_HD void walk_again(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T, const ChanView &v, WalkState *gstate,
+VDL2_HD __attribute__((always_inline)) void walk_again(int chan, uint32_t freq, float max_ppm, float ppm_thr, int64_t k_end, const Tables &T, const ChanView &v, WalkState *gstate,
 		unsigned long long *cnt, Burst *bursts, uint32_t cap_bursts, uint32_t *nbursts_out, OutCtl *ctl, const EvalLog &lg, WalkShared &sh, const WalkSnap &snap) {
 	LANE0
 		*gstate = snap.ws[chan];
@@ -2385,7 +2426,7 @@ struct BurstDefer { uint32_t *dq, *dq_n; uint32_t dq_cap; ScanReq *sq; uint32_t 
 
 // decode_vdl2_burst() DEC_DATA branch + decode_frame(): decode.c:259-380, 173-194.  burst_shared_init() first.
 // (df, tag: see BurstDefer - tag is what pass 1 lists the burst as)
-VDL2_HD void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const ChanView &v, unsigned long long *cnt,
+VDL2_HD __attribute__((always_inline)) void decode_burst(const Burst &b, uint32_t freq, const Tables &T, const ChanView &v, unsigned long long *cnt,
 		OutFrame *frames, uint8_t *pool, OutCtl *ctl, BurstShared &sh, const BurstDefer *df = nullptr, uint32_t tag = 0) {
 	// geometry again from TL (decode.c:233-256)
 	const uint32_t octets = b.tl_bits / 8 + (b.tl_bits % 8 != 0);

@@ -50,7 +50,7 @@ struct OutSlot {
 	OutFrame *d_frames_out = nullptr; uint8_t *d_pool_out = nullptr;    // what k_frame_finish delivers (no tombstones, no holes): what the host copies
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
 	uint32_t *d_dq = nullptr; ScanReq *d_sq = nullptr;      // referee, long feeds: the bursts that wait for a scan, the stretches they wait for (counts: d_rqn[1], d_rqn[2])
-	RefReq *d_rq = nullptr; uint32_t *d_rqn = nullptr, *d_rqflag = nullptr;   // referee, optimistic mode: this feed's decisions to check, its "walk again" flags
+	RefReq *d_rq = nullptr; uint32_t *d_rqn = nullptr, *d_rqflag = nullptr; RefBad *d_rqbad = nullptr;   // referee, optimistic mode: this feed's decisions to check, its "walk again" flags
 	OutMail *h_mail = nullptr;             // pinned
 	hipEvent_t done = nullptr, ev_front = nullptr, ev_chan = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
 	bool pending = false, ev_valid = false, fused = false; int ev_level = 0;
@@ -374,7 +374,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		// wavefronts of this feed's burst decoder: each owns kResSlots frame records of the output from the start, so a short block gets few
 		sl.k5_waves = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(16, (D * (int64_t)c->C) >> 14));
 		sl.k5_waves = (sl.k5_waves + kBurstWaves - 1) / kBurstWaves * kBurstWaves;
-		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0, sl.d_rqn, sl.d_rqflag };
+		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0, sl.d_rqn, sl.d_rqflag, sl.d_rqbad };
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
 		// on the front stream than a separate hipEventRecord.  (VDL2HIP_SYNC_ON=walk puts the exact tier in front of the walk on
 		// the walk stream, VDL2HIP_SYNC_ON=own both sync kernels on a stream of their own, so that the front stream goes on
@@ -444,7 +444,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		const int64_t k1 = k0 + D;
 		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(8 * sl.seq + 1),
-		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
+		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap, sl.d_rqbad };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
 		int64_t seglen = D;
 		if(nseg >= 2) {
 			seglen = (D + nseg - 1) / nseg;
@@ -556,7 +556,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
 	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
-		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag, sl.d_dq, sl.d_sq };
+		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag, sl.d_dq, sl.d_sq, sl.d_rqbad };
 		for(void *p : q) if(p) (void)hipFree(p);
 		if(sl.h_mail) (void)hipHostFree(sl.h_mail);
 		if(sl.done) (void)hipEventDestroy(sl.done);
@@ -748,6 +748,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		for(auto &sl : c->slot) {
 			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 16); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
 			DEV_ALLOC(sl.d_dq, (size_t)kDeferBursts * 4); DEV_ALLOC(sl.d_sq, (size_t)kDeferScans * sizeof(ScanReq));
+			DEV_ALLOC(sl.d_rqbad, (size_t)count * sizeof(RefBad)); DEV_CHK(hipMemset(sl.d_rqbad, 0, (size_t)count * sizeof(RefBad)));
 			DEV_CHK(hipMemset(sl.d_rqn, 0, 16)); DEV_CHK(hipMemset(sl.d_rqflag, 0, (size_t)count * 4));
 		}
 	}

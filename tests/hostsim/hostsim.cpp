@@ -53,7 +53,7 @@ struct Sim {
 	// referee: exact samples [nchan][exact_D] and the per-channel hooks; marg: candidates K3 marked as within the margin
 	std::vector<float> exact; int64_t exact_D = 0; std::vector<RefChan> rc; int64_t n_marg = 0, n_cand = 0, n_walk_windows = 0;
 	std::vector<float> pe, pa, pb;
-	bool optimistic = true; std::vector<RefReq> rq; uint32_t rq_n = 0; std::vector<uint32_t> rq_flag; std::vector<WalkState> ws_snap; std::vector<unsigned long long> cnt_snap; int64_t n_rewalk = 0, n_requests = 0;
+	bool optimistic = true; std::vector<RefReq> rq; uint32_t rq_n = 0; std::vector<uint32_t> rq_flag; std::vector<RefBad> rq_bad; std::vector<WalkState> ws_snap; std::vector<unsigned long long> cnt_snap; int64_t n_rewalk = 0, n_requests = 0;
 	std::vector<Burst> all_bursts;   // every burst descriptor the walker has emitted (debugging aid)
 };
 
@@ -196,13 +196,13 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 	s->ctl.cap_bursts = (uint32_t)s->bursts.size(); s->ctl.cap_frames = (uint32_t)s->frames.size(); s->ctl.cap_pool = (uint32_t)s->pool.size(); s->ctl.cap_log = s->cap_log;
 	static WalkShared wsh;
 	const bool opt = !s->rc.empty() && s->optimistic;
-	if(opt) { s->rq.resize(8192); s->rq_n = 0; s->rq_flag.assign(s->nchan, 0); s->ws_snap.resize(s->nchan); s->cnt_snap.resize((size_t)s->nchan * kNumCounters); }
+	if(opt) { s->rq.resize(8192); s->rq_n = 0; s->rq_flag.assign(s->nchan, 0); s->rq_bad.assign(s->nchan, RefBad{}); s->ws_snap.resize(s->nchan); s->cnt_snap.resize((size_t)s->nchan * kNumCounters); }
 	const WalkSnap snap{ opt ? s->ws_snap.data() : nullptr, opt ? s->cnt_snap.data() : nullptr };
 	std::vector<uint32_t> nb_first(s->nchan, 0);
 	for(int c = 0; c < s->nchan; c++) {
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
 		if(!s->rc.empty()) v.ref = &s->rc[c];
-		if(opt) { v.rq = s->rq.data(); v.rq_n = &s->rq_n; v.rq_cap = (uint32_t)s->rq.size(); v.rq_flag = s->rq_flag.data(); }
+		if(opt) { v.rq = s->rq.data(); v.rq_n = &s->rq_n; v.rq_cap = (uint32_t)s->rq.size(); v.rq_flag = s->rq_flag.data(); v.rq_bad = &s->rq_bad[c]; }
 		nb_first[c] = s->ctl.nbursts;
 		EvalLog lg{ &s->log[(size_t)c * s->cap_log], &s->nlog[c] };
 		uint32_t nbc = 0;
@@ -230,7 +230,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 			static float vlds[64];
 			ChanView vv = v; vv.rq = nullptr; vv.rq_n = nullptr; vv.rq_cap = 0; vv.rq_flag = nullptr;
 			const uint32_t nreq = s->rq_n < (uint32_t)s->rq.size() ? s->rq_n : (uint32_t)s->rq.size();
-			for(uint32_t i = 0; i < nreq; i++) { s->n_requests++; if(!ref_verify(s->rq[i], s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k1, s->T, vv, vlds)) s->rq_flag[c] = 1; }
+			for(uint32_t i = 0; i < nreq; i++) { s->n_requests++; if(!ref_verify(s->rq[i], s->freqs[c], s->max_ppm, ppm_gate_threshold(s->freqs[c], s->max_ppm), k1, s->T, vv, vlds)) { s->rq_flag[c] = 1; RefBad &B = s->rq_bad[c]; if(B.n < (uint32_t)kRefBad) B.at[B.n] = 4 * s->rq[i].n + s->rq[i].kind; B.n++; } }
 			s->rq_n = 0;
 			if(s->rq_flag[c] && nseg >= 2) {
 				s->n_rewalk++;

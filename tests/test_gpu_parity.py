@@ -976,7 +976,7 @@ def test_dpp_primitives_behave_as_the_scan_assumes(vh):
 
 @pytest.mark.parametrize("seed,profile", [(55, "plain"), (145, "plain"), (104, "extreme"), (4, "plain"), (8, "extreme"), (12, "rejects"),
                                           (17, "extreme"), (20, "extreme"), (31, "plain"), (41, "extreme"), (9, "rejects"),
-                                          (175, "plain"), (274, "plain"), (1014, "extreme"), (2274, "plain")])
+                                          (175, "plain"), (274, "plain"), (1014, "extreme"), (2274, "plain"), (1738, "plain")])
 def test_random_capture_in_random_pieces(vh, seed, profile):
     """tests/fuzz_gpu.py's seeds as a test: a random capture fed in random pieces (long feeds with the speculative walk and the back
     end on its own streams, short ones with everything on the front stream, in one stream; random drain lag).  The answer is the
