@@ -461,8 +461,11 @@ def group_from_c(case, args, torch, local, members=8):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             n = 0
+            t_call = 0.0                                   # host time inside vdl2hip_group_feed_pinned() alone: it only queues work (8 members x ~14 launches + the exchange)
             for _ in range(args.steps):
+                tc = time.perf_counter()
                 g.feed_pinned(pin.data_ptr(), case.nbytes)
+                t_call += time.perf_counter() - tc
                 n += g.drain_count()
             g.set_drain_lag(0)
             n += g.drain_count()
@@ -470,7 +473,7 @@ def group_from_c(case, args, torch, local, members=8):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             out["forms"][form] = {"ms_per_step": round(dt / args.steps * 1e3, 4), "value": round(case.nsamples * args.steps / dt / 1e6, 3),
-                                  "frames_per_step": n / args.steps, "ran_as": g.exchange()}
+                                  "frames_per_step": n / args.steps, "ran_as": g.exchange(), "host_ms_in_feed_call": round(t_call / args.steps * 1e3, 4)}
     finally:
         g.close()
         del pin

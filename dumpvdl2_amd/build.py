@@ -2,6 +2,7 @@
 import os
 import shutil
 import subprocess
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -33,10 +34,27 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc_path()] + FLAGS + ["-o", LIB, os.path.join(CSRC, "vdl2hip.hip")]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # (-save-temps: the device assembly comes out as a by-product, for the check below)
+    tmp = tempfile.mkdtemp(prefix="vdl2hip_build_")
+    try:
+        cmd = [hipcc_path()] + FLAGS + ["-save-temps=obj", "-o", os.path.join(tmp, "libvdl2hip.so"), os.path.join(CSRC, "vdl2hip.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=tmp)
+        # No out-of-line device function calls: every kernel of this library is one straight piece of code.  When the walker's call
+        # tree (walk_run & co.) was left to the inliner and grew past its patience, the kernels that called it faulted on the device
+        # (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION) - with nothing to see on the CPU build.  The functions concerned are
+        # always_inline; this is the guard for the next one.
+        calls = []
+        for f in os.listdir(tmp):
+            if f.endswith(".s") and "amdgcn" in f:
+                with open(os.path.join(tmp, f), errors="replace") as fh:
+                    calls += [ln.strip() for ln in fh if "s_swappc_b64" in ln]
+        if calls:
+            raise RuntimeError(f"the device code calls {len(calls)} function(s) out of line (mark them always_inline): {calls[:3]}")
+        shutil.move(os.path.join(tmp, "libvdl2hip.so"), LIB)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return LIB
 
 
