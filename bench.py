@@ -420,7 +420,8 @@ def measure_secondary(c2, name, oracle_check, args, dist, po):
     del fd
     rl = roofline_of(td, pmc_traffic(name, c2))
     step_hbm = td["dt"] / args.steps * 1e3
-    return {"workload": (f"configs[{WORKLOAD_INDEX[name]}] ({name})" if name in WORKLOAD_INDEX else name)
+    return {"name": name + ("_shard" if shard else ""),
+            "workload": (f"configs[{WORKLOAD_INDEX[name]}] ({name})" if name in WORKLOAD_INDEX else name)
                         + f": {c2.C} channels in the air, {c2.count} decoded here"
                         + (f" (channels {c2.first}..{c2.first + c2.count - 1}: a rank's share at N = 8)" if shard else "") + f", {c2.cfg.duration_s:g} s",
             "value": round(c2.nsamples * args.steps / th["dt"] / 1e6, 3), "value_hbm_resident": round(c2.nsamples * args.steps / td["dt"] / 1e6, 3),
@@ -827,11 +828,14 @@ def main():
             out[prefix + "channels"] = v["channels"]
             out[prefix + "oracle_identical"] = bool(v["oracle_identical"])
             out[prefix + "referee_scans"] = v["referee"].get("scans"); out[prefix + "referee_refused"] = v["referee"].get("refused")
-        if verified:
-            flat("parity_", verified)
-        for e in secondary:
-            if isinstance(e, dict) and e.get("verified"):
-                flat("parity_" + e["workload"].split("(")[1].split(")")[0] + "_", e["verified"])
+        try:
+            if verified:
+                flat("parity_", verified)
+            for e in secondary:
+                if isinstance(e, dict) and e.get("verified"):
+                    flat("parity_" + e.get("name", "secondary") + "_", e["verified"])
+        except Exception as e:  # noqa: BLE001 - the scalars repeat what config.verified holds; never lose the line over them
+            out["parity_scalars_error"] = f"{type(e).__name__}: {str(e)[:200]}"
         if referee_ab is not None:
             out["referee"] = referee_ab
         if world > 1:
