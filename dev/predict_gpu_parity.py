@@ -53,7 +53,7 @@ def exact_stream(cfg, raw, fmt, A, B, dphis, D):
     return y
 
 
-def run_seed(seed, profile, referee=False):
+def run_seed(seed, profile, referee=False, prescan=False):
     """referee: the host build asks its referee - the oracle's own decimated stream stands in for the device's sequential scan - and the
     comparison is strict (no tie allowances, all 18 counters on every channel)"""
     import fuzz_gpu
@@ -82,7 +82,7 @@ def run_seed(seed, profile, referee=False):
     hs = pyhostsim.HostSim(list(cfg.freqs), cfg.rx_max_ppm, cap_log2=21)
     hs.set_segments(6000, 8)
     if referee:
-        hs.set_exact(tr[:, :D, :])
+        hs.set_exact(tr[:, :D, :]); hs.set_prescan(prescan)      # (prescan: the device's VDL2HIP_REF_PRESCAN=1 - marked candidates' stretches made exact ahead of the walk)
     hs.feed(y)
     got = hs.frames()
     cg = [list(hs.counters(c)) for c in range(nch)]

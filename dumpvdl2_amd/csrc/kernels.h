@@ -100,6 +100,31 @@ typedef __attribute__((address_space(1))) const uint32_t ref_gu32;
 typedef __attribute__((address_space(1))) const uint16_t ref_gu16;
 typedef __attribute__((address_space(1))) const v4f ref_gf4;
 __device__ __forceinline__ float ref_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+// the list of stretches of a channel made exact: (lo / 256 : 32 bits, length / 256 : 16, launch : 16).  A stretch done by another
+// wavefront of THIS launch does not count: its samples may still sit in another XCD's L2; from the next launch on they are everybody's
+__device__ __forceinline__ bool ref_done_lookup(const unsigned long long *done, uint32_t ndv, int64_t n_lo, int64_t n_hi, uint32_t launch, int lane) {
+	const uint32_t nd = ndv < (uint32_t)kRefCache ? ndv : (uint32_t)kRefCache;
+	bool hit = false;
+	if((uint32_t)lane < nd) {
+		const unsigned long long e = __hip_atomic_load(done + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const int64_t lo = (int64_t)(e >> 32) << 8, hi = lo + ((int64_t)((e >> 16) & 0xffffull) << 8) + 255;
+		hit = lo <= n_lo && n_hi <= hi && (uint32_t)(e & 0xffffull) != (launch & 0xffffu);
+	}
+	return __any(hit) != 0;
+}
+// ref_window_done(): the stretch as ref_exact_window_dev() would ask for it (whole blocks of 256, as far as the input reaches)
+__device__ __forceinline__ bool ref_window_done_dev(const ChanView &v, int64_t n_lo, int64_t n_hi) {
+	RefChan *rp = v.ref;
+	if(!rp) return false;
+	const int npiece = rp->npiece, os = rp->os, c = v.ref_chan;
+	if(n_lo < 0) n_lo = 0;
+	if(n_hi < n_lo) return true;
+	if(npiece <= 0) return false;
+	const int64_t in_end = rp->piece[npiece - 1].s0 + rp->piece[npiece - 1].n, last = in_end / os - 1;
+	n_lo &= ~255ll;
+	if((n_hi | 255) <= last) n_hi |= 255; else if(n_hi < last) n_hi = last;
+	return ref_done_lookup(rp->done + (size_t)c * kRefCache, rp->done_n[c], n_lo, n_hi, v.ref_launch, threadIdx.x & 63);
+}
 __device__ __forceinline__ bool ref_exact_window_dev(const ChanView &v, int64_t n_lo, int64_t n_hi, int kind) {
 	#pragma clang fp contract(off)
 	RefChan *rp = v.ref;
@@ -130,18 +155,7 @@ __device__ __forceinline__ bool ref_exact_window_dev(const ChanView &v, int64_t 
 		if((n_hi | 255) <= last) n_hi |= 255; else if(n_hi < last) n_hi = last;
 	}
 	// done before?
-	{
-		const uint32_t ndv = *done_n, nd = ndv < (uint32_t)kRefCache ? ndv : (uint32_t)kRefCache;
-		bool hit = false;
-		if((uint32_t)lane < nd) {
-			// (lo / 256 : 32 bits, length / 256 : 16, launch : 16.  A stretch done by another wavefront of THIS launch does not count:
-			// its samples may still sit in another XCD's L2; from the next launch on they are everybody's)
-			const unsigned long long e = __hip_atomic_load(done + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const int64_t lo = (int64_t)(e >> 32) << 8, hi = lo + ((int64_t)((e >> 16) & 0xffffull) << 8) + 255;
-			hit = lo <= n_lo && n_hi <= hi && (uint32_t)(e & 0xffffull) != (v.ref_launch & 0xffffu);
-		}
-		if(__any(hit)) { if(lane == 0) atomicAdd(stats + 1, 1u); return true; }
-	}
+	if(ref_done_lookup(done, *done_n, n_lo, n_hi, v.ref_launch, lane)) { if(lane == 0) atomicAdd(stats + 1, 1u); return true; }
 	const int64_t s_end = (int64_t)os * (n_hi + 1);            // decimated sample k is the filter's output after input sample os (k + 1) - 1
 	int64_t s_beg = (int64_t)os * n_lo - warm;
 	bool shortened = false;
@@ -281,6 +295,14 @@ __global__ __launch_bounds__(64) void k_ref_probe(RefChan *ref, int chan, int nc
 	if(threadIdx.x == 0) out[blockIdx.x] = ok ? 1 : 0;
 }
 
+VDL2_HD bool ref_window_done(const ChanView &v, int64_t n_lo, int64_t n_hi) {
+#if VDL2_DEVICE_PASS
+	return ref_window_done_dev(v, n_lo, n_hi);
+#else
+	(void)v; (void)n_lo; (void)n_hi;
+	return false;
+#endif
+}
 VDL2_HD __attribute__((always_inline)) bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void *scratch, int kind) {
 #if VDL2_DEVICE_PASS
 	if(v.ref && !((v.ref->kinds >> kind) & 1)) return false;
@@ -901,7 +923,7 @@ struct K3Args {
 	int32_t wpl;              // exact tier: flag words scanned per lane (1..kK3bWordsPerLane)
 	OutCtl *ctl; uint32_t k5_waves;   // the feed's output control block, reset here (the last kernel of the front, so that no copy has to do it)
 	// referee (nullptr: off): the feed's hook - written here from `refv`, for the same reason - and what the candidate verdict needs
-	RefChan *ref; RefChan refv; float max_ppm; const float *ppm_thr; int32_t ref_on; uint32_t *rq_n, *rq_flag; RefBad *rq_bad;      // rq_n, rq_flag, rq_bad: the feed's list of decisions to check / its "walk again" flags / the decisions that fell, reset here;      // (ref != nullptr, ref_on == 0: the hook is written, the verdicts are the plain ones)
+	RefChan *ref; RefChan refv; float max_ppm; const float *ppm_thr; int32_t ref_on; uint32_t *rq_n, *rq_flag; RefBad *rq_bad; ScanReq *pq; uint32_t pq_cap;      // rq_n, rq_flag, rq_bad: the feed's list of decisions to check / its "walk again" flags / the decisions that fell, reset here;      // (ref != nullptr, ref_on == 0: the hook is written, the verdicts are the plain ones)
 };
 
 // K3: got_sync() metric (contiguous ring) + the candidate bitmap, in two tiers and two kernels.
@@ -927,6 +949,7 @@ constexpr int kK3Share = VDL2_K3_SHARE, kK3Threads = 320, kK3Tile = kK3Threads *
 static_assert(kK3Tile == kK3Threads * kK3Share && kK3Tile % 64 == 0 && kK3Threads % 10 == 0 && (kK3Tile / 64) % (kK3Threads / 64) == 0, "screen tile");
 
 __global__ __launch_bounds__(kK3Threads) void k_sync_screen(K3Args a) {
+	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && a.rq_n) a.rq_n[3] = 0u;      // (the exact tier's list of stretches to make exact ahead of the walk)
 	__shared__ float tile[kK3Tile + 150];           // screening phases of samples nblk-150 .. nblk+kK3Tile-1
 	__shared__ uint8_t verdict[kK3Tile];
 	const int c = blockIdx.y, tid = threadIdx.x;
@@ -1110,6 +1133,16 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
 		if((needj >> lane) & 1ull) a.pf[(size_t)c * a.cap + ((uint32_t)n & a.mask)] = cf32{ (vd & 2) ? -p0 : p0, fs[6 + lane] };
 		const unsigned long long bits = __ballot((vd & 1) != 0);
 		if(lane == 0) cand[(uint32_t)wj & wmask] = bits;
+		if(a.pq) {
+			// the marked candidates of the word: the stretch their decisions read goes on the list of those made exact before the walk
+			const unsigned long long mk = __ballot((vd & 2) != 0 && ((needj >> lane) & 1ull) != 0);
+			if(mk && lane == 0) {
+				const int64_t nf = (wj << 6) + __builtin_ctzll(mk), nl = (wj << 6) + 63 - __builtin_clzll(mk);
+				int64_t lo = (nf - kRefPre) & ~255ll, hi = (nl + kRefPost) | 255; if(lo < 0) lo = 0; if(hi > a.k1 - 1) hi = a.k1 - 1;
+				const uint32_t i = atomicAdd(a.rq_n + 3, 1u);
+				if(i < a.pq_cap) a.pq[i] = ScanReq{ c, REF_CANDIDATE, lo, hi };
+			}
+		}
 		WAVE_SYNC();
 	}
 }
@@ -1124,13 +1157,13 @@ struct K4Args {
 	uint32_t ref_launch;       // ... and a number that tells this launch from the others (k_walk_stitch: + 1, k_ref_verify: + 2, k_walk_again: + 3)
 	// optimistic mode (rq != nullptr; vdl2_core.h: ref_verify): the feed's list of decisions to check, the "walk again" flag per channel,
 	// and where the state and counters a channel's walk starts from are kept
-	RefReq *rq; uint32_t *rq_n; uint32_t rq_cap; uint32_t *rq_flag; WalkState *ws_snap; unsigned long long *cnt_snap; RefBad *rq_bad;
+	RefReq *rq; uint32_t *rq_n; uint32_t rq_cap; uint32_t *rq_flag; WalkState *ws_snap; unsigned long long *cnt_snap; RefBad *rq_bad; int32_t ref_pre;
 };
 
 __global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
 	__shared__ WalkShared sh;
 	const int c = blockIdx.x;
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch, a.rq, a.rq_n, a.rq_cap, a.rq_flag, a.rq_bad ? a.rq_bad + c : nullptr };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch, a.rq, a.rq_n, a.rq_cap, a.rq_flag, a.rq_bad ? a.rq_bad + c : nullptr, a.ref_pre != 0 };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	walk_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	             a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg, sh, WalkSnap{ a.rq ? a.ws_snap : nullptr, a.cnt_snap });
@@ -1181,7 +1214,7 @@ __global__ __launch_bounds__(64 * kWalkWaves, 4) void k_walk_spec(K4sArgs s) {
 	const int c = blockIdx.y, x = blockIdx.x * kWalkWaves + wave;
 	if(x >= 1 + 3 * (s.nseg - 1)) return;
 	WalkShared &sh = shw[wave];
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch, a.rq, a.rq_n, a.rq_cap, a.rq_flag, a.rq_bad ? a.rq_bad + c : nullptr };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch, a.rq, a.rq_n, a.rq_cap, a.rq_flag, a.rq_bad ? a.rq_bad + c : nullptr, a.ref_pre != 0 };
 	if(x == 0) return;         // (segment 0 is walked from the real state by the stitcher)
 	{
 		const int seg = 1 + (x - 1) / 3, r = (x - 1) % 3;
@@ -1204,7 +1237,7 @@ __global__ __launch_bounds__(256, 4) void k_walk_stitch(K4sArgs s) {
 	if(c >= a.nchan) return;
 	if(s.again && !a.rq_flag[c]) return;
 	StitchLds &lds = reinterpret_cast<StitchLds *>(k4_lds)[wave];
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + (s.again ? 3u : 1u), s.again ? nullptr : a.rq, a.rq_n, a.rq_cap, a.rq_flag, a.rq_bad ? a.rq_bad + c : nullptr };
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + (s.again ? 3u : 1u), s.again ? nullptr : a.rq, a.rq_n, a.rq_cap, a.rq_flag, a.rq_bad ? a.rq_bad + c : nullptr, a.ref_pre != 0 };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
 	stitch_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
 	               a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg,

@@ -191,6 +191,10 @@ struct ChanView {
 	// stand is walked again from the feed's start.  rq_flag: per channel, "walk again" (nullptr: a speculative walk - it gives up instead)
 	struct RefReq  *rq = nullptr; uint32_t *rq_n = nullptr; uint32_t rq_cap = 0; uint32_t *rq_flag = nullptr;
 	struct RefBad  *rq_bad = nullptr;  // this channel's noted decisions that did NOT stand (written by the check, read when the channel is stitched again)
+	// the stretches around the marked candidates have been made the reference's own BEFORE the walk (the exact sync tier lists them,
+	// k_ref_scan_multi runs between the front and the walk): a marked candidate is then decided on the spot - by speculative walks too,
+	// which only look whether the stretch is done (ref_window_done) - and the walk's chain from feed to feed holds no scan for it
+	bool            ref_pre = false;
 	VDL2_HD cf32  Y(int64_t n) const { return y[(uint32_t)n & mask]; }
 	VDL2_HD float Phi(int64_t n) const { return n < 0 ? 0.f : phase_of(y[(uint32_t)n & mask]); }   // atan2(lp_im, lp_re); 0 before the stream starts
 	VDL2_HD cf32  PF(int64_t n) const { return pf[(uint32_t)n & mask]; }
@@ -592,6 +596,7 @@ VDL2_HD bool ref_log_request(const ChanView &v, const RefReq &r) {
 	return true;
 }
 VDL2_HD bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void *scratch, int kind);
+VDL2_HD bool ref_window_done(const ChanView &v, int64_t n_lo, int64_t n_hi);      // has another launch made the stretch exact?  (never scans)
 
 // squared bound on the phase error of decimated sample n: the stream's error there is at most kRefKappa x the largest of the
 // sample and its three predecessors (the scan's rounding noise is an exponentially weighted average of |y| over ~2 decimated
@@ -1212,7 +1217,7 @@ VDL2_HD __attribute__((always_inline)) void walk_run(int chan, uint32_t freq, fl
 							// redone on the reference's own samples before anything is decided (below: sh.u_fire == 2), and comes by here again
 							const bool exact_here = sh.x_n == n;
 							const bool marked = v.ref && !exact_here && sh.wre[n - wbase] < 0.f;
-							if(marked && !v.rq) { pending = 2; break; }
+							if(marked && (!v.rq || v.ref_pre)) { pending = 2; break; }
 #ifdef VDL2_REF_DEBUG
 							ref_debug_log(v, exact_here ? 2 : 1, n, sh.wre[n - wbase], exact_here ? sh.x_p3 : sh.wre[n - 3 - wbase], (float)(e0 % 3));
 #endif
@@ -1298,11 +1303,18 @@ VDL2_HD __attribute__((always_inline)) void walk_run(int chan, uint32_t freq, fl
 					LANE0_END
 					if(sh.u_fire == 2) {
 						// ---- referee: the candidate at u_n on the reference's own samples ----
-						if(spec) { LANE0 ctl->overflow = 1; LANE0_END break; }
+						if(spec && !v.ref_pre) { LANE0 ctl->overflow = 1; LANE0_END break; }
 						const int64_t n = sh.u_n;
 						int64_t lo = (n - kRefPre) & ~255ll, hi = (n + kRefPost) | 255; if(lo < 0) lo = 0; if(hi > k_end - 1) hi = k_end - 1;   // (whole blocks of 256)
 						bool ok = sh.x_lo <= lo && hi <= sh.x_hi;
-						if(!ok) {
+						if(!ok && spec) {
+							// a speculative walk does not scan: the stretch has been made exact ahead of the walk, or the walk gives up
+							ok = ref_window_done(v, lo, hi);
+							if(!ok) { LANE0 ctl->overflow = 1; LANE0_END break; }
+							LANE0
+								sh.x_lo = lo; sh.x_hi = hi;
+							LANE0_END
+						} else if(!ok) {
 							ok = ref_exact_window(v, lo, hi, sh.cw, REF_CANDIDATE);      // (the word cache is the scratch: reloaded when the search comes by again)
 							LANE0
 								if(ok) { sh.x_lo = lo; sh.x_hi = hi; }

@@ -38,8 +38,9 @@ constexpr int kHistory = 65536;          // decimated samples kept behind the ne
 constexpr int kNumEv = 12;            // profiling: {start, stop} of K1, K2, K3, K4, K4b, K5
 constexpr int kColdParts = 4;         // pieces a cold-start block is copied and channelised in
 constexpr size_t kColdMinBytes = 8u << 20;
+constexpr uint32_t kPreScans = 4096;    // referee: stretches around marked candidates one feed may list for the scan ahead of the walk (what does not fit is asked for by the walk itself)
 constexpr uint32_t kDeferBursts = 256, kDeferScans = 512;   // referee: bursts of one feed that may wait for their scans, stretches they may wait for (what does not fit is scanned on the spot)
-constexpr int kSlots = VDL2HIP_MAX_DRAIN_LAG + 1;   // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered).  Four: with the referee a feed's way through the device - front, walk + check, bursts + their scans - is three fronts long
+constexpr int kSlots = VDL2HIP_MAX_DRAIN_LAG + 1;   // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered).  Four: with the referee a feed's way through the device - front, the scans ahead of the walk, walk + check, bursts + their scans - is about three fronts long
 
 }  // namespace
 
@@ -50,7 +51,8 @@ struct OutSlot {
 	OutFrame *d_frames_out = nullptr; uint8_t *d_pool_out = nullptr;    // what k_frame_finish delivers (no tombstones, no holes): what the host copies
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
 	uint32_t *d_dq = nullptr; ScanReq *d_sq = nullptr;      // referee, long feeds: the bursts that wait for a scan, the stretches they wait for (counts: d_rqn[1], d_rqn[2])
-	RefReq *d_rq = nullptr; uint32_t *d_rqn = nullptr, *d_rqflag = nullptr; RefBad *d_rqbad = nullptr;   // referee, optimistic mode: this feed's decisions to check, its "walk again" flags
+	RefReq *d_rq = nullptr; uint32_t *d_rqn = nullptr, *d_rqflag = nullptr; RefBad *d_rqbad = nullptr;
+	ScanReq *d_pq = nullptr; hipEvent_t ev_pre = nullptr;      // referee: the stretches around marked candidates, made exact between the front and the walk (count: d_rqn[3])   // referee, optimistic mode: this feed's decisions to check, its "walk again" flags
 	OutMail *h_mail = nullptr;             // pinned
 	hipEvent_t done = nullptr, ev_front = nullptr, ev_chan = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
 	bool pending = false, ev_valid = false, fused = false; int ev_level = 0;
@@ -108,7 +110,7 @@ struct vdl2hip_ctx {
 	// buffer) while its back end runs; what lies before it - up to ref_T samples: the run-up of the scan + the longest burst - is kept
 	// in a ring (ref_hist), appended to by every feed (its last min(n, ref_T) samples).  ref_pieces: what of the stream the ring holds,
 	// contiguously, newest last: {first absolute sample, count, ring position of the first}.
-	bool referee = true; int ref_kinds = 7; int64_t ref_warm = 1 << 17, ref_T = 0; uint8_t *d_refhist = nullptr; uint64_t ref_cap = 0, ref_wp = 0;
+	bool referee = true; int ref_kinds = 7; bool ref_prescan = false;   /* VDL2HIP_REF_PRESCAN=1: the stretches around marked candidates are made exact ahead of the walk (a rank-sized shard 4.05 -> 2.8 ms, 256 channels 7.1 -> 10.7: off) */ int64_t ref_warm = 1 << 17, ref_T = 0; uint8_t *d_refhist = nullptr; uint64_t ref_cap = 0, ref_wp = 0;
 	struct HistPiece { int64_t s0, n; uint64_t pos; }; std::vector<HistPiece> ref_pieces;
 	unsigned long long *d_refdbg = nullptr; int ref_dbg_chan = -1;
 	WalkState *d_ws_snap = nullptr; unsigned long long *d_cnt_snap = nullptr; uint32_t rq_cap = 8192; bool ref_optimistic = true;
@@ -374,7 +376,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		// wavefronts of this feed's burst decoder: each owns kResSlots frame records of the output from the start, so a short block gets few
 		sl.k5_waves = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(16, (D * (int64_t)c->C) >> 14));
 		sl.k5_waves = (sl.k5_waves + kBurstWaves - 1) / kBurstWaves * kBurstWaves;
-		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0, sl.d_rqn, sl.d_rqflag, sl.d_rqbad };
+		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0, sl.d_rqn, sl.d_rqflag, sl.d_rqbad, (c->referee && c->ref_prescan) ? sl.d_pq : nullptr, kPreScans };
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
 		// on the front stream than a separate hipEventRecord.  (VDL2HIP_SYNC_ON=walk puts the exact tier in front of the walk on
 		// the walk stream, VDL2HIP_SYNC_ON=own both sync kernels on a stream of their own, so that the front stream goes on
@@ -440,11 +442,23 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		if(gate) HIPCHK(hipStreamWaitEvent(sb_, gate, 0));
 	}
 	if(D <= 0) hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(1), 0, sb_, sl.d_ctl, 0u);     // (a feed with a front has had it reset by its last sync kernel)
+	if(D > 0 && c->referee && c->ref_prescan) {
+		// Referee: the stretches the exact sync tier has listed (around its marked candidates) are made the reference's own NOW, beside
+		// the next feed's front and off the walk stream - the walk of this feed waits for them, the walk of the next one does not
+		// (a scan on the walk stream is 3.7 ms that every following feed's walk queues behind: with 8 channels that was the step time)
+		// (on the noise-floor stream: its own work for this feed comes after the walk anyway.  NOT on a burst stream: HIP maps the context's
+		// ten streams onto four hardware queues, the second burst stream shares the front's, and a 4 ms scan there held up the next channeliser)
+		hipStream_t sp_ = small ? c->stream : sn_;
+		if(!small) HIPCHK(hipStreamWaitEvent(sp_, sl.ev_front, 0));
+		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kPreScans / kScanLanes), dim3(64 * (1 + kScanProd)), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
+		                  (const ScanReq *)sl.d_pq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 3), kPreScans, (int64_t)(k0 + D));
+		if(!small) { HIPCHK(hipEventRecord(sl.ev_pre, sp_)); HIPCHK(hipStreamWaitEvent(sb_, sl.ev_pre, 0)); }
+	}
 	if(D > 0) {
 		const int64_t k1 = k0 + D;
 		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
-		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(8 * sl.seq + 1),
-		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap, sl.d_rqbad };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
+		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(16 * sl.seq + 1),
+		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap, sl.d_rqbad, (c->referee && c->ref_prescan) ? 1 : 0 };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
 		int64_t seglen = D;
 		if(nseg >= 2) {
 			seglen = (D + nseg - 1) / nseg;
@@ -489,7 +503,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			HIPCHK(hipEventRecord(sl.ev_nf, sn_));
 		}
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, c->C,
-		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(8 * sl.seq + 5), BurstDefer{} };
+		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(16 * sl.seq + 5), BurstDefer{} };
 		// referee, long feeds: a burst that needs a scan is listed by the first pass, the scans run side by side, a second pass decodes the listed bursts
 		const bool defer5 = c->referee && c->ref_optimistic && !small && ((c->ref_kinds >> REF_SYMBOLS) & 1);
 		if(defer5) k5.df = BurstDefer{ sl.d_dq, sl.d_rqn + 1, kDeferBursts, sl.d_sq, sl.d_rqn + 2, kDeferScans, 1 };
@@ -499,8 +513,8 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		else if(!defer5) hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), EV(11), 0, k5);
 		else {
 			hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), (hipEvent_t) nullptr, 0, k5);
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kDeferScans / kScanLanes), dim3(64 * (1 + kScanProd)), 0, s5_, k5.ref, (uint32_t)(8 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), (uint32_t)kDeferScans, (int64_t)(k0 + D));
-			K5Args k5b = k5; k5b.df.pass = 2; k5b.ref_launch = (uint32_t)(8 * sl.seq + 7);
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kDeferScans / kScanLanes), dim3(64 * (1 + kScanProd)), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), (uint32_t)kDeferScans, (int64_t)(k0 + D));
+			K5Args k5b = k5; k5b.df.pass = 2; k5b.ref_launch = (uint32_t)(16 * sl.seq + 7);
 			hipExtLaunchKernelGGL(k_burst, dim3(kDeferBursts / kBurstWaves / 4), dim3(64 * kBurstWaves), k5_lds, s5_, (hipEvent_t) nullptr, EV(11), 0, k5b);
 		}
 		if(!small) HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
@@ -556,12 +570,13 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
 	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
-		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag, sl.d_dq, sl.d_sq, sl.d_rqbad };
+		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag, sl.d_dq, sl.d_sq, sl.d_rqbad, sl.d_pq };
 		for(void *p : q) if(p) (void)hipFree(p);
 		if(sl.h_mail) (void)hipHostFree(sl.h_mail);
 		if(sl.done) (void)hipEventDestroy(sl.done);
 		if(sl.ev_walk) (void)hipEventDestroy(sl.ev_walk);
 		if(sl.ev_front) (void)hipEventDestroy(sl.ev_front);
+		if(sl.ev_pre) (void)hipEventDestroy(sl.ev_pre);
 		if(sl.ev_chan) (void)hipEventDestroy(sl.ev_chan);
 		if(sl.ev_nf) (void)hipEventDestroy(sl.ev_nf);
 		if(sl.ev_k1) (void)hipEventDestroy(sl.ev_k1);
@@ -731,6 +746,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	}
 
 	if(const char *e = getenv("VDL2HIP_REFEREE")) c->referee = atoi(e) != 0;
+	if(const char *e = getenv("VDL2HIP_REF_PRESCAN")) c->ref_prescan = atoi(e) != 0;
 	if(const char *e = getenv("VDL2HIP_REF_WARM")) { const long long v = atoll(e); if(v >= 1024 && v <= (1ll << 24)) c->ref_warm = v; }
 	if(c->referee) {
 		c->ref_T = c->ref_warm + (int64_t)(kHistory + 256) * c->os + 4096;      // run-up + the longest burst (its symbols are sliced when its last one has arrived)
@@ -748,6 +764,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		for(auto &sl : c->slot) {
 			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 16); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
 			DEV_ALLOC(sl.d_dq, (size_t)kDeferBursts * 4); DEV_ALLOC(sl.d_sq, (size_t)kDeferScans * sizeof(ScanReq));
+			DEV_ALLOC(sl.d_pq, (size_t)kPreScans * sizeof(ScanReq)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_pre, hipEventDisableTiming));
 			DEV_ALLOC(sl.d_rqbad, (size_t)count * sizeof(RefBad)); DEV_CHK(hipMemset(sl.d_rqbad, 0, (size_t)count * sizeof(RefBad)));
 			DEV_CHK(hipMemset(sl.d_rqn, 0, 16)); DEV_CHK(hipMemset(sl.d_rqflag, 0, (size_t)count * 4));
 		}

@@ -15,13 +15,20 @@
 // The referee's hook of the CPU build: the "reference's own samples" come from a trace the test supplies (the oracle's decimated
 // stream); the device build works them out from the raw input (kernels.h).
 namespace vdl2 {
-struct RefChan { const float *exact; int64_t n_exact; cf32 *y; uint32_t mask; int64_t calls, samples; };
+struct RefChan { const float *exact; int64_t n_exact; cf32 *y; uint32_t mask; int64_t calls, samples; std::vector<uint8_t> *done; };
 inline void ref_debug_log(const ChanView &, int tag, int64_t a, float b, float c, float d) { if(getenv("HOSTSIM_REF_LOG")) fprintf(stderr, "reflog %d %lld %.9g %.9g %.9g\n", tag, (long long)a, b, c, d); }
 inline bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void *, int) {
 	RefChan *r = v.ref;
 	if(!r || !r->exact) return false;
 	r->calls++;
-	for(int64_t n = n_lo < 0 ? 0 : n_lo; n <= n_hi && n < r->n_exact; n++) { r->y[(uint32_t)n & r->mask] = cf32{ r->exact[2 * n], r->exact[2 * n + 1] }; r->samples++; }
+	for(int64_t n = n_lo < 0 ? 0 : n_lo; n <= n_hi && n < r->n_exact; n++) { r->y[(uint32_t)n & r->mask] = cf32{ r->exact[2 * n], r->exact[2 * n + 1] }; r->samples++; if(r->done) (*r->done)[n] = 1; }
+	return true;
+}
+// (the device: has ANOTHER launch made the stretch exact - here: has anybody)
+inline bool ref_window_done(const ChanView &v, int64_t n_lo, int64_t n_hi) {
+	RefChan *r = v.ref;
+	if(!r || !r->exact || !r->done) return false;
+	for(int64_t n = n_lo < 0 ? 0 : n_lo; n <= n_hi && n < r->n_exact; n++) if(!(*r->done)[n]) return false;
 	return true;
 }
 }
@@ -51,7 +58,7 @@ struct Sim {
 	bool two_tier = false; int64_t n_exact = 0, n_total = 0;   // K3's screening rule instead of the exact metric everywhere
 	std::vector<SpecOut> spec; uint32_t seg_stats[2] = {0, 0};
 	// referee: exact samples [nchan][exact_D] and the per-channel hooks; marg: candidates K3 marked as within the margin
-	std::vector<float> exact; int64_t exact_D = 0; std::vector<RefChan> rc; int64_t n_marg = 0, n_cand = 0, n_walk_windows = 0;
+	std::vector<float> exact; int64_t exact_D = 0; std::vector<RefChan> rc; std::vector<std::vector<uint8_t>> rdone; bool prescan = false; std::vector<int64_t> pre_lo, pre_hi; int64_t n_marg = 0, n_cand = 0, n_walk_windows = 0;
 	std::vector<float> pe, pa, pb;
 	bool optimistic = true; std::vector<RefReq> rq; uint32_t rq_n = 0; std::vector<uint32_t> rq_flag; std::vector<RefBad> rq_bad; std::vector<WalkState> ws_snap; std::vector<unsigned long long> cnt_snap; int64_t n_rewalk = 0, n_requests = 0;
 	std::vector<Burst> all_bursts;   // every burst descriptor the walker has emitted (debugging aid)
@@ -81,11 +88,12 @@ void hostsim_destroy(Sim *s) { delete s; }
 void hostsim_set_segments(Sim *s, int64_t seg_min, int seg_max) { s->seg_min = seg_min; s->seg_max = seg_max < 1 ? 1 : seg_max > kMaxSeg ? kMaxSeg : seg_max; }
 void hostsim_set_two_tier(Sim *s, int on) { s->two_tier = on != 0; }
 void hostsim_set_optimistic(Sim *s, int on) { s->optimistic = on != 0; }
+void hostsim_set_prescan(Sim *s, int on) { s->prescan = on != 0; }
 // referee on: decisions within the margin of the stream's error are taken on `exact` ([nchan][D] complex, the oracle's trace)
 void hostsim_set_exact(Sim *s, const float *exact, int64_t D) {
 	s->exact.assign(exact, exact + (size_t)s->nchan * D * 2); s->exact_D = D;
-	s->rc.resize(s->nchan);
-	for(int c = 0; c < s->nchan; c++) s->rc[c] = RefChan{ s->exact.data() + (size_t)c * D * 2, D, &s->y[(size_t)c * s->cap], s->mask, 0, 0 };
+	s->rc.resize(s->nchan); s->rdone.assign(s->nchan, std::vector<uint8_t>((size_t)D, 0));
+	for(int c = 0; c < s->nchan; c++) s->rc[c] = RefChan{ s->exact.data() + (size_t)c * D * 2, D, &s->y[(size_t)c * s->cap], s->mask, 0, 0, &s->rdone[c] };
 	s->pe.assign((size_t)s->nchan * s->cap, 0.f); s->pa.assign((size_t)s->nchan * s->cap, 0.f); s->pb.assign((size_t)s->nchan * s->cap, 0.f);
 }
 // [0] candidates K3 marked, [1] candidate bits set, [2] exact windows served, [3] samples replaced, [4] windows asked for by the walkers (one feed)
@@ -149,7 +157,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 			}
 		}
 		for(int64_t w = k0 >> 6; w < ((k1 + 63) >> 6); w++) {
-			uint64_t bits = 0;
+			uint64_t bits = 0; int64_t wm_first = -1, wm_last = -1;
 			for(int b = 0; b < 64; b++) {
 				int64_t n = (w << 6) + b;
 				if(n >= k1 || n < 3) continue;
@@ -186,11 +194,21 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 					if(tot % 5 == 0) fprintf(stderr, "reasons: p3~4 %ld, p0~p3 %ld, vertex(y1 max) %ld, vertex(p6) %ld, gate %ld, cannot tell %ld\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], cnt[5]);
 				}
 				if(vd & 1) { bits |= 1ull << b; s->n_cand++; }
-				if(vd & 2) { cf32 &q = pf[(uint32_t)n & s->mask]; q.re = -fabsf(q.re); s->n_marg++; }
+				if(vd & 2) { cf32 &q = pf[(uint32_t)n & s->mask]; q.re = -fabsf(q.re); s->n_marg++; if(wm_first < 0) wm_first = n; wm_last = n; }
 			}
 			cand[(uint32_t)w & (s->mask >> 6)] = bits;
+			if(wm_first >= 0 && s->prescan) {      // (the device's exact tier lists the stretch; k_ref_scan_multi makes it exact before the walk)
+				int64_t lo = (wm_first - kRefPre) & ~255ll, hi = (wm_last + kRefPost) | 255; if(lo < 0) lo = 0; if(hi > k1 - 1) hi = k1 - 1;
+				s->pre_lo.push_back(((int64_t)c << 40) | lo); s->pre_hi.push_back(hi);
+			}
 		}
 	}
+	for(size_t i = 0; i < s->pre_lo.size(); i++) {
+		const int c = (int)(s->pre_lo[i] >> 40); const int64_t lo = s->pre_lo[i] & ((1ll << 40) - 1);
+		ChanView cv{ &s->y[(size_t)c * s->cap], nullptr, nullptr, s->mask }; cv.ref = &s->rc[c];
+		(void)ref_exact_window(cv, lo, s->pre_hi[i], nullptr, REF_CANDIDATE);
+	}
+	s->pre_lo.clear(); s->pre_hi.clear();
 	s->k_total = k1;
 	memset(&s->ctl, 0, sizeof s->ctl);
 	s->ctl.cap_bursts = (uint32_t)s->bursts.size(); s->ctl.cap_frames = (uint32_t)s->frames.size(); s->ctl.cap_pool = (uint32_t)s->pool.size(); s->ctl.cap_log = s->cap_log;
@@ -201,7 +219,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 	std::vector<uint32_t> nb_first(s->nchan, 0);
 	for(int c = 0; c < s->nchan; c++) {
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
-		if(!s->rc.empty()) v.ref = &s->rc[c];
+		if(!s->rc.empty()) { v.ref = &s->rc[c]; v.ref_pre = s->prescan; }
 		if(opt) { v.rq = s->rq.data(); v.rq_n = &s->rq_n; v.rq_cap = (uint32_t)s->rq.size(); v.rq_flag = s->rq_flag.data(); v.rq_bad = &s->rq_bad[c]; }
 		nb_first[c] = s->ctl.nbursts;
 		EvalLog lg{ &s->log[(size_t)c * s->cap_log], &s->nlog[c] };
@@ -262,7 +280,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		const Burst &b = s->bursts[i];
 		int c = b.chan;
 		ChanView v{ &s->y[(size_t)c * s->cap], &s->pf[(size_t)c * s->cap], &s->cand[(size_t)c * (s->cap / 64)], s->mask };
-		if(!s->rc.empty()) v.ref = &s->rc[c];
+		if(!s->rc.empty()) { v.ref = &s->rc[c]; v.ref_pre = s->prescan; }
 		decode_burst(b, s->freqs[c], s->T, v, &s->cnt[(size_t)c * kNumCounters], s->frames.data(), s->pool.data(), &s->ctl, bsh);
 	}
 	burst_reserve_done(s->frames.data(), bsh);

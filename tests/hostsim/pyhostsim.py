@@ -87,6 +87,11 @@ class HostSim:
         return {"marked_candidates": a[0], "candidate_bits": a[1], "exact_windows": a[2], "exact_samples": a[3], "walker_windows_first_feed": a[4],
                 "decisions_checked": a[5], "channels_walked_again": a[6]}
 
+    def set_prescan(self, on=True):
+        """referee: the stretches around marked candidates are made exact before the walk (the device's default), or not"""
+        self.L.hostsim_set_prescan.argtypes = [C.c_void_p, C.c_int]
+        self.L.hostsim_set_prescan(self.h, 1 if on else 0)
+
     def set_optimistic(self, on=True):
         """referee mode: decisions within the margin are taken on the samples as they are and checked afterwards (the device's mode for long
         feeds; default) / the referee is asked on the spot"""
