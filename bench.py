@@ -135,7 +135,7 @@ class Case:
         return self.vdl2hip.Receiver.unpack(n, recs, octs)
 
     def timed(self, feeder, steps, dist, repeats=1):
-        """`repeats` times exactly `steps` steps in streaming mode (three blocks in flight); every block fully delivered inside
+        """`repeats` times exactly `steps` steps in streaming mode (four blocks in flight); every block fully delivered inside
         each timed region.  Returns the median repeat plus the list."""
         # the shader clock idles at ~100 MHz and needs some tens of ms of load to come up (profiles/r03_clocks_under_load.txt): after the CPU-side
         # pauses of this script (oracle gate, set-up of a receiver) a short region would otherwise start on a cold clock.  Untimed steps.
@@ -435,7 +435,7 @@ def measure_secondary(c2, name, oracle_check, args, dist, po):
 
 def group_from_c(case, args, torch, local, members=8):
     """vdl2hip_group_* (the multi-GPU path from plain C) with `members` virtual shards on this GPU: every transmitted frame recovered
-    in both exchange forms, K timed steps each (three blocks in flight, frames drained without a callback)"""
+    in both exchange forms, K timed steps each (four blocks in flight, frames drained without a callback)"""
     from util import truth_is_subset
     vh = case.vdl2hip
     cfg = case.cfg
@@ -644,7 +644,7 @@ def main():
         ts = case.timed(f_host, ks, dist, 1)
         steady = {"steps": ks, "value": round(case.nsamples * ks / ts["dt"] / 1e6, 3), "ms_per_step": round(ts["dt"] / ks * 1e3, 4),
                   "k_chanfir_ms": round(ts["k1_ms"], 5),
-                  "note": "host-fed, one timed region of this many steps: the fill and drain of the three-deep pipeline (paid once per "
+                  "note": "host-fed, one timed region of this many steps: the fill and drain of the four-deep pipeline (paid once per "
                           "region, whatever its length) weigh a tenth of what they do in the K-step regions `value` comes from"}
     del f_host
     # ---- the same with the block resident in HBM ----
@@ -734,7 +734,7 @@ def main():
         h2d = h2d_ms(torch, pin, case.device)
         del pin
         projected = {"what": f"rank-sized workload of the 8-GPU split on this GPU: {per} of the {case.C} channels of the same block, block resident in HBM "
-                             f"(as an RCCL exchange leaves it), three blocks in flight, the same K steps x {args.repeats} repeats (median)",
+                             f"(as an RCCL exchange leaves it), four blocks in flight, the same K steps x {args.repeats} repeats (median)",
                      "t_all_channels_ms": round(t256, 4), "t_rank_ms_max": round(t32, 4), "shards": shards,
                      "compute_ceiling_speedup_at_8": round(t256 / t32, 3),
                      "h2d_whole_block_ms": round(h2d, 4),
