@@ -564,6 +564,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
+    if world > 1:
+        # 32 channels per rank: the walk's chain, not the front, is the step - the referee's scans ahead of the walk shorten it
+        os.environ.setdefault("VDL2HIP_REF_PRESCAN", "1")
     case = Case(args.workload, args.duration, world, rank, local, torch, channels=args.channels)
     cfg = case.cfg
     if world > 1:        # every rank must hold the very same capture
@@ -808,6 +811,7 @@ def main():
                        "parallelism": (f"channels sharded x{world} ({case.count} per GPU), RCCL {mode} of every IQ block inside the timed steps"
                                        + (" [REHEARSAL: all ranks on one GPU over gloo - not a measurement]" if rehearsal else "")
                                        if world > 1 else "single GPU, all channels"),
+                       "referee_scans_ahead_of_the_walk": os.environ.get("VDL2HIP_REF_PRESCAN", "0") == "1",
                        "exchange": exchange_info,
                        "by_exchange": by_exchange,
                        "rank_ms_per_step": t_host.get("rank_ms_per_step"),

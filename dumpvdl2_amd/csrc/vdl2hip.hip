@@ -97,6 +97,7 @@ struct vdl2hip_ctx {
 	SpecOut *d_spec = nullptr; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
+	hipStream_t stream_pre[4] = {};        // referee, VDL2HIP_REF_PRESCAN=1: the scans ahead of the walk, a stream per feed in flight (one stream would put them in a row: 4.4 ms each)
 	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst[kSlots] = {};   // (a burst stream per feed in flight: a burst decoder that waits for the referee - a scan over a whole burst takes milliseconds - does not hold up the next feed's)
 	// Experiment switches (only read in builds with -DVDL2_EXPERIMENTS, dev/gpu_run.sh; the measured outcomes are in DESIGN 6).
 	// sync_on: 0 = both sync kernels on the front stream (the product); 1 = the exact tier in front of the walk on the walk stream;
@@ -110,7 +111,7 @@ struct vdl2hip_ctx {
 	// buffer) while its back end runs; what lies before it - up to ref_T samples: the run-up of the scan + the longest burst - is kept
 	// in a ring (ref_hist), appended to by every feed (its last min(n, ref_T) samples).  ref_pieces: what of the stream the ring holds,
 	// contiguously, newest last: {first absolute sample, count, ring position of the first}.
-	bool referee = true; int ref_kinds = 7; bool ref_prescan = false;   /* VDL2HIP_REF_PRESCAN=1: the stretches around marked candidates are made exact ahead of the walk (a rank-sized shard 4.05 -> 2.8 ms, 256 channels 7.1 -> 10.7: off) */ int64_t ref_warm = 1 << 17, ref_T = 0; uint8_t *d_refhist = nullptr; uint64_t ref_cap = 0, ref_wp = 0;
+	bool referee = true; int ref_kinds = 7; bool ref_prescan = false;   /* VDL2HIP_REF_PRESCAN=1: the stretches around marked candidates are made exact ahead of the walk - a rank-sized shard 4.05 -> 2.88 ms per step, 256 channels 7.2 -> 7.85: for receivers of few channels */ int64_t ref_warm = 1 << 17, ref_T = 0; uint8_t *d_refhist = nullptr; uint64_t ref_cap = 0, ref_wp = 0;
 	struct HistPiece { int64_t s0, n; uint64_t pos; }; std::vector<HistPiece> ref_pieces;
 	unsigned long long *d_refdbg = nullptr; int ref_dbg_chan = -1;
 	WalkState *d_ws_snap = nullptr; unsigned long long *d_cnt_snap = nullptr; uint32_t rq_cap = 8192; bool ref_optimistic = true;
@@ -446,9 +447,9 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		// Referee: the stretches the exact sync tier has listed (around its marked candidates) are made the reference's own NOW, beside
 		// the next feed's front and off the walk stream - the walk of this feed waits for them, the walk of the next one does not
 		// (a scan on the walk stream is 3.7 ms that every following feed's walk queues behind: with 8 channels that was the step time)
-		// (on the noise-floor stream: its own work for this feed comes after the walk anyway.  NOT on a burst stream: HIP maps the context's
-		// ten streams onto four hardware queues, the second burst stream shares the front's, and a 4 ms scan there held up the next channeliser)
-		hipStream_t sp_ = small ? c->stream : sn_;
+		// (on a stream of its own: behind this feed's noise floor - which waits for the walk - the next feed's scans would wait for this
+		// feed's whole walk chain: 10.7 ms per step)
+		hipStream_t sp_ = small ? c->stream : c->stream_pre[sl.seq % 4];
 		if(!small) HIPCHK(hipStreamWaitEvent(sp_, sl.ev_front, 0));
 		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kPreScans / kScanLanes), dim3(64 * (1 + kScanProd)), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
 		                  (const ScanReq *)sl.d_pq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 3), kPreScans, (int64_t)(k0 + D));
@@ -591,6 +592,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
 	if(c->stream_out) { (void)hipStreamSynchronize(c->stream_out); (void)hipStreamDestroy(c->stream_out); }
 	if(c->stream_sync) { (void)hipStreamSynchronize(c->stream_sync); (void)hipStreamDestroy(c->stream_sync); }
+	for(auto &sp : c->stream_pre) if(sp) { (void)hipStreamSynchronize(sp); (void)hipStreamDestroy(sp); }
 	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
 	if(c->stream_nf) { (void)hipStreamSynchronize(c->stream_nf); (void)hipStreamDestroy(c->stream_nf); }
 	for(auto &sb5 : c->stream_burst) if(sb5) { (void)hipStreamSynchronize(sb5); (void)hipStreamDestroy(sb5); }
@@ -669,6 +671,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		auto prio_of = [&](const char *name) { return strstr(lowp, name) ? prio_low : prio_high; };
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_back, hipStreamNonBlocking, prio_of("walk")));
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream_nf, hipStreamNonBlocking, prio_of("nf")));
+		for(auto &sp : c->stream_pre) DEV_CHK(hipStreamCreateWithPriority(&sp, hipStreamNonBlocking, prio_high));
 		for(auto &sb5 : c->stream_burst) DEV_CHK(hipStreamCreateWithPriority(&sb5, hipStreamNonBlocking, prio_of("burst")));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
