@@ -28,15 +28,17 @@ def test_exact_arithmetic_gives_the_oracles_answer(seed, profile):
     assert verdict == "ok" and info["frames"] > 40 and info["ties"] == 0, info
 
 
-@pytest.mark.parametrize("seed,profile", [(175, "plain"), (274, "plain"), (1014, "extreme"), (1738, "plain")])
+@pytest.mark.parametrize("seed,profile", [(175, "plain"), (274, "plain"), (1014, "extreme")])
 def test_decisions_that_hinge_on_the_references_own_rounding_go_to_the_referee(seed, profile):
+    """(seed 1738 - a lock the reference takes within 156 samples of a burst's end, where the metric's taps reach through the interval
+    history - runs in the next test, with the scans ahead of the walk; in the default mode it is one of the `-m gpu` fuzz seeds)"""
     import predict_gpu_parity as p
     s, prof, verdict, info = p.run_seed(seed, profile, referee=True)
     assert verdict == "ok" and info["ties"] == 0 and info["nf_ties"] == 0 and info["bookkeeping_channels"] == 0, info
     assert info["referee"]["exact_windows"] > 0, info
 
 
-@pytest.mark.parametrize("seed,profile", [(175, "plain"), (1738, "plain")])
+@pytest.mark.parametrize("seed,profile", [(1738, "plain")])
 def test_referee_with_the_scans_ahead_of_the_walk(seed, profile):
     """VDL2HIP_REF_PRESCAN=1 (off by default): the stretches around the marked candidates are made exact before the walk, which then
     decides them on the spot - speculative walks included; seed 1738: a lock the reference takes within 156 samples of a burst's end"""
