@@ -119,8 +119,19 @@ class Case:
         # shard = (first, count): a rank-sized receiver on this GPU (projected_scaling); else the rank's own share
         self.first, self.count = shard if shard else vdist.shard_channels(self.C, world, rank)
         self.device = torch.device("cuda", local)
-        self.rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm,
-                                   device=local, max_block_bytes=self.nbytes, chan_first=self.first, chan_count=self.count)
+        # A receiver of few channels (a rank's share, config2, config3) has a short front: its step is the walk's chain, and the
+        # referee's scans ahead of the walk (VDL2HIP_REF_PRESCAN=1) shorten that.  With 256 channels they cost more than they
+        # save and stay off.  An explicit setting in the environment wins.
+        self.prescan = os.environ.get("VDL2HIP_REF_PRESCAN") == "1"
+        auto = "VDL2HIP_REF_PRESCAN" not in os.environ and self.count <= 64
+        if auto:
+            os.environ["VDL2HIP_REF_PRESCAN"] = "1"; self.prescan = True
+        try:
+            self.rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm,
+                                       device=local, max_block_bytes=self.nbytes, chan_first=self.first, chan_count=self.count)
+        finally:
+            if auto:
+                del os.environ["VDL2HIP_REF_PRESCAN"]
         self.front = torch.cuda.ExternalStream(self.rx.stream(), device=self.device)
         self.host = torch.from_numpy(self.iq)
 
@@ -420,7 +431,7 @@ def measure_secondary(c2, name, oracle_check, args, dist, po):
     del fd
     rl = roofline_of(td, pmc_traffic(name, c2))
     step_hbm = td["dt"] / args.steps * 1e3
-    return {"name": name + ("_shard" if shard else ""),
+    return {"name": name + ("_shard" if shard else ""), "referee_scans_ahead_of_the_walk": c2.prescan,
             "workload": (f"configs[{WORKLOAD_INDEX[name]}] ({name})" if name in WORKLOAD_INDEX else name)
                         + f": {c2.C} channels in the air, {c2.count} decoded here"
                         + (f" (channels {c2.first}..{c2.first + c2.count - 1}: a rank's share at N = 8)" if shard else "") + f", {c2.cfg.duration_s:g} s",
@@ -564,9 +575,6 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    if world > 1:
-        # 32 channels per rank: the walk's chain, not the front, is the step - the referee's scans ahead of the walk shorten it
-        os.environ.setdefault("VDL2HIP_REF_PRESCAN", "1")
     case = Case(args.workload, args.duration, world, rank, local, torch, channels=args.channels)
     cfg = case.cfg
     if world > 1:        # every rank must hold the very same capture
@@ -726,7 +734,7 @@ def main():
             fd.step(); fd.step(); cs.rx.set_drain_lag(0); cs.rx.drain_packed()
             ts = cs.timed(fd, args.steps, dist, args.repeats)
             st = cs.stage_times(fd)
-            shards.append({"rank": r, "channels": [r * per, (r + 1) * per - 1], "ms_per_step": round(ts["dt"] / args.steps * 1e3, 4),
+            shards.append({"rank": r, "channels": [r * per, (r + 1) * per - 1], "referee_scans_ahead_of_the_walk": cs.prescan, "ms_per_step": round(ts["dt"] / args.steps * 1e3, 4),
                            "min_ms_per_step": ts["min_ms_per_step"], "k_chanfir_ms": round(ts["k1_ms"], 4), "stage_ms_per_step": st,
                            "frames_identical_to_the_oracle": vs_oracle})
             del fd
@@ -811,7 +819,7 @@ def main():
                        "parallelism": (f"channels sharded x{world} ({case.count} per GPU), RCCL {mode} of every IQ block inside the timed steps"
                                        + (" [REHEARSAL: all ranks on one GPU over gloo - not a measurement]" if rehearsal else "")
                                        if world > 1 else "single GPU, all channels"),
-                       "referee_scans_ahead_of_the_walk": os.environ.get("VDL2HIP_REF_PRESCAN", "0") == "1",
+                       "referee_scans_ahead_of_the_walk": case.prescan,
                        "exchange": exchange_info,
                        "by_exchange": by_exchange,
                        "rank_ms_per_step": t_host.get("rank_ms_per_step"),
