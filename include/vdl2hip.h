@@ -154,7 +154,7 @@ typedef struct {
 	 * from that by its rounding noise (<= 1.5e-4 of the local amplitude).  A decision of the reference that could come out differently
 	 * within that distance - candidate test, parabola vertex, --max-ppm gate (src/demod.c:173-192), a symbol at a slicer boundary
 	 * (:256-264) - is taken on the reference's own samples, recomputed by running its scan sequentially over the raw input: */
-	uint64_t referee_scans;     /* such scans run (one wavefront, ~2 ms each) */
+	uint64_t referee_scans;     /* such scans run (3.3 ms each by one wavefront, or 32 side by side by a workgroup) */
 	uint64_t referee_cached;    /* requests for a stretch that had been made exact already */
 	uint64_t referee_refused;   /* requests that could not be served (the raw input was no longer held): the decision stayed as it was */
 	uint64_t referee_short;     /* scans whose run-up was shorter than configured (early in a stream of short blocks) */

@@ -4,7 +4,7 @@ reference's own samples, which one wavefront recomputes from the raw input by ru
 
 1. the scan itself: a stretch made exact on the device is BIT-identical to the oracle's decimated stream - s16 and u8, offset-tuned and
    on-centre channels, whole-block and 320 000-byte feeds (the run-up then comes out of the history ring), at the stream's start
-   (zero state, exactly) and far into it (run-up from a zero state 2^18 samples back);
+   (zero state, exactly) and far into it (run-up from a zero state 2^17 samples back), one at a time and 75 side by side;
 2. the decisions: random captures that differ from the oracle in a frame or a counter without the referee (tests/fuzz_gpu.py's seeds
    175, 274, 1014: a symbol at a slicer boundary, a header bit, a preamble whose metric hangs on atan2()'s branch cut) are identical to
    it with the referee - frames, timing, the reference's 18 counters - strictly, no tie allowances."""
@@ -51,7 +51,7 @@ def test_scan_is_bit_exact(vh, oracle_mod, fmt, block):
     # ... is close to the oracle's but not it; the stretches the scan has been over are it, bit for bit
     checked = differed = 0
     for c in range(nch):
-        # (with short feeds: what the LAST feed can reach - its own block and the history ring, 2^18 samples of run-up + the longest burst)
+        # (with short feeds: what the LAST feed can reach - its own block and the history ring, 2^17 samples of run-up + the longest burst)
         for lo in ((0, 17, int(rng.integers(20000, D - 6000)), D - 400) if not block else (int(rng.integers(D - 40000, D - 6000)), D - 3000, D - 400)):
             hi = min(D - 1, lo + int(rng.integers(40, 700)) + (9000 if c % 3 == 1 else 0))       # (every third channel: a stretch as long as a burst)
             before = rx.read_decimated(c, lo, hi - lo + 1)
