@@ -53,7 +53,7 @@ def exact_stream(cfg, raw, fmt, A, B, dphis, D):
     return y
 
 
-def run_seed(seed, profile, referee=False, prescan=False):
+def run_seed(seed, profile, referee=False, prescan=False, pieces=1):
     """referee: the host build asks its referee - the oracle's own decimated stream stands in for the device's sequential scan - and the
     comparison is strict (no tie allowances, all 18 counters on every channel)"""
     import fuzz_gpu
@@ -83,7 +83,9 @@ def run_seed(seed, profile, referee=False, prescan=False):
     hs.set_segments(6000, 8)
     if referee:
         hs.set_exact(tr[:, :D, :]); hs.set_prescan(prescan)      # (prescan: the device's VDL2HIP_REF_PRESCAN=1 - marked candidates' stretches made exact ahead of the walk)
-    hs.feed(y)
+    step = (D + pieces - 1) // pieces            # (pieces > 1: several feeds - the walk's state, its snapshot and the noted decisions cross feed boundaries)
+    for k in range(0, D, step):
+        hs.feed(np.ascontiguousarray(y[:, k:k + step, :]))
     got = hs.frames()
     cg = [list(hs.counters(c)) for c in range(nch)]
     rst = hs.referee_stats() if referee else {}
@@ -98,17 +100,23 @@ def run_seed(seed, profile, referee=False, prescan=False):
 
 
 REFEREE = False
+PRESCAN = False
+PIECES = 1
 
 
 def _job(a):
     try:
-        return run_seed(*a, referee=REFEREE)
+        return run_seed(*a, referee=REFEREE, prescan=PRESCAN, pieces=PIECES)
     except Exception as e:  # noqa: BLE001
         return a[0], a[1], "error", {"why": f"{type(e).__name__}: {str(e)[:200]}"}
 
 
 def main():
-    global REFEREE
+    global REFEREE, PRESCAN, PIECES
+    if "--prescan" in sys.argv:          # ... with the scans ahead of the walk (VDL2HIP_REF_PRESCAN=1)
+        PRESCAN = True; sys.argv.remove("--prescan")
+    if "--pieces" in sys.argv:           # the capture in that many feeds
+        i = sys.argv.index("--pieces"); PIECES = int(sys.argv[i + 1]); del sys.argv[i:i + 2]
     if "--referee" in sys.argv:          # the host build with its referee, compared strictly (what the device does by default)
         REFEREE = True; sys.argv.remove("--referee")
     if sys.argv[1] == "--known":

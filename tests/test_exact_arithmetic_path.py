@@ -38,6 +38,13 @@ def test_decisions_that_hinge_on_the_references_own_rounding_go_to_the_referee(s
     assert info["referee"]["exact_windows"] > 0, info
 
 
+def test_referee_over_several_feeds():
+    """seed 175 in five feeds: the walk's state, its snapshot (a channel may be stitched again) and the noted decisions cross feed boundaries"""
+    import predict_gpu_parity as p
+    s, prof, verdict, info = p.run_seed(175, "plain", referee=True, pieces=5)
+    assert verdict == "ok" and info["ties"] == 0 and info["bookkeeping_channels"] == 0, info
+
+
 @pytest.mark.parametrize("seed,profile", [(1738, "plain")])
 def test_referee_with_the_scans_ahead_of_the_walk(seed, profile):
     """VDL2HIP_REF_PRESCAN=1 (off by default): the stretches around the marked candidates are made exact before the walk, which then
