@@ -1158,6 +1158,7 @@ struct K4Args {
 	// optimistic mode (rq != nullptr; vdl2_core.h: ref_verify): the feed's list of decisions to check, the "walk again" flag per channel,
 	// and where the state and counters a channel's walk starts from are kept
 	RefReq *rq; uint32_t *rq_n; uint32_t rq_cap; uint32_t *rq_flag; WalkState *ws_snap; unsigned long long *cnt_snap; RefBad *rq_bad; int32_t ref_pre;
+	int32_t force_again;       // test hook (vdl2hip_debug_option "force_again"): the check flags EVERY channel, so that every channel's state and counters go back to the snapshot and the feed is stitched a second time
 };
 
 __global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
@@ -1174,6 +1175,7 @@ __global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
 __global__ __launch_bounds__(64, 4) void k_ref_verify(K4Args a) {
 	__shared__ float lds[64];
 	const uint32_t nreq = *a.rq_n < a.rq_cap ? *a.rq_n : a.rq_cap;
+	if(a.force_again && blockIdx.x == 0) for(int c = (int)threadIdx.x; c < a.nchan; c += 64) a.rq_flag[c] = 1u;
 	for(uint32_t i = blockIdx.x; i < nreq; i += gridDim.x) {
 		const RefReq r = a.rq[i];
 		const int c = r.chan;

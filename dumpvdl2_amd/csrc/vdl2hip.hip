@@ -91,6 +91,11 @@ struct vdl2hip_ctx {
 	float4 *d_tcarry[2] = {nullptr, nullptr}; int tcarry_sel = 0;
 	unsigned long long *d_segpub = nullptr; uint32_t *d_synctmo = nullptr; bool fuse_k2 = true;   // K2 fused into K1 (one-step look-back between segments)
 	WalkState *d_ws = nullptr; unsigned long long *d_cnt = nullptr, *d_acnt = nullptr;
+	// The reference's per-channel counters live in TWO rows per channel, one per writer: d_cnt is the burst decoder's (atomic adds from
+	// k_burst on the burst streams), d_wcnt = d_cnt + C * kNumCounters the walker's (sync.good, the header outcomes, ppm_reject: plain
+	// read-modify-writes on the walk stream, and the only row the walk-again snapshot saves and restores).  A reader adds the two.  With one
+	// row, a channel walked again wiped whatever the previous feed's burst decoder had added since the snapshot (round 5's red test).
+	unsigned long long *d_wcnt = nullptr;
 	NfState *d_nf = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
 	float *d_nfring = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0, nf_ring = 0;
 	uint32_t cap_bursts_chan = 0;
@@ -105,7 +110,7 @@ struct vdl2hip_ctx {
 	// workgroup segment / K3b words per lane instead of the values chosen from the channel count.
 	int sync_on = 0; hipStream_t stream_sync = nullptr; int k3b_wpl = 0, tiles_force = 0; bool show_gaps = false; int ablate = 0;
 	OutCtl ctl_template{};                 // the capacities of a feed's output buffers (the counters are reset on the device: reset_out_ctl)
-	bool avlc_filter = false, failed = false; int debug_force_timeout = 0;
+	bool avlc_filter = false, failed = false; int debug_force_timeout = 0, debug_force_again = 0;
 	// Referee (kernels.h): decisions within the margin of the channeliser's distance from the reference's fp32 scan are taken on the
 	// reference's own samples, recomputed from the raw input.  The input of a feed stays where it is (d_in / the caller's device
 	// buffer) while its back end runs; what lies before it - up to ref_T samples: the run-up of the scan + the longest burst - is kept
@@ -457,9 +462,9 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	}
 	if(D > 0) {
 		const int64_t k1 = k0 + D;
-		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
+		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_wcnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(16 * sl.seq + 1),
-		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap, sl.d_rqbad, (c->referee && c->ref_prescan) ? 1 : 0 };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
+		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap, sl.d_rqbad, (c->referee && c->ref_prescan) ? 1 : 0, c->debug_force_again };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
 		int64_t seglen = D;
 		if(nseg >= 2) {
 			seglen = (D + nseg - 1) / nseg;
@@ -704,7 +709,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	// ~3 % slower): worth setting where the GPU is permanently shared, so that no time is spent waiting.
 	c->fuse_k2 = getenv("VDL2HIP_NO_FUSE") == nullptr;
 	if(const char *e = getenv("VDL2HIP_BACKEND")) c->defer_back = strcmp(e, "deferred") == 0;   // eager (default) | deferred
-	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, (size_t)count * kNumCounters * 8);
+	DEV_ALLOC(c->d_ws, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt, 2 * (size_t)count * kNumCounters * 8); c->d_wcnt = c->d_cnt + (size_t)count * kNumCounters;
 	DEV_ALLOC(c->d_acnt, (size_t)count * kNumAvlcCounters * 8);
 	// a decodable burst occupies >= 22 symbols = 220 decimated samples (header + 3 data + 2 FEC octets)
 	c->cap_bursts_chan = (uint32_t)(dmax / 220 + 4);
@@ -800,7 +805,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	DEV_CHK(hipMemset(c->d_y, 0, nring * sizeof(cf32))); DEV_CHK(hipMemset(c->d_pf, 0, nring * sizeof(cf32)));
 	DEV_CHK(hipMemset(c->d_cand, 0, nring / 8)); DEV_CHK(hipMemset(c->d_flag, 0, nring / 8));
 	DEV_CHK(hipMemset(c->d_tcarry[0], 0, count * sizeof(float4))); DEV_CHK(hipMemset(c->d_tcarry[1], 0, count * sizeof(float4)));
-	DEV_CHK(hipMemset(c->d_cnt, 0, (size_t)count * kNumCounters * 8)); DEV_CHK(hipMemset(c->d_acnt, 0, (size_t)count * kNumAvlcCounters * 8));
+	DEV_CHK(hipMemset(c->d_cnt, 0, 2 * (size_t)count * kNumCounters * 8)); DEV_CHK(hipMemset(c->d_acnt, 0, (size_t)count * kNumAvlcCounters * 8));
 	DEV_CHK(hipMemset(c->d_segend, 0, (size_t)count * c->nseg_cap * sizeof(float4)));
 	// the generic-oversample build may need more than the default dynamic LDS limit
 	const size_t lds = (size_t)c->run * c->os * 65 * sizeof(float2) + 8192;
@@ -985,7 +990,10 @@ int vdl2hip_counters(vdl2hip_ctx *c, uint32_t chan, uint64_t out[VDL2HIP_NUM_COU
 	OnDevice dev_guard(c);
 	int r = collect_pending(c);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
+	uint64_t w[kNumCounters];
 	HIPCHK(hipMemcpy(out, c->d_cnt + (size_t)(chan - c->chan_first) * kNumCounters, 8 * kNumCounters, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(w, c->d_wcnt + (size_t)(chan - c->chan_first) * kNumCounters, 8 * kNumCounters, hipMemcpyDeviceToHost));
+	for(int k = 0; k < kNumCounters; k++) out[k] += w[k];      // the burst decoder's row + the walker's
 	return VDL2HIP_OK;
 }
 
@@ -1024,8 +1032,9 @@ int vdl2hip_statsd_lines(vdl2hip_ctx *c, const char *ns, char *out, size_t cap) 
 	const size_t per = VDL2HIP_NUM_COUNTERS + VDL2HIP_NUM_AVLC_COUNTERS;
 	std::vector<uint64_t> now((size_t)c->C * per);
 	{
-		std::vector<uint64_t> a((size_t)c->C * kNumCounters), b((size_t)c->C * kNumAvlcCounters);      // two copies, whatever the channel count
+		std::vector<uint64_t> a(2 * (size_t)c->C * kNumCounters), b((size_t)c->C * kNumAvlcCounters);      // two copies, whatever the channel count
 		HIPCHK(hipMemcpy(a.data(), c->d_cnt, a.size() * 8, hipMemcpyDeviceToHost));
+		for(size_t k = 0, n = a.size() / 2; k < n; k++) a[k] += a[n + k];                               // the burst decoder's rows + the walker's
 		HIPCHK(hipMemcpy(b.data(), c->d_acnt, b.size() * 8, hipMemcpyDeviceToHost));
 		for(int ch = 0; ch < c->C; ch++) {
 			std::copy(a.begin() + (size_t)ch * kNumCounters, a.begin() + (size_t)(ch + 1) * kNumCounters, now.begin() + ch * per);
@@ -1100,6 +1109,7 @@ int vdl2hip_debug_option(vdl2hip_ctx *c, const char *name, long value) {
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	if(strcmp(name, "no_fuse") == 0) { c->fuse_k2 = value == 0; return VDL2HIP_OK; }
 	if(strcmp(name, "force_timeout") == 0) { c->debug_force_timeout = value != 0; return VDL2HIP_OK; }
+	if(strcmp(name, "force_again") == 0) { c->debug_force_again = value != 0; return VDL2HIP_OK; }   // every channel of every long feed is stitched a second time (the referee's walk-again path)
 	if(strcmp(name, "referee") == 0) { if(value && !c->d_refhist) return VDL2HIP_E_INVAL; c->referee = value != 0; return VDL2HIP_OK; }   // (on only where it was on at create: the history ring)
 	if(strcmp(name, "ref_debug_chan") == 0) {
 		if(!c->d_refdbg) { if(hipMalloc((void **)&c->d_refdbg, 8 * 4001) != hipSuccess) return VDL2HIP_E_NOMEM; }

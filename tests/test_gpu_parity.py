@@ -360,6 +360,32 @@ def test_many_channel_configs_vs_oracle(vh, oracle_mod, which, secs):
     rx.close()
 
 
+@pytest.mark.parametrize("which,secs,chunks", [("config3", 4.0, (2_000_000, 4_000_000)), ("config4", 3.0, (2_000_000, 4_000_000)),
+                                               ("config3", 2.0, (700_000, 1_500_000))])
+def test_every_channel_walked_again_beside_the_previous_feeds_burst_decoder(vh, oracle_mod, which, secs, chunks):
+    """Round 5's red test, made certain instead of likely: the test hook `force_again` makes the referee's check flag EVERY channel of
+    every long feed, so every channel's walker state and counters go back to the feed's snapshot and the feed is stitched a second
+    time - while the burst decoder of the feed before still adds its own counters (decoder.blocks.*, decoder.msg.*, decoder.errors.*)
+    on its burst stream.  Several long feeds in flight, drained once at the end.  The walker may only put back what it owns
+    (demod.sync.good, the header outcomes, ppm_reject): frames AND the reference's 18 counters identical to the oracle's on every
+    channel (src/decode.c:204-373).  (0.7-1.5 M-sample pieces: two to four walk segments per feed and a front of a fraction of a
+    millisecond, so the walks run as far ahead of the burst decoders as the slots allow.)"""
+    import os
+    from dumpvdl2_amd import workloads, synth
+    cfg = getattr(workloads, which)(secs)
+    iq, bursts = synth.synthesize(cfg)
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=20, max_ppm=cfg.rx_max_ppm)
+    o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=min(len(cfg.freqs), os.cpu_count() or 8))
+    fo = o.frames()
+    rx, fg, cnt = gpu_decode(vh, cfg, iq, chunks=chunks, max_block=16_000_000, debug={"force_again": 1})
+    s = rx.stats()
+    assert s["feeds"] >= 2 and s["referee_rewalks"] >= (s["feeds"] - 1) * len(cfg.freqs), s      # every channel, every long feed
+    assert len(fo) > 100
+    assert_frames_equal(fo, fg, label=which)
+    cases.assert_counters_equal(cnt, [list(o.counters(c).values()) for c in range(len(cfg.freqs))], which, exact_diagnostics=False)
+    rx.close()
+
+
 def test_burst_dense_block_vs_oracle(vh, oracle_mod):
     """The lock-dense secondary workload of bench.py (config4_bursty: 4x the bursts and ~4.6x the gate-dropped locks of config4) at 3 s
     against the oracle on all 256 channels: frames, timing and integer metadata identical, the reference's 18 counters identical on
