@@ -92,6 +92,7 @@ __device__ __forceinline__ bool ref_raw_sample(const RefChan &r, int64_t s, floa
 }
 
 __device__ __forceinline__ float dpp_wave_shr1(float v);
+__device__ __forceinline__ float dpp_wave_shr1_keep(float lane0, float v);
 #if VDL2_DEVICE_PASS
 // (no LDS, no memory traffic inside the recursion: the 64 feed-forward values of a block stay in the lanes that made them and are
 // handed to the recursion with v_readlane; the recursion itself is uniform - every lane does the same packed (I, Q) arithmetic.
@@ -395,6 +396,9 @@ __device__ __forceinline__ float dpp_row_shr(float v, int d) {     // value of l
 template<int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_bcast(float v) {               // row_bcast:15 (0x142) / row_bcast:31 (0x143) into the rows of ROWS, 0 elsewhere
 	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ float dpp_wave_shr1_keep(float lane0, float v) {   // value of lane - 1 across the whole wavefront, lane 0: `lane0`
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane0), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float dpp_wave_shr1(float v) {           // value of lane - 1 across the whole wavefront (lane 0: 0)
 	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
@@ -1325,26 +1329,40 @@ struct K5Args {
 };
 
 // ======================================================================
-// Many scans side by side.  ref_exact_window_dev() spends a whole wavefront on one recursion - 64 lanes doing the same packed
-// arithmetic, 60 % of a SIMD's issue slots for 3.3 ms: with a few hundred requests per feed that was 8 % (config4) to 28 %
-// (config4_bursty) of the channeliser's time.  Here a workgroup takes kScanLanes requests at once: two producer wavefronts do the part
-// without a recursion for one request and 64 input samples at a time (lane = sample), into LDS; one consumer wavefront runs the
-// recursions, lane = request, a step of all of them per turn.  Same arithmetic, operation for operation; ~45 clocks per input sample
-// for 32 requests instead of 58 for one.
+// Many scans side by side.  ref_exact_window_dev() spends a whole wavefront on one recursion - 64 lanes doing the same
+// arithmetic for 3.3 ms: with a few hundred requests per feed that was 8 % (config4) to 28 % (config4_bursty) of the channeliser's
+// time.  Here a workgroup takes kScanLanes requests at once: kScanProd producer wavefronts do the part without a recursion for one
+// request and 64 input samples at a time (lane = sample), into LDS; one consumer wavefront runs the recursions, a step of all of
+// them per turn.  Same arithmetic, operation for operation.
+// Round 6: the consumer's lane is one COMPONENT of one request (lanes 0-15: I of requests 0-15, lanes 16-31: Q) and its arithmetic
+// plain fp32 - v_mul, v_add, v_mul, v_add per step, the chain of three dependent operations 21 shader clocks - where round 5 ran a
+// request per lane in packed (I, Q) arithmetic: dependent v_pk_* operations take 31 clocks per step on the bare recursion
+// (dev/gpu_ubench_scan.hip, profiles/r06_ubench_scan.txt) and the kernel took 65.  The feed-forward values lie in LDS as
+// [component][request][sample], so a lane fetches four steps with one ds_read_b128.  With the consumer at 23 clocks per step the
+// producers became the bound: a wavefront alone on its SIMD issues one instruction per 4+ clocks, ~90 instructions per request and
+// block of 60 samples -> two requests per producer (8 producers, 16 requests per workgroup) keep pace with the consumer, four did not
+// (measured with either side switched off: consumer 1.35 ms per 136 192-sample scan, producers of four requests 2.3 ms).
 // ======================================================================
-constexpr int kScanLanes = 32, kScanProd = 4, kScanBlock = 64;
+constexpr int kScanLanes = 16, kScanProd = 8, kScanBlock = 64, kScanRow = kScanBlock + 4;
+#ifndef VDL2_SCAN_WAVES
+#define VDL2_SCAN_WAVES 11
+#endif
+constexpr int kScanWaves = VDL2_SCAN_WAVES;   // wavefronts launched per workgroup.  11: wavefronts 4 and 8 - which share SIMD 0 with the consumer (wavefront w runs on SIMD w mod 4) - leave at once, the 8 producers are wavefronts 1-3, 5-7, 9, 10: the consumer's chain of dependent operations has its SIMD to itself.  9: no idle wavefronts   // (row of 68 floats: 16-byte aligned, consecutive requests 4 banks apart)
 struct ScanShared {
-	v2f buf[2][kScanBlock][kScanLanes + 1];      // [block parity][sample][request] feed-forward values {I, Q}
+	alignas(16) float buf[2][2][kScanLanes][kScanRow];   // [block parity][component][request][sample] feed-forward values
 	int64_t s_beg[kScanLanes], len[kScanLanes], n_lo[kScanLanes], n_hi[kScanLanes];
 	uint32_t dphi[kScanLanes]; int32_t chan[kScanLanes], kind[kScanLanes]; uint32_t flags[kScanLanes];   // flags: 1 mix, 2 shortened run-up
 	int64_t lmax, smin;
 	v4f lut[256];                                // the NCO table
 };
-template<int FMT>
-__global__ __launch_bounds__(64 * (1 + kScanProd)) void k_ref_scan_multi(RefChan *rp, uint32_t launch, const ScanReq *sq, const RefReq *rq, const uint32_t *n_ptr, uint32_t cap, int64_t k_end) {
+// OS: the oversampling factor if it is 20 or 10 (a block is then 60 input samples - whole decimation periods - and the consumer's
+// steps are straight-line code with the outputs at fixed places: a compare + branch per step cost as much as the arithmetic), else 0
+template<int FMT, int OS>
+__global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp, uint32_t launch, const ScanReq *sq, const RefReq *rq, const uint32_t *n_ptr, uint32_t cap, int64_t k_end) {
 #if VDL2_DEVICE_PASS
 	#pragma clang fp contract(off)
 	__shared__ ScanShared sh;
+	constexpr int BLK = OS ? (kScanBlock / OS) * OS : kScanBlock;    // input samples per block
 	const uint32_t ntot = *n_ptr < cap ? *n_ptr : cap;
 	const uint32_t base = blockIdx.x * (uint32_t)kScanLanes;
 	if(base >= ntot) return;
@@ -1422,7 +1440,7 @@ __global__ __launch_bounds__(64 * (1 + kScanProd)) void k_ref_scan_multi(RefChan
 	const int64_t lmax = sh.lmax;
 	if(lmax <= 0) return;
 	__builtin_amdgcn_s_setprio(3);                               // (a few dozen wavefronts on the whole device, on the walk's critical path)
-	const int64_t nblk = (lmax + kScanBlock - 1) / kScanBlock;
+	const int64_t nblk = ((lmax + BLK - 1) / BLK + 2) / 4 * 4 + 1;   // blocks; 1 + a multiple of 4 (the producers' loop; a block too many computes on zeros and stores nothing)
 	for(int i = threadIdx.x; i < 256; i += blockDim.x) sh.lut[i] = ((ref_gf4 *)rp->lut)[i];
 	__syncthreads();
 
@@ -1431,23 +1449,32 @@ __global__ __launch_bounds__(64 * (1 + kScanProd)) void k_ref_scan_multi(RefChan
 	auto uni64 = [](int64_t v) -> int64_t { return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v)); };
 	auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 	constexpr int NQ = kScanLanes / kScanProd;                     // requests per producer wavefront
-	const v2f B1 = v2f{rp->B1, rp->B1}, B2 = v2f{rp->B2, rp->B2};
+	// producer number of this wavefront (-1: none)
+	const int pidx = kScanWaves == 1 + kScanProd ? wave - 1 : (wave == 0 || (wave & 3) == 0) ? -1 : wave - 1 - (wave > 4) - (wave > 8);
+	if(wave > 0 && pidx < 0) return;                              // (an idle wavefront: it has taken part in the set-up's barriers; s_barrier counts the wavefronts still there)
 	if(wave > 0) {
-		// ---- a producer: requests wave - 1, wave - 1 + kScanProd, ...; what it needs of each in registers (uniform values: where the
+#if defined(VDL2_SCAN_EXP) && VDL2_SCAN_EXP == 3
+		__builtin_amdgcn_s_setprio(1);
+#endif
+		// ---- a producer: requests pidx, pidx + kScanProd, ...; what it needs of each in registers (uniform values: where the
 		// request's sample 0 would lie if the stretch of raw input it is in went on for ever, how far that stretch does go) ----
-		const uint8_t *q_ptr[NQ]; uint32_t q_pend[NQ], q_ph0[NQ], q_len[NQ], q_dphi[NQ]; uint32_t mixmask = 0u;
+		const uint8_t *q_ptr[NQ]; uint32_t q_pend[NQ], q_ph0[NQ], q_len[NQ], q_dphi[NQ];
 		int64_t q_beg[NQ];
 		float pre[NQ], pim[NQ];                                       // a request's mixed samples of the block before (lanes 62, 63 are read)
-		uint32_t wq[NQ];
+		// the raw samples of the next PF blocks are in flight at any time (block b's in wq[b % PF]): a block lasts the consumer ~0.6 us,
+		// a load that misses the L2 takes longer - with one block of look-ahead the producers waited for memory, and the consumer for them
+		constexpr int PF = 4;
+		uint32_t wq[PF][NQ];
 		constexpr int SB = FMT == 1 ? 4 : 2;                          // bytes per raw sample
 		#pragma unroll
 		for(int q = 0; q < NQ; q++) {
-			const int r = wave - 1 + q * kScanProd;
+			const int r = pidx + q * kScanProd;
 			q_beg[q] = uni64(sh.s_beg[r]);
 			q_ph0[q] = (uint32_t)q_beg[q];
 			q_len[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sh.len[r]);
-			q_dphi[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dphi[r]);
-			if(__builtin_amdgcn_readfirstlane((int)sh.flags[r]) & 1) mixmask |= 1u << q;
+			// a channel that is not mixed (src/demod.c:312: offset_tuning == 0) gets the phase step 0: table entry 0 with fraction 0 is
+			// (sin, cos) = (0, 1) exactly, and multiplying by it leaves a sample exactly as it is (the conversions never produce a negative zero)
+			q_dphi[q] = (__builtin_amdgcn_readfirstlane((int)sh.flags[r]) & 1) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.dphi[r]) : 0u;
 			pre[q] = 0.f; pim[q] = 0.f; q_ptr[q] = nullptr; q_pend[q] = 0u;
 		}
 		// the stretch of raw input that holds sample p of request q (uniform; a handful of times per scan)
@@ -1465,9 +1492,9 @@ __global__ __launch_bounds__(64 * (1 + kScanProd)) void k_ref_scan_multi(RefChan
 		};
 		// the raw sample of request q and block b for this lane (0 past the request's end)
 		auto fetch = [&](int q, uint32_t b) -> uint32_t {
-			const uint32_t p0 = b * (uint32_t)kScanBlock;
+			const uint32_t p0 = b * (uint32_t)BLK;
 			if(p0 >= q_len[q]) return 0u;                                // (uniform)
-			const uint32_t n = q_len[q] - p0 < (uint32_t)kScanBlock ? q_len[q] - p0 : (uint32_t)kScanBlock;
+			const uint32_t n = q_len[q] - p0 < (uint32_t)BLK ? q_len[q] - p0 : (uint32_t)BLK;
 			if(p0 + n > q_pend[q]) {
 				// the block reaches past the stretch: lane by lane (the scan's first block, and where two stretches meet)
 				uint32_t w = 0u;
@@ -1482,79 +1509,142 @@ __global__ __launch_bounds__(64 * (1 + kScanProd)) void k_ref_scan_multi(RefChan
 			if((uint32_t)lane < n) w = FMT == 1 ? *(ref_gu32 *)(q_ptr[q] + (size_t)(p0 + (uint32_t)lane) * SB) : (uint32_t)*(ref_gu16 *)(q_ptr[q] + (size_t)(p0 + (uint32_t)lane) * SB);
 			return w;
 		};
-		// block b of all its requests (the raw samples are in wq): the NCO table entries first, all of them, then the arithmetic;
-		// the raw samples of block b + 1 are asked for before either
-		auto produce = [&](uint32_t b) {
-			uint32_t wn[NQ]; v4f eq[NQ]; uint32_t phq[NQ];
+		// block b of all its requests (the raw samples are in wq[SLOT]): the NCO table entries first, all of them, then the arithmetic;
+		// the raw samples of block b + PF are asked for before either
+		auto produce = [&](uint32_t b, auto SLOTC) {
+			constexpr int SLOT = decltype(SLOTC)::value;
+#if defined(VDL2_SCAN_EXP) && VDL2_SCAN_EXP == 1
+			return;
+#endif
+			uint32_t wc[NQ]; v4f eq[NQ]; uint32_t phq[NQ];
 			#pragma unroll
-			for(int q = 0; q < NQ; q++) wn[q] = fetch(q, b + 1);
+			for(int q = 0; q < NQ; q++) { wc[q] = wq[SLOT][q]; wq[SLOT][q] = fetch(q, b + PF); }
 			#pragma unroll
 			for(int q = 0; q < NQ; q++) {
-				phq[q] = ((q_ph0[q] + b * (uint32_t)kScanBlock + (uint32_t)lane) * q_dphi[q]) & 0xffffffu;
+				phq[q] = ((q_ph0[q] + b * (uint32_t)BLK + (uint32_t)lane) * q_dphi[q]) & 0xffffffu;
 				eq[q] = sh.lut[phq[q] >> 16];
 			}
+			// (straight-line for all its requests, so that their dependent chains - conversion, mixer, lane shifts, taps - interleave:
+			// a request that is through has zeros for raw samples and produces values nobody stores)
+			float re[NQ], im[NQ];
 			#pragma unroll
 			for(int q = 0; q < NQ; q++) {
-				if(b * (uint32_t)kScanBlock >= q_len[q]) continue;        // (uniform: the request is through)
-				const uint32_t w = wq[q];
-				float re, im;
-				if(FMT == 1) { re = (float)(int16_t)(w & 0xffff) / 32768.0f; im = (float)(int16_t)(w >> 16) / 32768.0f; }
-				else { re = ((float)(w & 0xff) - 127.5f) / 127.5f; im = ((float)((w >> 8) & 0xff) - 127.5f) / 127.5f; }
-				if((mixmask >> q) & 1u) {
-					const float F = (float)(phq[q] & 0xffffu);
-					const float sn = eq[q].x + eq[q].z * F, cs = eq[q].y + eq[q].w * F;
-					const float mr = re * cs - im * sn, mi = im * cs + re * sn;
-					re = mr; im = mi;
-				}
-				float x1r = dpp_wave_shr1(re), x1i = dpp_wave_shr1(im);
-				if(lane == 0) { x1r = ref_lane(pre[q], kScanBlock - 1); x1i = ref_lane(pim[q], kScanBlock - 1); }
-				float x2r = dpp_wave_shr1(x1r), x2i = dpp_wave_shr1(x1i);
-				if(lane == 0) { x2r = ref_lane(pre[q], kScanBlock - 2); x2i = ref_lane(pim[q], kScanBlock - 2); }
-				pre[q] = re; pim[q] = im;
-				float fa = A0 * re; fa += A1 * x1r + A2 * x2r;
-				float fb = A0 * im; fb += A1 * x1i + A2 * x2i;
-				sh.buf[b & 1][lane][wave - 1 + q * kScanProd] = v2f{fa, fb};
+				const uint32_t w = wc[q];
+				if(FMT == 1) { re[q] = (float)(int16_t)(w & 0xffff) / 32768.0f; im[q] = (float)(int16_t)(w >> 16) / 32768.0f; }
+				else { re[q] = ((float)(w & 0xff) - 127.5f) / 127.5f; im[q] = ((float)((w >> 8) & 0xff) - 127.5f) / 127.5f; }
+				const float F = (float)(phq[q] & 0xffffu);
+				const float sn = eq[q].x + eq[q].z * F, cs = eq[q].y + eq[q].w * F;
+				const float mr = re[q] * cs - im[q] * sn, mi = im[q] * cs + re[q] * sn;
+				re[q] = mr; im[q] = mi;
 			}
 			#pragma unroll
-			for(int q = 0; q < NQ; q++) wq[q] = wn[q];
+			for(int q = 0; q < NQ; q++) {
+				// in[1], in[2] (demod.c:75): the lane before's, lane 0 takes the block before's last ones (wave_shr:1 leaves lane 0 what it held)
+				const float x1r = dpp_wave_shr1_keep(ref_lane(pre[q], BLK - 1), re[q]), x1i = dpp_wave_shr1_keep(ref_lane(pim[q], BLK - 1), im[q]);
+				const float x2r = dpp_wave_shr1_keep(ref_lane(pre[q], BLK - 2), x1r), x2i = dpp_wave_shr1_keep(ref_lane(pim[q], BLK - 2), x1i);
+				pre[q] = re[q]; pim[q] = im[q];
+				float fa = A0 * re[q]; fa += A1 * x1r + A2 * x2r;
+				float fb = A0 * im[q]; fb += A1 * x1i + A2 * x2i;
+				sh.buf[b & 1][0][pidx + q * kScanProd][lane] = fa;
+				sh.buf[b & 1][1][pidx + q * kScanProd][lane] = fb;
+			}
 		};
 		#pragma unroll
-		for(int q = 0; q < NQ; q++) wq[q] = fetch(q, 0);
-		produce(0);
-		lds_barrier();
-		for(uint32_t b = 0; b < (uint32_t)nblk; b++) {
-			if(b + 1 < (uint32_t)nblk) produce(b + 1);
-			lds_barrier();
+		for(int k = 0; k < PF; k++) {
+			#pragma unroll
+			for(int q = 0; q < NQ; q++) wq[k][q] = fetch(q, (uint32_t)k);
 		}
+		produce(0u, std::integral_constant<int, 0>());
+		lds_barrier();
+		// blocks 1 .. nblk - 1, each followed by a barrier, and one barrier more (the consumer's last block).  nblk - 1 is a multiple of
+		// PF (see nblk): the loop body is PF blocks of straight-line code, block b1 + k in slot (1 + k) % PF, and the slots stay in the
+		// registers they were loaded into (a conditional tail made the compiler shuffle them with v_mov, each of which waits for its load)
+		static_assert(PF == 4, "the loop below is written out for four slots");
+		for(uint32_t b1 = 1; b1 < (uint32_t)nblk; b1 += PF) {
+			produce(b1, std::integral_constant<int, 1>()); lds_barrier();
+			produce(b1 + 1, std::integral_constant<int, 2>()); lds_barrier();
+			produce(b1 + 2, std::integral_constant<int, 3>()); lds_barrier();
+			produce(b1 + 3, std::integral_constant<int, 0>()); lds_barrier();
+		}
+		lds_barrier();
 		return;
 	}
-	// ---- the consumer: lane = request ----
+	// ---- the consumer: lane = (component, request) ----
 	lds_barrier();
-	const int r = lane < kScanLanes ? lane : 0;
-	v2f y1 = v2f{0.f, 0.f}, y2 = v2f{0.f, 0.f};
-	const int64_t my_lo = sh.n_lo[r], my_hi = (lane < kScanLanes && sh.len[r] > 0) ? sh.n_hi[r] : -1;
+	const int r = lane & (kScanLanes - 1), comp = (lane / kScanLanes) & 1;     // (lanes >= 2 * kScanLanes repeat the first ones' work and store the same values)
+	const float b1 = rp->B1, b2 = rp->B2;
+	float y1 = 0.f, t2 = 0.f;                                       // out[1] of demod.c:289-298 (this lane's component) and B2 * out[2], the product a step early
+	const int64_t my_lo = sh.n_lo[r], my_hi = (sh.len[r] > 0 && lane < 2 * kScanLanes) ? sh.n_hi[r] : -1;
 	int64_t k_out = sh.s_beg[r] / os;                                // the decimated sample this lane's next output is
-	__attribute__((address_space(1))) float *yout = (__attribute__((address_space(1))) float *)(rp->y + (size_t)sh.chan[r] * cap_y);
+	__attribute__((address_space(1))) float *yout = (__attribute__((address_space(1))) float *)(rp->y + (size_t)sh.chan[r] * cap_y) + comp;
 	int cnt = 0;                                                     // input samples since the last output (uniform: every request starts on a decimation boundary)
+	if constexpr(OS != 0) {
+		// whole decimation periods per block: chunks of 20 steps, the outputs at fixed places
+		constexpr int CH = 20, NV = CH / 4;
+		static_assert(BLK % CH == 0 && CH % OS == 0, "chunks of whole decimation periods");
+		(void)cnt;
+		for(int64_t b = 0; b < nblk; b++) {
+			const float *row = &sh.buf[b & 1][comp][r][0];
+			v4f cur[NV], nxt[NV];
+			#pragma unroll
+			for(int j = 0; j < NV; j++) cur[j] = *reinterpret_cast<const v4f *>(row + 4 * j);
+			#pragma unroll
+			for(int j0 = 0; j0 < BLK; j0 += CH) {
+				if(j0 + CH < BLK) {
+					#pragma unroll
+					for(int j = 0; j < NV; j++) nxt[j] = *reinterpret_cast<const v4f *>(row + j0 + CH + 4 * j);
+				}
+				#pragma unroll
+				for(int j = 0; j < CH; j++) {
+#if defined(VDL2_SCAN_EXP) && VDL2_SCAN_EXP == 2
+					if(j) continue;
+#endif
+					const float m = b1 * y1;
+					const float sm = m + t2;
+					t2 = b2 * y1;
+					y1 = cur[j >> 2][j & 3] + sm;
+					if((j + 1) % OS == 0) {
+						if(k_out >= my_lo && k_out <= my_hi) yout[2 * ((uint32_t)k_out & mask)] = y1;
+						k_out++;
+					}
+				}
+				#pragma unroll
+				for(int j = 0; j < NV; j++) cur[j] = nxt[j];
+			}
+			lds_barrier();
+		}
+	} else {
 	constexpr int kChunk = 16;
 	for(int64_t b = 0; b < nblk; b++) {
-		#pragma unroll 1
-		for(int j0 = 0; j0 < kScanBlock; j0 += kChunk) {
-			v2f r0v[kChunk];
-			#pragma unroll
-			for(int j = 0; j < kChunk; j++) r0v[j] = sh.buf[b & 1][j0 + j][r];      // (all asked for before the first is used)
+		const float *row = &sh.buf[b & 1][comp][r][0];
+		v4f cur[kChunk / 4], nxt[kChunk / 4];
+		#pragma unroll
+		for(int j = 0; j < kChunk / 4; j++) cur[j] = *reinterpret_cast<const v4f *>(row + 4 * j);
+		#pragma unroll
+		for(int j0 = 0; j0 < BLK; j0 += kChunk) {
+			// the next chunk's values are asked for before this chunk's steps: the LDS latency hides behind the recursion
+			if(j0 + kChunk < BLK) {
+				#pragma unroll
+				for(int j = 0; j < kChunk / 4; j++) nxt[j] = *reinterpret_cast<const v4f *>(row + j0 + kChunk + 4 * j);
+			}
 			#pragma unroll
 			for(int j = 0; j < kChunk; j++) {
-				const v2f yv = r0v[j] + (B1 * y1 + B2 * y2);
-				y2 = y1; y1 = yv;
+				// r = r0 + (B1 * out1 + B2 * out2): three roundings in the reference's order (demod.c:77)
+				const float m = b1 * y1;
+				const float sm = m + t2;
+				t2 = b2 * y1;
+				y1 = cur[j >> 2][j & 3] + sm;
 				if(__builtin_expect(++cnt == os, 0)) {
 					cnt = 0;
-					if(k_out >= my_lo && k_out <= my_hi) { yout[2 * ((uint32_t)k_out & mask)] = y1.x; yout[2 * ((uint32_t)k_out & mask) + 1] = y1.y; }
+					if(k_out >= my_lo && k_out <= my_hi) yout[2 * ((uint32_t)k_out & mask)] = y1;
 					k_out++;
 				}
 			}
+			#pragma unroll
+			for(int j = 0; j < kChunk / 4; j++) cur[j] = nxt[j];
 		}
 		lds_barrier();
+	}
 	}
 	if(lane < kScanLanes && sh.len[r] > 0) {
 		const int c = sh.chan[r];

@@ -424,7 +424,9 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 // workgroup slots from a channeliser (whose four waves per SIMD own the whole register file: every back-end workgroup keeps one
 // channeliser workgroup off its CU for as long as it lives).
 // (the kernel is compiled per sample format)
-#define LAUNCH_SCAN_MULTI(how, ...) do { if(c->fmt == 1) how(k_ref_scan_multi<1>, __VA_ARGS__); else how(k_ref_scan_multi<0>, __VA_ARGS__); } while(0)
+#define LAUNCH_SCAN_MULTI(how, ...) do { \
+	if(c->fmt == 1) { if(c->os == 20) how((k_ref_scan_multi<1, 20>), __VA_ARGS__); else if(c->os == 10) how((k_ref_scan_multi<1, 10>), __VA_ARGS__); else how((k_ref_scan_multi<1, 0>), __VA_ARGS__); } \
+	else { if(c->os == 20) how((k_ref_scan_multi<0, 20>), __VA_ARGS__); else if(c->os == 10) how((k_ref_scan_multi<0, 10>), __VA_ARGS__); else how((k_ref_scan_multi<0, 0>), __VA_ARGS__); } } while(0)
 static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	const int64_t D = sl.back_D, k0 = sl.back_k0;
 	// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
@@ -456,7 +458,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		// feed's whole walk chain: 10.7 ms per step)
 		hipStream_t sp_ = small ? c->stream : c->stream_pre[sl.seq % 4];
 		if(!small) HIPCHK(hipStreamWaitEvent(sp_, sl.ev_front, 0));
-		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kPreScans / kScanLanes), dim3(64 * (1 + kScanProd)), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
+		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kPreScans / kScanLanes), dim3(64 * kScanWaves), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
 		                  (const ScanReq *)sl.d_pq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 3), kPreScans, (int64_t)(k0 + D));
 		if(!small) { HIPCHK(hipEventRecord(sl.ev_pre, sp_)); HIPCHK(hipStreamWaitEvent(sb_, sl.ev_pre, 0)); }
 	}
@@ -481,7 +483,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			// referee, optimistic mode (long feeds): the decisions within the margin that the walk took are checked now, all at once, and
 			// the (rare) channel one of whose decisions does not stand is stitched again
 			// (the stretches first, many side by side - k_ref_scan_multi - then the decisions on them, a wavefront each)
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(c->rq_cap / kScanLanes), dim3(64 * (1 + kScanProd)), 0, sb_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, c->rq_cap, k1);
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(c->rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sb_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, c->rq_cap, k1);
 			hipLaunchKernelGGL(k_ref_verify, dim3(1024), dim3(64), 0, sb_, k4);
 			if(nseg >= 2) {
 				K4sArgs k4a{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, k0, seglen, c->d_segstats, 1 };
@@ -519,7 +521,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		else if(!defer5) hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), EV(11), 0, k5);
 		else {
 			hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), (hipEvent_t) nullptr, 0, k5);
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kDeferScans / kScanLanes), dim3(64 * (1 + kScanProd)), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), (uint32_t)kDeferScans, (int64_t)(k0 + D));
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kDeferScans / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), (uint32_t)kDeferScans, (int64_t)(k0 + D));
 			K5Args k5b = k5; k5b.df.pass = 2; k5b.ref_launch = (uint32_t)(16 * sl.seq + 7);
 			hipExtLaunchKernelGGL(k_burst, dim3(kDeferBursts / kBurstWaves / 4), dim3(64 * kBurstWaves), k5_lds, s5_, (hipEvent_t) nullptr, EV(11), 0, k5b);
 		}
@@ -1159,7 +1161,7 @@ int vdl2hip_debug_scan_multi(vdl2hip_ctx *c, const int32_t *chan, const int64_t 
 	bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess
 		&& hipMemcpy(d_sq, h.data(), sizeof(ScanReq) * (size_t)count, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_n, &count, 4, hipMemcpyHostToDevice) == hipSuccess
 		&& hipMemcpy(before, c->d_refstats, sizeof before, hipMemcpyDeviceToHost) == hipSuccess;
-	if(ok) LAUNCH_SCAN_MULTI(hipExtLaunchKernelGGL, dim3((count + kScanLanes - 1) / kScanLanes), dim3(64 * (1 + kScanProd)), 0, c->stream, e0, e1, 0, c->d_ref[(c->feed_no - 1) % kSlots], 0xfffeu,
+	if(ok) LAUNCH_SCAN_MULTI(hipExtLaunchKernelGGL, dim3((count + kScanLanes - 1) / kScanLanes), dim3(64 * kScanWaves), 0, c->stream, e0, e1, 0, c->d_ref[(c->feed_no - 1) % kSlots], 0xfffeu,
 	                             (const ScanReq *)d_sq, (const RefReq *) nullptr, (const uint32_t *)d_n, count, (int64_t)c->k_total);
 	ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(after, c->d_refstats, sizeof after, hipMemcpyDeviceToHost) == hipSuccess;
 	float t = 0.f;
