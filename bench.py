@@ -119,19 +119,14 @@ class Case:
         # shard = (first, count): a rank-sized receiver on this GPU (projected_scaling); else the rank's own share
         self.first, self.count = shard if shard else vdist.shard_channels(self.C, world, rank)
         self.device = torch.device("cuda", local)
-        # A receiver of few channels (a rank's share, config2, config3) has a short front: its step is the walk's chain, and the
-        # referee's scans ahead of the walk (VDL2HIP_REF_PRESCAN=1) shorten that.  With 256 channels they cost more than they
-        # save and stay off.  An explicit setting in the environment wins.
-        self.prescan = os.environ.get("VDL2HIP_REF_PRESCAN") == "1"
-        auto = "VDL2HIP_REF_PRESCAN" not in os.environ and self.count <= 64
-        if auto:
-            os.environ["VDL2HIP_REF_PRESCAN"] = "1"; self.prescan = True
-        try:
-            self.rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm,
-                                       device=local, max_block_bytes=self.nbytes, chan_first=self.first, chan_count=self.count)
-        finally:
-            if auto:
-                del os.environ["VDL2HIP_REF_PRESCAN"]
+        # A receiver of few channels (a rank's share, config2, config3) has a short front: its step would be the walk's chain, and the
+        # library puts the referee's scans AHEAD of the walk for receivers of <= 64 channels (vdl2hip_create).  With 256 channels
+        # they cost more than they save and stay behind the walk.  This is the library's own choice (VDL2HIP_REF_PRESCAN overrides it);
+        # the field below only reports it.
+        env = os.environ.get("VDL2HIP_REF_PRESCAN")
+        self.prescan = (env == "1") if env is not None else self.count <= 64
+        self.rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm,
+                                   device=local, max_block_bytes=self.nbytes, chan_first=self.first, chan_count=self.count)
         self.front = torch.cuda.ExternalStream(self.rx.stream(), device=self.device)
         self.host = torch.from_numpy(self.iq)
 

@@ -60,6 +60,7 @@ struct OutSlot {
 	// the burst-rate back end of this feed (K4, K4b, K5, frame finish) still has to be queued: launch_back()
 	bool back_queued = false; int64_t back_D = 0, back_k0 = 0; hipEvent_t ev_k1 = nullptr;
 	bool k1_timed = false;                 // the channeliser launch of this feed carries start/stop events (not on a cold-start feed: its pieces wait for copies in between)
+	bool prescan = false;                  // referee: the stretches around this feed's marked candidates are scanned ahead of its walk
 	unsigned k5_waves = 0; bool small = false;   // wavefronts of this feed's burst decoder; short feed: its whole back end runs on the front stream
 };
 
@@ -102,7 +103,7 @@ struct vdl2hip_ctx {
 	SpecOut *d_spec = nullptr; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
-	hipStream_t stream_pre[4] = {};        // referee, VDL2HIP_REF_PRESCAN=1: the scans ahead of the walk, a stream per feed in flight (one stream would put them in a row: 4.4 ms each)
+	hipStream_t stream_pre[kSlots] = {};        // referee, VDL2HIP_REF_PRESCAN=1: the scans ahead of the walk, a stream per feed in flight (one stream would put them in a row: 4.4 ms each)
 	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst[kSlots] = {};   // (a burst stream per feed in flight: a burst decoder that waits for the referee - a scan over a whole burst takes milliseconds - does not hold up the next feed's)
 	// Experiment switches (only read in builds with -DVDL2_EXPERIMENTS, dev/gpu_run.sh; the measured outcomes are in DESIGN 6).
 	// sync_on: 0 = both sync kernels on the front stream (the product); 1 = the exact tier in front of the walk on the walk stream;
@@ -165,6 +166,8 @@ static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds, 
 }
 
 static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate);
+// A short feed (fewer than two walk segments' worth of samples; the reference's own 320 000-byte blocks are 4 000): launch_back()
+static bool feed_is_small(const vdl2hip_ctx *c, int64_t D);
 
 static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 	if(!sl.pending) return VDL2HIP_OK;
@@ -382,7 +385,9 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		// wavefronts of this feed's burst decoder: each owns kResSlots frame records of the output from the start, so a short block gets few
 		sl.k5_waves = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(16, (D * (int64_t)c->C) >> 14));
 		sl.k5_waves = (sl.k5_waves + kBurstWaves - 1) / kBurstWaves * kBurstWaves;
-		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0, sl.d_rqn, sl.d_rqflag, sl.d_rqbad, (c->referee && c->ref_prescan) ? sl.d_pq : nullptr, kPreScans };
+		// (a short feed - launch_back: `small` - asks the referee on the spot whatever the mode: its one walk sits on the front stream)
+		sl.prescan = c->referee && c->ref_prescan && !feed_is_small(c, D);
+		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0, sl.d_rqn, sl.d_rqflag, sl.d_rqbad, sl.prescan ? sl.d_pq : nullptr, kPreScans };
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
 		// on the front stream than a separate hipEventRecord.  (VDL2HIP_SYNC_ON=walk puts the exact tier in front of the walk on
 		// the walk stream, VDL2HIP_SYNC_ON=own both sync kernels on a stream of their own, so that the front stream goes on
@@ -424,6 +429,10 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 // workgroup slots from a channeliser (whose four waves per SIMD own the whole register file: every back-end workgroup keeps one
 // channeliser workgroup off its CU for as long as it lives).
 // (the kernel is compiled per sample format)
+static bool feed_is_small(const vdl2hip_ctx *c, int64_t D) {
+	const int nseg = (int)std::min<int64_t>(c->seg_max, D / c->seg_min);
+	return D > 0 && D < 2 * c->seg_min && nseg < 2 && !c->defer_back && c->sync_on == 0;
+}
 #define LAUNCH_SCAN_MULTI(how, ...) do { \
 	if(c->fmt == 1) { if(c->os == 20) how((k_ref_scan_multi<1, 20>), __VA_ARGS__); else if(c->os == 10) how((k_ref_scan_multi<1, 10>), __VA_ARGS__); else how((k_ref_scan_multi<1, 0>), __VA_ARGS__); } \
 	else { if(c->os == 20) how((k_ref_scan_multi<0, 20>), __VA_ARGS__); else if(c->os == 10) how((k_ref_scan_multi<0, 10>), __VA_ARGS__); else how((k_ref_scan_multi<0, 0>), __VA_ARGS__); } } while(0)
@@ -436,7 +445,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	// with the three noise-floor passes as one kernel.  Whoever follows on the front stream is then behind it anyway.
 	// (... and only when both sync kernels ARE on the front stream - sync_on 0, the product; the experiment builds' other placements hand the
 	// candidate bitmap over with an event the short cut does not wait for)
-	const bool small = D > 0 && D < 2 * c->seg_min && nseg < 2 && !c->defer_back && c->sync_on == 0;
+	const bool small = feed_is_small(c, D);
 	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst[sl.seq % kSlots];
 	hipEvent_t *ev = sl.ev;
 	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
@@ -450,13 +459,13 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		if(gate) HIPCHK(hipStreamWaitEvent(sb_, gate, 0));
 	}
 	if(D <= 0) hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(1), 0, sb_, sl.d_ctl, 0u);     // (a feed with a front has had it reset by its last sync kernel)
-	if(D > 0 && c->referee && c->ref_prescan) {
+	if(D > 0 && sl.prescan) {
 		// Referee: the stretches the exact sync tier has listed (around its marked candidates) are made the reference's own NOW, beside
 		// the next feed's front and off the walk stream - the walk of this feed waits for them, the walk of the next one does not
 		// (a scan on the walk stream is 3.7 ms that every following feed's walk queues behind: with 8 channels that was the step time)
 		// (on a stream of its own: behind this feed's noise floor - which waits for the walk - the next feed's scans would wait for this
 		// feed's whole walk chain: 10.7 ms per step)
-		hipStream_t sp_ = small ? c->stream : c->stream_pre[sl.seq % 4];
+		hipStream_t sp_ = small ? c->stream : c->stream_pre[sl.seq % kSlots];
 		if(!small) HIPCHK(hipStreamWaitEvent(sp_, sl.ev_front, 0));
 		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kPreScans / kScanLanes), dim3(64 * kScanWaves), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
 		                  (const ScanReq *)sl.d_pq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 3), kPreScans, (int64_t)(k0 + D));
@@ -466,7 +475,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		const int64_t k1 = k0 + D;
 		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_wcnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(16 * sl.seq + 1),
-		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap, sl.d_rqbad, (c->referee && c->ref_prescan) ? 1 : 0, c->debug_force_again };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
+		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap, sl.d_rqbad, sl.prescan ? 1 : 0, c->debug_force_again };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
 		int64_t seglen = D;
 		if(nseg >= 2) {
 			seglen = (D + nseg - 1) / nseg;
@@ -756,6 +765,11 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	}
 
 	if(const char *e = getenv("VDL2HIP_REFEREE")) c->referee = atoi(e) != 0;
+	// Referee, long feeds: where do the scans go?  A receiver of few channels has a front of a fraction of a millisecond and its step is
+	// the walk's chain - walk, scan, check, walk again - unless the scans run AHEAD of the walk on a stream per slot (`prescan`); with
+	// hundreds of channels the front hides the chain and the 2.5x scans of that mode (every marked candidate, not every visited one)
+	// cost more than they save.  VDL2HIP_REF_PRESCAN=0/1 overrides the choice.
+	c->ref_prescan = count <= 64;
 	if(const char *e = getenv("VDL2HIP_REF_PRESCAN")) c->ref_prescan = atoi(e) != 0;
 	if(const char *e = getenv("VDL2HIP_REF_WARM")) { const long long v = atoll(e); if(v >= 1024 && v <= (1ll << 24)) c->ref_warm = v; }
 	if(c->referee) {

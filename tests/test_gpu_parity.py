@@ -656,6 +656,22 @@ def test_with_and_without_the_referee_on_the_golden_captures(vh, name):
         assert abs(a[0] - b[0]) <= 0.01 and abs(a[1] - b[1]) <= 0.05 and abs(a[2] - b[2]) <= 0.05
 
 
+@pytest.mark.parametrize("name,prescan", [("config2_1s", 0), ("config2_1s", 1), ("dirty25k_1s", 0), ("config4_0p4s", 1), ("config5_0p4s", 1), ("config3_0p6s", 0)])
+def test_referee_scans_ahead_of_or_behind_the_walk(vh, monkeypatch, name, prescan):
+    """The library puts the referee's scans ahead of the walk for receivers of <= 64 channels and behind it (note, scan, check, walk
+    again) for larger ones (vdl2hip_create).  Here each golden capture runs in the mode that is NOT its default
+    (VDL2HIP_REF_PRESCAN): golden frames, timing, integer metadata and counters, whole and in pieces long enough for segmented walks
+    with several feeds in flight."""
+    monkeypatch.setenv("VDL2HIP_REF_PRESCAN", str(prescan))
+    cfg, iq, bursts, gold = cases.load(name)
+    for kw in ({}, dict(chunks=(700_000, 1_200_000), max_block=4_800_000)):
+        rx, fr, cnt = gpu_decode(vh, cfg, iq, **kw)
+        cases.check_against_golden(fr, cnt, gold, label=f"{name} prescan={prescan} {kw}", exact_diagnostics=False)
+        s = rx.stats()
+        assert s["referee_refused"] == 0, s
+        rx.close()
+
+
 @pytest.mark.parametrize("name", ["config2_1s", "config4_0p4s"])
 def test_deferred_back_end_gives_the_same_answer(vh, monkeypatch, name):
     """VDL2HIP_BACKEND=deferred queues the back end of feed i behind the channeliser of feed i+1 (DESIGN 8: measured, not the default);
