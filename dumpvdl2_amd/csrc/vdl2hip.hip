@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -40,6 +41,17 @@ constexpr int kColdParts = 4;         // pieces a cold-start block is copied and
 constexpr size_t kColdMinBytes = 8u << 20;
 constexpr uint32_t kPreScans = 4096;    // referee: stretches around marked candidates one feed may list for the scan ahead of the walk (what does not fit is asked for by the walk itself)
 constexpr uint32_t kDeferBursts = 256, kDeferScans = 512;   // referee: bursts of one feed that may wait for their scans, stretches they may wait for (what does not fit is scanned on the spot)
+// Streams per priority class.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per
+// priority, round-robin in the order of their creation, and two streams on one queue run one after the other.  With a scan stream and
+// a burst stream per slot (four of each), a scan stream shared its queue with the walk stream and burst streams shared theirs with the
+// front and the noise-floor stream (all three of the front's priority): every fourth feed's 1.5 ms scan sat in front of the next walks
+// (a rank-sized receiver: 2.64 ms per step; 1.91 with GPU_MAX_HW_QUEUES=8 - which in turn cost the 256-channel receiver 4 %:
+// profiles/r06_hw_queues_ab.txt).  So: high priority = walk + 3 scan streams, the front's priority = front + noise floor + 2 burst
+// streams - four each, nobody shares.  (Feed i + 3's scan, feed i + 2's burst decoder behind feed i's: done long before.)
+// The streams of a receiver that is destroyed go to a pool (per device) and the next receiver takes them over: the runtime's mapping
+// of streams to queues depends on every stream the process has created so far, and a receiver made after a hundred others had come
+// and gone ran 30-60 % slower than the same receiver in a fresh process (bench.py's secondary workloads, round 6).
+constexpr int kSidePre = 3, kSideBurst = 2;
 constexpr int kSlots = VDL2HIP_MAX_DRAIN_LAG + 1;   // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered).  Four: with the referee a feed's way through the device - front, the scans ahead of the walk, walk + check, bursts + their scans - is about three fronts long
 
 }  // namespace
@@ -103,14 +115,15 @@ struct vdl2hip_ctx {
 	SpecOut *d_spec = nullptr; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
-	hipStream_t stream_pre[kSlots] = {};        // referee, VDL2HIP_REF_PRESCAN=1: the scans ahead of the walk, a stream per feed in flight (one stream would put them in a row: 4.4 ms each)
-	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst[kSlots] = {};   // (a burst stream per feed in flight: a burst decoder that waits for the referee - a scan over a whole burst takes milliseconds - does not hold up the next feed's)
+	hipStream_t stream_pre[kSidePre] = {};        // referee, VDL2HIP_REF_PRESCAN=1: the scans ahead of the walk, a stream per feed in flight (one stream would put them in a row: 4.4 ms each)
+	hipStream_t stream_back = nullptr, stream_nf = nullptr, stream_burst[kSideBurst] = {};   // (a burst stream per feed in flight: a burst decoder that waits for the referee - a scan over a whole burst takes milliseconds - does not hold up the next feed's)
 	// Experiment switches (only read in builds with -DVDL2_EXPERIMENTS, dev/gpu_run.sh; the measured outcomes are in DESIGN 6).
 	// sync_on: 0 = both sync kernels on the front stream (the product); 1 = the exact tier in front of the walk on the walk stream;
 	// 2 = both on a stream of their own (stream_sync), beside the channeliser of the next feed.  tiles_force / k3b_wpl: K1 tiles per
 	// workgroup segment / K3b words per lane instead of the values chosen from the channel count.
 	int sync_on = 0; hipStream_t stream_sync = nullptr; int k3b_wpl = 0, tiles_force = 0; bool show_gaps = false; int ablate = 0;
 	OutCtl ctl_template{};                 // the capacities of a feed's output buffers (the counters are reset on the device: reset_out_ctl)
+	bool pooled = false;                   // its streams are complete and of the product's priorities: they go to the pool when the receiver is destroyed
 	bool avlc_filter = false, failed = false; int debug_force_timeout = 0, debug_force_again = 0;
 	// Referee (kernels.h): decisions within the margin of the channeliser's distance from the reference's fp32 scan are taken on the
 	// reference's own samples, recomputed from the raw input.  The input of a feed stays where it is (d_in / the caller's device
@@ -446,7 +459,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	// (... and only when both sync kernels ARE on the front stream - sync_on 0, the product; the experiment builds' other placements hand the
 	// candidate bitmap over with an event the short cut does not wait for)
 	const bool small = feed_is_small(c, D);
-	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst[sl.seq % kSlots];
+	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst[sl.seq % kSideBurst];
 	hipEvent_t *ev = sl.ev;
 	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
 	sl.back_queued = false; sl.small = small;
@@ -465,7 +478,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		// (a scan on the walk stream is 3.7 ms that every following feed's walk queues behind: with 8 channels that was the step time)
 		// (on a stream of its own: behind this feed's noise floor - which waits for the walk - the next feed's scans would wait for this
 		// feed's whole walk chain: 10.7 ms per step)
-		hipStream_t sp_ = small ? c->stream : c->stream_pre[sl.seq % kSlots];
+		hipStream_t sp_ = small ? c->stream : c->stream_pre[sl.seq % kSidePre];
 		if(!small) HIPCHK(hipStreamWaitEvent(sp_, sl.ev_front, 0));
 		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kPreScans / kScanLanes), dim3(64 * kScanWaves), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
 		                  (const ScanReq *)sl.d_pq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 3), kPreScans, (int64_t)(k0 + D));
@@ -564,6 +577,13 @@ static void fill_frame(const vdl2hip_ctx *c, const HostFrame &h, vdl2hip_frame &
 	f.avlc_status = h.f.avlc_status; f.dst_addr = h.f.dst_addr; f.src_addr = h.f.src_addr;
 }
 
+namespace {
+// the streams of one receiver (see kSidePre): kept when the receiver goes, taken over by the next one on the same device
+struct StreamSet { int device = -1; hipStream_t front = nullptr, copy = nullptr, out = nullptr, back = nullptr, nf = nullptr, pre[kSidePre] = {}, burst[kSideBurst] = {}; };
+std::mutex g_pool_mutex;
+std::vector<StreamSet> g_pool;
+}  // namespace
+
 extern "C" {
 
 int vdl2hip_abi_version(void) { return VDL2HIP_ABI_VERSION; }
@@ -605,15 +625,22 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	{ void *q[] = { c->d_refhist, c->d_refdone, c->d_refdonen, c->d_refstats, c->d_mix, c->d_refdbg, c->d_ws_snap, c->d_cnt_snap }; for(void *p : q) if(p) (void)hipFree(p); }
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
 	for(auto &e : c->cold.ev) if(e) (void)hipEventDestroy(e);
-	if(c->stream_copy) { (void)hipStreamSynchronize(c->stream_copy); (void)hipStreamDestroy(c->stream_copy); }
-	if(c->stream_out) { (void)hipStreamSynchronize(c->stream_out); (void)hipStreamDestroy(c->stream_out); }
-	if(c->stream_sync) { (void)hipStreamSynchronize(c->stream_sync); (void)hipStreamDestroy(c->stream_sync); }
-	for(auto &sp : c->stream_pre) if(sp) { (void)hipStreamSynchronize(sp); (void)hipStreamDestroy(sp); }
-	if(c->stream_back) { (void)hipStreamSynchronize(c->stream_back); (void)hipStreamDestroy(c->stream_back); }
-	if(c->stream_nf) { (void)hipStreamSynchronize(c->stream_nf); (void)hipStreamDestroy(c->stream_nf); }
-	for(auto &sb5 : c->stream_burst) if(sb5) { (void)hipStreamSynchronize(sb5); (void)hipStreamDestroy(sb5); }
+	for(hipStream_t st_ : { c->stream_copy, c->stream_out, c->stream_sync, c->stream_back, c->stream_nf }) if(st_) (void)hipStreamSynchronize(st_);
+	for(auto &sp : c->stream_pre) if(sp) (void)hipStreamSynchronize(sp);
+	for(auto &sb5 : c->stream_burst) if(sb5) (void)hipStreamSynchronize(sb5);
+	if(c->stream_sync) (void)hipStreamDestroy(c->stream_sync);
 	for(void *p : ptrs) if(p) (void)hipFree(p);
-	if(c->stream) (void)hipStreamDestroy(c->stream);
+	if(c->stream && c->pooled) {
+		StreamSet ss; ss.device = c->cfg.device; ss.front = c->stream; ss.copy = c->stream_copy; ss.out = c->stream_out; ss.back = c->stream_back; ss.nf = c->stream_nf;
+		for(int i = 0; i < kSidePre; i++) ss.pre[i] = c->stream_pre[i];
+		for(int i = 0; i < kSideBurst; i++) ss.burst[i] = c->stream_burst[i];
+		std::lock_guard<std::mutex> lk(g_pool_mutex);
+		g_pool.push_back(ss);
+	} else {
+		for(hipStream_t st_ : { c->stream_copy, c->stream_out, c->stream_back, c->stream_nf, c->stream }) if(st_) (void)hipStreamDestroy(st_);
+		for(auto &sp : c->stream_pre) if(sp) (void)hipStreamDestroy(sp);
+		for(auto &sb5 : c->stream_burst) if(sb5) (void)hipStreamDestroy(sb5);
+	}
 	delete c;
 }
 
@@ -678,6 +705,21 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		if(const char *e = getenv("VDL2HIP_FRONT_PRIO")) { if(strcmp(e, "mid") == 0) prio_front = (prio_low + prio_high) / 2; else if(strcmp(e, "high") == 0) prio_front = prio_high; }
 		if(getenv("VDL2HIP_GAPS")) fprintf(stderr, "vdl2hip: stream priority range low %d .. high %d, front %d\n", prio_low, prio_high, prio_front);
 #endif
+		bool from_pool = false;
+#ifndef VDL2_EXPERIMENTS
+		{
+			std::lock_guard<std::mutex> lk(g_pool_mutex);
+			for(size_t i = 0; i < g_pool.size(); i++) if(g_pool[i].device == cfg->device) {
+				const StreamSet ss = g_pool[i]; g_pool.erase(g_pool.begin() + (long)i);
+				c->stream = ss.front; c->stream_copy = ss.copy; c->stream_out = ss.out; c->stream_back = ss.back; c->stream_nf = ss.nf;
+				for(int k = 0; k < kSidePre; k++) c->stream_pre[k] = ss.pre[k];
+				for(int k = 0; k < kSideBurst; k++) c->stream_burst[k] = ss.burst[k];
+				from_pool = true;
+				break;
+			}
+		}
+#endif
+		if(!from_pool) {
 		DEV_CHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_front));
 		// The walk goes first whenever it competes with the channeliser of a later feed (every later stage waits for it).  The
 		// noise-floor and burst streams do not: their many single-wave workgroups, dispatched with priority, each take the
@@ -691,6 +733,10 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		for(auto &sb5 : c->stream_burst) DEV_CHK(hipStreamCreateWithPriority(&sb5, hipStreamNonBlocking, prio_of("burst")));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
 		DEV_CHK(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
+		}
+#ifndef VDL2_EXPERIMENTS
+		c->pooled = true;
+#endif
 #ifdef VDL2_EXPERIMENTS
 		if(c->sync_on == 2) DEV_CHK(hipStreamCreateWithPriority(&c->stream_sync, hipStreamNonBlocking, strcmp(getenv("VDL2HIP_SYNC_ON"), "own-high") == 0 ? prio_high : prio_low));
 #endif
