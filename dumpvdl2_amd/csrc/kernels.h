@@ -101,15 +101,41 @@ typedef __attribute__((address_space(1))) const uint32_t ref_gu32;
 typedef __attribute__((address_space(1))) const uint16_t ref_gu16;
 typedef __attribute__((address_space(1))) const v4f ref_gf4;
 __device__ __forceinline__ float ref_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-// the list of stretches of a channel made exact: (lo / 256 : 32 bits, length / 256 : 16, launch : 16).  A stretch done by another
-// wavefront of THIS launch does not count: its samples may still sit in another XCD's L2; from the next launch on they are everybody's
+// the list of stretches of a channel made exact: (lo / 256 : 32 bits, length / 256 : 16, launch : 16).
+// WHOSE entries may a kernel believe?  The entry is an agent-scope atomic, the samples behind it are plain stores that may still sit
+// dirty in the writer's XCD-local L2 until the writing KERNEL ends: an entry counts only if its writer has ended before the reader
+// began.  launch = 16 * feed + kind; kinds of the walk chain, in the order they run on the walk stream(s) of a feed: 8 scans ahead of
+// the walk, 1 speculative / single walk, 2 stitch, 0 the noted decisions' scans, 3 check, 4 walk again; kinds of the burst stream of a
+// feed: 5 burst decoder (first pass), 6 its listed scans, 7 second pass.  Everything of the walk chain of feed s ends before anything
+// of the walk chain of feed s + 1 begins, and before the burst kernels of feed s begin; the burst kernels of a feed follow one another;
+// but the burst kernels of feed s run BESIDE the walk chains of the feeds after s and beside other feeds' burst kernels.  Hence:
+//   a walk-chain kernel believes walk-chain entries of earlier feeds, and of its own feed from the kinds before its own (the scans
+//   ahead of the walk excepted: they run beside the earlier feeds' walk chains and believe nobody);
+//   a burst kernel believes walk-chain entries of its own and earlier feeds, and its own feed's earlier burst kinds;
+//   nobody believes an entry of his own launch (another wavefront's, still running), and nothing else.
+// (Round 5 believed every entry of another launch - a burst decoder could pick up the entry of a later feed's scan that was still
+// writing.)  Feed numbers wrap at 4096: "earlier" = up to 2047 feeds back; what looks later is scanned again, which is only slower.
+// 0xfffe / 0xffff: the test hooks' launches, run with nothing else in flight - they believe everything but themselves and are believed.
+__device__ __forceinline__ bool ref_entry_visible(uint32_t entry, uint32_t mine) {
+	entry &= 0xffffu; mine &= 0xffffu;
+	if(entry == mine) return false;
+	if(mine >= 0xfffeu || entry >= 0xfffeu) return true;
+	const uint32_t ek = entry & 15u, mk = mine & 15u, d = ((mine >> 4) - (entry >> 4)) & 0xfffu;
+	if(mk == 8u) return false;                                    // the scans ahead of the walk start when their feed's front is done - beside the walk chains of the feeds before: they believe nobody
+	const bool older = d != 0u && d < 2048u, same = d == 0u;
+	// rank in the walk chain (15: not of the walk chain)
+	auto rank = [](uint32_t k) -> uint32_t { return k == 8u ? 0u : k == 1u ? 1u : k == 2u ? 2u : k == 0u ? 3u : k == 3u ? 4u : k == 4u ? 5u : 15u; };
+	const uint32_t er = rank(ek), mr = rank(mk);
+	if(mr != 15u) return er != 15u && (older || (same && er < mr));
+	return (er != 15u && (older || same)) || (er == 15u && same && ek < mk);
+}
 __device__ __forceinline__ bool ref_done_lookup(const unsigned long long *done, uint32_t ndv, int64_t n_lo, int64_t n_hi, uint32_t launch, int lane) {
 	const uint32_t nd = ndv < (uint32_t)kRefCache ? ndv : (uint32_t)kRefCache;
 	bool hit = false;
 	if((uint32_t)lane < nd) {
 		const unsigned long long e = __hip_atomic_load(done + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const int64_t lo = (int64_t)(e >> 32) << 8, hi = lo + ((int64_t)((e >> 16) & 0xffffull) << 8) + 255;
-		hit = lo <= n_lo && n_hi <= hi && (uint32_t)(e & 0xffffull) != (launch & 0xffffu);
+		hit = lo <= n_lo && n_hi <= hi && ref_entry_visible((uint32_t)(e & 0xffffull), launch);
 	}
 	return __any(hit) != 0;
 }
@@ -162,7 +188,7 @@ __device__ __forceinline__ bool ref_exact_window_dev(const ChanView &v, int64_t 
 	bool shortened = false;
 	if(s_beg < 0) s_beg = 0;                                     // the stream's own start: the reference's state there is zero, exactly
 	else {
-		if(ps0[0] > s_beg) { shortened = true; s_beg = ps0[0]; }
+		if(ps0[0] > s_beg) { shortened = true; s_beg = (ps0[0] + os - 1) / os * os; }      // (the oldest sample held, on the next decimation boundary: nothing that is not held is read)
 		if(s_beg > 0 && (int64_t)os * n_lo - s_beg < warm / 4) { if(lane == 0) atomicAdd(stats + 2, 1u); return false; }
 	}
 	if(npiece <= 0 || in_end < s_end) { if(lane == 0) atomicAdd(stats + 2, 1u); return false; }
@@ -1396,7 +1422,7 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 				for(uint32_t i = 0; i < nd; i++) {
 					const unsigned long long e = __hip_atomic_load(done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					const int64_t lo = (int64_t)(e >> 32) << 8, hi = lo + ((int64_t)((e >> 16) & 0xffffull) << 8) + 255;
-					hit = hit || (lo <= n_lo && n_hi <= hi && (uint32_t)(e & 0xffffull) != (launch & 0xffffu));
+					hit = hit || (lo <= n_lo && n_hi <= hi && ref_entry_visible((uint32_t)(e & 0xffffull), launch));
 				}
 				if(hit) { atomicAdd(stats + 1, 1u); go = false; }
 			}
@@ -1406,7 +1432,7 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 				bool refuse = in_end < s_end;
 				if(s_beg < 0) s_beg = 0;
 				else {
-					if(ps0[0] > s_beg) { fl |= 2u; s_beg = ps0[0]; }
+					if(ps0[0] > s_beg) { fl |= 2u; s_beg = (ps0[0] + os - 1) / os * os; }
 					if(s_beg > 0 && (int64_t)os * n_lo - s_beg < warm / 4) refuse = true;
 				}
 				if(refuse) { atomicAdd(stats + 2, 1u); go = false; }

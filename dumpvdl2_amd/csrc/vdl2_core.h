@@ -557,9 +557,10 @@ VDL2_HD Geometry header_to_geometry(uint32_t hdr, const uint32_t *tH, const uint
 // reference takes on those samples - candidate test, parabola vertex, --max-ppm gate, symbol slicer - is therefore taken
 // here WITH A MARGIN: when the decision could come out differently for some stream within that distance, the wavefront asks
 // ref_exact_window() for the reference's own samples of the stretch the decision reads (the scan re-run sequentially in the
-// reference's operation order from kRefWarm input samples back: two such scans started from different states are
-// bit-identical after 1.5e4 samples on average, after kRefWarm with probability 1 - 1e-7) and takes the decision again on those.
-// A decision is then either robust against the stream's error or taken on the reference's samples: the reference's decision.
+// reference's operation order from RefChan::warm input samples back - 2^17 by default: two such scans started from different
+// states are bit-identical after 1.6e4 samples on average, and had NOT yet met after 2^17 in 2.5e-4 of the cases measured
+// (kernels.h)) and takes the decision again on those.  A decision is then either robust against the stream's error or taken on
+// samples that are the reference's own with that probability; where they are not yet, they are within its rounding noise of them.
 // ======================================================================
 constexpr float kRefKappa = 3.0e-4f;       // bound used for |y - y_ref| / (largest |y| among the samples a decision reads): 2x the worst seen
 constexpr float kRefBig = 1.0e30f;
