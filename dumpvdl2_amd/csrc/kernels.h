@@ -104,15 +104,19 @@ __device__ __forceinline__ float ref_lane(float v, int l) { return __builtin_bit
 // the list of stretches of a channel made exact: (lo / 256 : 32 bits, length / 256 : 16, launch : 16).
 // WHOSE entries may a kernel believe?  The entry is an agent-scope atomic, the samples behind it are plain stores that may still sit
 // dirty in the writer's XCD-local L2 until the writing KERNEL ends: an entry counts only if its writer has ended before the reader
-// began.  launch = 16 * feed + kind; kinds of the walk chain, in the order they run on the walk stream(s) of a feed: 8 scans ahead of
-// the walk, 1 speculative / single walk, 2 stitch, 0 the noted decisions' scans, 3 check, 4 walk again; kinds of the burst stream of a
-// feed: 5 burst decoder (first pass), 6 its listed scans, 7 second pass.  Everything of the walk chain of feed s ends before anything
-// of the walk chain of feed s + 1 begins, and before the burst kernels of feed s begin; the burst kernels of a feed follow one another;
-// but the burst kernels of feed s run BESIDE the walk chains of the feeds after s and beside other feeds' burst kernels.  Hence:
-//   a walk-chain kernel believes walk-chain entries of earlier feeds, and of its own feed from the kinds before its own (the scans
-//   ahead of the walk excepted: they run beside the earlier feeds' walk chains and believe nobody);
-//   a burst kernel believes walk-chain entries of its own and earlier feeds, and its own feed's earlier burst kinds;
-//   nobody believes an entry of his own launch (another wavefront's, still running), and nothing else.
+// began.  launch = 16 * feed + kind.  Kinds of the walk chain of feed s and when they run (vdl2hip.hip: launch_back / launch_rest):
+//   8 scans ahead of the walk        own stream, after the feed's front: BESIDE the walk chains of the feeds before
+//   1 speculative / single walk, 2 stitch                 walk stream
+//   0 the noted decisions' scans, 3 check                 own stream, after stitch(s): beside stitch(s + 1)
+//   4 walk again (after check(s) AND stitch(s + 1)), 9 feed s once more from a corrected start (after 4 of s - 1): walk stream
+// so the walk stream runs  ... stitch(s)  4(s-1) 9(s)  stitch(s+1)  4(s) 9(s+1)  stitch(s+2) ...  with 0/3 of feed s anywhere between
+// stitch(s) and 4(s).  Kinds of the burst stream of feed s, after 4(s): 5 burst decoder (first pass), 6 its listed scans, 7 second pass;
+// they run beside the walk chains of the feeds after s and beside other feeds' burst kernels.  Hence a reader (feed m, kind mk)
+// believes an entry (feed e, kind ek), d = m - e:
+//   walk chain reading walk chain:  d >= 2: yes.  d = 1: kinds 8, 1, 2, 9 - and everything if the reader is 4 or 9 (check(m - 1) has
+//     ended by then).  d = 0: reader 1: {8}; 2: {8, 1}; 0: {8, 1, 2}; 3: {8, 1, 2, 0}; 9: {8, 1, 2}; 4: {8, 1, 2, 9, 0, 3}.
+//   burst kernel: walk-chain entries of its own and earlier feeds, and its own feed's earlier burst kinds.
+//   the scans ahead of the walk (8) believe nobody; nobody believes an entry of his own launch or a burst kernel of another feed.
 // (Round 5 believed every entry of another launch - a burst decoder could pick up the entry of a later feed's scan that was still
 // writing.)  Feed numbers wrap at 4096: "earlier" = up to 2047 feeds back; what looks later is scanned again, which is only slower.
 // 0xfffe / 0xffff: the test hooks' launches, run with nothing else in flight - they believe everything but themselves and are believed.
@@ -121,13 +125,20 @@ __device__ __forceinline__ bool ref_entry_visible(uint32_t entry, uint32_t mine)
 	if(entry == mine) return false;
 	if(mine >= 0xfffeu || entry >= 0xfffeu) return true;
 	const uint32_t ek = entry & 15u, mk = mine & 15u, d = ((mine >> 4) - (entry >> 4)) & 0xfffu;
-	if(mk == 8u) return false;                                    // the scans ahead of the walk start when their feed's front is done - beside the walk chains of the feeds before: they believe nobody
-	const bool older = d != 0u && d < 2048u, same = d == 0u;
-	// rank in the walk chain (15: not of the walk chain)
-	auto rank = [](uint32_t k) -> uint32_t { return k == 8u ? 0u : k == 1u ? 1u : k == 2u ? 2u : k == 0u ? 3u : k == 3u ? 4u : k == 4u ? 5u : 15u; };
-	const uint32_t er = rank(ek), mr = rank(mk);
-	if(mr != 15u) return er != 15u && (older || (same && er < mr));
-	return (er != 15u && (older || same)) || (er == 15u && same && ek < mk);
+	if(mk == 8u || d >= 2048u) return false;
+	auto walk_kind = [](uint32_t k) { return k <= 4u || k == 8u || k == 9u; };
+	if(!walk_kind(mk)) return walk_kind(ek) || (d == 0u && ek < mk);       // a burst kernel (5, 6, 7)
+	if(!walk_kind(ek)) return false;
+	if(d >= 2u) return true;
+	const bool early = ek == 8u || ek == 1u || ek == 2u;                        // ends before anything of the next feed's walk begins
+	if(d == 1u) return early || ek == 9u || mk == 4u || mk == 9u;
+	switch(mk) {                                                                 // d == 0
+		case 1: return ek == 8u;
+		case 2: return ek == 8u || ek == 1u;
+		case 0: case 9: return early;
+		case 3: return early || ek == 0u;
+		default: return true;                                                    // 4: everything else of its feed has ended
+	}
 }
 __device__ __forceinline__ bool ref_done_lookup(const unsigned long long *done, uint32_t ndv, int64_t n_lo, int64_t n_hi, uint32_t launch, int lane) {
 	const uint32_t nd = ndv < (uint32_t)kRefCache ? ndv : (uint32_t)kRefCache;
@@ -953,7 +964,7 @@ struct K3Args {
 	int32_t wpl;              // exact tier: flag words scanned per lane (1..kK3bWordsPerLane)
 	OutCtl *ctl; uint32_t k5_waves;   // the feed's output control block, reset here (the last kernel of the front, so that no copy has to do it)
 	// referee (nullptr: off): the feed's hook - written here from `refv`, for the same reason - and what the candidate verdict needs
-	RefChan *ref; RefChan refv; float max_ppm; const float *ppm_thr; int32_t ref_on; uint32_t *rq_n, *rq_flag; RefBad *rq_bad; ScanReq *pq; uint32_t pq_cap;      // rq_n, rq_flag, rq_bad: the feed's list of decisions to check / its "walk again" flags / the decisions that fell, reset here;      // (ref != nullptr, ref_on == 0: the hook is written, the verdicts are the plain ones)
+	RefChan *ref; RefChan refv; float max_ppm; const float *ppm_thr; int32_t ref_on; uint32_t *rq_n, *rq_flag; RefBad *rq_bad; ScanReq *pq; uint32_t pq_cap; uint32_t *rq_flag2;      // rq_n, rq_flag, rq_bad: the feed's list of decisions to check / its "walk again" flags / the decisions that fell, reset here;      // (ref != nullptr, ref_on == 0: the hook is written, the verdicts are the plain ones)
 };
 
 // K3: got_sync() metric (contiguous ring) + the candidate bitmap, in two tiers and two kernels.
@@ -1047,7 +1058,7 @@ constexpr int kK3bWordsPerLane = 4;      // at most; fewer when that leaves the 
 // (which read every tap from memory - five loads per tap with the referee - and kept three lanes in four idle during the metric).
 __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
 	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { reset_out_ctl(a.ctl, a.k5_waves); if(a.ref) *a.ref = a.refv; if(a.rq_n) { a.rq_n[0] = 0u; a.rq_n[1] = 0u; a.rq_n[2] = 0u; } }   // (rq_n[1], [2]: the burst decoder's lists, BurstDefer)
-	if(blockIdx.x == 0 && threadIdx.x == 0 && a.rq_flag) { a.rq_flag[blockIdx.y] = 0u; a.rq_bad[blockIdx.y].n = 0u; }
+	if(blockIdx.x == 0 && threadIdx.x == 0 && a.rq_flag) { a.rq_flag[blockIdx.y] = 0u; a.rq_bad[blockIdx.y].n = 0u; if(a.rq_flag2) a.rq_flag2[blockIdx.y] = 0u; }
 	constexpr int kBack = 160, kSpan = kBack + 64;        // staged samples: base - 160 .. base + 63
 	// [wave][6 + bit]: metric of sample word*64 + bit (entries 0..5 = the six samples before the word), its slope, and - for the
 	// referee - its error figure E and its value with the one discontinuity taken the other way (vdl2_core.h: sync_metric_ref)
@@ -1189,6 +1200,13 @@ struct K4Args {
 	// and where the state and counters a channel's walk starts from are kept
 	RefReq *rq; uint32_t *rq_n; uint32_t rq_cap; uint32_t *rq_flag; WalkState *ws_snap; unsigned long long *cnt_snap; RefBad *rq_bad; int32_t ref_pre;
 	int32_t force_again;       // test hook (vdl2hip_debug_option "force_again"): the check flags EVERY channel, so that every channel's state and counters go back to the snapshot and the feed is stitched a second time
+	// The walk of the NEXT feed does not wait for this feed's check (vdl2hip.hip: launch_rest): when it has run already, a channel
+	// walked again (k_walk_stitch, again = 2) leaves its end state and counters in ws_tmp / cnt_tmp instead of the live rows and compares
+	// them with what the next feed's walk started from (its snapshot: ws_snap_next / cnt_snap_next).  The same - all but always - and
+	// the next feed's walk stands; else the snapshot is corrected, rq_flag2_next[c] set, and the next feed is stitched once more for
+	// that channel from the corrected snapshot (again = 3, its own rq_flag2).
+	WalkState *ws_tmp; unsigned long long *cnt_tmp; WalkState *ws_snap_next; unsigned long long *cnt_snap_next; uint32_t *rq_flag2, *rq_flag2_next;
+	int32_t force_mismatch;    // test hook: every channel walked again is taken to have ended differently (the next feed is redone for it)
 };
 
 __global__ __launch_bounds__(64, 4) void k_walk(K4Args a) {
@@ -1267,14 +1285,37 @@ __global__ __launch_bounds__(256, 4) void k_walk_stitch(K4sArgs s) {
 	const K4Args &a = s.k;
 	const int wave = threadIdx.x >> 6, c = blockIdx.x * kStitchWaves + wave;      // a channel per wavefront
 	if(c >= a.nchan) return;
-	if(s.again && !a.rq_flag[c]) return;
+	// again: 0 the feed's walk; 1 a flagged channel once more, nothing walked after this feed yet (state and counters: the live rows);
+	// 2 the same when the next feed HAS been walked (K4Args: ws_tmp ...); 3 this feed once more for a channel whose start state the
+	// previous feed's second walk has corrected
+	const int mode = s.again;
+	if((mode == 1 || mode == 2) && !a.rq_flag[c]) return;
+	if(mode == 3 && !a.rq_flag2[c]) return;
 	StitchLds &lds = reinterpret_cast<StitchLds *>(k4_lds)[wave];
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + (s.again ? 3u : 1u), s.again ? nullptr : a.rq, a.rq_n, a.rq_cap, a.rq_flag, a.rq_bad ? a.rq_bad + c : nullptr, a.ref_pre != 0 };
+	// (launch kinds, ref_entry_visible(): a.ref_launch is kind 1; stitch 2, walk again 4, the corrected feed's second walk 9)
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + (mode == 0 ? 1u : mode == 3 ? 8u : 3u), mode ? nullptr : a.rq, a.rq_n, a.rq_cap, a.rq_flag,
+	            // (mode 3: this feed's check may not have run yet - no speculative walk that noted decisions is adopted: spec_requests_stand() without a list)
+	            (a.rq_bad && mode != 3) ? a.rq_bad + c : nullptr, a.ref_pre != 0 };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
-	stitch_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, &a.ws[c], a.cnt + (size_t)c * kNumCounters,
+	WalkState *gstate = mode == 2 ? &a.ws_tmp[c] : &a.ws[c];
+	unsigned long long *cnt = (mode == 2 ? a.cnt_tmp : a.cnt) + (size_t)c * kNumCounters;
+	stitch_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, gstate, cnt,
 	               a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg,
-	               s.spec + (size_t)c * s.spec_stride, lds.sh, lds.ss, s.seg_stats + 2 * c, WalkSnap{ a.rq ? a.ws_snap : nullptr, a.cnt_snap }, s.again != 0);
-	if(s.again && (threadIdx.x & 63) == 0) atomicAdd(a.ref->stats + 7, 1u);
+	               s.spec + (size_t)c * s.spec_stride, lds.sh, lds.ss, s.seg_stats + 2 * c, WalkSnap{ (a.rq || mode) ? a.ws_snap : nullptr, a.cnt_snap }, mode != 0);
+	if(mode && (threadIdx.x & 63) == 0) atomicAdd(a.ref->stats + 7, 1u);
+	if(mode == 2) {
+		// the channel's end state and counters after the second walk against what the next feed's walk started from
+		WAVE_SYNC_GLOBAL();
+		const int lane = threadIdx.x & 63;
+		bool same = true;
+		if(lane == 0) same = walk_state_equal(a.ws_tmp[c], a.ws_snap_next[c]) && !a.force_mismatch;
+		if(lane < kNumCounters) same = same && cnt[lane] == a.cnt_snap_next[(size_t)c * kNumCounters + lane];
+		if(__any(!same)) {
+			if(lane == 0) { a.ws_snap_next[c] = a.ws_tmp[c]; a.rq_flag2_next[c] = 1u; atomicAdd(a.ref->stats + 8, 1u); }
+			if(lane < kNumCounters) a.cnt_snap_next[(size_t)c * kNumCounters + lane] = cnt[lane];
+		}
+	}
+	if(mode == 3 && (threadIdx.x & 63) == 0) a.rq_flag2[c] = 0u;
 }
 
 struct K4bArgs {

@@ -263,6 +263,21 @@ struct WalkState {
 	Burst   pb;                        // burst in progress
 };
 
+VDL2_HD uint32_t float_bits_of(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+#define FLOAT_BITS(f) float_bits_of(f)
+// the same state, as far as anything that follows can depend on it (intervals beyond niv and a burst that is not in progress are leftovers)
+VDL2_HD bool burst_equal(const Burst &x, const Burst &y) {
+	return x.chan == y.chan && x.nsym == y.nsym && x.t_first == y.t_first && x.sync_sample == y.sync_sample && x.end_sample == y.end_sample && x.ord == y.ord
+		&& FLOAT_BITS(x.prev_phi0) == FLOAT_BITS(y.prev_phi0) && FLOAT_BITS(x.vdphi) == FLOAT_BITS(y.vdphi) && FLOAT_BITS(x.ppm) == FLOAT_BITS(y.ppm) && FLOAT_BITS(x.vdphi_err) == FLOAT_BITS(y.vdphi_err)
+		&& x.prev_n == y.prev_n && x.tl_bits == y.tl_bits && x.syndrome == y.syndrome && x.nf_upd == y.nf_upd && x.sync_evals == y.sync_evals;
+}
+VDL2_HD bool walk_state_equal(const WalkState &x, const WalkState &y) {
+	if(x.a != y.a || x.e != y.e || x.e0 != y.e0 || x.bursts != y.bursts || x.evals != y.evals || x.mode != y.mode || x.niv != y.niv) return false;
+	if(FLOAT_BITS(x.pherr1) != FLOAT_BITS(y.pherr1) || FLOAT_BITS(x.pherr2) != FLOAT_BITS(y.pherr2) || FLOAT_BITS(x.prev_dphi) != FLOAT_BITS(y.prev_dphi)) return false;
+	for(int i = 0; i < x.niv && i < kNumIv; i++) if(x.iva[i] != y.iva[i] || x.ivb[i] != y.ivb[i]) return false;
+	return x.mode == 0 || burst_equal(x.pb, y.pb);
+}
+
 VDL2_HD void walk_state_init(WalkState &s) {
 	s.a = 0; s.e = 2; s.e0 = 2; s.bursts = 0;
 	s.pherr1 = s.pherr2 = kPherrBig; s.prev_dphi = 0.f;

@@ -73,6 +73,10 @@ struct OutSlot {
 	bool back_queued = false; int64_t back_D = 0, back_k0 = 0; hipEvent_t ev_k1 = nullptr;
 	bool k1_timed = false;                 // the channeliser launch of this feed carries start/stop events (not on a cold-start feed: its pieces wait for copies in between)
 	bool prescan = false;                  // referee: the stretches around this feed's marked candidates are scanned ahead of its walk
+	// launch_back() / launch_rest(): the walk and check of this feed are queued, what follows them is not yet (rest_pending); what the
+	// second walks need of the first: its arguments, segmentation and speculative walks; has_chk: the walk noted decisions to a list that is checked
+	bool rest_pending = false, has_chk = false; int nseg = 1; int64_t seglen = 0; K4Args k4{}; SpecOut *d_spec_of = nullptr;
+	hipEvent_t ev_stitch = nullptr, ev_chk = nullptr; uint32_t *d_rqflag2 = nullptr;
 	unsigned k5_waves = 0; bool small = false;   // wavefronts of this feed's burst decoder; short feed: its whole back end runs on the front stream
 };
 
@@ -112,7 +116,7 @@ struct vdl2hip_ctx {
 	NfState *d_nf = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
 	float *d_nfring = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0, nf_ring = 0;
 	uint32_t cap_bursts_chan = 0;
-	SpecOut *d_spec = nullptr; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
+	SpecOut *d_spec[2] = {}; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
 	hipStream_t stream_pre[kSidePre] = {};        // referee, VDL2HIP_REF_PRESCAN=1: the scans ahead of the walk, a stream per feed in flight (one stream would put them in a row: 4.4 ms each)
@@ -133,7 +137,8 @@ struct vdl2hip_ctx {
 	bool referee = true; int ref_kinds = 7; bool ref_prescan = false;   /* VDL2HIP_REF_PRESCAN=1: the stretches around marked candidates are made exact ahead of the walk - a rank-sized shard 4.05 -> 2.88 ms per step, 256 channels 7.2 -> 7.85: for receivers of few channels */ int64_t ref_warm = 1 << 17, ref_T = 0; uint8_t *d_refhist = nullptr; uint64_t ref_cap = 0, ref_wp = 0;
 	struct HistPiece { int64_t s0, n; uint64_t pos; }; std::vector<HistPiece> ref_pieces;
 	unsigned long long *d_refdbg = nullptr; int ref_dbg_chan = -1;
-	WalkState *d_ws_snap = nullptr; unsigned long long *d_cnt_snap = nullptr; uint32_t rq_cap = 8192; bool ref_optimistic = true;
+	WalkState *d_ws_snap[2] = {}, *d_ws_tmp = nullptr; unsigned long long *d_cnt_snap[2] = {}, *d_cnt_tmp = nullptr; uint32_t rq_cap = 8192; bool ref_optimistic = true;
+	bool walk_ahead = true; int debug_force_mismatch = 0;   // launch_back(): the next feed's walk does not wait for this feed's check
 	RefChan *d_ref[kSlots] = {}; unsigned long long *d_refdone = nullptr; uint32_t *d_refdonen = nullptr, *d_refstats = nullptr; uint8_t *d_mix = nullptr;
 	bool defer_back = false;               // VDL2HIP_BACKEND=deferred: the back end of feed i is queued behind the channeliser of feed i+1 (launch_back)
 	std::vector<uint64_t> statsd_prev;
@@ -179,12 +184,14 @@ static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds, 
 }
 
 static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate);
+static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, struct OutSlot *succ);
 // A short feed (fewer than two walk segments' worth of samples; the reference's own 320 000-byte blocks are 4 000): launch_back()
 static bool feed_is_small(const vdl2hip_ctx *c, int64_t D);
 
 static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 	if(!sl.pending) return VDL2HIP_OK;
 	if(sl.back_queued) { int r = launch_back(c, sl, nullptr); if(r != VDL2HIP_OK) return r; }   // nothing followed this feed: its back end goes now
+	if(sl.rest_pending) { int r = launch_rest(c, sl, nullptr); if(r != VDL2HIP_OK) return r; }   // ... nor did a walk that its second walks could have been queued behind
 	HIPCHK(hipEventSynchronize(sl.done));
 	sl.pending = false;
 	if(c->profiling && sl.ev_valid) {
@@ -400,7 +407,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		sl.k5_waves = (sl.k5_waves + kBurstWaves - 1) / kBurstWaves * kBurstWaves;
 		// (a short feed - launch_back: `small` - asks the referee on the spot whatever the mode: its one walk sits on the front stream)
 		sl.prescan = c->referee && c->ref_prescan && !feed_is_small(c, D);
-		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0, sl.d_rqn, sl.d_rqflag, sl.d_rqbad, sl.prescan ? sl.d_pq : nullptr, kPreScans };
+		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0, sl.d_rqn, sl.d_rqflag, sl.d_rqbad, sl.prescan ? sl.d_pq : nullptr, kPreScans, sl.d_rqflag2 };
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
 		// on the front stream than a separate hipEventRecord.  (VDL2HIP_SYNC_ON=walk puts the exact tier in front of the walk on
 		// the walk stream, VDL2HIP_SYNC_ON=own both sync kernels on a stream of their own, so that the front stream goes on
@@ -449,6 +456,22 @@ static bool feed_is_small(const vdl2hip_ctx *c, int64_t D) {
 #define LAUNCH_SCAN_MULTI(how, ...) do { \
 	if(c->fmt == 1) { if(c->os == 20) how((k_ref_scan_multi<1, 20>), __VA_ARGS__); else if(c->os == 10) how((k_ref_scan_multi<1, 10>), __VA_ARGS__); else how((k_ref_scan_multi<1, 0>), __VA_ARGS__); } \
 	else { if(c->os == 20) how((k_ref_scan_multi<0, 20>), __VA_ARGS__); else if(c->os == 10) how((k_ref_scan_multi<0, 10>), __VA_ARGS__); else how((k_ref_scan_multi<0, 0>), __VA_ARGS__); } } while(0)
+// The walk of feed i + 1 does not wait for the check of feed i ("walk ahead").  walk(i + 1) needs the state walk(i) leaves, and that
+// state is final only when the decisions walk(i) noted have been checked - behind a scan of 1.5 ms that no hardware shortens; with a
+// front of 1 ms (a rank's 32 channels) that chain was the step.  But the check confirms the walk all but always.  So:
+//   walk stream:    ... stitch(i)   again(i-1) redo(i)   stitch(i+1)   again(i) redo(i+1)   stitch(i+2) ...
+//   check(i) = scans + verify on the scan stream of its slot, between stitch(i) and again(i), i.e. beside stitch(i+1);
+//   again(i): the channels whose decisions did not stand (or that flagged themselves) are walked again from feed i's snapshot, into a
+//     scratch row; their end state and counters are compared with what stitch(i+1) started from (feed i+1's snapshot).  The same:
+//     stitch(i+1) stands.  Different (a few per thousand second walks): the snapshot of feed i+1 is corrected and the channel flagged;
+//   redo(i+1): the flagged channels are stitched once more over feed i+1 from the corrected snapshot, into the live rows.
+// stitch(i+2) follows on the same stream: it starts from a state in which feeds <= i are checked - the check of feed i overlaps one
+// walk and one front.  launch_back() queues the walk and the check; launch_rest() - called when the NEXT feed's walk has been queued,
+// or, if nothing follows (a drain, a short feed, the old schedule with VDL2HIP_WALK_AHEAD=0), at once with `succ` = nullptr: again(i)
+// then works on the live rows as it always did - queues the second walks and everything behind them: noise floor, burst decoder,
+// frame finish, the copy of the control block.
+static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ);
+
 static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	const int64_t D = sl.back_D, k0 = sl.back_k0;
 	// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
@@ -459,26 +482,30 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	// (... and only when both sync kernels ARE on the front stream - sync_on 0, the product; the experiment builds' other placements hand the
 	// candidate bitmap over with an event the short cut does not wait for)
 	const bool small = feed_is_small(c, D);
-	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst[sl.seq % kSideBurst];
+	hipStream_t sb_ = small ? c->stream : c->stream_back;
 	hipEvent_t *ev = sl.ev;
 	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
-	sl.back_queued = false; sl.small = small;
+	sl.back_queued = false; sl.small = small; sl.has_chk = false; sl.nseg = 1; sl.seglen = D;
+	OutSlot &pv = c->slot[(sl.seq + kSlots - 1) % kSlots];
+	const bool opt = c->referee && c->ref_optimistic && !small && D > 0;
+	// does this feed's walk go ahead of the previous feed's check?  (both long feeds with a check, segmented walks)
+	const bool ahead = c->walk_ahead && opt && nseg >= 2 && !gate && sl.seq > 0 && pv.pending && pv.rest_pending && pv.has_chk && pv.nseg >= 2;
+	if(sl.seq > 0 && pv.pending && pv.rest_pending && !ahead) { int r = launch_rest(c, pv, nullptr); if(r != VDL2HIP_OK) return r; }
 	if(small) {
 		// the walker, the noise floor and the burst list carry state from feed to feed: wait for a predecessor whose back end is on the other streams
-		OutSlot &pv = c->slot[(sl.seq + kSlots - 1) % kSlots];
 		if(sl.seq > 0 && pv.pending && !pv.small && !pv.back_queued) HIPCHK(hipStreamWaitEvent(sb_, pv.done, 0));
 	} else {
 		HIPCHK(hipStreamWaitEvent(sb_, sl.ev_front, 0));
 		if(gate) HIPCHK(hipStreamWaitEvent(sb_, gate, 0));
 	}
 	if(D <= 0) hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(1), 0, sb_, sl.d_ctl, 0u);     // (a feed with a front has had it reset by its last sync kernel)
+	hipStream_t sp_ = small ? c->stream : c->stream_pre[sl.seq % kSidePre];
 	if(D > 0 && sl.prescan) {
 		// Referee: the stretches the exact sync tier has listed (around its marked candidates) are made the reference's own NOW, beside
 		// the next feed's front and off the walk stream - the walk of this feed waits for them, the walk of the next one does not
-		// (a scan on the walk stream is 3.7 ms that every following feed's walk queues behind: with 8 channels that was the step time)
+		// (a scan on the walk stream is 1.5 ms that every following feed's walk queues behind: with 8 channels that was the step time)
 		// (on a stream of its own: behind this feed's noise floor - which waits for the walk - the next feed's scans would wait for this
-		// feed's whole walk chain: 10.7 ms per step)
-		hipStream_t sp_ = small ? c->stream : c->stream_pre[sl.seq % kSidePre];
+		// feed's whole walk chain)
 		if(!small) HIPCHK(hipStreamWaitEvent(sp_, sl.ev_front, 0));
 		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kPreScans / kScanLanes), dim3(64 * kScanWaves), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
 		                  (const ScanReq *)sl.d_pq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 3), kPreScans, (int64_t)(k0 + D));
@@ -486,14 +513,18 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	}
 	if(D > 0) {
 		const int64_t k1 = k0 + D;
-		K4Args k4{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_wcnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
+		const int par = (int)(sl.seq & 1);        // feed i's snapshot and speculative walks are still needed when feed i + 1 is walked: two of each
+		sl.k4 = K4Args{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_wcnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(16 * sl.seq + 1),
-		           (c->referee && c->ref_optimistic && !small) ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap, c->d_cnt_snap, sl.d_rqbad, sl.prescan ? 1 : 0, c->debug_force_again };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
-		int64_t seglen = D;
+		           opt ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap[par], c->d_cnt_snap[par], sl.d_rqbad, sl.prescan ? 1 : 0, c->debug_force_again,
+		           c->d_ws_tmp, c->d_cnt_tmp, nullptr, nullptr, sl.d_rqflag2, nullptr, c->debug_force_mismatch };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
+		const K4Args &k4 = sl.k4;
+		sl.d_spec_of = c->d_spec[par];
 		if(nseg >= 2) {
-			seglen = (D + nseg - 1) / nseg;
-			nseg = (int)((D + seglen - 1) / seglen);
-			K4sArgs k4s{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, k0, seglen, c->d_segstats, 0 };
+			sl.seglen = (D + nseg - 1) / nseg;
+			nseg = (int)((D + sl.seglen - 1) / sl.seglen);
+			sl.nseg = nseg;
+			K4sArgs k4s{ k4, sl.d_spec_of, (uint32_t)(3 * (c->seg_max - 1)), nseg, k0, sl.seglen, c->d_segstats, 0 };
 			if(!(c->ablate & 1))
 			LAUNCH_EV(k_walk_spec, dim3((unsigned)((1 + 3 * (nseg - 1) + kWalkWaves - 1) / kWalkWaves), (unsigned)c->C), dim3(64 * kWalkWaves), sb_, EV(6), (hipEvent_t) nullptr, k4s);
 			if(!(c->ablate & 1))
@@ -502,21 +533,51 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			LAUNCH_EV(k_walk, dim3((unsigned)c->C), dim3(64), sb_, EV(6), EV(7), k4);
 		}
 		if(k4.rq) {
-			// referee, optimistic mode (long feeds): the decisions within the margin that the walk took are checked now, all at once, and
-			// the (rare) channel one of whose decisions does not stand is stitched again
-			// (the stretches first, many side by side - k_ref_scan_multi - then the decisions on them, a wavefront each)
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(c->rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sb_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, c->rq_cap, k1);
-			hipLaunchKernelGGL(k_ref_verify, dim3(1024), dim3(64), 0, sb_, k4);
-			if(nseg >= 2) {
-				K4sArgs k4a{ k4, c->d_spec, (uint32_t)(3 * (c->seg_max - 1)), nseg, k0, seglen, c->d_segstats, 1 };
-				hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0, k4a);
-			} else hipLaunchKernelGGL(k_walk_again, dim3((unsigned)c->C), dim3(64), 0, sb_, k4);
+			// referee, optimistic mode (long feeds): the decisions within the margin that the walk took are checked, all at once - the
+			// stretches first, many side by side (k_ref_scan_multi), then the decisions on them, a wavefront each - on the scan stream of
+			// the feed's slot (idle since the scans ahead of the walk): the walk stream goes on with the next feed meanwhile
+			sl.has_chk = true;
+			HIPCHK(hipEventRecord(sl.ev_stitch, sb_));
+			HIPCHK(hipStreamWaitEvent(sp_, sl.ev_stitch, 0));
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(c->rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sp_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, c->rq_cap, k1);
+			hipLaunchKernelGGL(k_ref_verify, dim3(1024), dim3(64), 0, sp_, k4);
+			HIPCHK(hipEventRecord(sl.ev_chk, sp_));
 		}
+	}
+	sl.rest_pending = true;
+	if(ahead) { int r = launch_rest(c, pv, &sl); if(r != VDL2HIP_OK) return r; }
+	// does the NEXT feed's walk get the chance to go ahead of this feed's check?  Not if there is nothing to check, nor in the old schedule
+	if(!(c->walk_ahead && sl.has_chk && sl.nseg >= 2 && !gate && !c->defer_back)) return launch_rest(c, sl, nullptr);
+	HIPCHK(hipGetLastError());
+	return VDL2HIP_OK;
+}
+
+static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ) {
+	const int64_t D = sl.back_D, k0 = sl.back_k0;
+	const bool small = sl.small;
+	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst[sl.seq % kSideBurst];
+	hipEvent_t *ev = sl.ev;
+	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
+	sl.rest_pending = false;
+	if(D > 0 && sl.has_chk) {
+		// the (rare) channel one of whose decisions did not stand is stitched again
+		HIPCHK(hipStreamWaitEvent(sb_, sl.ev_chk, 0));
+		K4Args k4 = sl.k4;
+		if(succ) { k4.ws_snap_next = succ->k4.ws_snap; k4.cnt_snap_next = succ->k4.cnt_snap; k4.rq_flag2_next = succ->d_rqflag2; }
+		if(sl.nseg >= 2) {
+			K4sArgs k4a{ k4, sl.d_spec_of, (uint32_t)(3 * (c->seg_max - 1)), sl.nseg, k0, sl.seglen, c->d_segstats, succ ? 2 : 1 };
+			hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0, k4a);
+		} else hipLaunchKernelGGL(k_walk_again, dim3((unsigned)c->C), dim3(64), 0, sb_, k4);      // (never with a successor: launch_back)
 	}
 	if(!small) {
 		HIPCHK(hipEventRecord(sl.ev_walk, sb_));
 		HIPCHK(hipStreamWaitEvent(sn_, sl.ev_walk, 0));
 		HIPCHK(hipStreamWaitEvent(s5_, sl.ev_walk, 0));
+	}
+	if(succ) {
+		// ... and the next feed once more for the channels whose start state that has corrected (none, all but always: the kernel looks at the flags and ends)
+		K4sArgs k4r{ succ->k4, succ->d_spec_of, (uint32_t)(3 * (c->seg_max - 1)), succ->nseg, succ->back_k0, succ->seglen, c->d_segstats, 3 };
+		hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0, k4r);
 	}
 	if(D > 0) {
 		K4bArgs k4b{ c->d_y, c->d_nf, sl.d_log, sl.d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfring, c->nf_ring - 1,
@@ -605,10 +666,12 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	OnDevice dev_guard(c);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec, c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
+	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec[0], c->d_spec[1], c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
-		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag, sl.d_dq, sl.d_sq, sl.d_rqbad, sl.d_pq };
+		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag, sl.d_dq, sl.d_sq, sl.d_rqbad, sl.d_pq, sl.d_rqflag2 };
 		for(void *p : q) if(p) (void)hipFree(p);
+		if(sl.ev_stitch) (void)hipEventDestroy(sl.ev_stitch);
+		if(sl.ev_chk) (void)hipEventDestroy(sl.ev_chk);
 		if(sl.h_mail) (void)hipHostFree(sl.h_mail);
 		if(sl.done) (void)hipEventDestroy(sl.done);
 		if(sl.ev_walk) (void)hipEventDestroy(sl.ev_walk);
@@ -622,7 +685,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(c->h_stage) (void)hipHostFree(c->h_stage);
 	for(auto &p : c->d_in) if(p) (void)hipFree(p);
 	for(auto &p : c->d_ref) if(p) (void)hipFree(p);
-	{ void *q[] = { c->d_refhist, c->d_refdone, c->d_refdonen, c->d_refstats, c->d_mix, c->d_refdbg, c->d_ws_snap, c->d_cnt_snap }; for(void *p : q) if(p) (void)hipFree(p); }
+	{ void *q[] = { c->d_refhist, c->d_refdone, c->d_refdonen, c->d_refstats, c->d_mix, c->d_refdbg, c->d_ws_snap[0], c->d_ws_snap[1], c->d_cnt_snap[0], c->d_cnt_snap[1], c->d_ws_tmp, c->d_cnt_tmp }; for(void *p : q) if(p) (void)hipFree(p); }
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
 	for(auto &e : c->cold.ev) if(e) (void)hipEventDestroy(e);
 	for(hipStream_t st_ : { c->stream_copy, c->stream_out, c->stream_sync, c->stream_back, c->stream_nf }) if(st_) (void)hipStreamSynchronize(st_);
@@ -792,7 +855,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		e = getenv("VDL2HIP_SEG_MAX");
 		if(e) smax = std::min<int64_t>(smax, atoll(e));
 		c->seg_max = (int)std::max<int64_t>(1, smax);
-		if(c->seg_max >= 2) DEV_ALLOC(c->d_spec, (size_t)count * 3 * (c->seg_max - 1) * sizeof(SpecOut));
+		if(c->seg_max >= 2) for(auto &sp_ : c->d_spec) DEV_ALLOC(sp_, (size_t)count * 3 * (c->seg_max - 1) * sizeof(SpecOut));
 		DEV_ALLOC(c->d_segstats, (size_t)count * 2 * 4);
 		DEV_CHK(hipMemset(c->d_segstats, 0, (size_t)count * 2 * 4));
 	}
@@ -830,12 +893,16 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipMemcpy(c->d_mix, mix.data(), count, hipMemcpyHostToDevice));
 		if(const char *e = getenv("VDL2HIP_REF_MODE")) c->ref_optimistic = strcmp(e, "sync") != 0;        // optimistic (default) | sync
 		if(const char *e = getenv("VDL2HIP_REF_KINDS")) c->ref_kinds = atoi(e) & 7;                          // (development: 1 candidates, 2 headers, 4 symbols)
-		DEV_ALLOC(c->d_ws_snap, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt_snap, (size_t)count * kNumCounters * 8);
+		for(int k = 0; k < 2; k++) { DEV_ALLOC(c->d_ws_snap[k], count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt_snap[k], (size_t)count * kNumCounters * 8); }
+		DEV_ALLOC(c->d_ws_tmp, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt_tmp, (size_t)count * kNumCounters * 8);
+		if(const char *e = getenv("VDL2HIP_WALK_AHEAD")) c->walk_ahead = atoi(e) != 0;      // 0: a feed's walk waits for the check of the feed before (round 5's schedule)
 		for(auto &sl : c->slot) {
 			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 16); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
 			DEV_ALLOC(sl.d_dq, (size_t)kDeferBursts * 4); DEV_ALLOC(sl.d_sq, (size_t)kDeferScans * sizeof(ScanReq));
 			DEV_ALLOC(sl.d_pq, (size_t)kPreScans * sizeof(ScanReq)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_pre, hipEventDisableTiming));
 			DEV_ALLOC(sl.d_rqbad, (size_t)count * sizeof(RefBad)); DEV_CHK(hipMemset(sl.d_rqbad, 0, (size_t)count * sizeof(RefBad)));
+			DEV_ALLOC(sl.d_rqflag2, (size_t)count * 4); DEV_CHK(hipMemset(sl.d_rqflag2, 0, (size_t)count * 4));
+			DEV_CHK(hipEventCreateWithFlags(&sl.ev_stitch, hipEventDisableTiming)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_chk, hipEventDisableTiming));
 			DEV_CHK(hipMemset(sl.d_rqn, 0, 16)); DEV_CHK(hipMemset(sl.d_rqflag, 0, (size_t)count * 4));
 		}
 	}
@@ -1143,10 +1210,10 @@ int vdl2hip_get_stats_sized(vdl2hip_ctx *c, vdl2hip_stats *out, size_t size) {
 		for(int i = 0; i < c->C; i++) { c->stats.seg_adopted += ss[2 * i]; c->stats.seg_walked += ss[2 * i + 1]; }
 	}
 	if(c->d_refstats) {
-		uint32_t rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		uint32_t rs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 		if(hipMemcpy(rs, c->d_refstats, sizeof rs, hipMemcpyDeviceToHost) != hipSuccess) return VDL2HIP_E_DEVICE;
 		c->stats.referee_scans = rs[0]; c->stats.referee_cached = rs[1]; c->stats.referee_refused = rs[2]; c->stats.referee_short = rs[3];
-		c->stats.referee_candidate_scans = rs[4]; c->stats.referee_header_scans = rs[5]; c->stats.referee_symbol_scans = rs[6]; c->stats.referee_rewalks = rs[7];
+		c->stats.referee_candidate_scans = rs[4]; c->stats.referee_header_scans = rs[5]; c->stats.referee_symbol_scans = rs[6]; c->stats.referee_rewalks = rs[7]; c->stats.referee_redone_next = rs[8];
 	}
 	memcpy(out, &c->stats, std::min(size, sizeof c->stats));
 	return (r == VDL2HIP_E_OVERFLOW || c->failed) ? VDL2HIP_OK : r;
@@ -1171,6 +1238,8 @@ int vdl2hip_debug_option(vdl2hip_ctx *c, const char *name, long value) {
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	if(strcmp(name, "no_fuse") == 0) { c->fuse_k2 = value == 0; return VDL2HIP_OK; }
 	if(strcmp(name, "force_timeout") == 0) { c->debug_force_timeout = value != 0; return VDL2HIP_OK; }
+	if(strcmp(name, "force_mismatch") == 0) { c->debug_force_mismatch = value != 0; return VDL2HIP_OK; }   // every channel walked again with the next feed's walk already done is taken to have ended differently: the next feed is redone for it
+	if(strcmp(name, "walk_ahead") == 0) { c->walk_ahead = value != 0; return VDL2HIP_OK; }
 	if(strcmp(name, "force_again") == 0) { c->debug_force_again = value != 0; return VDL2HIP_OK; }   // every channel of every long feed is stitched a second time (the referee's walk-again path)
 	if(strcmp(name, "referee") == 0) { if(value && !c->d_refhist) return VDL2HIP_E_INVAL; c->referee = value != 0; return VDL2HIP_OK; }   // (on only where it was on at create: the history ring)
 	if(strcmp(name, "ref_debug_chan") == 0) {

@@ -33,7 +33,7 @@ AVLC_COUNTER_NAMES = [
 ]
 NUM_AVLC_COUNTERS = len(AVLC_COUNTER_NAMES)
 AVLC_OK, AVLC_TOO_SHORT, AVLC_BAD_FCS = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_DRAIN_LAG = 3                     # include/vdl2hip.h: VDL2HIP_MAX_DRAIN_LAG
 EXPORTS = [
     "vdl2hip_abi_version", "vdl2hip_strerror", "vdl2hip_create", "vdl2hip_destroy", "vdl2hip_feed",
@@ -69,7 +69,8 @@ class Stats(C.Structure):
                 ("seg_adopted", C.c_uint64), ("seg_walked", C.c_uint64), ("front_sync_timeouts", C.c_uint64),
                 ("overflow_feeds", C.c_uint64), ("cold_start_feeds", C.c_uint64),
                 ("referee_scans", C.c_uint64), ("referee_cached", C.c_uint64), ("referee_refused", C.c_uint64), ("referee_short", C.c_uint64), ("referee_rewalks", C.c_uint64),
-                ("referee_candidate_scans", C.c_uint64), ("referee_header_scans", C.c_uint64), ("referee_symbol_scans", C.c_uint64)]
+                ("referee_candidate_scans", C.c_uint64), ("referee_header_scans", C.c_uint64), ("referee_symbol_scans", C.c_uint64),
+                ("referee_redone_next", C.c_uint64)]
 
 
 class PackedFrame(C.Structure):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VDL2HIP_ABI_VERSION 5   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added
+#define VDL2HIP_ABI_VERSION 6   /* 2: vdl2hip_frame carries the AVLC verdict; vdl2hip_stats grew; avlc/statsd calls added
                                  * 3: vdl2hip_feed_pinned(); vdl2hip_stats.overflow_feeds; vdl2hip_group_*: one receiver over several
                                  *    GPUs from C (a channeliser look-back that gives up is no longer an error: it falls back)
                                  * 4: vdl2hip_group_set_exchange() / vdl2hip_group_exchange(): striped ingest + all-gather is the group's
@@ -32,7 +32,8 @@ extern "C" {
                                  * 5: the referee (decisions within the margin of the channeliser's distance from the reference's fp32 scan are
                                  *    taken on the reference's own samples): vdl2hip_stats grew by referee_*; vdl2hip_get_stats_sized() for callers
                                  *    built against an older vdl2hip_stats.  (Since ABI 4 chanfir_ms / chanfir_launches / chan_samples cover only
-                                 *    the TIMED channeliser launches - profiling on, cold-start feeds excluded - not every launch.) */
+                                 *    the TIMED channeliser launches - profiling on, cold-start feeds excluded - not every launch.)
+                                 * 6: vdl2hip_stats.referee_redone_next (a feed's walk no longer waits for the check of the feed before) */
 
 /* enum sample_formats, src/dumpvdl2.h:319 */
 #define VDL2HIP_FMT_U8     0
@@ -161,6 +162,9 @@ typedef struct {
 	uint64_t referee_rewalks;   /* channels walked again because a decision taken on the channeliser's samples did not stand on the reference's */
 	uint64_t referee_candidate_scans, referee_header_scans, referee_symbol_scans;   /* referee_scans by the decision that asked: a preamble candidate
 	                             * (candidate test / vertex / gate), a header symbol, the symbols of a burst */
+	uint64_t referee_redone_next; /* ABI 6.  A feed's walk no longer waits for the check of the feed before (it starts from that feed's unchecked end
+	                             * state; referee_rewalks counts the channels walked again after a check): how often such a second walk ended in
+	                             * a DIFFERENT state or counters, so that the next feed was walked once more for that channel as well */
 } vdl2hip_stats;
 
 int  vdl2hip_abi_version(void);

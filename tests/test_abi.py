@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vdl2hip.h but not exported"
     assert sorted(vdl2hip.EXPORTS) == names
-    assert lib.vdl2hip_abi_version() == 5
+    assert lib.vdl2hip_abi_version() == 6
 
 
 def test_struct_layouts_match_header(lib):

@@ -360,16 +360,23 @@ def test_many_channel_configs_vs_oracle(vh, oracle_mod, which, secs):
     rx.close()
 
 
+@pytest.mark.parametrize("mode", ["ahead", "ahead_mismatch", "serial"])
 @pytest.mark.parametrize("which,secs,chunks", [("config3", 4.0, (2_000_000, 4_000_000)), ("config4", 3.0, (2_000_000, 4_000_000)),
                                                ("config3", 2.0, (700_000, 1_500_000))])
-def test_every_channel_walked_again_beside_the_previous_feeds_burst_decoder(vh, oracle_mod, which, secs, chunks):
+def test_every_channel_walked_again_beside_the_previous_feeds_burst_decoder(vh, oracle_mod, which, secs, chunks, mode):
     """Round 5's red test, made certain instead of likely: the test hook `force_again` makes the referee's check flag EVERY channel of
     every long feed, so every channel's walker state and counters go back to the feed's snapshot and the feed is stitched a second
     time - while the burst decoder of the feed before still adds its own counters (decoder.blocks.*, decoder.msg.*, decoder.errors.*)
     on its burst stream.  Several long feeds in flight, drained once at the end.  The walker may only put back what it owns
     (demod.sync.good, the header outcomes, ppm_reject): frames AND the reference's 18 counters identical to the oracle's on every
     channel (src/decode.c:204-373).  (0.7-1.5 M-sample pieces: two to four walk segments per feed and a front of a fraction of a
-    millisecond, so the walks run as far ahead of the burst decoders as the slots allow.)"""
+    millisecond, so the walks run as far ahead of the burst decoders as the slots allow.)
+
+    Round 6: a feed's walk no longer waits for the check of the feed before (vdl2hip.hip: launch_back / launch_rest).  `ahead`: the
+    product - every second walk runs after the next feed's first walk and must find that it ended where that walk started;
+    `ahead_mismatch`: the hook `force_mismatch` makes every such comparison fail, so every channel of every following feed is stitched
+    once more from the "corrected" snapshot - the path a real misprediction takes; `serial`: round 5's schedule (walk, check, walk
+    again, then the next feed's walk)."""
     import os
     from dumpvdl2_amd import workloads, synth
     cfg = getattr(workloads, which)(secs)
@@ -377,9 +384,16 @@ def test_every_channel_walked_again_beside_the_previous_feeds_burst_decoder(vh, 
     o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=20, max_ppm=cfg.rx_max_ppm)
     o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=min(len(cfg.freqs), os.cpu_count() or 8))
     fo = o.frames()
-    rx, fg, cnt = gpu_decode(vh, cfg, iq, chunks=chunks, max_block=16_000_000, debug={"force_again": 1})
+    dbg = {"force_again": 1, "walk_ahead": 0 if mode == "serial" else 1, "force_mismatch": 1 if mode == "ahead_mismatch" else 0}
+    rx, fg, cnt = gpu_decode(vh, cfg, iq, chunks=chunks, max_block=16_000_000, debug=dbg)
     s = rx.stats()
     assert s["feeds"] >= 2 and s["referee_rewalks"] >= (s["feeds"] - 1) * len(cfg.freqs), s      # every channel, every long feed
+    if mode == "ahead_mismatch":
+        assert s["referee_redone_next"] >= (s["feeds"] - 2) * len(cfg.freqs), s
+    elif mode == "ahead":
+        # (a second walk ends where the first did unless a decision really fell, or the burst in progress at the feed's end carries a
+        # slope that the second walk knows to be the reference's own and the first did not: a few channels, not all of them)
+        assert s["referee_redone_next"] <= s["referee_rewalks"] // 8, s
     assert len(fo) > 100
     assert_frames_equal(fo, fg, label=which)
     cases.assert_counters_equal(cnt, [list(o.counters(c).values()) for c in range(len(cfg.freqs))], which, exact_diagnostics=False)
