@@ -52,7 +52,7 @@ constexpr uint32_t kDeferBursts = 256, kDeferScans = 512;   // referee: bursts o
 // of streams to queues depends on every stream the process has created so far, and a receiver made after a hundred others had come
 // and gone ran 30-60 % slower than the same receiver in a fresh process (bench.py's secondary workloads, round 6).
 constexpr int kSidePre = 3, kSideBurst = 2;
-constexpr int kSlots = VDL2HIP_MAX_DRAIN_LAG + 1;   // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered).  Four: with the referee a feed's way through the device - front, the scans ahead of the walk, walk + check, bursts + their scans - is about three fronts long
+constexpr int kSlots = VDL2HIP_MAX_DRAIN_LAG + 1;   // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered).  Six: a feed's way through the device of a receiver of few channels - front 1 ms, the scans ahead of the walk 1.5, walk, the next feed's walk (the second walks are queued behind it), burst decoder and its scans 1.5-2.5 - is four to six fronts long (rank-sized receivers, walk ahead: 2.22 / 1.46 / 1.56 ms per step with four slots, 1.76 / 1.29 / 1.45 with six; with 256 channels it is three fronts and four slots were enough)
 
 }  // namespace
 
@@ -536,12 +536,14 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			// referee, optimistic mode (long feeds): the decisions within the margin that the walk took are checked, all at once - the
 			// stretches first, many side by side (k_ref_scan_multi), then the decisions on them, a wavefront each - on the scan stream of
 			// the feed's slot (idle since the scans ahead of the walk): the walk stream goes on with the next feed meanwhile
+			// (in the old schedule - receivers of many channels: the front hides the chain - the check stays on the walk stream: on a stream
+			// of its own it cost the 256-channel receiver 0.6 ms per step, profiles/r06_walk_ahead_ab.txt)
 			sl.has_chk = true;
-			HIPCHK(hipEventRecord(sl.ev_stitch, sb_));
-			HIPCHK(hipStreamWaitEvent(sp_, sl.ev_stitch, 0));
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(c->rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sp_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, c->rq_cap, k1);
-			hipLaunchKernelGGL(k_ref_verify, dim3(1024), dim3(64), 0, sp_, k4);
-			HIPCHK(hipEventRecord(sl.ev_chk, sp_));
+			hipStream_t sc_ = c->walk_ahead ? sp_ : sb_;
+			if(sc_ != sb_) { HIPCHK(hipEventRecord(sl.ev_stitch, sb_)); HIPCHK(hipStreamWaitEvent(sc_, sl.ev_stitch, 0)); }
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(c->rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sc_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, c->rq_cap, k1);
+			hipLaunchKernelGGL(k_ref_verify, dim3(1024), dim3(64), 0, sc_, k4);
+			HIPCHK(hipEventRecord(sl.ev_chk, sc_));
 		}
 	}
 	sl.rest_pending = true;
@@ -895,6 +897,9 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		if(const char *e = getenv("VDL2HIP_REF_KINDS")) c->ref_kinds = atoi(e) & 7;                          // (development: 1 candidates, 2 headers, 4 symbols)
 		for(int k = 0; k < 2; k++) { DEV_ALLOC(c->d_ws_snap[k], count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt_snap[k], (size_t)count * kNumCounters * 8); }
 		DEV_ALLOC(c->d_ws_tmp, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt_tmp, (size_t)count * kNumCounters * 8);
+		// Walk ahead (launch_back): for receivers whose front does not hide the chain walk - scans - check (a feed's results then come a
+		// feed later: with 256 channels, where the front hides the chain anyway, that extra depth cost 10 % and more)
+		c->walk_ahead = count >= 16 && count <= 64;   // (8 channels: the walk itself is longer than the front, the second walks' extra launches cost more than they save: 1.22 against 1.11 ms)
 		if(const char *e = getenv("VDL2HIP_WALK_AHEAD")) c->walk_ahead = atoi(e) != 0;      // 0: a feed's walk waits for the check of the feed before (round 5's schedule)
 		for(auto &sl : c->slot) {
 			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 16); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);

@@ -34,7 +34,7 @@ AVLC_COUNTER_NAMES = [
 NUM_AVLC_COUNTERS = len(AVLC_COUNTER_NAMES)
 AVLC_OK, AVLC_TOO_SHORT, AVLC_BAD_FCS = 0, 1, 2
 ABI_VERSION = 6
-MAX_DRAIN_LAG = 3                     # include/vdl2hip.h: VDL2HIP_MAX_DRAIN_LAG
+MAX_DRAIN_LAG = int(os.environ.get("VDL2HIP_PY_MAX_DRAIN_LAG", "5"))   # include/vdl2hip.h: VDL2HIP_MAX_DRAIN_LAG (the variable: development builds with another depth)
 EXPORTS = [
     "vdl2hip_abi_version", "vdl2hip_strerror", "vdl2hip_create", "vdl2hip_destroy", "vdl2hip_feed",
     "vdl2hip_feed_device", "vdl2hip_sync", "vdl2hip_drain", "vdl2hip_counters", "vdl2hip_set_profiling",
@@ -98,7 +98,8 @@ def load_library(path: str = None):
         raise RuntimeError(f"{path} is missing - build it with dumpvdl2_amd.build.build(); there is no CPU fallback")
     L = C.CDLL(path)
     L.vdl2hip_abi_version.restype = C.c_int
-    if L.vdl2hip_abi_version() != ABI_VERSION:      # (the structures below are this version's: a library of another would be read or written out of bounds)
+    # (development: VDL2HIP_LIB_ANY_ABI=1 lets dev/gpu_variants.py time an OLDER build beside this one - older structures are prefixes of these)
+    if L.vdl2hip_abi_version() != ABI_VERSION and not (os.environ.get("VDL2HIP_LIB_ANY_ABI") and L.vdl2hip_abi_version() < ABI_VERSION):      # (the structures below are this version's: a library of another would be read or written out of bounds)
         raise RuntimeError(f"{path} has ABI version {L.vdl2hip_abi_version()}, this binding is for {ABI_VERSION}")
     L.vdl2hip_strerror.restype = C.c_char_p
     L.vdl2hip_strerror.argtypes = [C.c_int]

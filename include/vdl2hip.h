@@ -193,7 +193,9 @@ int  vdl2hip_feed_device(vdl2hip_ctx *ctx, const void *dev_buf, size_t nbytes);
  * burst-rate back (K4-K5) of block i is still in flight.  By default the drain functions wait for everything (lag 0 =
  * the reference's blocking behaviour).  With lag L (1 .. VDL2HIP_MAX_DRAIN_LAG) they deliver every block except the L most recent ones,
  * so a feed/drain loop keeps L+1 blocks in flight; vdl2hip_sync() always completes everything. */
-#define VDL2HIP_MAX_DRAIN_LAG 3       /* feeds that may be under way undelivered: lag 0 .. 3 */
+#ifndef VDL2HIP_MAX_DRAIN_LAG
+#define VDL2HIP_MAX_DRAIN_LAG 5       /* feeds that may be under way undelivered: lag 0 .. 5 (ABI 6; 3 before) */
+#endif
 int  vdl2hip_set_drain_lag(vdl2hip_ctx *ctx, int lag);
 
 /* Wait for all queued blocks; moves finished frames to the host-side queue. */

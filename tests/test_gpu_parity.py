@@ -155,7 +155,7 @@ def test_drain_packed_equals_drain(vh):
     rx.close()
 
 
-@pytest.mark.parametrize("lag", [1, 2, 3])
+@pytest.mark.parametrize("lag", [1, 2, 3, 5])
 def test_pipelined_feeds_with_drain_lag(vh, lag):
     """Streaming mode (drain lag L): L+1 blocks in flight, frames arrive L blocks late, nothing is lost or reordered."""
     cfg, iq, _, gold = cases.load("config2_1s")
