@@ -205,8 +205,11 @@ __device__ __forceinline__ bool ref_exact_window_dev(const ChanView &v, int64_t 
 	if(npiece <= 0 || in_end < s_end) { if(lane == 0) atomicAdd(stats + 2, 1u); return false; }
 	__builtin_amdgcn_s_setprio(VDL2_REF_PRIO);
 
+	const int G = 64 / os, blk = G * os;                        // decimated outputs / input samples per block (os <= kMaxOversample = 32)
 	// raw sample s (this lane's of a block) as a 32-bit word, and its NCO table entry
-	auto fetch = [&](int64_t s, uint32_t &w, v4f &e) {
+	// (a uniform search for the one stretch a whole block lies in, with a single load behind it, was tried: 23.5 against 22.6 ns per sample)
+	auto fetch = [&](int64_t s0, uint32_t &w, v4f &e) {
+		const int64_t s = s0 + (lane < blk ? lane : 0);
 		w = 0u;
 		#pragma unroll
 		for(int j = 0; j < kRefPieces; j++) {
@@ -225,12 +228,19 @@ __device__ __forceinline__ bool ref_exact_window_dev(const ChanView &v, int64_t 
 	int64_t k_out = s_beg / os;                                  // the decimated sample the next output is
 	v2f y1 = v2f{0.f, 0.f}, y2 = v2f{0.f, 0.f};                 // (yr[1], yi[1]), (yr[2], yi[2]) of demod.c:289-298
 	float xm1r = 0.f, xm1i = 0.f, xm2r = 0.f, xm2i = 0.f;       // the mixed samples before the block (uniform)
-	const int G = 64 / os, blk = G * os;                        // (os <= kMaxOversample = 32)
-	uint32_t w_next; v4f e_next;
-	fetch(s_beg + (lane < blk ? lane : 0), w_next, e_next);
-	for(int64_t sb = s_beg; sb < s_end; sb += blk) {
-		const uint32_t w = w_next; const v4f e = e_next;
-		fetch(sb + blk + (lane < blk ? lane : 0), w_next, e_next);    // in flight during this block's recursion
+	// The raw samples and table entries of the next kRefAhead blocks are in flight at any time (a block lasts ~0.8 us, a load that misses
+	// the L2 longer: with one block of look-ahead the wavefront waited for memory at every other block - 24 ns per input sample where the
+	// bare recursion takes 13, dev/gpu_ubench_scan.hip).  The loop body is kRefAhead blocks of straight-line code, each with a slot of
+	// its own, so that the slots stay in the registers they were loaded into; the stretch is padded to whole groups of blocks (the
+	// padding reads nothing - fetch() stops at s_end - and stores nothing).
+	constexpr int kRefAhead = 3;
+	uint32_t w_q[kRefAhead]; v4f e_q[kRefAhead];
+	#pragma unroll
+	for(int k = 0; k < kRefAhead; k++) fetch(s_beg + (int64_t)k * blk, w_q[k], e_q[k]);
+	auto do_block = [&](int64_t sb, auto SLOTC) {
+		constexpr int SLOT = decltype(SLOTC)::value;
+		const uint32_t w = w_q[SLOT]; const v4f e = e_q[SLOT];
+		fetch(sb + (int64_t)kRefAhead * blk, w_q[SLOT], e_q[SLOT]);    // in flight during the next blocks' recursions
 		// ---- this lane's sample: conversion (demod.c:349-365), NCO (:58-72), mixer (:200-203) ----
 		float re, im;
 		if(fmt == 1) { re = (float)(int16_t)(w & 0xffff) / 32768.0f; im = (float)(int16_t)(w >> 16) / 32768.0f; }
@@ -281,6 +291,12 @@ __device__ __forceinline__ bool ref_exact_window_dev(const ChanView &v, int64_t 
 				k_out++;
 			}
 		}
+	};
+	static_assert(kRefAhead == 3, "the loop below is written out for three slots");
+	for(int64_t sb = s_beg; sb < s_end; sb += (int64_t)kRefAhead * blk) {
+		do_block(sb, std::integral_constant<int, 0>());
+		do_block(sb + blk, std::integral_constant<int, 1>());
+		do_block(sb + 2 * (int64_t)blk, std::integral_constant<int, 2>());
 	}
 	__builtin_amdgcn_s_setprio(0);
 	// The new samples are read back by the lanes of THIS wavefront: its stores must have landed (vmcnt(0)) and its CU's vector L1 and
@@ -1429,7 +1445,7 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 #if VDL2_DEVICE_PASS
 	#pragma clang fp contract(off)
 	__shared__ ScanShared sh;
-	constexpr int BLK = OS ? (kScanBlock / OS) * OS : kScanBlock;    // input samples per block
+	constexpr int BLK = OS ? (kScanBlock / (OS ? OS : 1)) * OS : kScanBlock;    // input samples per block
 	const uint32_t ntot = *n_ptr < cap ? *n_ptr : cap;
 	const uint32_t base = blockIdx.x * (uint32_t)kScanLanes;
 	if(base >= ntot) return;
