@@ -1215,10 +1215,10 @@ int vdl2hip_get_stats_sized(vdl2hip_ctx *c, vdl2hip_stats *out, size_t size) {
 		for(int i = 0; i < c->C; i++) { c->stats.seg_adopted += ss[2 * i]; c->stats.seg_walked += ss[2 * i + 1]; }
 	}
 	if(c->d_refstats) {
-		uint32_t rs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+		uint32_t rs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		if(hipMemcpy(rs, c->d_refstats, sizeof rs, hipMemcpyDeviceToHost) != hipSuccess) return VDL2HIP_E_DEVICE;
 		c->stats.referee_scans = rs[0]; c->stats.referee_cached = rs[1]; c->stats.referee_refused = rs[2]; c->stats.referee_short = rs[3];
-		c->stats.referee_candidate_scans = rs[4]; c->stats.referee_header_scans = rs[5]; c->stats.referee_symbol_scans = rs[6]; c->stats.referee_rewalks = rs[7]; c->stats.referee_redone_next = rs[8];
+		c->stats.referee_candidate_scans = rs[4]; c->stats.referee_header_scans = rs[5]; c->stats.referee_symbol_scans = rs[6]; c->stats.referee_rewalks = rs[7]; c->stats.referee_redone_next = rs[8]; c->stats.referee_unmet = rs[9];
 	}
 	memcpy(out, &c->stats, std::min(size, sizeof c->stats));
 	return (r == VDL2HIP_E_OVERFLOW || c->failed) ? VDL2HIP_OK : r;

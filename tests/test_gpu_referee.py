@@ -105,6 +105,35 @@ def test_many_scans_side_by_side_are_bit_exact(vh, oracle_mod, fmt, block):
     rx.close(); o.close()
 
 
+def test_witness_tells_a_run_up_that_was_too_short(vh, oracle_mod):
+    """Every scan of k_ref_scan_multi carries a witness: the same recursion over the same values from another state (idle lanes).  With
+    the product's run-up (2^17 input samples) the two have met by the stretch's first output all but always - and then the stretch IS
+    the oracle's, bit for bit; with a run-up of 2 048 samples (mean meeting time: 1.6e4) they mostly have not, the scans are counted in
+    referee_unmet, and such stretches are NOT all the oracle's: what the counter says is what the data shows."""
+    cfg, iq, _, _ = cases.load("config2_1s")
+    raw = iq.view(np.uint8)
+    D = raw.size // 4 // cfg.oversample
+    o, tr = _oracle_trace(oracle_mod, cfg, raw, 1, D)
+    rng = np.random.default_rng(21)
+    n = 96
+    out = {}
+    for warm in (1 << 17, 2048):
+        rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, 1, cfg.rx_max_ppm, max_block_bytes=raw.size)
+        rx.debug_option("referee", 0)
+        rx.feed(raw); rx.drain()
+        rx.debug_option("ref_warm", warm); rx.feed(raw[:4000]); rx.drain()          # (the run-up travels in the feed's hook)
+        chans = rng.integers(0, len(cfg.freqs), n); los = rng.integers(48000, D - 6000, n) & ~255; his = los + 255          # (what the history ring still holds of the stream, run-up included)
+        ran, ms = rx.scan_multi(chans, los, his)
+        exact = sum(rx.read_decimated(int(c), int(a), 256).tobytes() == tr[int(c), int(a):int(a) + 256].tobytes() for c, a in zip(chans, los))
+        out[warm] = (ran, rx.stats()["referee_unmet"], exact)
+        rx.close()
+    o.close()
+    ran, unmet, exact = out[1 << 17]
+    assert ran > n // 2 and unmet <= 1 and exact >= n - unmet, out
+    ran, unmet, exact = out[2048]
+    assert unmet >= ran // 2 and exact <= n - unmet // 2, out        # (not met by the first output, yet some meet within the stretch's first samples)
+
+
 @pytest.mark.parametrize("seed,profile", [(175, "plain"), (274, "plain"), (1014, "extreme")])
 def test_decisions_that_hang_on_the_references_rounding(vh, oracle_mod, seed, profile):
     import fuzz_gpu
