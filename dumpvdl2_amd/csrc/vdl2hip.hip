@@ -487,7 +487,11 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
 	sl.back_queued = false; sl.small = small; sl.has_chk = false; sl.nseg = 1; sl.seglen = D;
 	OutSlot &pv = c->slot[(sl.seq + kSlots - 1) % kSlots];
-	const bool opt = c->referee && c->ref_optimistic && !small && D > 0;
+	// (short feeds too, since round 6: a block with a decision within the margin - one in three of the reference's own 320 000-byte
+	// blocks at 256 channels - used to wait for a scan by the walker's own wavefront, 3.1 ms; noted, scanned side by side (1.5 ms for all
+	// of them) and checked, on the front stream like the rest of a short feed's back end, it is 1.34 -> 0.8 ms per block on average)
+	const bool opt = c->referee && c->ref_optimistic && D > 0;
+	const uint32_t rq_cap = small ? std::min<uint32_t>(c->rq_cap, 16u * kScanLanes) : c->rq_cap;      // (a short feed: few requests, small grids - it queues these kernels whether or not it notes anything)
 	// does this feed's walk go ahead of the previous feed's check?  (both long feeds with a check, segmented walks)
 	const bool ahead = c->walk_ahead && opt && nseg >= 2 && !gate && sl.seq > 0 && pv.pending && pv.rest_pending && pv.has_chk && pv.nseg >= 2;
 	if(sl.seq > 0 && pv.pending && pv.rest_pending && !ahead) { int r = launch_rest(c, pv, nullptr); if(r != VDL2HIP_OK) return r; }
@@ -516,7 +520,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		const int par = (int)(sl.seq & 1);        // feed i's snapshot and speculative walks are still needed when feed i + 1 is walked: two of each
 		sl.k4 = K4Args{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_wcnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(16 * sl.seq + 1),
-		           opt ? sl.d_rq : nullptr, sl.d_rqn, c->rq_cap, sl.d_rqflag, c->d_ws_snap[par], c->d_cnt_snap[par], sl.d_rqbad, sl.prescan ? 1 : 0, c->debug_force_again,
+		           opt ? sl.d_rq : nullptr, sl.d_rqn, rq_cap, sl.d_rqflag, c->d_ws_snap[par], c->d_cnt_snap[par], sl.d_rqbad, sl.prescan ? 1 : 0, c->debug_force_again,
 		           c->d_ws_tmp, c->d_cnt_tmp, nullptr, nullptr, sl.d_rqflag2, nullptr, c->debug_force_mismatch };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
 		const K4Args &k4 = sl.k4;
 		sl.d_spec_of = c->d_spec[par];
@@ -541,8 +545,8 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			sl.has_chk = true;
 			hipStream_t sc_ = c->walk_ahead ? sp_ : sb_;
 			if(sc_ != sb_) { HIPCHK(hipEventRecord(sl.ev_stitch, sb_)); HIPCHK(hipStreamWaitEvent(sc_, sl.ev_stitch, 0)); }
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(c->rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sc_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, c->rq_cap, k1);
-			hipLaunchKernelGGL(k_ref_verify, dim3(1024), dim3(64), 0, sc_, k4);
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sc_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, rq_cap, k1);
+			hipLaunchKernelGGL(k_ref_verify, dim3(small ? 64 : 1024), dim3(64), 0, sc_, k4);
 			HIPCHK(hipEventRecord(sl.ev_chk, sc_));
 		}
 	}
