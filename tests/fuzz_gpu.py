@@ -123,12 +123,20 @@ def run_seed(seed, profile, always_check=False, strict=None):
         rx.set_exchange(form)
         take = rx.drain
     lag = int(rng.integers(0, 3))
+    # seeds from 3000 on (round 6): up to six feeds in flight, and every third capture in LONG pieces only (each several walk segments:
+    # the walks then run ahead of the checks, second walks are compared with the next feed's start - vdl2hip.hip: launch_rest)
+    all_long = False
+    if seed >= 3000:
+        lag = int(rng2.integers(0, vdl2hip.MAX_DRAIN_LAG + 1))
+        all_long = rng2.random() < 0.34
     rx.set_drain_lag(lag)
     got = []
     t, nfeeds, nsmall = 0, 0, 0
     while t < raw.size:
         r = rng.random()
-        if style == 0:
+        if all_long:
+            m = int(rng2.integers(700_000, 3_000_000)) * sb
+        elif style == 0:
             m = 320000
         elif style == 1:
             m = big
@@ -172,7 +180,8 @@ def run_seed(seed, profile, always_check=False, strict=None):
     rx.close()
     return {"frames": len(fo), "ties": st["timing_ties"], "nf_ties": st["nf_update_ties"], "bookkeeping_channels": nbad, "feeds": nfeeds,
             "short_feeds": int(nsmall), "lag": lag, "nch": nch, "os": cfg.oversample, "fallbacks": s["front_sync_timeouts"], "host_build_check": check,
-            "fmt": "u8" if fmt == vdl2hip.FMT_U8 else "s16", "referee_scans": s.get("referee_scans", 0), "referee_refused": s.get("referee_refused", 0), "receiver": "one context" if ndev == 1 else f"group of {ndev}, {form}"}
+            "fmt": "u8" if fmt == vdl2hip.FMT_U8 else "s16", "referee_scans": s.get("referee_scans", 0), "referee_refused": s.get("referee_refused", 0),
+            "referee_unmet": s.get("referee_unmet", 0), "referee_rewalks": s.get("referee_rewalks", 0), "referee_redone_next": s.get("referee_redone_next", 0), "all_long": all_long, "receiver": "one context" if ndev == 1 else f"group of {ndev}, {form}"}
 
 
 def o2_trace(cfg, raw, D, fmt):
@@ -190,7 +199,8 @@ def main():
     profiles = ["plain", "extreme", "rejects"] if which == "all" else [which]
     t0 = time.time()
     tot = {"seeds": 0, "frames": 0, "ties": 0, "nf_ties": 0, "bookkeeping_channels": 0, "feeds": 0, "short_feeds": 0, "failed": 0,
-           "differ_from_oracle": 0, "of_those_explained_by_the_samples": 0, "host_build_checks": 0, "referee_scans": 0, "referee_refused": 0, "strict": STRICT}
+           "differ_from_oracle": 0, "of_those_explained_by_the_samples": 0, "host_build_checks": 0, "referee_scans": 0, "referee_refused": 0,
+           "referee_unmet": 0, "referee_rewalks": 0, "referee_redone_next": 0, "strict": STRICT}
     i = 0
     while time.time() - t0 < budget:
         seed, profile = seed0 + i, profiles[i % len(profiles)]
@@ -208,7 +218,7 @@ def main():
             print(f"seed {seed} {profile}: FAILED: {str(e)[:500]}", flush=True)
             continue
         tot["seeds"] += 1; tot["host_build_checks"] += bool(r.get("host_build_check"))
-        for k in ("frames", "ties", "nf_ties", "bookkeeping_channels", "feeds", "short_feeds", "referee_scans", "referee_refused"):
+        for k in ("frames", "ties", "nf_ties", "bookkeeping_channels", "feeds", "short_feeds", "referee_scans", "referee_refused", "referee_unmet", "referee_rewalks", "referee_redone_next"):
             tot[k] += r[k]
         print(f"seed {seed} {profile}: ok {r}", flush=True)
     print(f"SUMMARY ({time.time() - t0:.0f} s): {tot}", flush=True)
