@@ -141,7 +141,7 @@ class Case:
         return self.vdl2hip.Receiver.unpack(n, recs, octs)
 
     def timed(self, feeder, steps, dist, repeats=1):
-        """`repeats` times exactly `steps` steps in streaming mode (four blocks in flight); every block fully delivered inside
+        """`repeats` times exactly `steps` steps in streaming mode (six blocks in flight: VDL2HIP_MAX_DRAIN_LAG + 1); every block fully delivered inside
         each timed region.  Returns the median repeat plus the list."""
         # the shader clock idles at ~100 MHz and needs some tens of ms of load to come up (profiles/r03_clocks_under_load.txt): after the CPU-side
         # pauses of this script (oracle gate, set-up of a receiver) a short region would otherwise start on a cold clock.  Untimed steps.
@@ -413,7 +413,7 @@ class OracleRef(list):
 
 
 def pieces_gate(case, oref, label, seed=6):
-    """The parity gate again with the block fed in 5-8 LONG pieces (each several walk segments), four in flight, drained as they complete:
+    """The parity gate again with the block fed in 5-8 LONG pieces (each several walk segments), six in flight, drained as they complete:
     the path a streaming caller takes - feed i + 1's front beside feed i's walk, check and burst decoder, state carried from feed to
     feed, a channel walked again while the previous feed's burst decoder still runs (round 5's red test).  A fresh receiver (its counters
     start at zero); frames, burst timing, integer metadata and the reference's 18 counters must be the oracle's, as for the whole block."""
@@ -491,7 +491,7 @@ def measure_secondary(c2, name, oracle_check, args, dist, po):
 
 def group_from_c(case, args, torch, local, members=8):
     """vdl2hip_group_* (the multi-GPU path from plain C) with `members` virtual shards on this GPU: every transmitted frame recovered
-    in both exchange forms, K timed steps each (four blocks in flight, frames drained without a callback)"""
+    in both exchange forms, K timed steps each (six blocks in flight, frames drained without a callback)"""
     from util import truth_is_subset
     vh = case.vdl2hip
     cfg = case.cfg
@@ -702,7 +702,7 @@ def main():
         ts = case.timed(f_host, ks, dist, 1)
         steady = {"steps": ks, "value": round(case.nsamples * ks / ts["dt"] / 1e6, 3), "ms_per_step": round(ts["dt"] / ks * 1e3, 4),
                   "k_chanfir_ms": round(ts["k1_ms"], 5),
-                  "note": "host-fed, one timed region of this many steps: the fill and drain of the four-deep pipeline (paid once per "
+                  "note": "host-fed, one timed region of this many steps: the fill and drain of the pipeline (six blocks deep) (paid once per "
                           "region, whatever its length) weigh a tenth of what they do in the K-step regions `value` comes from"}
     del f_host
     # ---- the same with the block resident in HBM ----
@@ -792,7 +792,7 @@ def main():
         h2d = h2d_ms(torch, pin, case.device)
         del pin
         projected = {"what": f"rank-sized workload of the 8-GPU split on this GPU: {per} of the {case.C} channels of the same block, block resident in HBM "
-                             f"(as an RCCL exchange leaves it), four blocks in flight, the same K steps x {args.repeats} repeats (median)",
+                             f"(as an RCCL exchange leaves it), six blocks in flight, the same K steps x {args.repeats} repeats (median)",
                      "t_all_channels_ms": round(t256, 4), "t_rank_ms_max": round(t32, 4), "shards": shards,
                      "compute_ceiling_speedup_at_8": round(t256 / t32, 3),
                      "h2d_whole_block_ms": round(h2d, 4),
@@ -862,7 +862,7 @@ def main():
                        "channel; float metadata within SURVEY 8.5's tolerances (0.01 ppm, 0.05 dB); no tie allowances (config.verified)") if verified else "not checked (--no-verify)",
             "config": {"workload": (f"configs[{widx}] " if widx else "") + f"({args.workload}): synthetic 2.1 MS/s cs16 IQ, {cfg.duration_s:g} s per step, {case.C} VDL2 channels "
                                    f"in total, {case.count} per GPU; value = block in page-locked host memory -> frames in host memory "
-                                   f"(H2D inside the step, overlapped); four blocks in flight",
+                                   f"(H2D inside the step, overlapped); six blocks in flight",
                        "channels_total": case.C, "channels_per_gpu": case.count, "samples_per_step": case.nsamples,
                        "channel_MS_per_s": round(value * case.C, 1),
                        "realtime_channels_at_2.1MSps": round(value * case.C / 2.1, 1),

@@ -180,7 +180,7 @@ void vdl2hip_destroy(vdl2hip_ctx *ctx);
 
 /* = process_buf_uchar()/process_buf_short(): one block of raw IQ from host memory.
  * Returns after the block has been queued on the device (the copy out of `buf` is complete).  The copy runs on a
- * stream of its own into one of four device buffers (one per block in flight), so it overlaps the kernels of the blocks fed before. */
+ * stream of its own into one of six device buffers (one per block in flight), so it overlaps the kernels of the blocks fed before. */
 int  vdl2hip_feed(vdl2hip_ctx *ctx, const void *buf, size_t nbytes);
 /* Same for page-locked host memory (hipHostMalloc / hipHostRegister), without waiting for the copy: the call only queues.
  * `buf` must stay unmodified until the NEXT vdl2hip_feed*() call or vdl2hip_sync() has returned - i.e. a producer
