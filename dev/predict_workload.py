@@ -1,4 +1,4 @@
-"""dev/predict_gpu_parity.py's prediction for a bench workload (e.g. config4, 16 s, 256 channels): the channel filter in double
+"""tests/predict_gpu_parity.py's prediction for a bench workload (e.g. config4, 16 s, 256 channels): the channel filter in double
 precision per channel (a process pool; the capture is shared by fork), the host build of the device logic behind it, against the
 oracle with bench.py's own gate (tests/util.compare_at_full_size / compare_reference_counters).
 usage: python dev/predict_workload.py [config4|config4_bursty|config5] [seconds] [procs]"""

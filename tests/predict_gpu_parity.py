@@ -9,7 +9,7 @@ oracle with tests/fuzz_gpu.py's own comparison.  A capture that differs here is 
 own rounding noise; no time-parallel implementation can be expected to agree on it.
 
 Checked against the GPU on the twelve seeds of profiles/r04_parity_ab_state_basis.txt (--known).
-usage: python dev/predict_gpu_parity.py --known | <seed0> <count> [procs]"""
+usage: python tests/predict_gpu_parity.py --known | <seed0> <count> [procs]"""
 import os
 import sys
 import time

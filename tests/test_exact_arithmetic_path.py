@@ -1,4 +1,4 @@
-"""The whole path on the CPU from raw IQ, with the channel filter evaluated in DOUBLE precision (dev/predict_gpu_parity.py: the
+"""The whole path on the CPU from raw IQ, with the channel filter evaluated in DOUBLE precision (tests/predict_gpu_parity.py: the
 reference's table mixer and coefficients, scipy's lfilter) and everything behind it by the host build of the device logic: since
 the channeliser's state is carried in normal form the GPU's stream IS that filter to 2e-7 of the peak, so this is
 what the GPU answers - checked seed by seed against the GPU in profiles/r04_cpu_prediction_of_gpu_parity.txt (12 of 12).
@@ -16,7 +16,7 @@ import pytest
 pytest.importorskip("scipy")           # (the double-precision channel filter is scipy.signal.lfilter)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "dev"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "hostsim"))
 
 
