@@ -1073,7 +1073,7 @@ constexpr int kK3bWordsPerLane = 4;      // at most; fewer when that leaves the 
 // referee's error figure beside it.  Same atan2, same metric, bit-identical values as the four-lanes-per-sample form it replaces
 // (which read every tap from memory - five loads per tap with the referee - and kept three lanes in four idle during the metric).
 __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
-	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { reset_out_ctl(a.ctl, a.k5_waves); if(a.ref) *a.ref = a.refv; if(a.rq_n) { a.rq_n[0] = 0u; a.rq_n[1] = 0u; a.rq_n[2] = 0u; } }   // (rq_n[1], [2]: the burst decoder's lists, BurstDefer)
+	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { reset_out_ctl(a.ctl, a.k5_waves); if(a.ref) *a.ref = a.refv; if(a.rq_n) { a.rq_n[0] = 0u; a.rq_n[1] = 0u; a.rq_n[2] = 0u; a.rq_n[4] = 0u; a.rq_n[5] = 0u; a.rq_n[6] = 0u; } }   // (rq_n[1], [2]: the burst decoder's lists, BurstDefer)
 	if(blockIdx.x == 0 && threadIdx.x == 0 && a.rq_flag) { a.rq_flag[blockIdx.y] = 0u; a.rq_bad[blockIdx.y].n = 0u; if(a.rq_flag2) a.rq_flag2[blockIdx.y] = 0u; }
 	constexpr int kBack = 160, kSpan = kBack + 64;        // staged samples: base - 160 .. base + 63
 	// [wave][6 + bit]: metric of sample word*64 + bit (entries 0..5 = the six samples before the word), its slope, and - for the
@@ -1438,10 +1438,14 @@ struct ScanShared {
 	int64_t lmax, smin;
 	v4f lut[256];                                // the NCO table
 };
+// retry_q / retry_n / retry_cap: where a scan that has NOT met its witness by its stretch's first output (see the consumer) is listed
+// instead of being published; the host queues a second launch behind the first that takes that list as `sq` with warm_mul = 4 - the
+// same scan from four times further back (nullptr: nothing is listed, an unmet scan is published as it is and counted).
 // OS: the oversampling factor if it is 20 or 10 (a block is then 60 input samples - whole decimation periods - and the consumer's
 // steps are straight-line code with the outputs at fixed places: a compare + branch per step cost as much as the arithmetic), else 0
 template<int FMT, int OS>
-__global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp, uint32_t launch, const ScanReq *sq, const RefReq *rq, const uint32_t *n_ptr, uint32_t cap, int64_t k_end) {
+__global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp, uint32_t launch, const ScanReq *sq, const RefReq *rq, const uint32_t *n_ptr, uint32_t cap, int64_t k_end,
+                      ScanReq *retry_q, uint32_t *retry_n, uint32_t retry_cap, int32_t warm_mul) {
 #if VDL2_DEVICE_PASS
 	#pragma clang fp contract(off)
 	__shared__ ScanShared sh;
@@ -1452,7 +1456,7 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 	const int os = rp->os, npiece = rp->npiece;
 	const uint32_t mask = rp->mask, cap_y = rp->cap;
-	const int64_t warm = rp->warm;
+	const int64_t warm = rp->warm * (int64_t)(warm_mul > 1 ? warm_mul : 1);
 	int64_t ps0[kRefPieces], pn[kRefPieces]; const void *pp[kRefPieces];
 	#pragma unroll
 	for(int j = 0; j < kRefPieces; j++) { ps0[j] = j < npiece ? rp->piece[j].s0 : 0; pn[j] = j < npiece ? rp->piece[j].n : 0; pp[j] = j < npiece ? rp->piece[j].p : nullptr; }
@@ -1490,7 +1494,8 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 				if(s_beg < 0) s_beg = 0;
 				else {
 					if(ps0[0] > s_beg) { fl |= 2u; s_beg = (ps0[0] + os - 1) / os * os; }
-					if(s_beg > 0 && (int64_t)os * n_lo - s_beg < warm / 4) refuse = true;
+					// (a retry goes with what is held - it was not refused the first time)
+					if(s_beg > 0 && (int64_t)os * n_lo - s_beg < rp->warm / 4) refuse = true;
 				}
 				if(refuse) { atomicAdd(stats + 2, 1u); go = false; }
 				else {
@@ -1660,7 +1665,8 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 	// 2^17) - a trajectory that has met its witness by the stretch's first output has forgotten where it started.  Costs nothing: the
 	// lanes were idle.  Not met: counted (stats[9] -> vdl2hip_stats.referee_unmet); the stretch is then within the rounding noise of the
 	// reference's, like the channeliser's own, not bit for bit it.  (A scan from the stream's very start begins in the reference's
-	// state, zero, exactly: its witness starts there too.)
+	// state, zero, exactly: its witness starts there too.)  Round 6: such a scan is listed and run again from four times further back
+	// (retry_q), where the history ring reaches that far.
 	const int r = lane & (kScanLanes - 1), comp = (lane / kScanLanes) & 1;
 	const bool witness = lane >= 2 * kScanLanes;
 	const float b1 = rp->B1, b2 = rp->B2;
@@ -1746,10 +1752,16 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 	if(lane < kScanLanes && sh.len[r] > 0) {
 		const int c = sh.chan[r];
 		const int64_t n_lo = sh.n_lo[r], n_hi = sh.n_hi[r];
-		if(unmet) atomicAdd(stats + 9, 1u);
-		const uint32_t i = atomicAdd(rp->done_n + c, 1u);
+		bool listed = false;
+		if(unmet && retry_q) {
+			const uint32_t k = atomicAdd(retry_n, 1u);
+			if(k < retry_cap) { retry_q[k] = ScanReq{ c, sh.kind[r], n_lo, n_hi }; listed = true; atomicAdd(stats + 10, 1u); }
+		}
+		if(unmet && !listed) atomicAdd(stats + 9, 1u);
+		const uint32_t i = listed ? 0u : atomicAdd(rp->done_n + c, 1u);
 		int64_t len = (n_hi - n_lo) >> 8; if(len > 0xffff) len = 0xffff;
 		if(((n_hi + 1) & 255) != 0) len -= 1;
+		if(listed) len = -1;                                          // (not published: the retry does that)
 		if(len >= 0) __hip_atomic_store(rp->done + (size_t)c * kRefCache + (i % (uint32_t)kRefCache), ((unsigned long long)(n_lo >> 8) << 32) | ((unsigned long long)len << 16) | (unsigned long long)(launch & 0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		atomicAdd(stats + 0, 1u); atomicAdd(stats + 4 + sh.kind[r], 1u);
 		if(sh.flags[r] & 2u) atomicAdd(stats + 3, 1u);

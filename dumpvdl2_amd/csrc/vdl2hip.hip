@@ -39,6 +39,7 @@ constexpr int kHistory = 65536;          // decimated samples kept behind the ne
 constexpr int kNumEv = 12;            // profiling: {start, stop} of K1, K2, K3, K4, K4b, K5
 constexpr int kColdParts = 4;         // pieces a cold-start block is copied and channelised in
 constexpr size_t kColdMinBytes = 8u << 20;
+constexpr uint32_t kRetryScans = 64;       // referee: scans of one launch that may be run again from further back because they had not met their witness (more: published as they are, counted)
 constexpr uint32_t kPreScans = 4096;    // referee: stretches around marked candidates one feed may list for the scan ahead of the walk (what does not fit is asked for by the walk itself)
 constexpr uint32_t kDeferBursts = 256, kDeferScans = 512;   // referee: bursts of one feed that may wait for their scans, stretches they may wait for (what does not fit is scanned on the spot)
 // Streams per priority class.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per
@@ -64,6 +65,7 @@ struct OutSlot {
 	EvalChunk *d_log = nullptr; uint32_t *d_nlog = nullptr;   // the walker's evaluation log of this feed (read by K4b)
 	uint32_t *d_dq = nullptr; ScanReq *d_sq = nullptr;      // referee, long feeds: the bursts that wait for a scan, the stretches they wait for (counts: d_rqn[1], d_rqn[2])
 	RefReq *d_rq = nullptr; uint32_t *d_rqn = nullptr, *d_rqflag = nullptr; RefBad *d_rqbad = nullptr;
+	ScanReq *d_retry = nullptr;            // [3][kRetryScans]: the unmet scans of the scans ahead of the walk / of the check / of the burst decoder (counts: d_rqn[4..6])
 	ScanReq *d_pq = nullptr; hipEvent_t ev_pre = nullptr;      // referee: the stretches around marked candidates, made exact between the front and the walk (count: d_rqn[3])   // referee, optimistic mode: this feed's decisions to check, its "walk again" flags
 	OutMail *h_mail = nullptr;             // pinned
 	hipEvent_t done = nullptr, ev_front = nullptr, ev_chan = nullptr, ev_walk = nullptr, ev_nf = nullptr, ev[kNumEv] = {};
@@ -512,7 +514,10 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		// feed's whole walk chain)
 		if(!small) HIPCHK(hipStreamWaitEvent(sp_, sl.ev_front, 0));
 		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kPreScans / kScanLanes), dim3(64 * kScanWaves), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
-		                  (const ScanReq *)sl.d_pq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 3), kPreScans, (int64_t)(k0 + D));
+		                  (const ScanReq *)sl.d_pq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 3), kPreScans, (int64_t)(k0 + D), sl.d_retry, sl.d_rqn + 4, kRetryScans, 1);
+		// (... and those of them that had not met their witness - a few in ten thousand - again, from four times further back)
+		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
+		                  (const ScanReq *)sl.d_retry, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 4), kRetryScans, (int64_t)(k0 + D), (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, 4);
 		if(!small) { HIPCHK(hipEventRecord(sl.ev_pre, sp_)); HIPCHK(hipStreamWaitEvent(sb_, sl.ev_pre, 0)); }
 	}
 	if(D > 0) {
@@ -545,7 +550,10 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			sl.has_chk = true;
 			hipStream_t sc_ = c->walk_ahead ? sp_ : sb_;
 			if(sc_ != sb_) { HIPCHK(hipEventRecord(sl.ev_stitch, sb_)); HIPCHK(hipStreamWaitEvent(sc_, sl.ev_stitch, 0)); }
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sc_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, rq_cap, k1);
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sc_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, rq_cap, k1,
+			                  sl.d_retry + kRetryScans, sl.d_rqn + 5, kRetryScans, 1);
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, sc_, k4.ref, k4.ref_launch - 1u, (const ScanReq *)(sl.d_retry + kRetryScans), (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 5), kRetryScans, k1,
+			                  (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, 4);
 			hipLaunchKernelGGL(k_ref_verify, dim3(small ? 64 : 1024), dim3(64), 0, sc_, k4);
 			HIPCHK(hipEventRecord(sl.ev_chk, sc_));
 		}
@@ -610,7 +618,9 @@ static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ) {
 		else if(!defer5) hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), EV(11), 0, k5);
 		else {
 			hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), (hipEvent_t) nullptr, 0, k5);
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kDeferScans / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), (uint32_t)kDeferScans, (int64_t)(k0 + D));
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kDeferScans / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), (uint32_t)kDeferScans, (int64_t)(k0 + D), sl.d_retry + 2 * kRetryScans, sl.d_rqn + 6, kRetryScans, 1);
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)(sl.d_retry + 2 * kRetryScans), (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 6), kRetryScans, (int64_t)(k0 + D),
+			                  (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, 4);
 			K5Args k5b = k5; k5b.df.pass = 2; k5b.ref_launch = (uint32_t)(16 * sl.seq + 7);
 			hipExtLaunchKernelGGL(k_burst, dim3(kDeferBursts / kBurstWaves / 4), dim3(64 * kBurstWaves), k5_lds, s5_, (hipEvent_t) nullptr, EV(11), 0, k5b);
 		}
@@ -674,7 +684,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
 	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec[0], c->d_spec[1], c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
-		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag, sl.d_dq, sl.d_sq, sl.d_rqbad, sl.d_pq, sl.d_rqflag2 };
+		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag, sl.d_dq, sl.d_sq, sl.d_rqbad, sl.d_pq, sl.d_rqflag2, sl.d_retry };
 		for(void *p : q) if(p) (void)hipFree(p);
 		if(sl.ev_stitch) (void)hipEventDestroy(sl.ev_stitch);
 		if(sl.ev_chk) (void)hipEventDestroy(sl.ev_chk);
@@ -888,7 +898,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	if(const char *e = getenv("VDL2HIP_REF_PRESCAN")) c->ref_prescan = atoi(e) != 0;
 	if(const char *e = getenv("VDL2HIP_REF_WARM")) { const long long v = atoll(e); if(v >= 1024 && v <= (1ll << 24)) c->ref_warm = v; }
 	if(c->referee) {
-		c->ref_T = c->ref_warm + (int64_t)(kHistory + 256) * c->os + 4096;      // run-up + the longest burst (its symbols are sliced when its last one has arrived)
+		c->ref_T = 4 * c->ref_warm + (int64_t)(kHistory + 256) * c->os + 4096;      // run-up (of a retry: four times the configured one) + the longest burst (its symbols are sliced when its last one has arrived)
 		c->ref_cap = 1; while(c->ref_cap < (uint64_t)(kSlots + 2) * (uint64_t)c->ref_T) c->ref_cap <<= 1;
 		DEV_ALLOC(c->d_refhist, c->ref_cap * sb);
 		for(int k = 0; k < kSlots; k++) { DEV_ALLOC(c->d_ref[k], sizeof(RefChan)); DEV_CHK(hipMemset(c->d_ref[k], 0, sizeof(RefChan))); }
@@ -906,13 +916,13 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		c->walk_ahead = count >= 16 && count <= 64;   // (8 channels: the walk itself is longer than the front, the second walks' extra launches cost more than they save: 1.22 against 1.11 ms)
 		if(const char *e = getenv("VDL2HIP_WALK_AHEAD")) c->walk_ahead = atoi(e) != 0;      // 0: a feed's walk waits for the check of the feed before (round 5's schedule)
 		for(auto &sl : c->slot) {
-			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 16); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
+			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 32); DEV_ALLOC(sl.d_retry, 3 * (size_t)kRetryScans * sizeof(ScanReq)); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
 			DEV_ALLOC(sl.d_dq, (size_t)kDeferBursts * 4); DEV_ALLOC(sl.d_sq, (size_t)kDeferScans * sizeof(ScanReq));
 			DEV_ALLOC(sl.d_pq, (size_t)kPreScans * sizeof(ScanReq)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_pre, hipEventDisableTiming));
 			DEV_ALLOC(sl.d_rqbad, (size_t)count * sizeof(RefBad)); DEV_CHK(hipMemset(sl.d_rqbad, 0, (size_t)count * sizeof(RefBad)));
 			DEV_ALLOC(sl.d_rqflag2, (size_t)count * 4); DEV_CHK(hipMemset(sl.d_rqflag2, 0, (size_t)count * 4));
 			DEV_CHK(hipEventCreateWithFlags(&sl.ev_stitch, hipEventDisableTiming)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_chk, hipEventDisableTiming));
-			DEV_CHK(hipMemset(sl.d_rqn, 0, 16)); DEV_CHK(hipMemset(sl.d_rqflag, 0, (size_t)count * 4));
+			DEV_CHK(hipMemset(sl.d_rqn, 0, 32)); DEV_CHK(hipMemset(sl.d_rqflag, 0, (size_t)count * 4));
 		}
 	}
 
@@ -1219,10 +1229,10 @@ int vdl2hip_get_stats_sized(vdl2hip_ctx *c, vdl2hip_stats *out, size_t size) {
 		for(int i = 0; i < c->C; i++) { c->stats.seg_adopted += ss[2 * i]; c->stats.seg_walked += ss[2 * i + 1]; }
 	}
 	if(c->d_refstats) {
-		uint32_t rs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		uint32_t rs[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 		if(hipMemcpy(rs, c->d_refstats, sizeof rs, hipMemcpyDeviceToHost) != hipSuccess) return VDL2HIP_E_DEVICE;
 		c->stats.referee_scans = rs[0]; c->stats.referee_cached = rs[1]; c->stats.referee_refused = rs[2]; c->stats.referee_short = rs[3];
-		c->stats.referee_candidate_scans = rs[4]; c->stats.referee_header_scans = rs[5]; c->stats.referee_symbol_scans = rs[6]; c->stats.referee_rewalks = rs[7]; c->stats.referee_redone_next = rs[8]; c->stats.referee_unmet = rs[9];
+		c->stats.referee_candidate_scans = rs[4]; c->stats.referee_header_scans = rs[5]; c->stats.referee_symbol_scans = rs[6]; c->stats.referee_rewalks = rs[7]; c->stats.referee_redone_next = rs[8]; c->stats.referee_unmet = rs[9]; c->stats.referee_retried = rs[10];
 	}
 	memcpy(out, &c->stats, std::min(size, sizeof c->stats));
 	return (r == VDL2HIP_E_OVERFLOW || c->failed) ? VDL2HIP_OK : r;
@@ -1300,7 +1310,7 @@ int vdl2hip_debug_scan_multi(vdl2hip_ctx *c, const int32_t *chan, const int64_t 
 		&& hipMemcpy(d_sq, h.data(), sizeof(ScanReq) * (size_t)count, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_n, &count, 4, hipMemcpyHostToDevice) == hipSuccess
 		&& hipMemcpy(before, c->d_refstats, sizeof before, hipMemcpyDeviceToHost) == hipSuccess;
 	if(ok) LAUNCH_SCAN_MULTI(hipExtLaunchKernelGGL, dim3((count + kScanLanes - 1) / kScanLanes), dim3(64 * kScanWaves), 0, c->stream, e0, e1, 0, c->d_ref[(c->feed_no - 1) % kSlots], 0xfffeu,
-	                             (const ScanReq *)d_sq, (const RefReq *) nullptr, (const uint32_t *)d_n, count, (int64_t)c->k_total);
+	                             (const ScanReq *)d_sq, (const RefReq *) nullptr, (const uint32_t *)d_n, count, (int64_t)c->k_total, (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, 1);
 	ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(after, c->d_refstats, sizeof after, hipMemcpyDeviceToHost) == hipSuccess;
 	float t = 0.f;
 	if(ok && ms) { (void)hipEventElapsedTime(&t, e0, e1); *ms = t; }

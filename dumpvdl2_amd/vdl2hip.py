@@ -70,7 +70,7 @@ class Stats(C.Structure):
                 ("overflow_feeds", C.c_uint64), ("cold_start_feeds", C.c_uint64),
                 ("referee_scans", C.c_uint64), ("referee_cached", C.c_uint64), ("referee_refused", C.c_uint64), ("referee_short", C.c_uint64), ("referee_rewalks", C.c_uint64),
                 ("referee_candidate_scans", C.c_uint64), ("referee_header_scans", C.c_uint64), ("referee_symbol_scans", C.c_uint64),
-                ("referee_redone_next", C.c_uint64), ("referee_unmet", C.c_uint64)]
+                ("referee_redone_next", C.c_uint64), ("referee_unmet", C.c_uint64), ("referee_retried", C.c_uint64)]
 
 
 class PackedFrame(C.Structure):
