@@ -714,6 +714,10 @@ def main():
     t_hbm = case.timed(f_hbm, args.steps, dist, args.repeats)
     rs1 = case.rx.stats()
     stage_ms_hbm = case.stage_times(f_hbm)
+    t_hbm_steady = None
+    if world == 1 and not args.no_secondary:      # (one long region, as `steady_state` above: what the projection below divides by)
+        ks = max(100, 10 * args.steps)
+        t_hbm_steady = case.timed(f_hbm, ks, dist, 1)["dt"] / ks * 1e3
     # ---- what the referee costs: the same timed region with it switched off (the answer is then no longer the oracle's on every input) ----
     referee_ab = None
     if world == 1 and not args.no_secondary:
@@ -781,8 +785,11 @@ def main():
             fd.step(); fd.step(); cs.rx.set_drain_lag(0); cs.rx.drain_packed()
             ts = cs.timed(fd, args.steps, dist, args.repeats)
             st = cs.stage_times(fd)
+            ks = max(100, 10 * args.steps)
+            tl = cs.timed(fd, ks, dist, 1)
             shards.append({"rank": r, "channels": [r * per, (r + 1) * per - 1], "referee_scans_ahead_of_the_walk": cs.prescan, "ms_per_step": round(ts["dt"] / args.steps * 1e3, 4),
-                           "min_ms_per_step": ts["min_ms_per_step"], "k_chanfir_ms": round(ts["k1_ms"], 4), "stage_ms_per_step": st,
+                           "min_ms_per_step": ts["min_ms_per_step"], "steady_ms_per_step": round(tl["dt"] / ks * 1e3, 4), "steady_steps": ks,
+                           "k_chanfir_ms": round(ts["k1_ms"], 4), "stage_ms_per_step": st,
                            "frames_identical_to_the_oracle": vs_oracle})
             del fd
             cs.close()
@@ -795,6 +802,10 @@ def main():
                              f"(as an RCCL exchange leaves it), six blocks in flight, the same K steps x {args.repeats} repeats (median)",
                      "t_all_channels_ms": round(t256, 4), "t_rank_ms_max": round(t32, 4), "shards": shards,
                      "compute_ceiling_speedup_at_8": round(t256 / t32, 3),
+                     # the same from one long timed region each (max(100, 10 K) steps): a K-step region pays a feed's way through the device - four
+                     # to six fronts for a rank-sized receiver - once, which at K = 20 is a fifth of a rank's step and a thirtieth of all channels'
+                     "steady": None if t_hbm_steady is None else {"t_all_channels_ms": round(t_hbm_steady, 4), "t_rank_ms_max": max(s["steady_ms_per_step"] for s in shards),
+                                                                   "compute_ceiling_speedup_at_8": round(t_hbm_steady / max(s["steady_ms_per_step"] for s in shards), 3)},
                      "h2d_whole_block_ms": round(h2d, 4),
                      "ingest_bounds": {"broadcast_from_one_host_link": {"ms_per_block": round(h2d, 4), "speedup_ceiling": round(t_host["dt"] / args.steps * 1e3 / max(h2d, t32), 3),
                                                                         "note": "north_star's literal form, host-fed: the whole block crosses ONE PCIe link per step"},

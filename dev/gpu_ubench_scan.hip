@@ -77,6 +77,38 @@ __global__ __launch_bounds__(512) void k_scan(const float *in, float *out, int n
 				const float yi = ri + (b1 * yi1 + b2 * yi2);
 				yi2 = yi1; yi1 = yi;
 			}
+		} else if(V == 6 || V == 7) {
+			// V6: the two products of a step in ONE instruction - a component lives in a pair of lanes, the even one multiplies by B1, the
+			// odd one by B2 (per-lane coefficient), y comes to both from the even lane (quad_perm [0,0,2,2] on the multiply), the sum
+			// m + t2 takes the odd lane's product of the step before (quad_perm [1,0,3,2] on the add): 3 VALU per step.  V7: the same with
+			// the feed-forward value from a register (as the kernel has it) instead of v_readlane
+			const float bb = odd ? b2 : b1;
+			float pprev = 0.f;
+			#pragma unroll
+			for(int j = 0; j < 64; j++) {
+				const float ri = V == 6 ? lane_of(fa, j) : (j & 1 ? fb : fa);
+				const float ysrc = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, yi1), 0xA0, 0xf, 0xf, false));
+				const float p = bb * ysrc;
+				const float tp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pprev), 0xB1, 0xf, 0xf, false));
+				const float s = p + tp;
+				pprev = p;
+				yi1 = ri + s;
+			}
+			yi2 = pprev;
+		} else if(V == 8 || V == 9 || V == 10) {
+			// V4 with the feed-forward value from a register; V9 / V10: only lanes 0-31 / 0-15 active (does the SIMD skip the idle quarters?)
+			if(V == 8 || (V == 9 && lane < 32) || (V == 10 && lane < 16)) {
+				float t2 = b2 * yi2;
+				#pragma unroll
+				for(int j = 0; j < 64; j++) {
+					const float ri = j & 1 ? fb : fa;
+					const float m = b1 * yi1;
+					const float s = m + t2;
+					t2 = b2 * yi1;
+					yi1 = ri + s;
+				}
+				yi2 = t2;
+			}
 		}
 	}
 	const unsigned long long t1 = clock64();
@@ -117,6 +149,11 @@ int main() {
 		run<3>("V3 I in even lanes, Q in odd: 2 readlane + select + 4", w);
 		run<4>("V4 one component, B2*y2 a step early by hand", w);
 		run<5>("V5 one component, r0 by readfirstlane + wave_rol", w);
+		run<6>("V6 lane pair (B1 | B2 per lane), DPP: 1 readlane + 3 VALU", w);
+		run<7>("V7 lane pair, r0 from a register: 3 VALU", w);
+		run<8>("V8 one component, r0 from a register: 4 VALU", w);
+		run<9>("V9 = V8, lanes 0-31 only", w);
+		run<10>("V10 = V8, lanes 0-15 only", w);
 	}
 	return 0;
 }

@@ -36,11 +36,13 @@ def synth_to_tmp(name, duration):
 
 
 def measure(rx, torch, dev_block, nbytes, steps, repeats, stage_n=6):
+    from dumpvdl2_amd import vdl2hip
+    LAG = vdl2hip.MAX_DRAIN_LAG
     out = {}
     times, k1 = [], []
     rx.set_profiling(1)
     for _ in range(repeats):
-        rx.set_drain_lag(3)
+        rx.set_drain_lag(LAG)
         s0 = rx.stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -57,7 +59,7 @@ def measure(rx, torch, dev_block, nbytes, steps, repeats, stage_n=6):
     out["ms"] = round(statistics.median(times), 4)
     out["ms_all"] = [round(t, 4) for t in times]
     out["k1"] = round(statistics.median(k1), 4)
-    rx.set_profiling(2); rx.set_drain_lag(3)
+    rx.set_profiling(2); rx.set_drain_lag(LAG)
     sa = rx.stats()
     for _ in range(stage_n):
         rx.feed_device(dev_block.data_ptr(), nbytes); rx.drain_packed()
@@ -82,9 +84,13 @@ def child(args):
     cfg = getattr(workloads, args.workload)(args.duration)
     nbytes = iq.size * 2
     dev_block = torch.from_numpy(iq).to("cuda:0")
-    for label, first, count in (("all", 0, len(cfg.freqs)), ("shard", 96, 32)):
-        if label not in args.parts:
-            continue
+    todo = []
+    for part in args.parts.split(","):       # all | shard (= shard96) | shard<first channel>
+        if part == "all":
+            todo.append(("all", 0, len(cfg.freqs)))
+        elif part.startswith("shard"):
+            todo.append((part, int(part[5:] or 96), 32))
+    for label, first, count in todo:
         rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm,
                               max_block_bytes=nbytes, chan_first=first, chan_count=count)
         rx.set_drain_lag(0)
@@ -152,7 +158,7 @@ def main():
                 print(parts[0], w, "ERROR", j["error"][-300:], flush=True)
             else:
                 print(parts[0], w, " ".join(f"{lab}: {j[lab]['ms']} ms (K1 {j[lab]['k1']}; {j[lab]['stage']}; frames {j[lab]['frames']}/{j[lab]['tx_frames']} missing {j[lab]['missing']}; referee {j[lab].get('referee')} in {j[lab].get('feeds')} feeds)"
-                                            for lab in ("all", "shard") if lab in j), flush=True)
+                                            for lab in j if isinstance(j[lab], dict) and "ms" in j[lab]), flush=True)
 
 
 if __name__ == "__main__":

@@ -41,13 +41,15 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // process_samples() (src/demod.c:302-329) is a sequential scan per channel: sincosf_lut() (:58-72), multiply() (:200-203),
 // chebyshev_lpf_2pole() (:74-79) on I and Q, every product and sum rounded to float in exactly that order.  Two such scans over
 // the same input started from different filter states become BIT-IDENTICAL after a while - the difference of two fp32
-// trajectories of a contracting recursion does not shrink below an ulp, it hits zero (measured on the bench workloads:
-// exponentially distributed, 1.6e4 input samples on average per component; dev/iir_state_coalescence.c, dev/ref_short_runup.py -
-// which also shows that until they meet the two differ by as much as the channeliser's stream does from either, 1e-4 of the
-// signal: a short run-up buys nothing).  So the reference's trajectory over [n_lo, n_hi] is obtained by running ITS arithmetic
-// from `warm` (default 2^17) input samples earlier with a zero state: not yet the reference's with probability 2.5e-4 (measured on
-// the device with a second, witness scan from another state: 9 of 35 838 had not met; the witness costs 40% more time per sample
-// and is not kept - VDL2HIP_REF_WARM=262144 squares that probability for twice the time).
+// trajectories of a contracting recursion does not shrink below an ulp, it hits zero: the waiting time is exponentially distributed,
+// 1.7e4 input samples on average per component where the channel carries noise, 2.6e4 inside a burst (dev/iir_state_coalescence.c,
+// dev/ref_short_runup.py - which also shows that until they meet the two differ by as much as the channeliser's stream does from
+// either, 2e-5 .. 1e-4 of the signal: a short run-up buys nothing).  So the reference's trajectory over [n_lo, n_hi] is obtained by
+// running ITS arithmetic from `warm` input samples earlier with a zero state.  How often that is not yet the reference's, measured
+// on the device against the oracle's stream over 91 773 stretches of a 64-channel capture (dev/gpu_scan_soundness.py,
+// profiles/r06_scan_soundness.txt): run-up 2^17: 1.9e-3 of the stretches; 2^18: 2.2e-5; 2^19 and 2^20: none.  The default is
+// 3 * 2^16 = 196 608 (VDL2HIP_REF_WARM): a few in 10^4, for half as much again as 2^17 costs (rounds 5 and 6 ran 2^17 and took the
+// share for 2.5e-4, from a witness count - see k_ref_scan_multi: a witness started at the same sample sees about half of them).
 //
 // One wavefront does it.  The part without a recursion - sample conversion, NCO, mixer, the three feed-forward taps - is done
 // for 60-odd input samples at a time by the lanes; the recursion y = r0 + (B1 y1 + B2 y2) is uniform: every lane does the same
@@ -107,14 +109,17 @@ __device__ __forceinline__ float ref_lane(float v, int l) { return __builtin_bit
 // began.  launch = 16 * feed + kind.  Kinds of the walk chain of feed s and when they run (vdl2hip.hip: launch_back / launch_rest):
 //   8 scans ahead of the walk        own stream, after the feed's front: BESIDE the walk chains of the feeds before
 //   1 speculative / single walk, 2 stitch                 walk stream
-//   0 the noted decisions' scans, 3 check                 own stream, after stitch(s): beside stitch(s + 1)
-//   4 walk again (after check(s) AND stitch(s + 1)), 9 feed s once more from a corrected start (after 4 of s - 1): walk stream
-// so the walk stream runs  ... stitch(s)  4(s-1) 9(s)  stitch(s+1)  4(s) 9(s+1)  stitch(s+2) ...  with 0/3 of feed s anywhere between
-// stitch(s) and 4(s).  Kinds of the burst stream of feed s, after 4(s): 5 burst decoder (first pass), 6 its listed scans, 7 second pass;
-// they run beside the walk chains of the feeds after s and beside other feeds' burst kernels.  Hence a reader (feed m, kind mk)
-// believes an entry (feed e, kind ek), d = m - e:
-//   walk chain reading walk chain:  d >= 2: yes.  d = 1: kinds 8, 1, 2, 9 - and everything if the reader is 4 or 9 (check(m - 1) has
-//     ended by then).  d = 0: reader 1: {8}; 2: {8, 1}; 0: {8, 1, 2}; 3: {8, 1, 2, 0}; 9: {8, 1, 2}; 4: {8, 1, 2, 9, 0, 3}.
+//   0 the noted decisions' scans, 3 check                 own stream, after stitch(s): beside the walks of the next one or two feeds
+//   4 walk again (after check(s) AND the walks that went ahead of it), 9 / 10 feed s once more from a corrected start - as the first /
+//     the second feed behind the one whose second walk corrected it: walk stream
+// The walk stream runs (walk ahead by two feeds)  ... S(s) 4(s-2) 9(s-1) 10(s)  S(s+1) 4(s-1) 9(s) 10(s+1)  S(s+2) 4(s) ...  - by one:
+// ... S(s) 4(s-1) 9(s)  S(s+1) 4(s) 9(s+1) ... - with 0/3 of feed s anywhere between S(s) and 4(s).  Kinds of the burst stream of feed
+// s, after 4(s): 5 burst decoder (first pass), 6 its listed scans, 7 second pass; they run beside the walk chains of the feeds after s
+// and beside other feeds' burst kernels.  Hence a reader (feed m, kind mk) believes an entry (feed e, kind ek), d = m - e - rules that
+// hold for either depth:
+//   4, 9: every walk-chain entry of an earlier feed (check(m - 1) has ended by then); of its own feed 4: everything, 9: {8, 1, 2}.
+//   10: d >= 2: yes; d = 1: {8, 1, 2, 9, 10} (check(m - 1) may still run); d = 0: {8, 1, 2}.
+//   1, 2, 0, 3: d >= 3: yes; d = 2: {8, 1, 2, 9, 10}; d = 1: {8, 1, 2}; d = 0: reader 1: {8}; 2: {8, 1}; 0: {8, 1, 2}; 3: {8, 1, 2, 0}.
 //   burst kernel: walk-chain entries of its own and earlier feeds, and its own feed's earlier burst kinds.
 //   the scans ahead of the walk (8) believe nobody; nobody believes an entry of his own launch or a burst kernel of another feed.
 // (Round 5 believed every entry of another launch - a burst decoder could pick up the entry of a later feed's scan that was still
@@ -126,18 +131,21 @@ __device__ __forceinline__ bool ref_entry_visible(uint32_t entry, uint32_t mine)
 	if(mine >= 0xfffeu || entry >= 0xfffeu) return true;
 	const uint32_t ek = entry & 15u, mk = mine & 15u, d = ((mine >> 4) - (entry >> 4)) & 0xfffu;
 	if(mk == 8u || d >= 2048u) return false;
-	auto walk_kind = [](uint32_t k) { return k <= 4u || k == 8u || k == 9u; };
+	auto walk_kind = [](uint32_t k) { return k <= 4u || (k >= 8u && k <= 10u); };
 	if(!walk_kind(mk)) return walk_kind(ek) || (d == 0u && ek < mk);       // a burst kernel (5, 6, 7)
 	if(!walk_kind(ek)) return false;
-	if(d >= 2u) return true;
 	const bool early = ek == 8u || ek == 1u || ek == 2u;                        // ends before anything of the next feed's walk begins
-	if(d == 1u) return early || ek == 9u || mk == 4u || mk == 9u;
+	const bool redone = ek == 9u || ek == 10u;
+	if(mk == 4u || mk == 9u) return d >= 1u || mk == 4u || early;
+	if(mk == 10u) return d >= 2u || early || (d == 1u && redone);
+	if(d >= 3u) return true;
+	if(d == 2u) return early || redone;
+	if(d == 1u) return early;
 	switch(mk) {                                                                 // d == 0
 		case 1: return ek == 8u;
 		case 2: return ek == 8u || ek == 1u;
-		case 0: case 9: return early;
-		case 3: return early || ek == 0u;
-		default: return true;                                                    // 4: everything else of its feed has ended
+		case 0: return early;
+		default: return early || ek == 0u;                                       // 3
 	}
 }
 __device__ __forceinline__ bool ref_done_lookup(const unsigned long long *done, uint32_t ndv, int64_t n_lo, int64_t n_hi, uint32_t launch, int lane) {
@@ -1222,6 +1230,7 @@ struct K4Args {
 	// the next feed's walk stands; else the snapshot is corrected, rq_flag2_next[c] set, and the next feed is stitched once more for
 	// that channel from the corrected snapshot (again = 3, its own rq_flag2).
 	WalkState *ws_tmp; unsigned long long *cnt_tmp; WalkState *ws_snap_next; unsigned long long *cnt_snap_next; uint32_t *rq_flag2, *rq_flag2_next;
+	uint32_t *rq_flag2_next2;  // walk ahead by two feeds: the feed after the next has been walked as well and is stitched once more too (again = 4 for the next feed: into the snapshot the feed after it starts from; 3 for that one)
 	int32_t force_mismatch;    // test hook: every channel walked again is taken to have ended differently (the next feed is redone for it)
 };
 
@@ -1304,17 +1313,20 @@ __global__ __launch_bounds__(256, 4) void k_walk_stitch(K4sArgs s) {
 	// again: 0 the feed's walk; 1 a flagged channel once more, nothing walked after this feed yet (state and counters: the live rows);
 	// 2 the same when the next feed HAS been walked (K4Args: ws_tmp ...); 3 this feed once more for a channel whose start state the
 	// previous feed's second walk has corrected
+	// 4: as 3 when the feed AFTER this one has been walked too (walk ahead by two): the end state and counters go where that feed starts
+	// from (its snapshot: ws_snap_next), and it is stitched once more itself (3; its flag was set together with this feed's); 5: as 3,
+	// as the second feed behind the corrected one (launch kind 10: ref_entry_visible())
 	const int mode = s.again;
 	if((mode == 1 || mode == 2) && !a.rq_flag[c]) return;
-	if(mode == 3 && !a.rq_flag2[c]) return;
+	if(mode >= 3 && !a.rq_flag2[c]) return;
 	StitchLds &lds = reinterpret_cast<StitchLds *>(k4_lds)[wave];
-	// (launch kinds, ref_entry_visible(): a.ref_launch is kind 1; stitch 2, walk again 4, the corrected feed's second walk 9)
-	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + (mode == 0 ? 1u : mode == 3 ? 8u : 3u), mode ? nullptr : a.rq, a.rq_n, a.rq_cap, a.rq_flag,
-	            // (mode 3: this feed's check may not have run yet - no speculative walk that noted decisions is adopted: spec_requests_stand() without a list)
-	            (a.rq_bad && mode != 3) ? a.rq_bad + c : nullptr, a.ref_pre != 0 };
+	// (launch kinds, ref_entry_visible(): a.ref_launch is kind 1; stitch 2, walk again 4, the corrected feed's second walk 9 / 10)
+	ChanView v{ a.y + (size_t)c * a.cap, a.pf + (size_t)c * a.cap, a.cand + (size_t)c * (a.cap >> 6), a.mask, a.ref, c, a.ref_launch + (mode == 0 ? 1u : mode == 5 ? 9u : mode >= 3 ? 8u : 3u), mode ? nullptr : a.rq, a.rq_n, a.rq_cap, a.rq_flag,
+	            // (mode 3, 4, 5: this feed's check may not have run yet - no speculative walk that noted decisions is adopted: spec_requests_stand() without a list)
+	            (a.rq_bad && mode < 3) ? a.rq_bad + c : nullptr, a.ref_pre != 0 };
 	EvalLog lg{ a.log + (size_t)c * a.cap_log, a.nlog + c };
-	WalkState *gstate = mode == 2 ? &a.ws_tmp[c] : &a.ws[c];
-	unsigned long long *cnt = (mode == 2 ? a.cnt_tmp : a.cnt) + (size_t)c * kNumCounters;
+	WalkState *gstate = mode == 2 ? &a.ws_tmp[c] : mode == 4 ? &a.ws_snap_next[c] : &a.ws[c];
+	unsigned long long *cnt = (mode == 2 ? a.cnt_tmp : mode == 4 ? a.cnt_snap_next : a.cnt) + (size_t)c * kNumCounters;
 	stitch_channel(c, a.freq[c], a.max_ppm, a.ppm_thr[c], s.k0, s.seglen, s.nseg, a.k_end, *a.tab, v, gstate, cnt,
 	               a.bursts + (size_t)c * a.cap_bursts_chan, a.cap_bursts_chan, a.nb_chan + c, a.ctl, lg,
 	               s.spec + (size_t)c * s.spec_stride, lds.sh, lds.ss, s.seg_stats + 2 * c, WalkSnap{ (a.rq || mode) ? a.ws_snap : nullptr, a.cnt_snap }, mode != 0);
@@ -1327,11 +1339,11 @@ __global__ __launch_bounds__(256, 4) void k_walk_stitch(K4sArgs s) {
 		if(lane == 0) same = walk_state_equal(a.ws_tmp[c], a.ws_snap_next[c]) && !a.force_mismatch;
 		if(lane < kNumCounters) same = same && cnt[lane] == a.cnt_snap_next[(size_t)c * kNumCounters + lane];
 		if(__any(!same)) {
-			if(lane == 0) { a.ws_snap_next[c] = a.ws_tmp[c]; a.rq_flag2_next[c] = 1u; atomicAdd(a.ref->stats + 8, 1u); }
+			if(lane == 0) { a.ws_snap_next[c] = a.ws_tmp[c]; a.rq_flag2_next[c] = 1u; if(a.rq_flag2_next2) a.rq_flag2_next2[c] = 1u; atomicAdd(a.ref->stats + 8, 1u); }
 			if(lane < kNumCounters) a.cnt_snap_next[(size_t)c * kNumCounters + lane] = cnt[lane];
 		}
 	}
-	if(mode == 3 && (threadIdx.x & 63) == 0) a.rq_flag2[c] = 0u;
+	if(mode >= 3 && (threadIdx.x & 63) == 0) a.rq_flag2[c] = 0u;
 }
 
 struct K4bArgs {
@@ -1661,9 +1673,11 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 	lds_barrier();
 	// Lanes 32-63 are the WITNESS: the same requests over the same feed-forward values from ANOTHER state.  Two fp32 trajectories of
 	// this recursion become bit-identical after a while (1.6e4 samples on average) and stay so; that the run-up was long enough for the
-	// zero-start trajectory to have become the reference's is what "the reference's own samples" rests on (not yet in 2.5e-4 of scans at
-	// 2^17) - a trajectory that has met its witness by the stretch's first output has forgotten where it started.  Costs nothing: the
-	// lanes were idle.  Not met: counted (stats[9] -> vdl2hip_stats.referee_unmet); the stretch is then within the rounding noise of the
+	// zero-start trajectory to have become the reference's is what "the reference's own samples" rests on - a trajectory that has NOT
+	// met its witness by the stretch's first output has certainly not forgotten where it started.  The converse does not hold: the two
+	// start at the same sample from states close to each other and often meet each other before either meets the reference's (of 174
+	// stretches that differed from the oracle's after 2^17 samples the witness had flagged 37, and it flagged 52 that did not differ:
+	// profiles/r06_scan_soundness.txt) - it is a monitor, the run-up's length is the guarantee.  Costs nothing: the lanes were idle.  Not met: counted (stats[9] -> vdl2hip_stats.referee_unmet); the stretch is then within the rounding noise of the
 	// reference's, like the channeliser's own, not bit for bit it.  (A scan from the stream's very start begins in the reference's
 	// state, zero, exactly: its witness starts there too.)  Round 6: such a scan is listed and run again from four times further back
 	// (retry_q), where the history ring reaches that far.

@@ -572,9 +572,9 @@ VDL2_HD Geometry header_to_geometry(uint32_t hdr, const uint32_t *tH, const uint
 // reference takes on those samples - candidate test, parabola vertex, --max-ppm gate, symbol slicer - is therefore taken
 // here WITH A MARGIN: when the decision could come out differently for some stream within that distance, the wavefront asks
 // ref_exact_window() for the reference's own samples of the stretch the decision reads (the scan re-run sequentially in the
-// reference's operation order from RefChan::warm input samples back - 2^17 by default: two such scans started from different
-// states are bit-identical after 1.6e4 samples on average, and had NOT yet met after 2^17 in 2.5e-4 of the cases measured
-// (kernels.h)) and takes the decision again on those.  A decision is then either robust against the stream's error or taken on
+// reference's operation order from RefChan::warm input samples back - 196 608 by default: two such scans started from different
+// states are bit-identical after 1.7e4 - 2.6e4 samples on average, and a zero-start scan had not yet become the reference's after
+// 2^17 in 1.9e-3 of the stretches measured, after 2^18 in 2.2e-5 (kernels.h)) and takes the decision again on those.  A decision is then either robust against the stream's error or taken on
 // samples that are the reference's own with that probability; where they are not yet, they are within its rounding noise of them.
 // ======================================================================
 constexpr float kRefKappa = 3.0e-4f;       // bound used for |y - y_ref| / (largest |y| among the samples a decision reads): 2x the worst seen
@@ -2448,7 +2448,7 @@ VDL2_HD void burst_shared_init(const Tables &T, uint32_t wave, const OutCtl *ctl
 // Referee, long feeds: a burst some of whose symbols have to be sliced on the reference's own samples is not held up for the
 // scans (milliseconds each, one after the other) - the first pass lists it and the stretches it needs (pass 1), k_ref_scan makes
 // them all at once, a wavefront each, and a second pass decodes the listed bursts (pass 2: every stretch it asks for is then done).
-constexpr int kRefPieceBits = 12;           // a burst's stretches are asked for in pieces of 2^12 decimated samples, each scanned on its own
+constexpr int kRefPieceBits = 10;           // a burst's stretches are asked for in pieces of 2^10 decimated samples, each scanned on its own (a scan is its run-up, 2^17 input samples, plus its stretch: with pieces of 2^12 - 82 000 input samples - a listed burst's scans took 2.2 ms instead of 1.6)
 struct ScanReq { int32_t chan, kind; int64_t lo, hi; };
 struct BurstDefer { uint32_t *dq, *dq_n; uint32_t dq_cap; ScanReq *sq; uint32_t *sq_n; uint32_t sq_cap; int32_t pass; };
 

@@ -118,7 +118,7 @@ struct vdl2hip_ctx {
 	NfState *d_nf = nullptr; int64_t *d_scfirst = nullptr, *d_sccum = nullptr;
 	float *d_nfring = nullptr, *d_lpbuf = nullptr; NfFeed *d_nffeed = nullptr; uint32_t cap_log = 0, cap_comb = 0, cap_hist = 0, nf_ring = 0;
 	uint32_t cap_bursts_chan = 0;
-	SpecOut *d_spec[2] = {}; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
+	SpecOut *d_spec[3] = {}; uint32_t *d_segstats = nullptr; int seg_max = 1; int64_t seg_min = 16384;   // segmented walk
 	OutSlot slot[kSlots];                  // per-feed output buffers: the fronts of feeds i+1, i+2 run while feed i's back still fills slot i%kSlots
 	uint64_t feed_no = 0; int drain_lag = 0;
 	hipStream_t stream_pre[kSidePre] = {};        // referee, VDL2HIP_REF_PRESCAN=1: the scans ahead of the walk, a stream per feed in flight (one stream would put them in a row: 4.4 ms each)
@@ -136,11 +136,12 @@ struct vdl2hip_ctx {
 	// buffer) while its back end runs; what lies before it - up to ref_T samples: the run-up of the scan + the longest burst - is kept
 	// in a ring (ref_hist), appended to by every feed (its last min(n, ref_T) samples).  ref_pieces: what of the stream the ring holds,
 	// contiguously, newest last: {first absolute sample, count, ring position of the first}.
-	bool referee = true; int ref_kinds = 7; bool ref_prescan = false;   /* VDL2HIP_REF_PRESCAN=1: the stretches around marked candidates are made exact ahead of the walk - a rank-sized shard 4.05 -> 2.88 ms per step, 256 channels 7.2 -> 7.85: for receivers of few channels */ int64_t ref_warm = 1 << 17, ref_T = 0; uint8_t *d_refhist = nullptr; uint64_t ref_cap = 0, ref_wp = 0;
+	bool referee = true; int ref_kinds = 7; bool ref_prescan = false;   /* VDL2HIP_REF_PRESCAN=1: the stretches around marked candidates are made exact ahead of the walk - a rank-sized shard 4.05 -> 2.88 ms per step, 256 channels 7.2 -> 7.85: for receivers of few channels */ int64_t ref_warm = 3 << 16 /* 196 608: kernels.h */, ref_T = 0; uint8_t *d_refhist = nullptr; uint64_t ref_cap = 0, ref_wp = 0;
 	struct HistPiece { int64_t s0, n; uint64_t pos; }; std::vector<HistPiece> ref_pieces;
 	unsigned long long *d_refdbg = nullptr; int ref_dbg_chan = -1;
-	WalkState *d_ws_snap[2] = {}, *d_ws_tmp = nullptr; unsigned long long *d_cnt_snap[2] = {}, *d_cnt_tmp = nullptr; uint32_t rq_cap = 8192; bool ref_optimistic = true;
-	bool walk_ahead = true; int debug_force_mismatch = 0;   // launch_back(): the next feed's walk does not wait for this feed's check
+	WalkState *d_ws_snap[3] = {}, *d_ws_tmp = nullptr; unsigned long long *d_cnt_snap[3] = {}, *d_cnt_tmp = nullptr; uint32_t rq_cap = 8192; bool ref_optimistic = true;
+	int walk_ahead = 1; int debug_force_mismatch = 0;   // launch_back(): the walks of the next feed (1) or the next two (2) do not wait for this feed's check
+	int ref_retry_mul = 2;                 // a scan that has not met its witness is run again from this many times further back (0: not at all; VDL2HIP_REF_RETRY)
 	RefChan *d_ref[kSlots] = {}; unsigned long long *d_refdone = nullptr; uint32_t *d_refdonen = nullptr, *d_refstats = nullptr; uint8_t *d_mix = nullptr;
 	bool defer_back = false;               // VDL2HIP_BACKEND=deferred: the back end of feed i is queued behind the channeliser of feed i+1 (launch_back)
 	std::vector<uint64_t> statsd_prev;
@@ -186,14 +187,15 @@ static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds, 
 }
 
 static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate);
-static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, struct OutSlot *succ);
+static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, struct OutSlot *succ, struct OutSlot *succ2);
+static int flush_rest(vdl2hip_ctx *c, const OutSlot *upto);
 // A short feed (fewer than two walk segments' worth of samples; the reference's own 320 000-byte blocks are 4 000): launch_back()
 static bool feed_is_small(const vdl2hip_ctx *c, int64_t D);
 
 static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 	if(!sl.pending) return VDL2HIP_OK;
 	if(sl.back_queued) { int r = launch_back(c, sl, nullptr); if(r != VDL2HIP_OK) return r; }   // nothing followed this feed: its back end goes now
-	if(sl.rest_pending) { int r = launch_rest(c, sl, nullptr); if(r != VDL2HIP_OK) return r; }   // ... nor did a walk that its second walks could have been queued behind
+	if(sl.rest_pending) { int r = flush_rest(c, &sl); if(r != VDL2HIP_OK) return r; }   // ... nor did the walks that its second walks could have been queued behind (it and what is older, oldest first)
 	HIPCHK(hipEventSynchronize(sl.done));
 	sl.pending = false;
 	if(c->profiling && sl.ev_valid) {
@@ -215,7 +217,12 @@ static int collect_slot(vdl2hip_ctx *c, OutSlot &sl) {
 			if(!sl.fused) { (void)hipEventElapsedTime(&g12, ev[1], ev[2]); (void)hipEventElapsedTime(&g23, ev[3], ev[4]); } else (void)hipEventElapsedTime(&g23, ev[1], ev[4]);
 			OutSlot &pv = c->slot[(sl.seq + kSlots - 1) % kSlots];
 			if(sl.seq > 0 && pv.ev_level >= 2) (void)hipEventElapsedTime(&g31, pv.ev_front, ev[0]);
-			fprintf(stderr, "gaps feed %llu: K1->K2 %.1f us, K2->K3 %.1f us, K3(prev)->K1 %.1f us\n", (unsigned long long)sl.seq, g12 * 1e3, g23 * 1e3, g31 * 1e3);
+			float lat = -1, per = -1, fr = -1, wk = -1, w2d = -1, w2b = -1, bb = -1, b2d = -1, w2n = -1;
+			(void)hipEventElapsedTime(&w2b, ev[7], ev[10]); (void)hipEventElapsedTime(&bb, ev[10], ev[11]); (void)hipEventElapsedTime(&b2d, ev[11], sl.done); (void)hipEventElapsedTime(&w2n, ev[7], ev[8]);
+			fprintf(stderr, "tail feed %llu: walk end -> burst start %.3f (nf start %.3f), burst %.3f, burst end -> done %.3f\n", (unsigned long long)sl.seq, w2b, w2n, bb, b2d);
+			(void)hipEventElapsedTime(&lat, ev[0], sl.done); (void)hipEventElapsedTime(&fr, ev[0], sl.ev_front); (void)hipEventElapsedTime(&wk, sl.ev_front, ev[6]); (void)hipEventElapsedTime(&w2d, ev[7], sl.done);
+			if(sl.seq > 0 && pv.ev_level >= 2) (void)hipEventElapsedTime(&per, pv.ev[0], ev[0]);
+			fprintf(stderr, "gaps feed %llu: K1->K2 %.1f us, K2->K3 %.1f us, K3(prev)->K1 %.1f us | K1 start -> done %.3f ms, front %.3f, front end -> walk start %.3f, walk end -> done %.3f, K1 start (prev) -> K1 start %.3f\n", (unsigned long long)sl.seq, g12 * 1e3, g23 * 1e3, g31 * 1e3, lat, fr, wk, w2d, per);
 		}
 		}
 	}
@@ -472,7 +479,7 @@ static bool feed_is_small(const vdl2hip_ctx *c, int64_t D) {
 // or, if nothing follows (a drain, a short feed, the old schedule with VDL2HIP_WALK_AHEAD=0), at once with `succ` = nullptr: again(i)
 // then works on the live rows as it always did - queues the second walks and everything behind them: noise floor, burst decoder,
 // frame finish, the copy of the control block.
-static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ);
+static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ, OutSlot *succ2);
 
 static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	const int64_t D = sl.back_D, k0 = sl.back_k0;
@@ -494,9 +501,10 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	// of them) and checked, on the front stream like the rest of a short feed's back end, it is 1.34 -> 0.8 ms per block on average)
 	const bool opt = c->referee && c->ref_optimistic && D > 0;
 	const uint32_t rq_cap = small ? std::min<uint32_t>(c->rq_cap, 16u * kScanLanes) : c->rq_cap;      // (a short feed: few requests, small grids - it queues these kernels whether or not it notes anything)
-	// does this feed's walk go ahead of the previous feed's check?  (both long feeds with a check, segmented walks)
+	// does this feed's walk go ahead of the check of the feed(s) before?  (long feeds with a check, segmented walks)  If not, what is
+	// still waiting for a successor's walk is queued now, oldest first
 	const bool ahead = c->walk_ahead && opt && nseg >= 2 && !gate && sl.seq > 0 && pv.pending && pv.rest_pending && pv.has_chk && pv.nseg >= 2;
-	if(sl.seq > 0 && pv.pending && pv.rest_pending && !ahead) { int r = launch_rest(c, pv, nullptr); if(r != VDL2HIP_OK) return r; }
+	if(!ahead) { int r = flush_rest(c, nullptr); if(r != VDL2HIP_OK) return r; }
 	if(small) {
 		// the walker, the noise floor and the burst list carry state from feed to feed: wait for a predecessor whose back end is on the other streams
 		if(sl.seq > 0 && pv.pending && !pv.small && !pv.back_queued) HIPCHK(hipStreamWaitEvent(sb_, pv.done, 0));
@@ -506,6 +514,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	}
 	if(D <= 0) hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(1), 0, sb_, sl.d_ctl, 0u);     // (a feed with a front has had it reset by its last sync kernel)
 	hipStream_t sp_ = small ? c->stream : c->stream_pre[sl.seq % kSidePre];
+	const int rty = c->ref_retry_mul;
 	if(D > 0 && sl.prescan) {
 		// Referee: the stretches the exact sync tier has listed (around its marked candidates) are made the reference's own NOW, beside
 		// the next feed's front and off the walk stream - the walk of this feed waits for them, the walk of the next one does not
@@ -514,19 +523,19 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		// feed's whole walk chain)
 		if(!small) HIPCHK(hipStreamWaitEvent(sp_, sl.ev_front, 0));
 		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kPreScans / kScanLanes), dim3(64 * kScanWaves), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
-		                  (const ScanReq *)sl.d_pq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 3), kPreScans, (int64_t)(k0 + D), sl.d_retry, sl.d_rqn + 4, kRetryScans, 1);
-		// (... and those of them that had not met their witness - a few in ten thousand - again, from four times further back)
-		LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
-		                  (const ScanReq *)sl.d_retry, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 4), kRetryScans, (int64_t)(k0 + D), (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, 4);
+		                  (const ScanReq *)sl.d_pq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 3), kPreScans, (int64_t)(k0 + D), rty ? sl.d_retry : (ScanReq *) nullptr, sl.d_rqn + 4, kRetryScans, 1);
+		// (... and those of them that had not met their witness - a few in ten thousand - again, from further back)
+		if(rty) LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, sp_, c->d_ref[sl.seq % kSlots], (uint32_t)(16 * sl.seq + 8),
+		                  (const ScanReq *)sl.d_retry, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 4), kRetryScans, (int64_t)(k0 + D), (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, rty);
 		if(!small) { HIPCHK(hipEventRecord(sl.ev_pre, sp_)); HIPCHK(hipStreamWaitEvent(sb_, sl.ev_pre, 0)); }
 	}
 	if(D > 0) {
 		const int64_t k1 = k0 + D;
-		const int par = (int)(sl.seq & 1);        // feed i's snapshot and speculative walks are still needed when feed i + 1 is walked: two of each
+		const int par = (int)(sl.seq % 3);        // feed i's snapshot and speculative walks are still needed when feeds i + 1 and i + 2 are walked: three of each
 		sl.k4 = K4Args{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_wcnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(16 * sl.seq + 1),
 		           opt ? sl.d_rq : nullptr, sl.d_rqn, rq_cap, sl.d_rqflag, c->d_ws_snap[par], c->d_cnt_snap[par], sl.d_rqbad, sl.prescan ? 1 : 0, c->debug_force_again,
-		           c->d_ws_tmp, c->d_cnt_tmp, nullptr, nullptr, sl.d_rqflag2, nullptr, c->debug_force_mismatch };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
+		           c->d_ws_tmp, c->d_cnt_tmp, nullptr, nullptr, sl.d_rqflag2, nullptr, nullptr, c->debug_force_mismatch };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
 		const K4Args &k4 = sl.k4;
 		sl.d_spec_of = c->d_spec[par];
 		if(nseg >= 2) {
@@ -551,33 +560,55 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			hipStream_t sc_ = c->walk_ahead ? sp_ : sb_;
 			if(sc_ != sb_) { HIPCHK(hipEventRecord(sl.ev_stitch, sb_)); HIPCHK(hipStreamWaitEvent(sc_, sl.ev_stitch, 0)); }
 			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sc_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, rq_cap, k1,
-			                  sl.d_retry + kRetryScans, sl.d_rqn + 5, kRetryScans, 1);
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, sc_, k4.ref, k4.ref_launch - 1u, (const ScanReq *)(sl.d_retry + kRetryScans), (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 5), kRetryScans, k1,
-			                  (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, 4);
+			                  rty ? sl.d_retry + kRetryScans : (ScanReq *) nullptr, sl.d_rqn + 5, kRetryScans, 1);
+			if(rty) LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, sc_, k4.ref, k4.ref_launch - 1u, (const ScanReq *)(sl.d_retry + kRetryScans), (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 5), kRetryScans, k1,
+			                  (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, rty);
 			hipLaunchKernelGGL(k_ref_verify, dim3(small ? 64 : 1024), dim3(64), 0, sc_, k4);
 			HIPCHK(hipEventRecord(sl.ev_chk, sc_));
 		}
 	}
 	sl.rest_pending = true;
-	if(ahead) { int r = launch_rest(c, pv, &sl); if(r != VDL2HIP_OK) return r; }
+	// the feeds whose second walks have now waited for as many successors' walks as they may (walk_ahead: 1 or 2) ...
+	for(;;) {
+		OutSlot *old = nullptr;
+		for(auto &x : c->slot) if(x.pending && x.rest_pending && (!old || x.seq < old->seq)) old = &x;
+		if(!old || old == &sl || sl.seq - old->seq < (uint64_t)c->walk_ahead) break;
+		int r = flush_rest(c, old); if(r != VDL2HIP_OK) return r;
+	}
 	// does the NEXT feed's walk get the chance to go ahead of this feed's check?  Not if there is nothing to check, nor in the old schedule
-	if(!(c->walk_ahead && sl.has_chk && sl.nseg >= 2 && !gate && !c->defer_back)) return launch_rest(c, sl, nullptr);
+	if(!(c->walk_ahead && sl.has_chk && sl.nseg >= 2 && !gate && !c->defer_back)) return flush_rest(c, nullptr);
 	HIPCHK(hipGetLastError());
 	return VDL2HIP_OK;
 }
 
-static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ) {
+// The feeds whose walk and check are queued and the rest is not (rest_pending), oldest first, up to and including `upto` (nullptr: all
+// of them): each with the one or two feeds behind it whose walks are queued as its successors (their walks went ahead of its check).
+static int flush_rest(vdl2hip_ctx *c, const OutSlot *upto) {
+	for(;;) {
+		OutSlot *old = nullptr;
+		for(auto &x : c->slot) if(x.pending && x.rest_pending && (!old || x.seq < old->seq)) old = &x;
+		if(!old || (upto && old->seq > upto->seq)) return VDL2HIP_OK;
+		OutSlot *s1 = &c->slot[(old->seq + 1) % kSlots], *s2 = &c->slot[(old->seq + 2) % kSlots];
+		if(!(s1->pending && s1->rest_pending && s1->seq == old->seq + 1)) s1 = nullptr;
+		if(!(s1 && s2->pending && s2->rest_pending && s2->seq == old->seq + 2)) s2 = nullptr;
+		int r = launch_rest(c, *old, s1, s2); if(r != VDL2HIP_OK) return r;
+	}
+}
+
+static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ, OutSlot *succ2) {
 	const int64_t D = sl.back_D, k0 = sl.back_k0;
 	const bool small = sl.small;
 	hipStream_t sb_ = small ? c->stream : c->stream_back, sn_ = small ? c->stream : c->stream_nf, s5_ = small ? c->stream : c->stream_burst[sl.seq % kSideBurst];
+
 	hipEvent_t *ev = sl.ev;
 	const bool prof_all = sl.ev_valid && sl.ev_level >= 2;
 	sl.rest_pending = false;
+	const int rty = c->ref_retry_mul;
 	if(D > 0 && sl.has_chk) {
 		// the (rare) channel one of whose decisions did not stand is stitched again
 		HIPCHK(hipStreamWaitEvent(sb_, sl.ev_chk, 0));
 		K4Args k4 = sl.k4;
-		if(succ) { k4.ws_snap_next = succ->k4.ws_snap; k4.cnt_snap_next = succ->k4.cnt_snap; k4.rq_flag2_next = succ->d_rqflag2; }
+		if(succ) { k4.ws_snap_next = succ->k4.ws_snap; k4.cnt_snap_next = succ->k4.cnt_snap; k4.rq_flag2_next = succ->d_rqflag2; k4.rq_flag2_next2 = succ2 ? succ2->d_rqflag2 : nullptr; }
 		if(sl.nseg >= 2) {
 			K4sArgs k4a{ k4, sl.d_spec_of, (uint32_t)(3 * (c->seg_max - 1)), sl.nseg, k0, sl.seglen, c->d_segstats, succ ? 2 : 1 };
 			hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0, k4a);
@@ -590,8 +621,14 @@ static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ) {
 	}
 	if(succ) {
 		// ... and the next feed once more for the channels whose start state that has corrected (none, all but always: the kernel looks at the flags and ends)
-		K4sArgs k4r{ succ->k4, succ->d_spec_of, (uint32_t)(3 * (c->seg_max - 1)), succ->nseg, succ->back_k0, succ->seglen, c->d_segstats, 3 };
+		// (walk ahead by two: the feed after it has been walked as well - the next feed's end state then goes into THAT feed's snapshot, and it is stitched once more too)
+		K4sArgs k4r{ succ->k4, succ->d_spec_of, (uint32_t)(3 * (c->seg_max - 1)), succ->nseg, succ->back_k0, succ->seglen, c->d_segstats, succ2 ? 4 : 3 };
+		if(succ2) { k4r.k.ws_snap_next = succ2->k4.ws_snap; k4r.k.cnt_snap_next = succ2->k4.cnt_snap; }
 		hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0, k4r);
+		if(succ2) {
+			K4sArgs k4q{ succ2->k4, succ2->d_spec_of, (uint32_t)(3 * (c->seg_max - 1)), succ2->nseg, succ2->back_k0, succ2->seglen, c->d_segstats, 5 };
+			hipExtLaunchKernelGGL(k_walk_stitch, dim3((unsigned)((c->C + kStitchWaves - 1) / kStitchWaves)), dim3(64 * kStitchWaves), (unsigned)(sizeof(StitchLds) * kStitchWaves), sb_, (hipEvent_t) nullptr, (hipEvent_t) nullptr, 0, k4q);
+		}
 	}
 	if(D > 0) {
 		K4bArgs k4b{ c->d_y, c->d_nf, sl.d_log, sl.d_nlog, c->d_scfirst, c->d_sccum, c->d_nffeed, c->d_lpbuf, c->d_nfring, c->nf_ring - 1,
@@ -618,9 +655,9 @@ static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ) {
 		else if(!defer5) hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), EV(11), 0, k5);
 		else {
 			hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), (hipEvent_t) nullptr, 0, k5);
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kDeferScans / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), (uint32_t)kDeferScans, (int64_t)(k0 + D), sl.d_retry + 2 * kRetryScans, sl.d_rqn + 6, kRetryScans, 1);
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)(sl.d_retry + 2 * kRetryScans), (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 6), kRetryScans, (int64_t)(k0 + D),
-			                  (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, 4);
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kDeferScans / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), (uint32_t)kDeferScans, (int64_t)(k0 + D), rty ? sl.d_retry + 2 * kRetryScans : (ScanReq *) nullptr, sl.d_rqn + 6, kRetryScans, 1);
+			if(rty) LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)(sl.d_retry + 2 * kRetryScans), (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 6), kRetryScans, (int64_t)(k0 + D),
+			                  (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, rty);
 			K5Args k5b = k5; k5b.df.pass = 2; k5b.ref_launch = (uint32_t)(16 * sl.seq + 7);
 			hipExtLaunchKernelGGL(k_burst, dim3(kDeferBursts / kBurstWaves / 4), dim3(64 * kBurstWaves), k5_lds, s5_, (hipEvent_t) nullptr, EV(11), 0, k5b);
 		}
@@ -682,7 +719,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	OnDevice dev_guard(c);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	void *ptrs[] = { c->d_bf, c->d_lut, c->d_tab, c->d_dphi, c->d_freq, c->d_ppmthr, c->d_carry[0], c->d_carry[1], c->d_y, c->d_pf,
-	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec[0], c->d_spec[1], c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
+	                 c->d_cand, c->d_flag, c->d_segend, c->d_qpow, c->d_tcarry[0], c->d_tcarry[1], c->d_ws, c->d_cnt, c->d_nf, c->d_scfirst, c->d_sccum, c->d_nfring, c->d_lpbuf, c->d_nffeed, c->d_spec[0], c->d_spec[1], c->d_spec[2], c->d_segstats, c->d_acnt, c->d_segpub, c->d_synctmo };
 	for(auto &sl : c->slot) {
 		void *q[] = { sl.d_bursts, sl.d_nbchan, sl.d_frames, sl.d_pool, sl.d_frames_out, sl.d_pool_out, sl.d_mail, sl.d_log, sl.d_nlog, sl.d_rq, sl.d_rqn, sl.d_rqflag, sl.d_dq, sl.d_sq, sl.d_rqbad, sl.d_pq, sl.d_rqflag2, sl.d_retry };
 		for(void *p : q) if(p) (void)hipFree(p);
@@ -701,7 +738,7 @@ void vdl2hip_destroy(vdl2hip_ctx *c) {
 	if(c->h_stage) (void)hipHostFree(c->h_stage);
 	for(auto &p : c->d_in) if(p) (void)hipFree(p);
 	for(auto &p : c->d_ref) if(p) (void)hipFree(p);
-	{ void *q[] = { c->d_refhist, c->d_refdone, c->d_refdonen, c->d_refstats, c->d_mix, c->d_refdbg, c->d_ws_snap[0], c->d_ws_snap[1], c->d_cnt_snap[0], c->d_cnt_snap[1], c->d_ws_tmp, c->d_cnt_tmp }; for(void *p : q) if(p) (void)hipFree(p); }
+	{ void *q[] = { c->d_refhist, c->d_refdone, c->d_refdonen, c->d_refstats, c->d_mix, c->d_refdbg, c->d_ws_snap[0], c->d_ws_snap[1], c->d_ws_snap[2], c->d_cnt_snap[0], c->d_cnt_snap[1], c->d_cnt_snap[2], c->d_ws_tmp, c->d_cnt_tmp }; for(void *p : q) if(p) (void)hipFree(p); }
 	for(auto &e : c->ev_copied) if(e) (void)hipEventDestroy(e);
 	for(auto &e : c->cold.ev) if(e) (void)hipEventDestroy(e);
 	for(hipStream_t st_ : { c->stream_copy, c->stream_out, c->stream_sync, c->stream_back, c->stream_nf }) if(st_) (void)hipStreamSynchronize(st_);
@@ -896,9 +933,10 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 	// cost more than they save.  VDL2HIP_REF_PRESCAN=0/1 overrides the choice.
 	c->ref_prescan = count <= 64;
 	if(const char *e = getenv("VDL2HIP_REF_PRESCAN")) c->ref_prescan = atoi(e) != 0;
+	if(const char *e = getenv("VDL2HIP_REF_RETRY")) { const int v = atoi(e); if(v == 0 || (v >= 2 && v <= 8)) c->ref_retry_mul = v; }
 	if(const char *e = getenv("VDL2HIP_REF_WARM")) { const long long v = atoll(e); if(v >= 1024 && v <= (1ll << 24)) c->ref_warm = v; }
 	if(c->referee) {
-		c->ref_T = 4 * c->ref_warm + (int64_t)(kHistory + 256) * c->os + 4096;      // run-up (of a retry: four times the configured one) + the longest burst (its symbols are sliced when its last one has arrived)
+		c->ref_T = std::max(1, c->ref_retry_mul) * c->ref_warm + (int64_t)(kHistory + 256) * c->os + 4096;      // run-up (of a retry: ref_retry_mul times the configured one) + the longest burst (its symbols are sliced when its last one has arrived)
 		c->ref_cap = 1; while(c->ref_cap < (uint64_t)(kSlots + 2) * (uint64_t)c->ref_T) c->ref_cap <<= 1;
 		DEV_ALLOC(c->d_refhist, c->ref_cap * sb);
 		for(int k = 0; k < kSlots; k++) { DEV_ALLOC(c->d_ref[k], sizeof(RefChan)); DEV_CHK(hipMemset(c->d_ref[k], 0, sizeof(RefChan))); }
@@ -909,12 +947,12 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		DEV_CHK(hipMemcpy(c->d_mix, mix.data(), count, hipMemcpyHostToDevice));
 		if(const char *e = getenv("VDL2HIP_REF_MODE")) c->ref_optimistic = strcmp(e, "sync") != 0;        // optimistic (default) | sync
 		if(const char *e = getenv("VDL2HIP_REF_KINDS")) c->ref_kinds = atoi(e) & 7;                          // (development: 1 candidates, 2 headers, 4 symbols)
-		for(int k = 0; k < 2; k++) { DEV_ALLOC(c->d_ws_snap[k], count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt_snap[k], (size_t)count * kNumCounters * 8); }
+		for(int k = 0; k < 3; k++) { DEV_ALLOC(c->d_ws_snap[k], count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt_snap[k], (size_t)count * kNumCounters * 8); }
 		DEV_ALLOC(c->d_ws_tmp, count * sizeof(WalkState)); DEV_ALLOC(c->d_cnt_tmp, (size_t)count * kNumCounters * 8);
 		// Walk ahead (launch_back): for receivers whose front does not hide the chain walk - scans - check (a feed's results then come a
 		// feed later: with 256 channels, where the front hides the chain anyway, that extra depth cost 10 % and more)
-		c->walk_ahead = count >= 16 && count <= 64;   // (8 channels: the walk itself is longer than the front, the second walks' extra launches cost more than they save: 1.22 against 1.11 ms)
-		if(const char *e = getenv("VDL2HIP_WALK_AHEAD")) c->walk_ahead = atoi(e) != 0;      // 0: a feed's walk waits for the check of the feed before (round 5's schedule)
+		c->walk_ahead = (count >= 16 && count <= 64) ? 1 : 0;   // (8 channels: the walk itself is longer than the front, the second walks' extra launches cost more than they save: 1.22 against 1.11 ms)
+		if(const char *e = getenv("VDL2HIP_WALK_AHEAD")) { const int v = atoi(e); c->walk_ahead = v < 0 ? 0 : v > 2 ? 2 : v; }      // 0: a feed's walk waits for the check of the feed before (round 5's schedule)
 		for(auto &sl : c->slot) {
 			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 32); DEV_ALLOC(sl.d_retry, 3 * (size_t)kRetryScans * sizeof(ScanReq)); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
 			DEV_ALLOC(sl.d_dq, (size_t)kDeferBursts * 4); DEV_ALLOC(sl.d_sq, (size_t)kDeferScans * sizeof(ScanReq));
@@ -1258,7 +1296,7 @@ int vdl2hip_debug_option(vdl2hip_ctx *c, const char *name, long value) {
 	if(strcmp(name, "no_fuse") == 0) { c->fuse_k2 = value == 0; return VDL2HIP_OK; }
 	if(strcmp(name, "force_timeout") == 0) { c->debug_force_timeout = value != 0; return VDL2HIP_OK; }
 	if(strcmp(name, "force_mismatch") == 0) { c->debug_force_mismatch = value != 0; return VDL2HIP_OK; }   // every channel walked again with the next feed's walk already done is taken to have ended differently: the next feed is redone for it
-	if(strcmp(name, "walk_ahead") == 0) { c->walk_ahead = value != 0; return VDL2HIP_OK; }
+	if(strcmp(name, "walk_ahead") == 0) { c->walk_ahead = value < 0 ? 0 : value > 2 ? 2 : (int)value; return VDL2HIP_OK; }   // feeds whose walks may go ahead of a feed's check: 0, 1, 2
 	if(strcmp(name, "force_again") == 0) { c->debug_force_again = value != 0; return VDL2HIP_OK; }   // every channel of every long feed is stitched a second time (the referee's walk-again path)
 	if(strcmp(name, "referee") == 0) { if(value && !c->d_refhist) return VDL2HIP_E_INVAL; c->referee = value != 0; return VDL2HIP_OK; }   // (on only where it was on at create: the history ring)
 	if(strcmp(name, "ref_debug_chan") == 0) {
@@ -1294,31 +1332,42 @@ int vdl2hip_debug_exact_window_many(vdl2hip_ctx *c, uint32_t chan, int64_t n_lo,
 	return n;            // stretches done (of `count`)
 }
 // test hook (not declared in vdl2hip.h): the same through k_ref_scan_multi - `count` stretches (chan[i], lo[i], hi[i]) side by side;
-// returns the number of scans run, *ms = the kernel's time
-int vdl2hip_debug_scan_multi(vdl2hip_ctx *c, const int32_t *chan, const int64_t *lo, const int64_t *hi, uint32_t count, float *ms) {
+// returns the number of scans run, *ms = the kernels' time.  with_retry: as the product's launches do it - the scans that have not met
+// their witness are listed and run again from ref_retry_mul times further back (without: they are counted as unmet and published)
+int vdl2hip_debug_scan_multi2(vdl2hip_ctx *c, const int32_t *chan, const int64_t *lo, const int64_t *hi, uint32_t count, int with_retry, float *ms) {
 	if(!c || !c->d_refhist || c->feed_no == 0 || count == 0 || count > 65536 || !chan || !lo || !hi) return VDL2HIP_E_INVAL;
 	OnDevice dev_guard(c);
 	int r = collect_pending(c);
 	if(r != VDL2HIP_OK && r != VDL2HIP_E_OVERFLOW) return r;
 	std::vector<ScanReq> h(count);
 	for(uint32_t i = 0; i < count; i++) { if(chan[i] < 0 || chan[i] >= c->C) return VDL2HIP_E_INVAL; h[i] = ScanReq{ chan[i], REF_CANDIDATE, lo[i], hi[i] }; }
-	ScanReq *d_sq = nullptr; uint32_t *d_n = nullptr;
-	if(hipMalloc((void **)&d_sq, sizeof(ScanReq) * (size_t)count) != hipSuccess || hipMalloc((void **)&d_n, 4) != hipSuccess) { if(d_sq) (void)hipFree(d_sq); return VDL2HIP_E_NOMEM; }
+	const bool rty = with_retry && c->ref_retry_mul > 0;
+	ScanReq *d_sq = nullptr, *d_rt = nullptr; uint32_t *d_n = nullptr;
+	if(hipMalloc((void **)&d_sq, sizeof(ScanReq) * (size_t)count) != hipSuccess || hipMalloc((void **)&d_n, 8) != hipSuccess || hipMalloc((void **)&d_rt, sizeof(ScanReq) * (size_t)kRetryScans) != hipSuccess) {
+		if(d_sq) (void)hipFree(d_sq);
+		if(d_n) (void)hipFree(d_n);
+		return VDL2HIP_E_NOMEM;
+	}
 	uint32_t before[8] = {0}, after[8] = {0};
+	const uint32_t nn[2] = { count, 0u };
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess
-		&& hipMemcpy(d_sq, h.data(), sizeof(ScanReq) * (size_t)count, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_n, &count, 4, hipMemcpyHostToDevice) == hipSuccess
+		&& hipMemcpy(d_sq, h.data(), sizeof(ScanReq) * (size_t)count, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_n, nn, 8, hipMemcpyHostToDevice) == hipSuccess
 		&& hipMemcpy(before, c->d_refstats, sizeof before, hipMemcpyDeviceToHost) == hipSuccess;
-	if(ok) LAUNCH_SCAN_MULTI(hipExtLaunchKernelGGL, dim3((count + kScanLanes - 1) / kScanLanes), dim3(64 * kScanWaves), 0, c->stream, e0, e1, 0, c->d_ref[(c->feed_no - 1) % kSlots], 0xfffeu,
-	                             (const ScanReq *)d_sq, (const RefReq *) nullptr, (const uint32_t *)d_n, count, (int64_t)c->k_total, (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, 1);
+	RefChan *ref = c->d_ref[(c->feed_no - 1) % kSlots];
+	if(ok) LAUNCH_SCAN_MULTI(hipExtLaunchKernelGGL, dim3((count + kScanLanes - 1) / kScanLanes), dim3(64 * kScanWaves), 0, c->stream, e0, rty ? (hipEvent_t) nullptr : e1, 0, ref, 0xfffeu,
+	                             (const ScanReq *)d_sq, (const RefReq *) nullptr, (const uint32_t *)d_n, count, (int64_t)c->k_total, rty ? d_rt : (ScanReq *) nullptr, d_n + 1, kRetryScans, 1);
+	if(ok && rty) LAUNCH_SCAN_MULTI(hipExtLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, c->stream, (hipEvent_t) nullptr, e1, 0, ref, 0xfffeu,
+	                             (const ScanReq *)d_rt, (const RefReq *) nullptr, (const uint32_t *)(d_n + 1), kRetryScans, (int64_t)c->k_total, (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, c->ref_retry_mul);
 	ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipMemcpy(after, c->d_refstats, sizeof after, hipMemcpyDeviceToHost) == hipSuccess;
 	float t = 0.f;
 	if(ok && ms) { (void)hipEventElapsedTime(&t, e0, e1); *ms = t; }
 	if(e0) (void)hipEventDestroy(e0);
 	if(e1) (void)hipEventDestroy(e1);
-	(void)hipFree(d_sq); (void)hipFree(d_n);
+	(void)hipFree(d_sq); (void)hipFree(d_n); (void)hipFree(d_rt);
 	return ok ? (int)(after[0] - before[0]) : VDL2HIP_E_DEVICE;
 }
+int vdl2hip_debug_scan_multi(vdl2hip_ctx *c, const int32_t *chan, const int64_t *lo, const int64_t *hi, uint32_t count, float *ms) { return vdl2hip_debug_scan_multi2(c, chan, lo, hi, count, 0, ms); }
 int vdl2hip_debug_exact_window(vdl2hip_ctx *c, uint32_t chan, int64_t n_lo, int64_t n_hi) { return vdl2hip_debug_exact_window_many(c, chan, n_lo, n_hi, 1, 0, nullptr); }
 
 // test hook (not declared in vdl2hip.h): what the DPP controls the channeliser's scan relies on do on this device

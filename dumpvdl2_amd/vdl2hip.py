@@ -304,13 +304,14 @@ class Receiver:
         ms = C.c_float(0)
         return self._chk(f(self.h, chan, n_lo, n_hi, count, stride, C.byref(ms)), "vdl2hip_debug_exact_window_many"), ms.value
 
-    def scan_multi(self, chans, los, his):
-        """test hook: the stretches (chans[i], los[i] .. his[i]) made exact side by side (k_ref_scan_multi) -> (scans run, kernel ms)"""
-        f = self.L.vdl2hip_debug_scan_multi
-        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+    def scan_multi(self, chans, los, his, retry=False):
+        """test hook: the stretches (chans[i], los[i] .. his[i]) made exact side by side (k_ref_scan_multi) -> (scans run, kernel ms).
+        retry: as the product's launches - a scan that has not met its witness is listed and run again from further back"""
+        f = self.L.vdl2hip_debug_scan_multi2
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_float)]
         ch = np.ascontiguousarray(chans, dtype=np.int32); lo = np.ascontiguousarray(los, dtype=np.int64); hi = np.ascontiguousarray(his, dtype=np.int64)
         ms = C.c_float(0)
-        return self._chk(f(self.h, ch.ctypes.data, lo.ctypes.data, hi.ctypes.data, len(ch), C.byref(ms)), "vdl2hip_debug_scan_multi"), ms.value
+        return self._chk(f(self.h, ch.ctypes.data, lo.ctypes.data, hi.ctypes.data, len(ch), 1 if retry else 0, C.byref(ms)), "vdl2hip_debug_scan_multi2"), ms.value
 
     def read_sync(self, chan: int, first: int, count: int):
         """test hook: (pf [count, 2] = tabulated {pherr with the referee's mark as its sign, slope}, cand [count] candidate bits) of one channel"""

@@ -166,10 +166,12 @@ typedef struct {
 	                             * state; referee_rewalks counts the channels walked again after a check): how often such a second walk ended in
 	                             * a DIFFERENT state or counters, so that the next feed was walked once more for that channel as well */
 	uint64_t referee_unmet;     /* ABI 6.  Scans (of those run side by side: all of a long feed's) whose zero-start trajectory had NOT become
-	                             * bit-identical to a witness trajectory started elsewhere by the stretch's first output - the run-up (2^17 input
-	                             * samples) was too short for it to have forgotten its start: that stretch is within the reference's rounding
-	                             * noise of the reference's samples, not bit for bit them.  Counted here: those that could NOT be run again (below) */
-	uint64_t referee_retried;   /* ABI 6.  ... and those that were: listed and scanned again from four times further back (3-8 in 10 000 scans) */
+	                             * bit-identical to a witness trajectory started elsewhere by the stretch's first output - the run-up (196 608
+	                             * input samples; VDL2HIP_REF_WARM) was too short for it to have forgotten its start: that stretch is within the
+	                             * reference's rounding noise of the reference's samples, not bit for bit them.  Counted here: those that could
+	                             * NOT be run again (below).  A monitor, not a proof: a scan can meet its witness before it meets the reference's
+	                             * trajectory (measured share of stretches that are not the reference's bit for bit: DESIGN 5) */
+	uint64_t referee_retried;   /* ABI 6.  ... and those that were: listed and scanned again from twice as far back (VDL2HIP_REF_RETRY) */
 } vdl2hip_stats;
 
 int  vdl2hip_abi_version(void);

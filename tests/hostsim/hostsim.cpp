@@ -17,10 +17,11 @@
 namespace vdl2 {
 struct RefChan { const float *exact; int64_t n_exact; cf32 *y; uint32_t mask; int64_t calls, samples; std::vector<uint8_t> *done; };
 inline void ref_debug_log(const ChanView &, int tag, int64_t a, float b, float c, float d) { if(getenv("HOSTSIM_REF_LOG")) fprintf(stderr, "reflog %d %lld %.9g %.9g %.9g\n", tag, (long long)a, b, c, d); }
-inline bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void *, int) {
+inline bool ref_exact_window(const ChanView &v, int64_t n_lo, int64_t n_hi, void *, int kind) {
 	RefChan *r = v.ref;
 	if(!r || !r->exact) return false;
 	r->calls++;
+	if(getenv("HOSTSIM_REF_CALLS")) fprintf(stderr, "refcall y=%p kind %d lo %lld hi %lld\n", (void *)r->y, kind, (long long)n_lo, (long long)n_hi);
 	for(int64_t n = n_lo < 0 ? 0 : n_lo; n <= n_hi && n < r->n_exact; n++) { r->y[(uint32_t)n & r->mask] = cf32{ r->exact[2 * n], r->exact[2 * n + 1] }; r->samples++; if(r->done) (*r->done)[n] = 1; }
 	return true;
 }

@@ -360,7 +360,7 @@ def test_many_channel_configs_vs_oracle(vh, oracle_mod, which, secs):
     rx.close()
 
 
-@pytest.mark.parametrize("mode", ["ahead", "ahead_mismatch", "serial"])
+@pytest.mark.parametrize("mode", ["ahead2", "ahead2_mismatch", "ahead", "ahead_mismatch", "serial"])
 @pytest.mark.parametrize("which,secs,chunks", [("config3", 4.0, (2_000_000, 4_000_000)), ("config4", 3.0, (2_000_000, 4_000_000)),
                                                ("config3", 2.0, (700_000, 1_500_000))])
 def test_every_channel_walked_again_beside_the_previous_feeds_burst_decoder(vh, oracle_mod, which, secs, chunks, mode):
@@ -376,7 +376,9 @@ def test_every_channel_walked_again_beside_the_previous_feeds_burst_decoder(vh, 
     product - every second walk runs after the next feed's first walk and must find that it ended where that walk started;
     `ahead_mismatch`: the hook `force_mismatch` makes every such comparison fail, so every channel of every following feed is stitched
     once more from the "corrected" snapshot - the path a real misprediction takes; `serial`: round 5's schedule (walk, check, walk
-    again, then the next feed's walk)."""
+    again, then the next feed's walk).  `ahead2`, `ahead2_mismatch`: the walks of the next TWO feeds go ahead of a feed's check (the
+    choice for receivers of 16-64 channels: a check is a scan of 2.3 ms, a walk a fraction of that); a second walk that ends elsewhere
+    has both of them stitched once more, the first into the snapshot the second starts from."""
     import os
     from dumpvdl2_amd import workloads, synth
     cfg = getattr(workloads, which)(secs)
@@ -384,13 +386,13 @@ def test_every_channel_walked_again_beside_the_previous_feeds_burst_decoder(vh, 
     o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=20, max_ppm=cfg.rx_max_ppm)
     o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=min(len(cfg.freqs), os.cpu_count() or 8))
     fo = o.frames()
-    dbg = {"force_again": 1, "walk_ahead": 0 if mode == "serial" else 1, "force_mismatch": 1 if mode == "ahead_mismatch" else 0}
+    dbg = {"force_again": 1, "walk_ahead": 0 if mode == "serial" else 2 if mode.startswith("ahead2") else 1, "force_mismatch": 1 if mode.endswith("_mismatch") else 0}
     rx, fg, cnt = gpu_decode(vh, cfg, iq, chunks=chunks, max_block=16_000_000, debug=dbg)
     s = rx.stats()
     assert s["feeds"] >= 2 and s["referee_rewalks"] >= (s["feeds"] - 1) * len(cfg.freqs), s      # every channel, every long feed
-    if mode == "ahead_mismatch":
-        assert s["referee_redone_next"] >= (s["feeds"] - 2) * len(cfg.freqs), s
-    elif mode == "ahead":
+    if mode.endswith("_mismatch"):
+        assert s["referee_redone_next"] >= (s["feeds"] - 3) * len(cfg.freqs), s
+    elif mode.startswith("ahead"):
         # (a second walk ends where the first did unless a decision really fell, or the burst in progress at the feed's end carries a
         # slope that the second walk knows to be the reference's own and the first did not: a few channels, not all of them)
         assert s["referee_redone_next"] <= s["referee_rewalks"] // 8, s

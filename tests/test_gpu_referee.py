@@ -137,7 +137,7 @@ def test_witness_tells_a_run_up_that_was_too_short(vh, oracle_mod):
 
 
 def test_unmet_scans_are_run_again_from_further_back(vh, oracle_mod):
-    """In the product's launches a scan that has not met its witness is listed and run again from four times further back.  With a
+    """In the product's launches a scan that has not met its witness is listed and run again from further back (twice as far: VDL2HIP_REF_RETRY).  With a
     run-up of 4 096 samples (most scans unmet the first time) a config2 capture in long pieces must still come out as the golden
     answers say, `referee_retried` counts the second tries, and with the product's run-up nothing is retried on this capture."""
     cfg, iq, bursts, gold = cases.load("config2_1s")
