@@ -1080,6 +1080,8 @@ constexpr int kK3bWordsPerLane = 4;      // at most; fewer when that leaves the 
 // work is ONE lane's: sixteen phases out of LDS, the reference's metric on them in its own operation order (sync_metric), the
 // referee's error figure beside it.  Same atan2, same metric, bit-identical values as the four-lanes-per-sample form it replaces
 // (which read every tap from memory - five loads per tap with the referee - and kept three lanes in four idle during the metric).
+// FULL: sync_metric_ref()'s `full` (receivers that scan ahead of the walk; a template so that the other form is the old code exactly)
+template<bool FULL>
 __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
 	if(blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { reset_out_ctl(a.ctl, a.k5_waves); if(a.ref) *a.ref = a.refv; if(a.rq_n) { a.rq_n[0] = 0u; a.rq_n[1] = 0u; a.rq_n[2] = 0u; a.rq_n[4] = 0u; a.rq_n[5] = 0u; a.rq_n[6] = 0u; } }   // (rq_n[1], [2]: the burst decoder's lists, BurstDefer)
 	if(blockIdx.x == 0 && threadIdx.x == 0 && a.rq_flag) { a.rq_flag[blockIdx.y] = 0u; a.rq_bad[blockIdx.y].n = 0u; if(a.rq_flag2) a.rq_flag2[blockIdx.y] = 0u; }
@@ -1179,7 +1181,7 @@ __global__ __launch_bounds__(256, 4) void k_sync_exact4(K3Args a) {
 				#pragma unroll
 				for(int i = 0; i < kPreamble; i++) p[i] = ph[i0 + 10 * i];
 				float pv, fv, E = 0.f, pa, pb;
-				if(ref_on) sync_metric_ref(p, e2 + i0, 10, T, pv, fv, E, pa, pb);
+				if(ref_on) sync_metric_ref(p, e2 + i0, 10, T, pv, fv, E, pa, pb, FULL);
 				else { sync_metric(p, T, pv, fv); pa = pb = pv; }
 				ps[6 + bit] = pv; fs[6 + bit] = fv; es[6 + bit] = E; as[6 + bit] = pa; bs[6 + bit] = pb;
 			}

@@ -714,12 +714,66 @@ VDL2_HD float sync_metric_flipped(const float *ph, const Tables &T, int flip, in
 }
 
 VDL2_HD void sync_metric_two(const float *ph, const Tables &T, const int *ev, const int *kind, float pherr, float &lo, float &hi);
+// The values the metric takes when ONE or TWO unwrap decisions (taps ev[0], ev[1]; n of them) go the other way, without running the
+// metric again: a decision taken the other way moves the unwrapped phases from its tap on by +-2 pi, a step H_i; mean and slope
+// removal are a projection R, so the residual moves by +-2 pi R H_i and
+//   p' = p + 2 (2 pi) sum s_i (r . H_i) + (2 pi)^2 sum s_i s_j (H_i . R H_j),   r . H_i = the sum of the residuals from tap i on,
+//   H_i . R H_j = 16 - max(i, j) - (16 - i)(16 - j) / 16 - L_i L_j / lr_den,   L_i = sum of lrx from tap i on = i (16 - i) / 2.
+// Equal to sync_metric_flipped()'s value up to rounding (a few 1e-5 on values of tens to hundreds: the caller's range is widened by
+// what that could be); a tenth of its work - these windows are most of what the exact sync tier's margins cost: inside a burst the phase
+// steps between taps are multiples of pi / 4 and one in eight is +-pi to within the noise.  lo / hi: the smallest / largest value.
+VDL2_HD void sync_metric_unwrap_alts(const float *ph, const Tables &T, const int *ev, int n, float pherr, float &lo, float &hi) {
+	float e[kPreamble];
+	float mean = 0.f, unwrap = 0.f;
+	float sgn[2] = {0.f, 0.f};
+	float prev = mean = e[0] = ph[0] - T.pr_phase[0];
+	for(int i = 1; i < kPreamble; i++) {
+		const float cur = ph[i] - T.pr_phase[i], diff = cur - prev;
+		prev = cur;
+		const double step = diff > kPiBelow ? -(2.0f * M_PI) : (diff < -kPiBelow ? (2.0f * M_PI) : 0.0);
+		// the other way: a step that was taken is not (+-1 turn back), one that was not is taken in the direction of the difference
+		for(int k = 0; k < n; k++) if(ev[k] == i) sgn[k] = step != 0.0 ? (step < 0.0 ? 1.f : -1.f) : (diff > 0.f ? -1.f : 1.f);
+		unwrap = (float)((double)unwrap + step);
+		e[i] = cur + unwrap;
+		mean += e[i];
+	}
+	mean /= kPreamble;
+	float slope = 0.f;
+	for(int i = 0; i < kPreamble; i++) { e[i] -= mean; slope += T.lrx[i] * e[i]; }
+	slope /= T.lr_den;
+	float rho[2] = {0.f, 0.f};
+	for(int i = kPreamble - 1; i >= 1; i--) {
+		const float r = e[i] - slope * T.lrx[i];
+		for(int k = 0; k < n; k++) if(i >= ev[k]) rho[k] += r;
+	}
+	const float tp = (float)(2.0 * M_PI);
+	auto G = [&](int i, int j) { const float Li = 0.5f * (float)(i * (kPreamble - i)), Lj = 0.5f * (float)(j * (kPreamble - j));
+	                             return (float)(kPreamble - (i > j ? i : j)) - (float)((kPreamble - i) * (kPreamble - j)) / (float)kPreamble - Li * Lj / T.lr_den; };
+	lo = hi = pherr;
+	for(int c = 1; c < (1 << n); c++) {
+		float v = pherr;
+		for(int k = 0; k < n; k++) if((c >> k) & 1) {
+			v += 2.0f * tp * sgn[k] * rho[k] + tp * tp * G(ev[k], ev[k]);
+			for(int m = 0; m < k; m++) if((c >> m) & 1) v += 2.0f * tp * tp * sgn[k] * sgn[m] * G(ev[k], ev[m]);
+		}
+		const float slack = 1e-3f + 2e-5f * fabsf(v);
+		lo = v - slack < lo ? v - slack : lo; hi = v + slack > hi ? v + slack : hi;
+	}
+	if(lo < 0.f) lo = 0.f;
+}
 // sync_metric() plus what the referee needs: E (see ref_pherr_margin) and palt - the value the reference gets when the ONE
 // discontinuity within the stream's error goes the other way on its samples: an unwrap decision (a phase difference within the
 // margin of +-pi), or a tap whose phase is within the margin of atan2()'s branch cut (it then reads +pi for -pi: with the
 // reference's single unwrap step per tap the metric is not continuous there).  palt = pherr when there is none; with several, or
 // a tap that is exactly zero, E = kRefBig: "cannot tell".  eps2[i]: ref_eps2() of tap i
-VDL2_HD void sync_metric_ref(const float *ph, const float *eps2, int estride, const Tables &T, float &pherr, float &slope_out, float &E_out, float &alo, float &ahi) {      // eps2[i * estride]; [alo, ahi]: the alternatives' values
+// `full`: one or two unwrap decisions within the margin are worked out (sync_metric_unwrap_alts) - the commonest kind by far: 93 % of
+// config4's marked candidates were windows with two of them, inside bursts, whose metric is 20-200 whichever way the two go and which
+// round 5 gave up on ("cannot tell": two unwrap decisions could not both be taken the other way).  On for receivers that scan the
+// stretches around EVERY marked candidate ahead of the walk (<= 64 channels: a tenth of the scans, their step 10-40 % shorter); off -
+// the old verdicts, `template` in the exact sync tier so that its code is the old code - for the others, whose walk visits few of
+// those windows (159 -> 121 scans per config4 block) and whose front paid 4-5 % for the extra arithmetic and registers
+// (profiles/r06_fewer_marks_ab.txt).
+VDL2_HD void sync_metric_ref(const float *ph, const float *eps2, int estride, const Tables &T, float &pherr, float &slope_out, float &E_out, float &alo, float &ahi, bool full = true) {      // eps2[i * estride]; [alo, ahi]: the alternatives' values
 	sync_metric(ph, T, pherr, slope_out);
 	float s = 0.f; bool big = false; int nev = 0, flip = -1, cut = -1; int ev[2] = {0, 0}, kind[2] = {0, 0};
 	float eprev = sqrtf(eps2[0]), cprev = ph[0] - T.pr_phase[0];
@@ -735,7 +789,8 @@ VDL2_HD void sync_metric_ref(const float *ph, const float *eps2, int estride, co
 	}
 	alo = ahi = pherr;
 	if(s == 0.f && !big) { E_out = 0.f; return; }                 // (every tap is the reference's own)
-	if(nev == 1 && !big) alo = ahi = sync_metric_flipped(ph, T, flip, cut);
+	if(full && nev >= 1 && nev <= 2 && !big && !kind[0] && (nev == 1 || !kind[1])) sync_metric_unwrap_alts(ph, T, ev, nev, pherr, alo, ahi);
+	else if(nev == 1 && !big) alo = ahi = sync_metric_flipped(ph, T, flip, cut);
 	else if(nev == 2 && !big) { sync_metric_two(ph, T, ev, kind, pherr, alo, ahi); if(ahi >= kRefBig) big = true; }
 	E_out = (big || nev > 2) ? kRefBig : sqrtf(s);
 }
@@ -748,7 +803,8 @@ VDL2_HD void sync_metric_two(const float *ph, const Tables &T, const int *ev, co
 		for(int i = 0; i < kPreamble; i++) q[i] = ph[i];
 		int flip = -1;
 		for(int k = 0; k < 2; k++) if((c >> k) & 1) { if(kind[k]) q[ev[k]] = -q[ev[k]]; else flip = ev[k]; }
-		// (two unwrap decisions cannot both go through sync_metric_flipped(): the second is applied by hand on top of the first)
+		// (two unwrap decisions cannot both go through sync_metric_flipped(): "cannot tell" here - sync_metric_ref's `full` form works
+		// them out another way, sync_metric_unwrap_alts)
 		float v;
 		if((c == 3) && !kind[0] && !kind[1]) { lo = 0.f; hi = kRefBig; return; }
 		v = sync_metric_flipped(q, T, flip, -1);
@@ -1048,7 +1104,7 @@ VDL2_HD __attribute__((always_inline)) void walk_run(int chan, uint32_t freq, fl
 									float pv, fv, E = 0.f, alo, ahi;
 									RefRange r;
 									if(exact_ring) { sync_metric(ph, T, pv, fv); r = RefRange{ pv, pv }; }
-									else { sync_metric_ref(ph, e2, 1, T, pv, fv, E, alo, ahi); r = ref_pherr_range(pv, alo, ahi, E); }
+									else { sync_metric_ref(ph, e2, 1, T, pv, fv, E, alo, ahi, v.ref_pre); r = ref_pherr_range(pv, alo, ahi, E); }
 									sr.sp[i] = pv; sr.sf[i] = fv; sr.sE[i] = E; sr.slo[i] = r.lo; sr.shi[i] = r.hi;
 								} else { sr.sp[i] = kPherrBig; sr.sf[i] = 0.f; sr.sE[i] = 0.f; sr.slo[i] = kPherrBig; sr.shi[i] = kPherrBig; }
 							}

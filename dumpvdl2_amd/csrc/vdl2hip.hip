@@ -433,7 +433,9 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		for(int wpl = kK3bWordsPerLane; wpl >= 1; wpl >>= 1) { k3.wpl = wpl; if(((nwords + 256 * wpl - 1) / (256 * wpl)) * c->C >= 2048 || wpl == 1) break; }
 		if(c->k3b_wpl) k3.wpl = c->k3b_wpl;                                   // experiments only (VDL2HIP_K3B_WPL)
 		const int64_t wpb = 256 * k3.wpl;                                      // words per block
-		LAUNCH_EV(k_sync_exact4, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
+		// (receivers that scan ahead of the walk work out the windows with one or two unwrap decisions within the margin: sync_metric_ref)
+		if(c->referee && c->ref_prescan) LAUNCH_EV(k_sync_exact4<true>, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
+		else LAUNCH_EV(k_sync_exact4<false>, dim3((unsigned)((nwords + wpb - 1) / wpb), (unsigned)c->C), dim3(256), sx, (hipEvent_t) nullptr, sl.ev_front, k3);
 	}
 	if(D <= 0) HIPCHK(hipEventRecord(sl.ev_front, st));
 	if(D > 0) { sl.ev_valid = prof; sl.ev_level = c->profiling; sl.fused = a.fuse != 0; if(sl.k1_timed) c->stats.chan_samples += (uint64_t)D * c->os * c->C; } else sl.k1_timed = false;

@@ -37,10 +37,10 @@ inline bool ref_window_done(const ChanView &v, int64_t n_lo, int64_t n_hi) {
 using namespace vdl2;
 
 // metric_contiguous() plus the referee's error figure E (vdl2_core.h: sync_metric_ref)
-static void metric_contiguous_ref(const ChanView &v, int64_t n, const Tables &T, float &p, float &f, float &E, float &alo, float &ahi) {
+static void metric_contiguous_ref(const ChanView &v, int64_t n, const Tables &T, float &p, float &f, float &E, float &alo, float &ahi, bool full) {
 	float ph[kPreamble], e2[kPreamble];
 	for(int i = 0; i < kPreamble; i++) { const int64_t t = n - 150 + 10 * i; ph[i] = v.Phi(t); e2[i] = ref_eps2(v, t); }
-	sync_metric_ref(ph, e2, 1, T, p, f, E, alo, ahi);
+	sync_metric_ref(ph, e2, 1, T, p, f, E, alo, ahi, full);
 }
 
 struct Sim {
@@ -66,6 +66,52 @@ struct Sim {
 };
 
 extern "C" {
+
+// sync_metric_unwrap_alts() (vdl2_core.h: the values of the sync metric with one or two unwrap decisions taken the other way, from the
+// residuals of the metric as it is) against the metric run again with those decisions forced: `trials` random windows; returns the
+// number of windows whose brute-force range is NOT inside the short cut's, *worst = the largest excess of the short cut's range over
+// the brute-force one in units of its own slack (1e-3 + 2e-5 |v|)
+int hostsim_check_unwrap_alts(int trials, unsigned seed, double *worst) {
+	static Tables T; build_tables(T);
+	srand(seed);
+	auto forced = [&](const float *ph, int f1, int f2) {
+		float e[kPreamble]; float mean = 0.f, unwrap = 0.f;
+		float prev = mean = e[0] = ph[0] - T.pr_phase[0];
+		for(int i = 1; i < kPreamble; i++) {
+			const float cur = ph[i] - T.pr_phase[i], diff = cur - prev; prev = cur;
+			double step = diff > kPiBelow ? -(2.0f * M_PI) : (diff < -kPiBelow ? (2.0f * M_PI) : 0.0);
+			if(i == f1 || i == f2) step = step != 0.0 ? 0.0 : (diff > 0.f ? -(2.0f * M_PI) : (2.0f * M_PI));
+			unwrap = (float)((double)unwrap + step); e[i] = cur + unwrap; mean += e[i];
+		}
+		mean /= kPreamble;
+		for(int i = 0; i < kPreamble; i++) e[i] -= mean;
+		float slope = 0.f;
+		for(int i = 0; i < kPreamble; i++) slope += T.lrx[i] * e[i];
+		slope /= T.lr_den;
+		float acc = 0.f;
+		for(int i = 0; i < kPreamble; i++) { const float r = e[i] - slope * T.lrx[i]; acc += r * r; }
+		return acc;
+	};
+	int bad = 0; double w = 0.0;
+	for(int t = 0; t < trials; t++) {
+		float ph[kPreamble];
+		for(int i = 0; i < kPreamble; i++) ph[i] = (float)((rand() / (double)RAND_MAX * 2 - 1) * M_PI);
+		int ev[2] = { 1 + rand() % (kPreamble - 1), 1 + rand() % (kPreamble - 1) }; const int nev = 1 + rand() % 2;
+		if(nev == 2 && ev[0] == ev[1]) continue;
+		if(nev == 2 && ev[0] > ev[1]) std::swap(ev[0], ev[1]);
+		float p, f; sync_metric(ph, T, p, f);
+		float lo, hi; sync_metric_unwrap_alts(ph, T, ev, nev, p, lo, hi);
+		float blo = p, bhi = p;
+		for(int c = 1; c < (1 << nev); c++) {
+			const float v = forced(ph, (c & 1) ? ev[0] : -1, (c & 2) ? ev[1] : -1);
+			blo = std::min(blo, v); bhi = std::max(bhi, v);
+		}
+		if((lo > blo && !(lo == 0.f)) || hi < bhi) bad++;
+		w = std::max(w, std::max((double)blo - lo, (double)hi - bhi) / (1e-3 + 2e-5 * std::max(fabs(bhi), fabs(blo))));
+	}
+	if(worst) *worst = w;
+	return bad;
+}
 
 Sim *hostsim_create(int nchan, const uint32_t *freqs, float max_ppm, int cap_log2) {
 	Sim *s = new Sim();
@@ -122,7 +168,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 		if(!s->two_tier) {
 			for(int64_t n = k0 & ~63ll; n < ((k1 + 63) & ~63ll); n++) {
 				cf32 r = (n < k1) ? metric_contiguous(cv, n, s->T) : cf32{kPherrBig, 0.f};
-				if(ref_on && n < k1) { float p_, f_, E_, a_, b_; metric_contiguous_ref(cv, n, s->T, p_, f_, E_, a_, b_); pe[(uint32_t)n & s->mask] = E_; pa[(uint32_t)n & s->mask] = a_; pb[(uint32_t)n & s->mask] = b_; }
+				if(ref_on && n < k1) { float p_, f_, E_, a_, b_; metric_contiguous_ref(cv, n, s->T, p_, f_, E_, a_, b_, s->prescan); pe[(uint32_t)n & s->mask] = E_; pa[(uint32_t)n & s->mask] = a_; pb[(uint32_t)n & s->mask] = b_; }
 				pf[(uint32_t)n & s->mask] = r;
 			}
 		} else {
@@ -151,7 +197,7 @@ int hostsim_feed(Sim *s, const float *yin, int64_t D) {
 					// the kernel stores a metric value only where it computed the exact one; everywhere else the ring keeps whatever
 					// an earlier lap left there, which the walker must never look at: the simulation puts poison there
 					r = need ? metric_contiguous(cv, n, s->T) : cf32{12345.f, 54321.f};
-					if(ref_on && need) { float p_, f_, E_, a_, b_; metric_contiguous_ref(cv, n, s->T, p_, f_, E_, a_, b_); pe[(uint32_t)n & s->mask] = E_; pa[(uint32_t)n & s->mask] = a_; pb[(uint32_t)n & s->mask] = b_; }
+					if(ref_on && need) { float p_, f_, E_, a_, b_; metric_contiguous_ref(cv, n, s->T, p_, f_, E_, a_, b_, s->prescan); pe[(uint32_t)n & s->mask] = E_; pa[(uint32_t)n & s->mask] = a_; pb[(uint32_t)n & s->mask] = b_; }
 					s->n_exact += need; s->n_total++;
 				}
 				pf[(uint32_t)n & s->mask] = r;

@@ -160,3 +160,16 @@ def test_lane_order_does_not_matter(oracle_mod, name, chunks, segments):
     fo, fh, co, ch = run_both(oracle_mod, cfg, iq, chunks, cap_log2=17 if chunks else None, segments=segments, two_tier=True, reverse_lanes=True)
     assert_frames_equal(fo, fh, label=name)
     assert co == ch
+
+
+def test_unwrap_alternatives_short_cut_contains_the_brute_force_range():
+    """sync_metric_unwrap_alts() (the exact sync tier's `full` form, receivers that scan ahead of the walk): the values the sync metric takes
+    with one or two unwrap decisions the other way, worked out from the residuals instead of running the metric again - its range must
+    contain what the metric gives with those decisions forced, and exceed it by no more than its own slack."""
+    import ctypes as C
+    import pyhostsim
+    L = C.CDLL(pyhostsim.build())
+    L.hostsim_check_unwrap_alts.argtypes = [C.c_int, C.c_uint, C.POINTER(C.c_double)]
+    worst = C.c_double(0)
+    assert L.hostsim_check_unwrap_alts(200000, 7, C.byref(worst)) == 0
+    assert worst.value < 1.5, worst.value
