@@ -95,7 +95,15 @@ def main():
     ap.add_argument("--sweep", default="", help='e.g. "VDL2HIP_CR=1,2,4;VDL2HIP_K1_TILES=2,4,8": every combination (the library reads its knobs at create)')
     a = ap.parse_args()
     cfg = getattr(workloads, a.workload)(a.duration)
-    iq, bursts = synth.synthesize(cfg)
+    import pickle
+    cache = f"/tmp/vdl2_shard32_{a.workload}_{a.duration:g}.pkl"      # (several processes in one call: the capture is synthesised once)
+    if os.path.exists(cache):
+        with open(cache, "rb") as f:
+            iq, bursts = pickle.load(f)
+    else:
+        iq, bursts = synth.synthesize(cfg)
+        with open(cache, "wb") as f:
+            pickle.dump((iq, bursts), f, protocol=4)
     dev = torch.from_numpy(iq).cuda()
     res = {"workload": a.workload, "duration_s": a.duration, "channels_in_the_air": len(cfg.freqs), "steps": a.steps, "repeats": a.repeats,
            "env": {k: v for k, v in os.environ.items() if k.startswith("VDL2HIP_")}, "ranks": []}

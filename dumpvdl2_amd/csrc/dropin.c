@@ -15,6 +15,23 @@
  * every frame of a block has been pushed before process_buf_*() of the next block gets past
  * demods_ready, and main()'s final demods_ready wait returns only when the last block's frames
  * are out - before avlc_decoder_shutdown(), as in the reference.
+ *
+ * Blocks per feed.  The reference's file reader hands over FILE_BUFSIZE = 320 000 bytes at a time
+ * (src/dumpvdl2.h:48, src/dumpvdl2.c:353-356): 4 000 decimated samples per channel, microseconds of
+ * GPU work behind a fixed chain of kernel launches - and, one block in three at 256 channels, a 2 ms
+ * sequential scan of the referee's.  A producer that comes back for the next block at
+ * once (a file, a fast pipe) therefore has its blocks COLLECTED: process_buf_*() copies the block
+ * into a staging buffer and returns; every `batch` blocks (as many as make a feed long enough to be
+ * walked in segments and pipelined: 16 of the reference's s16 blocks at oversample 20, 5 of its u8
+ * blocks at 10; VDL2HIP_DROPIN_BATCH=<n> sets it, 1 = every block on its own as before) the buffer
+ * goes to the GPU as one feed and the frames of the feed before it are pushed (drain lag 1).  The
+ * results are the same frames in the same order (any chunking gives the same answer:
+ * tests/test_gpu_parity.py), pushed up to two batches late.  The end of the stream - a block
+ * shorter than the one before, or an empty one: what ends process_iq_file()'s loop - flushes
+ * everything before process_buf_*()'s partner thread returns to demods_ready, so main()'s final
+ * wait still means "every frame is out".  A producer that stays away for more than LIVE_GAP_US
+ * between two calls (an SDR delivering in real time) gets every block fed and delivered on the
+ * spot, as before: collecting would only add latency there.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -34,8 +51,11 @@
 extern pthread_barrier_t demods_ready, samples_ready;   /* src/dumpvdl2.c:66-67 */
 
 #define MAX_CHANNELS 1024
-#define BLOCK_MAX (4u << 20)
+#define BLOCK_MAX (8u << 20)
 #define ARRIVALS 256
+#define BATCH_MAX 64u
+#define BATCH_DECIMATED 64000u     /* decimated samples per feed the collector aims for (two walk segments are 32 768: vdl2hip.hip, feed_is_small) */
+#define LIVE_GAP_US 2000L          /* a producer away for longer than this between two blocks is a live source */
 
 float *sbuf;                       /* callers allocate it (src/dumpvdl2.c:342,346; src/rtl.c:194); never read here */
 
@@ -51,6 +71,15 @@ static struct {
 	/* when each of the last blocks arrived and which decimated samples (105 kS/s clock) it begins with: burst_timestamp */
 	struct { int64_t k_first; struct timeval tv; } arrival[ARRIVALS];
 	uint64_t nblocks;
+	/* the collector (see the head of this file) */
+	unsigned char *stage;          /* blocks waiting to go to the GPU as one feed */
+	uint32_t stage_cap, stage_len, stage_blocks;
+	uint32_t batch;                /* blocks per feed; 1: every block on its own */
+	uint32_t prev_len;             /* length of the block before (a shorter one ends the stream) */
+	struct timeval left;           /* when process_buf_*() last returned to the producer */
+	int fed;                       /* between the barriers of this block: something went to the GPU (or the stream ended) - there is something to deliver */
+	int flush;                     /* ... and every frame still on the GPU is wanted now (stream end, live source) */
+	int lag;                       /* the group's current drain lag */
 #ifndef VDL2HIP_IN_TREE
 	float max_ppm;
 	char *station_id;
@@ -156,7 +185,35 @@ static uint32_t parse_devices(int32_t *dev, uint32_t cap) {
 	return n;
 }
 
-static void feed_block(unsigned char *buf, uint32_t len, int fmt) {
+static void gpu_feed(const unsigned char *p, uint32_t len) {
+	for(uint32_t off = 0; off < len; off += BLOCK_MAX) {
+		uint32_t n = len - off < BLOCK_MAX ? len - off : BLOCK_MAX;
+		int r = vdl2hip_group_feed(G.grp, p + off, n);       /* returns when the copy out of p is complete: buf is only ours during the call */
+		if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_group_feed: %s\n", vdl2hip_strerror(r)); _exit(2); }
+	}
+}
+
+/* blocks per feed: VDL2HIP_DROPIN_BATCH, or as many of this size as hold BATCH_DECIMATED decimated samples */
+static uint32_t pick_batch(uint32_t len, int fmt) {
+	const char *e = getenv("VDL2HIP_DROPIN_BATCH");
+	uint32_t b;
+	if(e && atoi(e) >= 1) b = (uint32_t)atoi(e);
+	else {
+		uint32_t dec = len / (fmt == VDL2HIP_FMT_S16LE ? 4u : 2u) / (G.oversample ? G.oversample : 1u);
+		b = dec ? (BATCH_DECIMATED + dec - 1) / dec : 1;
+	}
+	if(b > BATCH_MAX) b = BATCH_MAX;
+	if(len && b > BLOCK_MAX / len) b = BLOCK_MAX / len;
+	return b ? b : 1;
+}
+
+static void stage_to_gpu(void) {
+	if(G.stage_len) gpu_feed(G.stage, G.stage_len);
+	G.stage_len = 0; G.stage_blocks = 0;
+}
+
+/* one block from the producer (between the two barriers, on the producer's thread) */
+static void take_block(unsigned char *buf, uint32_t len, int fmt, struct timeval now) {
 	if(!G.grp) {
 		vdl2hip_cfg cfg;
 		memset(&cfg, 0, sizeof cfg);
@@ -174,22 +231,46 @@ static void feed_block(unsigned char *buf, uint32_t len, int fmt) {
 		int r = vdl2hip_group_create(&cfg, dev, ndev, &G.grp);
 		if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_group_create: %s\n", vdl2hip_strerror(r)); _exit(2); }
 		G.fmt = fmt;
+		G.batch = pick_batch(len, fmt);
+		if(G.batch > 1) { G.stage_cap = G.batch * len; G.stage = must_calloc(G.stage_cap, 1); }
 	}
-	uint64_t slot = G.nblocks % ARRIVALS;
-	G.arrival[slot].k_first = (int64_t)(G.samples_total / G.oversample);
-	gettimeofday(&G.arrival[slot].tv, NULL);
-	G.nblocks++;
-	G.samples_total += len / (fmt == VDL2HIP_FMT_S16LE ? 4u : 2u);
-	for(uint32_t off = 0; off < len; off += BLOCK_MAX) {
-		uint32_t n = len - off < BLOCK_MAX ? len - off : BLOCK_MAX;
-		int r = vdl2hip_group_feed(G.grp, buf + off, n);     /* returns when the copy out of buf is complete: buf is only ours during the call */
-		if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_group_feed: %s\n", vdl2hip_strerror(r)); _exit(2); }
+	/* what the producer did since it last left: a file reader is back within microseconds, an SDR in real time */
+	const long away_us = G.nblocks ? (now.tv_sec - G.left.tv_sec) * 1000000L + (now.tv_usec - G.left.tv_usec) : 0;
+	/* (the very first block goes at once as well: a stream that is one short block long ends without a shorter one) */
+	const int live = away_us > LIVE_GAP_US || G.nblocks == 0;
+	const int end = len == 0 || len < G.prev_len;           /* what ends process_iq_file()'s loop, src/dumpvdl2.c:353-356 */
+	G.prev_len = len;
+	if(len) {
+		uint64_t slot = G.nblocks % ARRIVALS;
+		G.arrival[slot].k_first = (int64_t)(G.samples_total / G.oversample);
+		G.arrival[slot].tv = now;
+		G.nblocks++;
+		G.samples_total += len / (fmt == VDL2HIP_FMT_S16LE ? 4u : 2u);
 	}
+	if(G.batch <= 1) {                                       /* every block on its own, every frame of it out before the next */
+		if(len) { gpu_feed(buf, len); G.fed = 1; G.flush = 1; }
+		return;
+	}
+	if(len && G.stage_len + len > G.stage_cap) {             /* (a block larger than the first one was) */
+		stage_to_gpu(); gpu_feed(buf, len); G.fed = 1;
+	} else if(len) {
+		memcpy(G.stage + G.stage_len, buf, len);
+		G.stage_len += len; G.stage_blocks++;
+	}
+	if(G.stage_blocks >= G.batch || end || live) {
+		stage_to_gpu();
+		G.fed = 1;
+	}
+	if(end || live) G.flush = 1;
 }
 
 /* wait for the frames of the block(s) handed over and push them (first channel's thread, between samples_ready and demods_ready) */
 static void deliver_block(void) {
-	if(!G.grp) return;
+	if(!G.grp || !G.fed) return;                           /* (a collected block: nothing new on the GPU) */
+	/* a feed of collected blocks leaves the feed before it on the GPU; the stream's end and a live source want everything */
+	const int lag = G.flush ? 0 : 1;
+	G.fed = 0; G.flush = 0;
+	if(lag != G.lag) { vdl2hip_group_set_drain_lag(G.grp, lag); G.lag = lag; }
 	int r = vdl2hip_group_drain(G.grp, push_frame, NULL);
 	if(r < 0) { fprintf(stderr, "vdl2hip_group_drain: %s\n", vdl2hip_strerror(r)); _exit(2); }
 	/* the drain calls only count device-side buffer overflows (bursts or frames dropped): say so once per occurrence */
@@ -201,18 +282,24 @@ static void deliver_block(void) {
 	if(ov != G.overflow_seen) { fprintf(stderr, "vdl2hip: device output buffers overflowed in %llu block(s): frames were dropped\n", (unsigned long long)(ov - G.overflow_seen)); G.overflow_seen = ov; }
 }
 
+static void process_buf(unsigned char *buf, uint32_t len, int fmt) {
+	/* an empty block: the reference's threads find nothing to do; here it may be the end of a stream some of whose blocks are
+	 * still collected or whose last feed's frames are still on the GPU */
+	if(len == 0 && (!G.grp || G.batch <= 1)) return;
+	struct timeval now;
+	gettimeofday(&now, NULL);                              /* (before the wait: that is the delivering thread's time, not the producer's) */
+	pthread_barrier_wait(&demods_ready);
+	take_block(buf, len, fmt, now);
+	pthread_barrier_wait(&samples_ready);
+	gettimeofday(&G.left, NULL);
+}
+
 void process_buf_uchar(unsigned char *buf, uint32_t len, void *ctx) {   /* src/demod.c:339-347 */
 	(void)ctx;
-	if(len == 0) return;
-	pthread_barrier_wait(&demods_ready);
-	feed_block(buf, len, VDL2HIP_FMT_U8);
-	pthread_barrier_wait(&samples_ready);
+	process_buf(buf, len, VDL2HIP_FMT_U8);
 }
 
 void process_buf_short(unsigned char *buf, uint32_t len, void *ctx) {   /* src/demod.c:356-365 */
 	(void)ctx;
-	if(len == 0) return;
-	pthread_barrier_wait(&demods_ready);
-	feed_block(buf, len, VDL2HIP_FMT_S16LE);
-	pthread_barrier_wait(&samples_ready);
+	process_buf(buf, len, VDL2HIP_FMT_S16LE);
 }

@@ -52,7 +52,10 @@ constexpr uint32_t kDeferBursts = 256, kDeferScans = 512;   // referee: bursts o
 // The streams of a receiver that is destroyed go to a pool (per device) and the next receiver takes them over: the runtime's mapping
 // of streams to queues depends on every stream the process has created so far, and a receiver made after a hundred others had come
 // and gone ran 30-60 % slower than the same receiver in a fresh process (bench.py's secondary workloads, round 6).
-constexpr int kSidePre = 3, kSideBurst = 2;
+#ifndef VDL2_SIDE_PRE
+#define VDL2_SIDE_PRE 3
+#endif
+constexpr int kSidePre = VDL2_SIDE_PRE, kSideBurst = 2;
 constexpr int kSlots = VDL2HIP_MAX_DRAIN_LAG + 1;   // feeds in flight (vdl2hip_set_drain_lag: at most kSlots - 1 undelivered).  Six: a feed's way through the device of a receiver of few channels - front 1 ms, the scans ahead of the walk 1.5, walk, the next feed's walk (the second walks are queued behind it), burst decoder and its scans 1.5-2.5 - is four to six fronts long (rank-sized receivers, walk ahead: 2.22 / 1.46 / 1.56 ms per step with four slots, 1.76 / 1.29 / 1.45 with six; with 256 channels it is three fronts and four slots were enough)
 
 }  // namespace

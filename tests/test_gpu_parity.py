@@ -1014,6 +1014,44 @@ def test_dropin_adapter_over_several_devices(vh, tmp_path):
     assert sorted(got) == sorted(want) and len(got) > 20
 
 
+@pytest.mark.parametrize("blocks", [None, 10])
+def test_dropin_adapter_collects_blocks(vh, tmp_path, blocks):
+    """The adapter hands a fast producer's 320 000-byte blocks to the GPU several at a time (csrc/dropin.c, "Blocks per feed"):
+    the frames pushed to avlc_decoder_queue_push() must be the golden capture's whatever the collecting - the default (16 blocks of
+    this size), 5 (the last batch of the stream is a partial one), 1 (every block on its own: the old behaviour) - per channel in the
+    same order, none lost at the end of the stream: neither when the file ends in a short block (`blocks` None: 26.25 blocks) nor
+    when it ends on a block boundary and process_iq_file()'s last fread() returns nothing (10 blocks exactly; there the runs are
+    compared with each other)."""
+    import os, subprocess, hashlib
+    from dumpvdl2_amd import build
+    cfg, iq, _, gold = cases.load("config2_1s")
+    exe = build.build_harness(str(tmp_path / "dropin_harness"))
+    raw = iq.view(np.uint8)
+    if blocks: raw = raw[: blocks * 320000]
+    path = tmp_path / "cap.cs16"
+    raw.tofile(path)
+    runs = {}
+    for batch in (None, "5", "1"):
+        env = dict(os.environ)
+        env.pop("VDL2HIP_DROPIN_BATCH", None)
+        if batch: env["VDL2HIP_DROPIN_BATCH"] = batch
+        out = subprocess.run([exe, str(path), str(cfg.oversample), str(cfg.centerfreq)] + [str(f) for f in cfg.freqs], check=True,
+                             capture_output=True, text=True, timeout=180, env=env).stdout
+        got = {}
+        for l in out.splitlines():
+            if l.startswith("FRAME"):
+                kv = dict(t.split("=", 1) for t in l.split()[1:])
+                got.setdefault(int(kv["freq"]), []).append((int(kv["idx"]), hashlib.sha1(bytes.fromhex(kv["octets"])).hexdigest(), int(kv["S"]), int(kv["L"]), int(kv["F"]),
+                                                            kv["pwr"], kv["nf"], kv["ppm"]))
+        runs[batch] = got
+    assert runs[None] == runs["5"] == runs["1"] and sum(len(v) for v in runs["1"].values()) > (5 if blocks else 20)
+    if not blocks:
+        want = {}
+        for f in gold["frames"]:
+            want.setdefault(cfg.freqs[f["chan"]], []).append((f["idx"], f["sha1"], f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"]))
+        assert {k: sorted(t[:5] for t in v) for k, v in runs[None].items()} == {k: sorted(v) for k, v in want.items()}
+
+
 def test_dpp_primitives_behave_as_the_scan_assumes(vh):
     """The channeliser's wave scan (kernels.h) moves filter states between lanes with DPP controls: row_shr inside rows of 16 lanes
     (out-of-row sources read 0), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3, wave_shr:1 across the wavefront."""

@@ -4,6 +4,10 @@
  * It reproduces the part of the reference's command line that feeds the hot path
  * (src/dumpvdl2.c:831-1099 option handling, :168-180 centre-frequency rule, :323-358 file loop):
  *   --iq-file <path|->            raw IQ file, read in FILE_BUFSIZE (320000-byte) blocks; sets oversample 10 and U8
+ *   --blocks-per-feed <n>         how many of those blocks go to the GPU as one feed (default: as many as hold 64 000 decimated
+ *                                 samples - 16 s16 blocks at oversample 20, 5 u8 blocks at 10; 1 = the reference's block by block).
+ *                                 A block is microseconds of GPU work behind a fixed chain of launches (and, now and then, a 2 ms
+ *                                 scan of the referee's): collected blocks give the same frames at 5-7x the rate
  *   --sample-format U8|S16_LE     (the reference's token is S16_LE, src/dumpvdl2.c:849)
  *   --oversample <n>  --centerfreq <Hz>  --max-ppm <x>  --station-id <s>
  *   --avlc-filter                 deliver only frames that pass avlc_parse()'s first checks (length, FCS) - src/avlc.c:168-187
@@ -51,6 +55,7 @@ static void on_frame(const vdl2hip_frame *f, void *user) {
 int main(int argc, char **argv) {
 	const char *infile = NULL, *rawpath = NULL, *statsd_path = NULL;
 	int avlc_filter = 0;
+	uint32_t per_feed = 0;
 	uint32_t oversample = 0, centerfreq = 0, fmt = VDL2HIP_FMT_U8, freqs[1024], nfreq = 0;
 	float max_ppm = 0.f;
 	int fmt_set = 0;
@@ -71,12 +76,13 @@ int main(int argc, char **argv) {
 		else if(!strcmp(a, "--raw-frames-out")) { NEEDARG(); rawpath = argv[++i]; }
 		else if(!strcmp(a, "--statsd-out")) { NEEDARG(); statsd_path = argv[++i]; }
 		else if(!strcmp(a, "--avlc-filter")) avlc_filter = 1;
+		else if(!strcmp(a, "--blocks-per-feed")) { NEEDARG(); per_feed = (uint32_t)strtoul(argv[++i], NULL, 10); }
 		else if(a[0] == '-' && a[1]) { fprintf(stderr, "unknown option %s\n", a); return 1; }
 		else if(nfreq < 1024) freqs[nfreq++] = (uint32_t)strtoul(a, NULL, 10);
 	}
 	(void)fmt_set;
 	if(!infile) { fprintf(stderr, "usage: %s --iq-file <file|-> [--sample-format U8|S16_LE] [--oversample n] [--centerfreq Hz] "
-			"[--max-ppm x] [--station-id s] [--raw-frames-out file] [--avlc-filter] [--statsd-out file] [freq ...]\n", argv[0]); return 1; }
+			"[--max-ppm x] [--station-id s] [--raw-frames-out file] [--avlc-filter] [--statsd-out file] [--blocks-per-feed n] [freq ...]\n", argv[0]); return 1; }
 	if(nfreq == 0) {
 		fprintf(stderr, "Warning: frequency not set - using VDL2 Common Signalling Channel as a default (%u Hz)\n", CSC_FREQ);
 		freqs[nfreq++] = CSC_FREQ;
@@ -96,20 +102,32 @@ int main(int argc, char **argv) {
 	vdl2hip_cfg cfg;
 	memset(&cfg, 0, sizeof cfg);
 	cfg.struct_size = sizeof cfg; cfg.centerfreq = centerfreq; cfg.oversample = oversample; cfg.sample_fmt = fmt;
-	cfg.nchan = nfreq; cfg.freqs = freqs; cfg.max_ppm = max_ppm; cfg.device = 0; cfg.max_block_bytes = FILE_BUFSIZE;
+	if(per_feed == 0) {
+		const uint32_t dec = FILE_BUFSIZE / (fmt == VDL2HIP_FMT_S16LE ? 4u : 2u) / oversample;      /* decimated samples per block */
+		per_feed = dec ? (64000u + dec - 1) / dec : 1;
+	}
+	if(per_feed > 64) per_feed = 64;
+	cfg.nchan = nfreq; cfg.freqs = freqs; cfg.max_ppm = max_ppm; cfg.device = 0; cfg.max_block_bytes = (size_t)per_feed * FILE_BUFSIZE;
 	vdl2hip_ctx *rx = NULL;
 	int r = vdl2hip_create(&cfg, &rx);
 	if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_create: %s\n", vdl2hip_strerror(r)); return 3; }
 
 	if(avlc_filter) vdl2hip_set_avlc_filter(rx, 1);
 
-	static unsigned char buf[FILE_BUFSIZE];
-	size_t len;
+	unsigned char *buf = malloc((size_t)per_feed * FILE_BUFSIZE);
+	if(!buf) { perror("malloc"); return 3; }
+	size_t len, held = 0;
+	if(per_feed > 1) vdl2hip_set_drain_lag(rx, 1);                              /* the frames of a feed are printed while the next one is on the GPU */
 	do {                                                                        /* process_iq_file(), src/dumpvdl2.c:353-356 */
-		len = fread(buf, 1, FILE_BUFSIZE, f);
-		if((r = vdl2hip_feed(rx, buf, len)) != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_feed: %s\n", vdl2hip_strerror(r)); return 3; }
+		len = fread(buf + held, 1, FILE_BUFSIZE, f);
+		held += len;
+		if(held + FILE_BUFSIZE <= (size_t)per_feed * FILE_BUFSIZE && len == FILE_BUFSIZE) continue;      /* room for another block, and there may be one */
+		if(len != FILE_BUFSIZE) vdl2hip_set_drain_lag(rx, 0);                   /* the last feed: every frame out */
+		if((r = vdl2hip_feed(rx, buf, held)) != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_feed: %s\n", vdl2hip_strerror(r)); return 3; }
 		if((r = vdl2hip_drain(rx, on_frame, NULL)) < 0) { fprintf(stderr, "vdl2hip_drain: %s\n", vdl2hip_strerror(r)); return 3; }
+		held = 0;
 	} while(len == FILE_BUFSIZE);
+	free(buf);
 	uint64_t cnt[VDL2HIP_NUM_COUNTERS];
 	for(uint32_t c = 0; c < nfreq; c++)
 		if(vdl2hip_counters(rx, c, cnt) == VDL2HIP_OK)
