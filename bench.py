@@ -549,8 +549,8 @@ def dropin_block_rate(case, torch, seconds=2.0, block=320000):
     out = {"workload": f"dropin_320kB_block: {case.C} channels, {seconds:g} s of the same capture in {nblk} blocks of {block} bytes from pageable memory, "
                        f"one feed + drain per block (lag0, lag1) or per 16 collected blocks (the adapter's default for a file)", "block_bytes": block, "blocks": nblk}
     # (blocks per feed, drain lag): the block on its own, blocking / one block late; and what csrc/dropin.c and tools/vdl2hip_iqfile do
-    # by default for a producer that comes straight back (a file): 16 blocks collected per feed, the feed before it delivered meanwhile
-    for per_feed, lag, key in ((1, 0, "lag0"), (1, 1, "lag1"), (16, 1, "collected16_lag1")):
+    # by default for a producer that comes straight back (a file): 16 blocks collected per feed, the feed two before it delivered meanwhile
+    for per_feed, lag, key in ((1, 0, "lag0"), (1, 1, "lag1"), (16, 2, "collected16_lag2")):
         piece = per_feed * block
         if per_feed > 1:                                   # (enough feeds for the rate to mean something: 8 s = 210 blocks = 14 feeds)
             raw = case.iq.view(np.uint8)[: int(4 * seconds * 2100000) * 4]

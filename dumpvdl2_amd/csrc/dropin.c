@@ -24,9 +24,9 @@
  * into a staging buffer and returns; every `batch` blocks (as many as make a feed long enough to be
  * walked in segments and pipelined: 16 of the reference's s16 blocks at oversample 20, 5 of its u8
  * blocks at 10; VDL2HIP_DROPIN_BATCH=<n> sets it, 1 = every block on its own as before) the buffer
- * goes to the GPU as one feed and the frames of the feed before it are pushed (drain lag 1).  The
+ * goes to the GPU as one feed and the frames of the feed two before it are pushed (drain lag 2).  The
  * results are the same frames in the same order (any chunking gives the same answer:
- * tests/test_gpu_parity.py), pushed up to two batches late.  The end of the stream - a block
+ * tests/test_gpu_parity.py), pushed up to three batches late.  The end of the stream - a block
  * shorter than the one before, or an empty one: what ends process_iq_file()'s loop - flushes
  * everything before process_buf_*()'s partner thread returns to demods_ready, so main()'s final
  * wait still means "every frame is out".  A producer that stays away for more than LIVE_GAP_US
@@ -267,8 +267,8 @@ static void take_block(unsigned char *buf, uint32_t len, int fmt, struct timeval
 /* wait for the frames of the block(s) handed over and push them (first channel's thread, between samples_ready and demods_ready) */
 static void deliver_block(void) {
 	if(!G.grp || !G.fed) return;                           /* (a collected block: nothing new on the GPU) */
-	/* a feed of collected blocks leaves the feed before it on the GPU; the stream's end and a live source want everything */
-	const int lag = G.flush ? 0 : 1;
+	/* a feed of collected blocks leaves the two feeds before it on the GPU; the stream's end and a live source want everything */
+	const int lag = G.flush ? 0 : 2;
 	G.fed = 0; G.flush = 0;
 	if(lag != G.lag) { vdl2hip_group_set_drain_lag(G.grp, lag); G.lag = lag; }
 	int r = vdl2hip_group_drain(G.grp, push_frame, NULL);

@@ -143,7 +143,7 @@ struct vdl2hip_ctx {
 	struct HistPiece { int64_t s0, n; uint64_t pos; }; std::vector<HistPiece> ref_pieces;
 	unsigned long long *d_refdbg = nullptr; int ref_dbg_chan = -1;
 	WalkState *d_ws_snap[3] = {}, *d_ws_tmp = nullptr; unsigned long long *d_cnt_snap[3] = {}, *d_cnt_tmp = nullptr; uint32_t rq_cap = 8192; bool ref_optimistic = true;
-	int walk_ahead = 1; int debug_force_mismatch = 0;   // launch_back(): the walks of the next feed (1) or the next two (2) do not wait for this feed's check
+	int walk_ahead = 1; bool walk_ahead_auto = true; double walk_ahead_below = 1.1e8; int debug_force_mismatch = 0;   // launch_back(): the walks of the next feed (1) or the next two (2) do not wait for this feed's check
 	int ref_retry_mul = 2;                 // a scan that has not met its witness is run again from this many times further back (0: not at all; VDL2HIP_REF_RETRY)
 	RefChan *d_ref[kSlots] = {}; unsigned long long *d_refdone = nullptr; uint32_t *d_refdonen = nullptr, *d_refstats = nullptr; uint8_t *d_mix = nullptr;
 	bool defer_back = false;               // VDL2HIP_BACKEND=deferred: the back end of feed i is queued behind the channeliser of feed i+1 (launch_back)
@@ -486,8 +486,20 @@ static bool feed_is_small(const vdl2hip_ctx *c, int64_t D) {
 // frame finish, the copy of the control block.
 static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ, OutSlot *succ2);
 
+// Does the walk of the feed after this one go ahead of this feed's check?  It pays when a feed's front is shorter than a check (a scan:
+// 2.3 ms) - a front is 6.2 ms for 1.68 M decimated samples of 256 channels, 1.45e-8 ms per channel-sample: receivers of 16-64 channels
+// on the bench's 16 s blocks (rounds 6a/b), and ANY receiver of >= 16 channels on feeds of a second or so - the drop-in adapter's
+// sixteen collected 320 000-byte blocks at 256 channels: 0.155 -> 0.10 ms per block (profiles/r06_block_batch.txt).  With fewer than
+// 16 channels the walk itself is longer than the front and the second walks' extra launches cost more than they save (1.22 against
+// 1.11 ms at 8).  VDL2HIP_WALK_AHEAD / the debug option fix the depth for every feed.
+static int walk_ahead_of(const vdl2hip_ctx *c, int64_t D) {
+	if(!c->walk_ahead_auto) return c->walk_ahead;
+	return c->C >= 16 && (double)D * (double)c->C < c->walk_ahead_below ? 1 : 0;
+}
+
 static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	const int64_t D = sl.back_D, k0 = sl.back_k0;
+	const int wa = walk_ahead_of(c, D);
 	// long feeds: the walk runs in speculative segments (vdl2_core.h), one wavefront per (channel, segment, grid phase)
 	int nseg = (int)std::min<int64_t>(c->seg_max, D / c->seg_min);
 	// A short feed (fewer than two walk segments' worth of samples; the reference's own 320 000-byte blocks are 4 000) is a chain of kernels that each run for
@@ -508,7 +520,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	const uint32_t rq_cap = small ? std::min<uint32_t>(c->rq_cap, 16u * kScanLanes) : c->rq_cap;      // (a short feed: few requests, small grids - it queues these kernels whether or not it notes anything)
 	// does this feed's walk go ahead of the check of the feed(s) before?  (long feeds with a check, segmented walks)  If not, what is
 	// still waiting for a successor's walk is queued now, oldest first
-	const bool ahead = c->walk_ahead && opt && nseg >= 2 && !gate && sl.seq > 0 && pv.pending && pv.rest_pending && pv.has_chk && pv.nseg >= 2;
+	const bool ahead = wa && opt && nseg >= 2 && !gate && sl.seq > 0 && pv.pending && pv.rest_pending && pv.has_chk && pv.nseg >= 2;
 	if(!ahead) { int r = flush_rest(c, nullptr); if(r != VDL2HIP_OK) return r; }
 	if(small) {
 		// the walker, the noise floor and the burst list carry state from feed to feed: wait for a predecessor whose back end is on the other streams
@@ -562,7 +574,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 			// (in the old schedule - receivers of many channels: the front hides the chain - the check stays on the walk stream: on a stream
 			// of its own it cost the 256-channel receiver 0.6 ms per step, profiles/r06_walk_ahead_ab.txt)
 			sl.has_chk = true;
-			hipStream_t sc_ = c->walk_ahead ? sp_ : sb_;
+			hipStream_t sc_ = wa ? sp_ : sb_;
 			if(sc_ != sb_) { HIPCHK(hipEventRecord(sl.ev_stitch, sb_)); HIPCHK(hipStreamWaitEvent(sc_, sl.ev_stitch, 0)); }
 			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(rq_cap / kScanLanes), dim3(64 * kScanWaves), 0, sc_, k4.ref, k4.ref_launch - 1u, (const ScanReq *) nullptr, (const RefReq *)k4.rq, (const uint32_t *)k4.rq_n, rq_cap, k1,
 			                  rty ? sl.d_retry + kRetryScans : (ScanReq *) nullptr, sl.d_rqn + 5, kRetryScans, 1);
@@ -577,11 +589,11 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 	for(;;) {
 		OutSlot *old = nullptr;
 		for(auto &x : c->slot) if(x.pending && x.rest_pending && (!old || x.seq < old->seq)) old = &x;
-		if(!old || old == &sl || sl.seq - old->seq < (uint64_t)c->walk_ahead) break;
+		if(!old || old == &sl || sl.seq - old->seq < (uint64_t)wa) break;
 		int r = flush_rest(c, old); if(r != VDL2HIP_OK) return r;
 	}
 	// does the NEXT feed's walk get the chance to go ahead of this feed's check?  Not if there is nothing to check, nor in the old schedule
-	if(!(c->walk_ahead && sl.has_chk && sl.nseg >= 2 && !gate && !c->defer_back)) return flush_rest(c, nullptr);
+	if(!(wa && sl.has_chk && sl.nseg >= 2 && !gate && !c->defer_back)) return flush_rest(c, nullptr);
 	HIPCHK(hipGetLastError());
 	return VDL2HIP_OK;
 }
@@ -957,7 +969,7 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		// Walk ahead (launch_back): for receivers whose front does not hide the chain walk - scans - check (a feed's results then come a
 		// feed later: with 256 channels, where the front hides the chain anyway, that extra depth cost 10 % and more)
 		c->walk_ahead = (count >= 16 && count <= 64) ? 1 : 0;   // (8 channels: the walk itself is longer than the front, the second walks' extra launches cost more than they save: 1.22 against 1.11 ms)
-		if(const char *e = getenv("VDL2HIP_WALK_AHEAD")) { const int v = atoi(e); c->walk_ahead = v < 0 ? 0 : v > 2 ? 2 : v; }      // 0: a feed's walk waits for the check of the feed before (round 5's schedule)
+		if(const char *e = getenv("VDL2HIP_WALK_AHEAD")) { const int v = atoi(e); c->walk_ahead = v < 0 ? 0 : v > 2 ? 2 : v; c->walk_ahead_auto = false; }      // 0: a feed's walk waits for the check of the feed before (round 5's schedule)
 		for(auto &sl : c->slot) {
 			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 32); DEV_ALLOC(sl.d_retry, 3 * (size_t)kRetryScans * sizeof(ScanReq)); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
 			DEV_ALLOC(sl.d_dq, (size_t)kDeferBursts * 4); DEV_ALLOC(sl.d_sq, (size_t)kDeferScans * sizeof(ScanReq));
@@ -1301,7 +1313,8 @@ int vdl2hip_debug_option(vdl2hip_ctx *c, const char *name, long value) {
 	if(strcmp(name, "no_fuse") == 0) { c->fuse_k2 = value == 0; return VDL2HIP_OK; }
 	if(strcmp(name, "force_timeout") == 0) { c->debug_force_timeout = value != 0; return VDL2HIP_OK; }
 	if(strcmp(name, "force_mismatch") == 0) { c->debug_force_mismatch = value != 0; return VDL2HIP_OK; }   // every channel walked again with the next feed's walk already done is taken to have ended differently: the next feed is redone for it
-	if(strcmp(name, "walk_ahead") == 0) { c->walk_ahead = value < 0 ? 0 : value > 2 ? 2 : (int)value; return VDL2HIP_OK; }   // feeds whose walks may go ahead of a feed's check: 0, 1, 2
+	if(strcmp(name, "walk_ahead_below") == 0) { c->walk_ahead_below = (double)value; c->walk_ahead_auto = true; return VDL2HIP_OK; }   // (tests: feeds of fewer channel-samples than this let the next walk go ahead)
+	if(strcmp(name, "walk_ahead") == 0) { c->walk_ahead = value < 0 ? 0 : value > 2 ? 2 : (int)value; c->walk_ahead_auto = false; return VDL2HIP_OK; }   // feeds whose walks may go ahead of a feed's check: 0, 1, 2
 	if(strcmp(name, "force_again") == 0) { c->debug_force_again = value != 0; return VDL2HIP_OK; }   // every channel of every long feed is stitched a second time (the referee's walk-again path)
 	if(strcmp(name, "referee") == 0) { if(value && !c->d_refhist) return VDL2HIP_E_INVAL; c->referee = value != 0; return VDL2HIP_OK; }   // (on only where it was on at create: the history ring)
 	if(strcmp(name, "ref_debug_chan") == 0) {

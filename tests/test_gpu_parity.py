@@ -360,6 +360,38 @@ def test_many_channel_configs_vs_oracle(vh, oracle_mod, which, secs):
     rx.close()
 
 
+@pytest.mark.parametrize("mode", ["plain", "again", "straddle_again", "straddle_mismatch"])
+@pytest.mark.parametrize("which,secs,chunks", [("config4", 3.0, (1_100_000, 1_500_000)), ("config3", 4.0, (700_000, 4_000_000))])
+def test_walk_ahead_chosen_feed_by_feed(vh, oracle_mod, which, secs, chunks, mode):
+    """Whether the next feed's walk goes ahead of a feed's check is decided per feed from its channel-samples (vdl2hip.hip:
+    walk_ahead_of): a 256-channel receiver fed a second or so at a time - the drop-in adapter's collected blocks - walks ahead
+    like a rank-sized one does on 16 s blocks.  `plain`: the library's own choice on pieces of 1.1-1.5 M samples (256 channels) /
+    0.7-4 M (64); `again`: the hook that flags every channel of every feed, so every second walk runs and is compared with what
+    the next feed started from; `straddle_*`: the threshold moved into the range of the pieces (debug option walk_ahead_below), so
+    feeds that let the next walk go ahead and feeds that do not alternate in one stream - with every channel walked again, and
+    with every comparison forced to fail (every channel of the following feed stitched once more).  Frames, burst timing and the
+    reference's 18 counters identical to the oracle's (src/demod.c:173-286, src/decode.c:204-373)."""
+    import os
+    from dumpvdl2_amd import workloads, synth
+    cfg = getattr(workloads, which)(secs)
+    iq, bursts = synth.synthesize(cfg)
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=20, max_ppm=cfg.rx_max_ppm)
+    o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=min(len(cfg.freqs), os.cpu_count() or 8))
+    fo = o.frames()
+    dbg = {}
+    if mode != "plain": dbg["force_again"] = 1
+    if mode.startswith("straddle"): dbg["walk_ahead_below"] = len(cfg.freqs) * ((chunks[0] + chunks[1]) // 2 // 20)
+    if mode.endswith("mismatch"): dbg["force_mismatch"] = 1
+    rx, fg, cnt = gpu_decode(vh, cfg, iq, chunks=chunks, max_block=16_000_000, debug=dbg)
+    assert len(fo) > 100
+    assert_frames_equal(fo, fg, label=f"{which} {mode}")
+    cases.assert_counters_equal(cnt, [list(o.counters(c).values()) for c in range(len(cfg.freqs))], f"{which} {mode}", exact_diagnostics=False)
+    st = rx.stats()
+    assert st["referee_refused"] == 0
+    if mode != "plain": assert st["referee_rewalks"] >= len(cfg.freqs)
+    rx.close()
+
+
 @pytest.mark.parametrize("mode", ["ahead2", "ahead2_mismatch", "ahead", "ahead_mismatch", "serial"])
 @pytest.mark.parametrize("which,secs,chunks", [("config3", 4.0, (2_000_000, 4_000_000)), ("config4", 3.0, (2_000_000, 4_000_000)),
                                                ("config3", 2.0, (700_000, 1_500_000))])

@@ -117,7 +117,7 @@ int main(int argc, char **argv) {
 	unsigned char *buf = malloc((size_t)per_feed * FILE_BUFSIZE);
 	if(!buf) { perror("malloc"); return 3; }
 	size_t len, held = 0;
-	if(per_feed > 1) vdl2hip_set_drain_lag(rx, 1);                              /* the frames of a feed are printed while the next one is on the GPU */
+	if(per_feed > 1) vdl2hip_set_drain_lag(rx, 2);                              /* the frames of a feed are printed while the next two are on the GPU */
 	do {                                                                        /* process_iq_file(), src/dumpvdl2.c:353-356 */
 		len = fread(buf + held, 1, FILE_BUFSIZE, f);
 		held += len;
