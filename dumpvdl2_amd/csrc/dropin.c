@@ -95,6 +95,10 @@ static float cfg_max_ppm(void) { return Config.max_ppm; }
 static char *cfg_station_id(void) { return Config.station_id; }
 #endif
 
+/* VDL2HIP_DROPIN_TIMING=1: where the wall clock goes, printed at the stream's end (development aid) */
+static struct { double wait_demods, feed, wait_samples, drain, stats, push; unsigned long feeds, drains, frames; int on; } T;
+static double now_ms(void) { struct timeval t; gettimeofday(&t, NULL); return t.tv_sec * 1e3 + t.tv_usec * 1e-3; }
+
 static void *must_calloc(size_t n, size_t sz) {   /* XCALLOC semantics, src/util.c:32-40 */
 	void *p = calloc(n ? n : 1, sz);
 	if(!p) { fprintf(stderr, "vdl2hip dropin: calloc(%zu, %zu) failed\n", n, sz); _exit(1); }
@@ -145,6 +149,7 @@ static struct timeval arrival_of(int64_t sync_sample) {
 
 static void push_frame(const vdl2hip_frame *f, void *user) {
 	(void)user;
+	const double tp0 = T.on ? now_ms() : 0;
 	/* decode_frame(), src/decode.c:173-194 */
 	vdl2_msg_metadata *m = must_calloc(1, sizeof *m);
 	m->version = 1;
@@ -165,6 +170,7 @@ static void push_frame(const vdl2hip_frame *f, void *user) {
 	octet_string_t *os = must_calloc(1, sizeof *os);   /* octet_string_new(), src/util.c:145-150 */
 	os->buf = copy; os->len = f->len;
 	avlc_decoder_queue_push(m, os, 0);
+	if(T.on) T.push += now_ms() - tp0;
 }
 
 /* VDL2HIP_DEVICES=0,1,2,...: the GPUs the channels are spread over (contiguous ranges, src/dumpvdl2.c:117-135 has one worker
@@ -186,11 +192,13 @@ static uint32_t parse_devices(int32_t *dev, uint32_t cap) {
 }
 
 static void gpu_feed(const unsigned char *p, uint32_t len) {
+	const double t0 = T.on ? now_ms() : 0;
 	for(uint32_t off = 0; off < len; off += BLOCK_MAX) {
 		uint32_t n = len - off < BLOCK_MAX ? len - off : BLOCK_MAX;
 		int r = vdl2hip_group_feed(G.grp, p + off, n);       /* returns when the copy out of p is complete: buf is only ours during the call */
 		if(r != VDL2HIP_OK) { fprintf(stderr, "vdl2hip_group_feed: %s\n", vdl2hip_strerror(r)); _exit(2); }
 	}
+	if(T.on) { T.feed += now_ms() - t0; T.feeds++; }
 }
 
 /* blocks per feed: VDL2HIP_DROPIN_BATCH, or as many of this size as hold BATCH_DECIMATED decimated samples */
@@ -271,8 +279,10 @@ static void deliver_block(void) {
 	const int lag = G.flush ? 0 : 2;
 	G.fed = 0; G.flush = 0;
 	if(lag != G.lag) { vdl2hip_group_set_drain_lag(G.grp, lag); G.lag = lag; }
+	const double t0 = T.on ? now_ms() : 0;
 	int r = vdl2hip_group_drain(G.grp, push_frame, NULL);
 	if(r < 0) { fprintf(stderr, "vdl2hip_group_drain: %s\n", vdl2hip_strerror(r)); _exit(2); }
+	const double t1 = T.on ? now_ms() : 0;
 	/* the drain calls only count device-side buffer overflows (bursts or frames dropped): say so once per occurrence */
 	uint64_t ov = 0;
 	for(uint32_t i = 0; i < vdl2hip_group_size(G.grp); i++) {
@@ -280,6 +290,11 @@ static void deliver_block(void) {
 		if(vdl2hip_get_stats(vdl2hip_group_ctx(G.grp, i), &st) == VDL2HIP_OK) ov += st.overflow_feeds;
 	}
 	if(ov != G.overflow_seen) { fprintf(stderr, "vdl2hip: device output buffers overflowed in %llu block(s): frames were dropped\n", (unsigned long long)(ov - G.overflow_seen)); G.overflow_seen = ov; }
+	if(T.on) {
+		T.drain += t1 - t0; T.stats += now_ms() - t1; T.drains++; T.frames += (unsigned long)r;
+		if(lag == 0) fprintf(stderr, "vdl2hip dropin timing: %llu blocks, %lu feeds, %lu drains, %lu frames; producer: %.1f ms waiting at demods_ready, %.1f in feeds, %.1f waiting at samples_ready; "
+				"delivering thread: %.1f ms in drains (%.1f of it pushing frames), %.1f reading stats\n", (unsigned long long)G.nblocks, T.feeds, T.drains, T.frames, T.wait_demods, T.feed, T.wait_samples, T.drain, T.push, T.stats);
+	}
 }
 
 static void process_buf(unsigned char *buf, uint32_t len, int fmt) {
@@ -288,10 +303,16 @@ static void process_buf(unsigned char *buf, uint32_t len, int fmt) {
 	if(len == 0 && (!G.grp || G.batch <= 1)) return;
 	struct timeval now;
 	gettimeofday(&now, NULL);                              /* (before the wait: that is the delivering thread's time, not the producer's) */
+	if(!G.grp) T.on = getenv("VDL2HIP_DROPIN_TIMING") != NULL;
+	const double t0 = T.on ? now_ms() : 0;
 	pthread_barrier_wait(&demods_ready);
+	const double t1 = T.on ? now_ms() : 0;
 	take_block(buf, len, fmt, now);
+	if(getenv("VDL2HIP_DROPIN_EXPERIMENT_DRAIN_HERE")) deliver_block();
+	const double t2 = T.on ? now_ms() : 0;
 	pthread_barrier_wait(&samples_ready);
 	gettimeofday(&G.left, NULL);
+	if(T.on && G.nblocks > 1) { T.wait_demods += t1 - t0; T.wait_samples += now_ms() - t2; }
 }
 
 void process_buf_uchar(unsigned char *buf, uint32_t len, void *ctx) {   /* src/demod.c:339-347 */

@@ -41,7 +41,11 @@ constexpr int kColdParts = 4;         // pieces a cold-start block is copied and
 constexpr size_t kColdMinBytes = 8u << 20;
 constexpr uint32_t kRetryScans = 64;       // referee: scans of one launch that may be run again from further back because they had not met their witness (more: published as they are, counted)
 constexpr uint32_t kPreScans = 4096;    // referee: stretches around marked candidates one feed may list for the scan ahead of the walk (what does not fit is asked for by the walk itself)
-constexpr uint32_t kDeferBursts = 256, kDeferScans = 512;   // referee: bursts of one feed that may wait for their scans, stretches they may wait for (what does not fit is scanned on the spot)
+// referee: bursts of one feed that may wait for their scans, stretches they may wait for.  What does not fit is scanned on the spot, by the
+// burst's own wavefront, one stretch after the other at 4.4 ms each: with 256 / 512 (rounds 5, 6a/b) a capture full of weak bursts - config4
+// WITHOUT its --max-ppm gate: the neighbours' leakage is locked on to and decoded, a symbol in a few hundred within the margin - ran over
+// and a 16-block feed took 68 ms instead of 2 (profiles/r06_weak_bursts.txt).  A short feed lists a sixteenth of these.
+constexpr uint32_t kDeferBursts = 4096, kDeferScans = 8192;
 // Streams per priority class.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per
 // priority, round-robin in the order of their creation, and two streams on one queue run one after the other.  With a scan stream and
 // a burst stream per slot (four of each), a scan stream shared its queue with the walk stream and burst streams shared theirs with the
@@ -663,20 +667,23 @@ static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ, OutSlot *succ
 		}
 		K5Args k5{ c->d_y, c->d_tab, c->d_cnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, c->C,
 		           sl.d_frames, sl.d_pool, sl.d_ctl, c->d_freq, c->cap, c->cap - 1, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(16 * sl.seq + 5), BurstDefer{} };
-		// referee, long feeds: a burst that needs a scan is listed by the first pass, the scans run side by side, a second pass decodes the listed bursts
-		const bool defer5 = c->referee && c->ref_optimistic && !small && ((c->ref_kinds >> REF_SYMBOLS) & 1);
-		if(defer5) k5.df = BurstDefer{ sl.d_dq, sl.d_rqn + 1, kDeferBursts, sl.d_sq, sl.d_rqn + 2, kDeferScans, 1 };
+		// referee: a burst that needs a scan is listed by the first pass, the scans run side by side, a second pass decodes the listed bursts.
+		// (Short feeds too, since round 6c: their burst wavefronts used to scan on the spot - a weak burst with ten marked symbols held its
+		// block for 22 ms, profiles/r06_weak_bursts.txt; their lists and the grids that serve them are a sixteenth of a long feed's.)
+		const bool defer5 = c->referee && c->ref_optimistic && ((c->ref_kinds >> REF_SYMBOLS) & 1);
+		const uint32_t dq_cap = small ? kDeferBursts / 16 : kDeferBursts, sq_cap = small ? kDeferScans / 16 : kDeferScans;
+		if(defer5) k5.df = BurstDefer{ sl.d_dq, sl.d_rqn + 1, dq_cap, sl.d_sq, sl.d_rqn + 2, sq_cap, 1 };
 		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: no bursts to decode)
 		const unsigned k5_lds = (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves);
-		if(small) hipExtLaunchKernelGGL(k_nf_burst, dim3(nf_grid + sl.k5_waves / kBurstWaves), dim3(64 * kNfWaves), std::max(nf_lds, k5_lds), s5_, EV(8), EV(11), 0, k4b, k5, (uint32_t)nf_grid);
-		else if(!defer5) hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), EV(11), 0, k5);
-		else {
-			hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), (hipEvent_t) nullptr, 0, k5);
-			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kDeferScans / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), (uint32_t)kDeferScans, (int64_t)(k0 + D), rty ? sl.d_retry + 2 * kRetryScans : (ScanReq *) nullptr, sl.d_rqn + 6, kRetryScans, 1);
+		hipEvent_t ev_last5 = defer5 ? (hipEvent_t) nullptr : EV(11);
+		if(small) hipExtLaunchKernelGGL(k_nf_burst, dim3(nf_grid + sl.k5_waves / kBurstWaves), dim3(64 * kNfWaves), std::max(nf_lds, k5_lds), s5_, EV(8), ev_last5, 0, k4b, k5, (uint32_t)nf_grid);
+		else hipExtLaunchKernelGGL(k_burst, dim3(sl.k5_waves / kBurstWaves), dim3(64 * kBurstWaves), k5_lds, s5_, EV(10), ev_last5, 0, k5);
+		if(defer5) {
+			LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(sq_cap / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)sl.d_sq, (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 2), sq_cap, (int64_t)(k0 + D), rty ? sl.d_retry + 2 * kRetryScans : (ScanReq *) nullptr, sl.d_rqn + 6, kRetryScans, 1);
 			if(rty) LAUNCH_SCAN_MULTI(hipLaunchKernelGGL, dim3(kRetryScans / kScanLanes), dim3(64 * kScanWaves), 0, s5_, k5.ref, (uint32_t)(16 * sl.seq + 6), (const ScanReq *)(sl.d_retry + 2 * kRetryScans), (const RefReq *) nullptr, (const uint32_t *)(sl.d_rqn + 6), kRetryScans, (int64_t)(k0 + D),
 			                  (ScanReq *) nullptr, (uint32_t *) nullptr, 0u, rty);
 			K5Args k5b = k5; k5b.df.pass = 2; k5b.ref_launch = (uint32_t)(16 * sl.seq + 7);
-			hipExtLaunchKernelGGL(k_burst, dim3(kDeferBursts / kBurstWaves / 4), dim3(64 * kBurstWaves), k5_lds, s5_, (hipEvent_t) nullptr, EV(11), 0, k5b);
+			hipExtLaunchKernelGGL(k_burst, dim3(std::max(1u, dq_cap / kBurstWaves / 4)), dim3(64 * kBurstWaves), k5_lds, s5_, (hipEvent_t) nullptr, EV(11), 0, k5b);
 		}
 		if(!small) HIPCHK(hipStreamWaitEvent(s5_, sl.ev_nf, 0));
 		// record chunks of kFrameChunk: enough workgroups for the records the burst decoder's wavefronts own, at most 256

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/time.h>
 #include "vdl2hip_dropin.h"
 
 #define FILE_BUFSIZE 320000U     /* src/dumpvdl2.h:48 */
@@ -35,7 +36,7 @@ int main(int argc, char **argv) {
 	int nchan = argc - 4;
 	uint32_t sample_rate = 10500u * 10u * oversample;            /* src/dumpvdl2.c:1073 */
 	vdl2_channel_t **ch = calloc((size_t)nchan, sizeof *ch);
-	vdl2hip_dropin_configure(0.f, "HARNESS");
+	vdl2hip_dropin_configure(getenv("HARNESS_MAX_PPM") ? strtof(getenv("HARNESS_MAX_PPM"), NULL) : 0.f, "HARNESS");   /* Config.max_ppm (--max-ppm), Config.station_id */
 	for(int i = 0; i < nchan; i++)
 		if((ch[i] = vdl2_channel_init(centerfreq, (uint32_t)strtoul(argv[4 + i], NULL, 10), sample_rate, oversample)) == NULL) return 2;
 	if(rs_init() < 0) return 3;
@@ -51,13 +52,20 @@ int main(int argc, char **argv) {
 	if(!f) { perror("open"); return 2; }
 	static unsigned char buf[FILE_BUFSIZE];
 	sbuf = calloc(FILE_BUFSIZE / sizeof(int16_t), sizeof(float));
-	uint32_t len;
+	uint32_t len, nblk = 0;
+	struct timeval t0, t1, t2;
+	gettimeofday(&t0, NULL); t1 = t0;
 	do {
 		len = (uint32_t)fread(buf, 1, FILE_BUFSIZE, f);
 		process_buf_short(buf, len, NULL);
+		if(nblk++ == 0) gettimeofday(&t1, NULL);                  /* (the first call creates the receiver: hundreds of milliseconds) */
 	} while(len == FILE_BUFSIZE);
 	fclose(f);
 	pthread_barrier_wait(&demods_ready);                        /* src/dumpvdl2.c:1170 */
+	gettimeofday(&t2, NULL);
+	if(getenv("HARNESS_TIMING") && nblk > 1)
+		fprintf(stderr, "HARNESS %u blocks of %u bytes: %.3f ms per block after the first (which took %.1f ms)\n", nblk, FILE_BUFSIZE,
+				((t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_usec - t1.tv_usec) * 1e-3) / (nblk - 1), (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_usec - t0.tv_usec) * 1e-3);
 	fflush(stdout);
 	return 0;
 }

@@ -360,6 +360,32 @@ def test_many_channel_configs_vs_oracle(vh, oracle_mod, which, secs):
     rx.close()
 
 
+@pytest.mark.parametrize("pieces", ["blocks", "collected", "long"])
+def test_weak_bursts_without_the_ppm_gate(vh, oracle_mod, pieces):
+    """config4 WITHOUT its --max-ppm gate (the reference's default, demod.c:190-192): idle channels lock on to what leaks over from
+    neighbours 8 kHz away and decode it - hundreds of weak bursts a second, a symbol in a few hundred within the referee's margin:
+    40 listed stretches per 320 000-byte block where the gated workload has one.  The burst decoder lists such bursts, the
+    stretches are scanned side by side and a second pass decodes them (vdl2hip.hip: launch_rest) - in short feeds too since round
+    6c (`blocks`: the reference's own block size, every block a short feed), in the adapter's collected blocks (16 per feed) and in
+    long pieces.  Frames, timing and the 18 counters identical to the oracle's; and the lists hold: almost nothing is scanned by a
+    burst's own wavefront (a stretch costs 4.4 ms there)."""
+    import dataclasses, os
+    from dumpvdl2_amd import workloads, synth
+    cfg = dataclasses.replace(workloads.config4(1.5), rx_max_ppm=0.0)
+    iq, bursts = synth.synthesize(cfg)
+    o = oracle_mod.Oracle(cfg.centerfreq, list(cfg.freqs), oversample=20, max_ppm=0.0)
+    o.process(iq.view(np.uint8), block_bytes=1 << 24, nthreads=min(len(cfg.freqs), os.cpu_count() or 8))
+    fo = o.frames()
+    chunks = {"blocks": (80_000, 80_001), "collected": (1_280_000, 1_280_001), "long": (2_000_000, 4_000_000)}[pieces]
+    rx, fg, cnt = gpu_decode(vh, cfg, iq, chunks=chunks, max_block=16_000_000)
+    assert len(fo) > 300
+    assert_frames_equal(fo, fg, label=f"no gate, {pieces}")
+    cases.assert_counters_equal(cnt, [list(o.counters(c).values()) for c in range(len(cfg.freqs))], f"no gate, {pieces}", exact_diagnostics=False)
+    st = rx.stats()
+    assert st["referee_refused"] == 0 and st["referee_symbol_scans"] > 200, st
+    rx.close()
+
+
 @pytest.mark.parametrize("mode", ["plain", "again", "straddle_again", "straddle_mismatch"])
 @pytest.mark.parametrize("which,secs,chunks", [("config4", 3.0, (1_100_000, 1_500_000)), ("config3", 4.0, (700_000, 4_000_000))])
 def test_walk_ahead_chosen_feed_by_feed(vh, oracle_mod, which, secs, chunks, mode):
