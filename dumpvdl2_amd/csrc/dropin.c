@@ -283,13 +283,16 @@ static void deliver_block(void) {
 	int r = vdl2hip_group_drain(G.grp, push_frame, NULL);
 	if(r < 0) { fprintf(stderr, "vdl2hip_group_drain: %s\n", vdl2hip_strerror(r)); _exit(2); }
 	const double t1 = T.on ? now_ms() : 0;
-	/* the drain calls only count device-side buffer overflows (bursts or frames dropped): say so once per occurrence */
-	uint64_t ov = 0;
-	for(uint32_t i = 0; i < vdl2hip_group_size(G.grp); i++) {
-		vdl2hip_stats st;
-		if(vdl2hip_get_stats(vdl2hip_group_ctx(G.grp, i), &st) == VDL2HIP_OK) ov += st.overflow_feeds;
+	/* the drain calls only count device-side buffer overflows (bursts or frames dropped): say so once per occurrence.
+	 * (vdl2hip_get_stats() collects every feed in flight first - it waits for the device: only where that is wanted anyway) */
+	if(lag == 0) {
+		uint64_t ov = 0;
+		for(uint32_t i = 0; i < vdl2hip_group_size(G.grp); i++) {
+			vdl2hip_stats st;
+			if(vdl2hip_get_stats(vdl2hip_group_ctx(G.grp, i), &st) == VDL2HIP_OK) ov += st.overflow_feeds;
+		}
+		if(ov != G.overflow_seen) { fprintf(stderr, "vdl2hip: device output buffers overflowed in %llu block(s): frames were dropped\n", (unsigned long long)(ov - G.overflow_seen)); G.overflow_seen = ov; }
 	}
-	if(ov != G.overflow_seen) { fprintf(stderr, "vdl2hip: device output buffers overflowed in %llu block(s): frames were dropped\n", (unsigned long long)(ov - G.overflow_seen)); G.overflow_seen = ov; }
 	if(T.on) {
 		T.drain += t1 - t0; T.stats += now_ms() - t1; T.drains++; T.frames += (unsigned long)r;
 		if(lag == 0) fprintf(stderr, "vdl2hip dropin timing: %llu blocks, %lu feeds, %lu drains, %lu frames; producer: %.1f ms waiting at demods_ready, %.1f in feeds, %.1f waiting at samples_ready; "
@@ -308,7 +311,6 @@ static void process_buf(unsigned char *buf, uint32_t len, int fmt) {
 	pthread_barrier_wait(&demods_ready);
 	const double t1 = T.on ? now_ms() : 0;
 	take_block(buf, len, fmt, now);
-	if(getenv("VDL2HIP_DROPIN_EXPERIMENT_DRAIN_HERE")) deliver_block();
 	const double t2 = T.on ? now_ms() : 0;
 	pthread_barrier_wait(&samples_ready);
 	gettimeofday(&G.left, NULL);

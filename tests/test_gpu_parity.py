@@ -1100,9 +1100,14 @@ def test_dropin_adapter_collects_blocks(vh, tmp_path, blocks):
             if l.startswith("FRAME"):
                 kv = dict(t.split("=", 1) for t in l.split()[1:])
                 got.setdefault(int(kv["freq"]), []).append((int(kv["idx"]), hashlib.sha1(bytes.fromhex(kv["octets"])).hexdigest(), int(kv["S"]), int(kv["L"]), int(kv["F"]),
-                                                            kv["pwr"], kv["nf"], kv["ppm"]))
+                                                            float(kv["pwr"]), float(kv["nf"]), float(kv["ppm"])))
         runs[batch] = got
-    assert runs[None] == runs["5"] == runs["1"] and sum(len(v) for v in runs["1"].values()) > (5 if blocks else 20)
+    for other in ("5", "1"):        # octets and integer metadata identical and in the same order per channel; the floats (printed to 0.001) within SURVEY 8.5
+        assert runs[None].keys() == runs[other].keys()
+        for k in runs[None]:
+            assert [t[:5] for t in runs[None][k]] == [t[:5] for t in runs[other][k]]
+            assert all(abs(p - q) <= 0.0011 for a, b in zip(runs[None][k], runs[other][k]) for p, q in zip(a[5:], b[5:]))
+    assert sum(len(v) for v in runs["1"].values()) > (5 if blocks else 20)
     if not blocks:
         want = {}
         for f in gold["frames"]:
