@@ -1,11 +1,11 @@
 """config4 with and without its --max-ppm gate in the reference's own blocks (320 000 bytes), k per feed: without the gate idle channels
 lock on to their neighbours' leakage and decode it - weak bursts, many symbols within the referee's margin.
-usage: python dev/gpu_weak_bursts.py [max_ppm] [k,k,...]"""
+usage: python dev/gpu_weak_bursts.py [max_ppm] [k,k,...] [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dumpvdl2_amd import vdl2hip, synth, workloads
-cfg = workloads.config4(4.0)
+cfg = workloads.config4(float(sys.argv[3]) if len(sys.argv) > 3 else 4.0)
 iq, _ = synth.synthesize(cfg)
 raw = iq.view(np.uint8)
 BLK = 320000

@@ -45,7 +45,15 @@ constexpr uint32_t kPreScans = 4096;    // referee: stretches around marked cand
 // burst's own wavefront, one stretch after the other at 4.4 ms each: with 256 / 512 (rounds 5, 6a/b) a capture full of weak bursts - config4
 // WITHOUT its --max-ppm gate: the neighbours' leakage is locked on to and decoded, a symbol in a few hundred within the margin - ran over
 // and a 16-block feed took 68 ms instead of 2 (profiles/r06_weak_bursts.txt).  A short feed lists a sixteenth of these.
-constexpr uint32_t kDeferBursts = 4096, kDeferScans = 8192;
+// The lists grow with the feed: a stretch per 8 192 channel-samples of the feed (a 16 s block of 256 channels: 52 000; a rank's 32
+// channels: 6 500), half as many bursts, at least kDeferScans / kDeferBursts; the grids that serve them are sized the same way - a
+// workgroup that finds no request is gone within a microsecond.
+constexpr uint32_t kDeferBursts = 4096, kDeferScans = 8192, kDeferScansMax = 1u << 17;
+static uint32_t defer_scans_for(int64_t D, int C) {
+	const uint64_t want = (uint64_t)(D > 0 ? D : 0) * (uint64_t)C / 8192u;
+	const uint64_t cap = std::min<uint64_t>(kDeferScansMax, std::max<uint64_t>(kDeferScans, want));
+	return (uint32_t)((cap + 63) / 64 * 64);
+}
 // Streams per priority class.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per
 // priority, round-robin in the order of their creation, and two streams on one queue run one after the other.  With a scan stream and
 // a burst stream per slot (four of each), a scan stream shared its queue with the walk stream and burst streams shared theirs with the
@@ -146,7 +154,7 @@ struct vdl2hip_ctx {
 	bool referee = true; int ref_kinds = 7; bool ref_prescan = false;   /* VDL2HIP_REF_PRESCAN=1: the stretches around marked candidates are made exact ahead of the walk - a rank-sized shard 4.05 -> 2.88 ms per step, 256 channels 7.2 -> 7.85: for receivers of few channels */ int64_t ref_warm = 3 << 16 /* 196 608: kernels.h */, ref_T = 0; uint8_t *d_refhist = nullptr; uint64_t ref_cap = 0, ref_wp = 0;
 	struct HistPiece { int64_t s0, n; uint64_t pos; }; std::vector<HistPiece> ref_pieces;
 	unsigned long long *d_refdbg = nullptr; int ref_dbg_chan = -1;
-	WalkState *d_ws_snap[3] = {}, *d_ws_tmp = nullptr; unsigned long long *d_cnt_snap[3] = {}, *d_cnt_tmp = nullptr; uint32_t rq_cap = 8192; bool ref_optimistic = true;
+	WalkState *d_ws_snap[3] = {}, *d_ws_tmp = nullptr; unsigned long long *d_cnt_snap[3] = {}, *d_cnt_tmp = nullptr; uint32_t rq_cap = 8192; uint32_t sq_alloc = 8192; bool ref_optimistic = true;
 	int walk_ahead = 1; bool walk_ahead_auto = true; double walk_ahead_below = 1.1e8; int debug_force_mismatch = 0;   // launch_back(): the walks of the next feed (1) or the next two (2) do not wait for this feed's check
 	int ref_retry_mul = 2;                 // a scan that has not met its witness is run again from this many times further back (0: not at all; VDL2HIP_REF_RETRY)
 	RefChan *d_ref[kSlots] = {}; unsigned long long *d_refdone = nullptr; uint32_t *d_refdonen = nullptr, *d_refstats = nullptr; uint8_t *d_mix = nullptr;
@@ -671,7 +679,7 @@ static int launch_rest(vdl2hip_ctx *c, OutSlot &sl, OutSlot *succ, OutSlot *succ
 		// (Short feeds too, since round 6c: their burst wavefronts used to scan on the spot - a weak burst with ten marked symbols held its
 		// block for 22 ms, profiles/r06_weak_bursts.txt; their lists and the grids that serve them are a sixteenth of a long feed's.)
 		const bool defer5 = c->referee && c->ref_optimistic && ((c->ref_kinds >> REF_SYMBOLS) & 1);
-		const uint32_t dq_cap = small ? kDeferBursts / 16 : kDeferBursts, sq_cap = small ? kDeferScans / 16 : kDeferScans;
+		const uint32_t sq_cap = small ? kDeferScans / 16 : std::min(c->sq_alloc, defer_scans_for(D, c->C)), dq_cap = sq_cap / 2;
 		if(defer5) k5.df = BurstDefer{ sl.d_dq, sl.d_rqn + 1, dq_cap, sl.d_sq, sl.d_rqn + 2, sq_cap, 1 };
 		if(c->ablate & 4) k5.nchan = 0;      // (experiment builds: no bursts to decode)
 		const unsigned k5_lds = (unsigned)((sizeof(BurstShared) + 4 * (kK5MaxChan + 1)) * kBurstWaves);
@@ -977,9 +985,10 @@ int vdl2hip_create(const vdl2hip_cfg *cfg, vdl2hip_ctx **out) {
 		// feed later: with 256 channels, where the front hides the chain anyway, that extra depth cost 10 % and more)
 		c->walk_ahead = (count >= 16 && count <= 64) ? 1 : 0;   // (8 channels: the walk itself is longer than the front, the second walks' extra launches cost more than they save: 1.22 against 1.11 ms)
 		if(const char *e = getenv("VDL2HIP_WALK_AHEAD")) { const int v = atoi(e); c->walk_ahead = v < 0 ? 0 : v > 2 ? 2 : v; c->walk_ahead_auto = false; }      // 0: a feed's walk waits for the check of the feed before (round 5's schedule)
+		c->sq_alloc = defer_scans_for((int64_t)dmax, (int)count);
 		for(auto &sl : c->slot) {
 			DEV_ALLOC(sl.d_rq, (size_t)c->rq_cap * sizeof(RefReq)); DEV_ALLOC(sl.d_rqn, 32); DEV_ALLOC(sl.d_retry, 3 * (size_t)kRetryScans * sizeof(ScanReq)); DEV_ALLOC(sl.d_rqflag, (size_t)count * 4);
-			DEV_ALLOC(sl.d_dq, (size_t)kDeferBursts * 4); DEV_ALLOC(sl.d_sq, (size_t)kDeferScans * sizeof(ScanReq));
+			DEV_ALLOC(sl.d_dq, (size_t)(c->sq_alloc / 2) * 4); DEV_ALLOC(sl.d_sq, (size_t)c->sq_alloc * sizeof(ScanReq));
 			DEV_ALLOC(sl.d_pq, (size_t)kPreScans * sizeof(ScanReq)); DEV_CHK(hipEventCreateWithFlags(&sl.ev_pre, hipEventDisableTiming));
 			DEV_ALLOC(sl.d_rqbad, (size_t)count * sizeof(RefBad)); DEV_CHK(hipMemset(sl.d_rqbad, 0, (size_t)count * sizeof(RefBad)));
 			DEV_ALLOC(sl.d_rqflag2, (size_t)count * 4); DEV_CHK(hipMemset(sl.d_rqflag2, 0, (size_t)count * 4));
