@@ -55,7 +55,7 @@ extern pthread_barrier_t demods_ready, samples_ready;   /* src/dumpvdl2.c:66-67 
 #define ARRIVALS 256
 #define BATCH_MAX 64u
 #define BATCH_DECIMATED 64000u     /* decimated samples per feed the collector aims for (two walk segments are 32 768: vdl2hip.hip, feed_is_small) */
-#define LIVE_GAP_US 2000L          /* a producer away for longer than this between two blocks is a live source */
+#define LIVE_GAP_US 10000L         /* a producer away for longer than this between two blocks is a live source (an SDR's blocks are tens of milliseconds apart; a file on a slow disk is not to be taken for one) */
 
 float *sbuf;                       /* callers allocate it (src/dumpvdl2.c:342,346; src/rtl.c:194); never read here */
 
