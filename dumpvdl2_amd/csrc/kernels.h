@@ -62,7 +62,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define VDL2_K1_PRIO 0
 #endif
 constexpr int kRefPieces = 6;              // stretches of raw input a feed can reach back into: the feed's own block + the history ring (it may wrap)
-constexpr int kRefCache = 64;              // stretches of a channel already made exact (a speculative walker and the stitcher come by the same places)
+constexpr int kRefCache = 256;             // stretches of a channel already made exact (a speculative walker and the stitcher come by the same places; the burst decoder's second pass looks its listed stretches up here: with 64 - until round 6c - a 16 s feed full of weak bursts, 105 listed stretches per channel, pushed its own out before they were read and scanned them again, one by one)
 struct RefPiece { const void *p; int64_t s0, n; };   // raw samples with absolute index s0 <= s < s0 + n, contiguous at p
 struct RefChan {
 	cf32 *y; uint32_t cap, mask;           // the decimated rings, [nchan][cap]
@@ -151,10 +151,10 @@ __device__ __forceinline__ bool ref_entry_visible(uint32_t entry, uint32_t mine)
 __device__ __forceinline__ bool ref_done_lookup(const unsigned long long *done, uint32_t ndv, int64_t n_lo, int64_t n_hi, uint32_t launch, int lane) {
 	const uint32_t nd = ndv < (uint32_t)kRefCache ? ndv : (uint32_t)kRefCache;
 	bool hit = false;
-	if((uint32_t)lane < nd) {
-		const unsigned long long e = __hip_atomic_load(done + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	for(uint32_t i = (uint32_t)lane; i < nd; i += 64u) {          // (an entry per lane and round: four rounds when the ring is full)
+		const unsigned long long e = __hip_atomic_load(done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const int64_t lo = (int64_t)(e >> 32) << 8, hi = lo + ((int64_t)((e >> 16) & 0xffffull) << 8) + 255;
-		hit = lo <= n_lo && n_hi <= hi && ref_entry_visible((uint32_t)(e & 0xffffull), launch);
+		hit = hit || (lo <= n_lo && n_hi <= hi && ref_entry_visible((uint32_t)(e & 0xffffull), launch));
 	}
 	return __any(hit) != 0;
 }
@@ -1477,8 +1477,11 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 	const float A0 = rp->A0, A1 = rp->A1, A2 = rp->A2;
 	uint32_t *stats = rp->stats;
 	// ---- the requests of this workgroup: stretch, run-up, what has been done before (as ref_exact_window_dev) ----
-	if(threadIdx.x < kScanLanes) {
-		const int r = threadIdx.x;
+	// (the whole first wavefront: four lanes per request - lanes r, r + 16, r + 32, r + 48 work out the same values and share the look-up in
+	// the channel's ring of finished stretches, a quarter of its entries each; lane r alone counts and writes)
+	static_assert(kScanLanes == 16, "four lanes of the first wavefront per request");
+	if(threadIdx.x < 64) {
+		const int r = threadIdx.x & (kScanLanes - 1), part = threadIdx.x >> 4;
 		int64_t n_lo = 0, n_hi = -1, s_beg = 0, len = 0; int c = 0, kind = 0; uint32_t fl = 0;
 		if(base + r < ntot && npiece > 0) {
 			if(sq) { const ScanReq q = sq[base + r]; c = q.chan; kind = q.kind; n_lo = q.lo; n_hi = q.hi; }
@@ -1494,12 +1497,18 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 				const unsigned long long *done = rp->done + (size_t)c * kRefCache;
 				const uint32_t ndv = rp->done_n[c], nd = ndv < (uint32_t)kRefCache ? ndv : (uint32_t)kRefCache;
 				bool hit = false;
-				for(uint32_t i = 0; i < nd; i++) {
+				for(uint32_t i = (uint32_t)part; i < nd; i += 4u) {
 					const unsigned long long e = __hip_atomic_load(done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					const int64_t lo = (int64_t)(e >> 32) << 8, hi = lo + ((int64_t)((e >> 16) & 0xffffull) << 8) + 255;
 					hit = hit || (lo <= n_lo && n_hi <= hi && ref_entry_visible((uint32_t)(e & 0xffffull), launch));
 				}
-				if(hit) { atomicAdd(stats + 1, 1u); go = false; }
+				// (the four lanes of a request have taken the same branches up to here: its partners are active whenever a lane is)
+				// (no short cut: a lane that skipped the exchange would not be read by its partners)
+				int h = hit ? 1 : 0;
+				h |= __shfl_xor(h, 16);
+				h |= __shfl_xor(h, 32);
+				hit = h != 0;
+				if(hit) { if(part == 0) atomicAdd(stats + 1, 1u); go = false; }
 			}
 			if(go) {
 				const int64_t s_end = (int64_t)os * (n_hi + 1);
@@ -1511,7 +1520,7 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 					// (a retry goes with what is held - it was not refused the first time)
 					if(s_beg > 0 && (int64_t)os * n_lo - s_beg < rp->warm / 4) refuse = true;
 				}
-				if(refuse) { atomicAdd(stats + 2, 1u); go = false; }
+				if(refuse) { if(part == 0) atomicAdd(stats + 2, 1u); go = false; }
 				else {
 					s_beg -= s_beg % os;
 					len = s_end - s_beg;
@@ -1520,8 +1529,10 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_ref_scan_multi(RefChan *rp,
 			}
 			if(!go) len = 0;
 		}
-		sh.s_beg[r] = s_beg; sh.len[r] = len; sh.n_lo[r] = n_lo; sh.n_hi[r] = n_hi; sh.chan[r] = c; sh.kind[r] = kind; sh.flags[r] = fl;
-		sh.dphi[r] = len ? rp->dphi[c] : 0u;
+		if(part == 0) {
+			sh.s_beg[r] = s_beg; sh.len[r] = len; sh.n_lo[r] = n_lo; sh.n_hi[r] = n_hi; sh.chan[r] = c; sh.kind[r] = kind; sh.flags[r] = fl;
+			sh.dphi[r] = len ? rp->dphi[c] : 0u;
+		}
 	}
 	__syncthreads();
 	if(threadIdx.x < kScanLanes) {
