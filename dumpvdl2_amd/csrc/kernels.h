@@ -504,7 +504,21 @@ __device__ unsigned long long vdl2_k1_prof[64][16];
 #define K1_END() do {} while(0)
 #endif
 
-template<int OS, int R, int CR>
+// (i - 127.5f) / 127.5f of an unsigned byte (demod.c:349-354) without the division: d = i - 127.5 is exact, q = d * fl(1 / 127.5) is within an
+// ulp, one Newton step on the residual d - 127.5 q makes it the correctly rounded quotient - for all 256 values (checked on the device
+// against the division: tests/test_gpu_parity.py::test_uint8_conversion_without_the_division)
+__device__ __forceinline__ float u8_level(uint32_t i) {
+	const float d = (float)i - 127.5f, r = 1.0f / 127.5f;
+	const float q = d * r;
+	return __builtin_fmaf(__builtin_fmaf(-127.5f, q, d), r, q);
+}
+__global__ void k_u8_level_probe(float *out) { const uint32_t i = threadIdx.x; out[i] = u8_level(i); out[256 + i] = ((float)i - 127.5f) / 127.5f; }
+
+// U8: the build for unsigned-byte input (the reference's default for --iq-file and what an RTL-SDR delivers): its tiles are fetched a tile
+// ahead and converted without per-sample range checks or divisions, as the s16 tiles of the other build are (round 6c: the generic
+// staging path cost a 256-channel receiver 18 % of its channeliser: 4.46 against 3.77 ms per 16 s).  Only instantiated where the tile
+// prefetch is (kPrefetch below); U8 = false is the code as it was.
+template<int OS, int R, int CR, bool U8 = false>
 __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MIN_BLOCKS)) void k_chanfir(K1Args a) {
 	static_assert(64 * R == kFixW || R == 1, "the fused fix-up assumes the fix window is the segment's first tile");
 	static_assert(R >= 1 && R <= 2, "the run's outputs are held in two register pairs");
@@ -535,6 +549,7 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	// registers (114 -> 128, a few loop-invariant values spilled outside the loops): only where four channels per wave leave that room
 	// and the tile is a whole number of 256-sample rows.
 	constexpr bool kPrefetch = OS != 0 && CR >= 4 && (64 * R * OS + 255) / 256 <= 10 && (64 * R * OS) % 256 == 0;
+	static_assert(!U8 || kPrefetch, "the unsigned-byte build exists where the tile prefetch does");
 	constexpr int kPre = kPrefetch ? (64 * R * OS) / 256 : 1;
 	constexpr bool kPipeGather = kPrefetch;
 	uint32_t pre[kPre]; bool have_pre = false;
@@ -542,11 +557,17 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 	for(int k = 0; k < kPre; k++) pre[k] = 0u;
 	if(kPrefetch) {
 		const int64_t s0 = (int64_t)seg * a.tiles * (64 * R * (OS ? OS : 1));      // first sample of the segment's first tile
-		have_pre = a.fmt == 1 && s0 >= (int64_t)a.ncarry && s0 + 64 * R * (OS ? OS : 1) <= (int64_t)a.nlogical && (int64_t)seg * a.tiles * (64 * R) < a.D;
+		have_pre = a.fmt == (U8 ? 0 : 1) && s0 >= (int64_t)a.ncarry && s0 + 64 * R * (OS ? OS : 1) <= (int64_t)a.nlogical && (int64_t)seg * a.tiles * (64 * R) < a.D;
 		if(have_pre) {
+			if constexpr(U8) {
+				const uint16_t *sn = (const uint16_t *)a.in + (s0 - a.ncarry);
+				#pragma unroll
+				for(int k = 0; k < kPre; k++) pre[k] = sn[tid + 256 * k];
+			} else {
 			const uint32_t *sn = (const uint32_t *)a.in + (s0 - a.ncarry);
 			#pragma unroll
 			for(int k = 0; k < kPre; k++) pre[k] = sn[tid + 256 * k];
+			}
 		}
 	}
 	lut[tid] = ((const float4 *)a.lut)[tid];
@@ -592,8 +613,25 @@ __global__ __launch_bounds__(256, (CR >= 4 ? VDL2_K1_MIN_BLOCKS_CR4 : VDL2_K1_MI
 		K1_MARK(ts ? 4 : 0);                                     // 0: prologue (tables, first prefetch); 4: scan, outputs, carry of the previous tile
 		if(ts) __syncthreads();                                  // everyone is done with the previous tile
 		K1_MARK(5);                                              // 5: waiting for the workgroup's other waves before the tile is overwritten
-		const bool fast_now = a.fmt == 1 && sbase >= (int64_t)a.ncarry && sbase + tile_n <= (int64_t)a.nlogical;
-		if(kPrefetch && fast_now) {
+		const bool fast_now = a.fmt == (U8 ? 0 : 1) && sbase >= (int64_t)a.ncarry && sbase + tile_n <= (int64_t)a.nlogical;
+		if(kPrefetch && U8 && fast_now) {
+			// (the unsigned-byte build: the same, two bytes per sample)
+			const uint16_t *src = (const uint16_t *)a.in + (sbase - a.ncarry);
+			#pragma unroll
+			for(int k = 0; k < kPre; k++) {
+				const int t = tid + 256 * k;
+				const uint32_t w = have_pre ? pre[k] : (uint32_t)src[t];
+				const int l = t / run, m = t - l * run;
+				tile[m * 65 + l] = make_float2(u8_level(w & 0xffu), u8_level((w >> 8) & 0xffu));
+			}
+			const int64_t snext = sbase + tile_n;
+			have_pre = ts + 1 < a.tiles && (tix + 1) * L < a.D && snext + tile_n <= (int64_t)a.nlogical;
+			if(have_pre) {
+				const uint16_t *sn = (const uint16_t *)a.in + (snext - a.ncarry);
+				#pragma unroll
+				for(int k = 0; k < kPre; k++) pre[k] = sn[tid + 256 * k];
+			}
+		} else if(kPrefetch && fast_now) {
 			// the usual case - a cs16 tile that lies entirely inside this feed's block: no per-sample range or carry checks
 			const uint32_t *src = (const uint32_t *)a.in + (sbase - a.ncarry);
 			#pragma unroll

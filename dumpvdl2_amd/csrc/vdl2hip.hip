@@ -195,7 +195,10 @@ static void launch_chanfir(vdl2hip_ctx *c, const K1Args &a, int cr, size_t lds, 
 	// e0/e1 (profiling only, else null): the runtime stamps them with the kernel's own start and stop, so the roofline figure is
 	// the kernel's duration and not the time the launch spent queued behind other streams' work
 	switch(cr) {
-		case 4: hipExtLaunchKernelGGL((k_chanfir<OS, R, 4>), grid, block, (uint32_t)lds, c->stream, e0, e1, 0, b); break;
+		case 4:
+			// (unsigned-byte input where the tile prefetch exists: the build that fetches and converts its tiles the way the s16 build does)
+			if constexpr(OS == 20 || OS == 10) { if(c->fmt == VDL2HIP_FMT_U8) { hipExtLaunchKernelGGL((k_chanfir<OS, R, 4, true>), grid, block, (uint32_t)lds, c->stream, e0, e1, 0, b); break; } }
+			hipExtLaunchKernelGGL((k_chanfir<OS, R, 4>), grid, block, (uint32_t)lds, c->stream, e0, e1, 0, b); break;
 		case 2: hipExtLaunchKernelGGL((k_chanfir<OS, R, 2>), grid, block, (uint32_t)lds, c->stream, e0, e1, 0, b); break;
 		default: hipExtLaunchKernelGGL((k_chanfir<OS, R, 1>), grid, block, (uint32_t)lds, c->stream, e0, e1, 0, b); break;
 	}
@@ -1405,6 +1408,15 @@ int vdl2hip_debug_scan_multi(vdl2hip_ctx *c, const int32_t *chan, const int64_t 
 int vdl2hip_debug_exact_window(vdl2hip_ctx *c, uint32_t chan, int64_t n_lo, int64_t n_hi) { return vdl2hip_debug_exact_window_many(c, chan, n_lo, n_hi, 1, 0, nullptr); }
 
 // test hook (not declared in vdl2hip.h): what the DPP controls the channeliser's scan relies on do on this device
+int vdl2hip_debug_u8_levels(float out[512]) {        // out[0..255]: the channeliser's division-free (i - 127.5) / 127.5, out[256..511]: the division (tests)
+	float *d = nullptr;
+	if(hipMalloc((void **)&d, 512 * sizeof(float)) != hipSuccess) return VDL2HIP_E_NOMEM;
+	hipLaunchKernelGGL(k_u8_level_probe, dim3(1), dim3(256), 0, 0, d);
+	const bool ok = hipMemcpy(out, d, 512 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+	(void)hipFree(d);
+	return ok ? VDL2HIP_OK : VDL2HIP_E_DEVICE;
+}
+
 int vdl2hip_debug_dpp_probe(const float in[64], float out[256]) {
 	float *d_in = nullptr, *d_out = nullptr;
 	if(hipMalloc((void **)&d_in, 64 * 4) != hipSuccess || hipMalloc((void **)&d_out, 256 * 4) != hipSuccess) return VDL2HIP_E_NOMEM;

@@ -275,6 +275,26 @@ def test_uint8_input(vh, oracle_mod):
     assert cnt == [list(o.counters(c).values()) for c in range(2)]
 
 
+@pytest.mark.parametrize("os_", [20, 10])
+def test_uint8_input_many_channels(vh, oracle_mod, os_):
+    """The channeliser's unsigned-byte build (four channels per wavefront, tiles fetched a tile ahead, conversion without the division:
+    oversampling 20 and 10, the reference's --iq-file default): 64 channels of a u8 capture, 1.5 s in pieces from a few samples to
+    1.5 M, against the oracle fed the same bytes (process_buf_uchar, src/demod.c:339-354)."""
+    from dumpvdl2_amd import synth
+    import os
+    cfg = synth.SynthConfig(centerfreq=CF, freqs=synth.channel_plan(64, CF, 25000 if os_ == 20 else 12000), oversample=os_, duration_s=1.5, seed=77 + os_,
+                            amplitude=0.2, noise_sigma=0.01, tdm_slots=4, tdm_slot_s=0.2, rx_max_ppm=5.0)
+    iq8, bursts = synth.synthesize(cfg, dtype=np.uint8)
+    o = oracle_mod.Oracle(CF, list(cfg.freqs), oversample=os_, sample_fmt=oracle_mod.FMT_U8, max_ppm=cfg.rx_max_ppm)
+    o.process(iq8, block_bytes=1 << 22, nthreads=min(64, os.cpu_count() or 8))
+    fo = o.frames()
+    rx, fr, cnt = gpu_decode(vh, cfg, iq8, fmt=0, chunks=(11, 1_500_000), max_block=4_000_000)
+    assert len(fo) > 40
+    assert_frames_equal(fo, fr, label=f"u8 x 64, os {os_}")
+    cases.assert_counters_equal(cnt, [list(o.counters(c).values()) for c in range(64)], f"u8 x 64, os {os_}", exact_diagnostics=False)
+    rx.close()
+
+
 @pytest.mark.parametrize("os_", [13, 16, 7])
 def test_other_oversampling_factors(vh, oracle_mod, os_):
     """13 = Mirics rate (specialised build), 16 and 7 go through the generic-oversample build."""
@@ -1113,6 +1133,19 @@ def test_dropin_adapter_collects_blocks(vh, tmp_path, blocks):
         for f in gold["frames"]:
             want.setdefault(cfg.freqs[f["chan"]], []).append((f["idx"], f["sha1"], f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"]))
         assert {k: sorted(t[:5] for t in v) for k, v in runs[None].items()} == {k: sorted(v) for k, v in want.items()}
+
+
+def test_uint8_conversion_without_the_division(vh):
+    """The channeliser's unsigned-byte build converts (i - 127.5f) / 127.5f (src/demod.c:349-354) with a multiplication and one Newton
+    step instead of the division: the same float for every one of the 256 byte values, on the device and against numpy."""
+    import ctypes as C
+    L = vh.load_library()
+    L.vdl2hip_debug_u8_levels.argtypes = [C.POINTER(C.c_float)]
+    out = (C.c_float * 512)()
+    assert L.vdl2hip_debug_u8_levels(out) == 0
+    o = np.array(out[:], dtype=np.float32)
+    want = ((np.arange(256, dtype=np.float32) - np.float32(127.5)) / np.float32(127.5)).astype(np.float32)
+    assert o[:256].tobytes() == o[256:].tobytes() == want.tobytes()
 
 
 def test_dpp_primitives_behave_as_the_scan_assumes(vh):
