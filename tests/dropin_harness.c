@@ -6,6 +6,7 @@
  * barrier wait :1170; and of the consumer behind avlc_decoder_queue_push() (src/decode.c:165-171,
  * 523-525: it free()s metadata, frame->buf and frame).  Prints one line per frame.
  *   usage: dropin_harness <iq-file> <oversample> <centerfreq> <freq> [freq...]
+ *   environment: HARNESS_U8=1 (the file holds unsigned bytes: process_buf_uchar), HARNESS_MAX_PPM=<x> (--max-ppm), HARNESS_TIMING=1
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -57,7 +58,8 @@ int main(int argc, char **argv) {
 	gettimeofday(&t0, NULL); t1 = t0;
 	do {
 		len = (uint32_t)fread(buf, 1, FILE_BUFSIZE, f);
-		process_buf_short(buf, len, NULL);
+		if(getenv("HARNESS_U8")) process_buf_uchar(buf, len, NULL);     /* --sample-format U8, the --iq-file default (src/dumpvdl2.c:849) */
+		else process_buf_short(buf, len, NULL);
 		if(nblk++ == 0) gettimeofday(&t1, NULL);                  /* (the first call creates the receiver: hundreds of milliseconds) */
 	} while(len == FILE_BUFSIZE);
 	fclose(f);

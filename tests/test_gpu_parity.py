@@ -1148,6 +1148,32 @@ def test_uint8_conversion_without_the_division(vh):
     assert o[:256].tobytes() == o[256:].tobytes() == want.tobytes()
 
 
+def test_dropin_adapter_unsigned_bytes(vh, oracle_mod, tmp_path):
+    """process_buf_uchar() (src/demod.c:339-347: the --iq-file default format) through the adapter, blocks collected (4 u8 blocks of
+    320 000 bytes at oversample 10 hold 64 000 decimated samples) and one by one: the oracle's frames."""
+    import os, subprocess
+    from dumpvdl2_amd import build, synth
+    cfg = synth.SynthConfig(centerfreq=CF, freqs=[CF, CF + 40000], oversample=10, duration_s=1.9, seed=12, amplitude=0.3, noise_sigma=0.01)
+    iq8, _ = synth.synthesize(cfg, dtype=np.uint8)
+    o = oracle_mod.Oracle(CF, list(cfg.freqs), oversample=10, sample_fmt=oracle_mod.FMT_U8)
+    o.process(iq8)
+    want = sorted((cfg.freqs[f["chan"]], f["idx"], f["octets"], f["synd_weight"], f["datalen_octets"], f["num_fec_corrections"]) for f in o.frames())
+    exe = build.build_harness(str(tmp_path / "dropin_harness"))
+    path = tmp_path / "cap.cu8"
+    iq8.tofile(path)
+    for batch in (None, "1"):
+        env = dict(os.environ, HARNESS_U8="1")
+        env.pop("VDL2HIP_DROPIN_BATCH", None)
+        if batch: env["VDL2HIP_DROPIN_BATCH"] = batch
+        out = subprocess.run([exe, str(path), "10", str(CF)] + [str(f) for f in cfg.freqs], check=True, capture_output=True, text=True, timeout=180, env=env).stdout
+        got = []
+        for l in out.splitlines():
+            if l.startswith("FRAME"):
+                kv = dict(t.split("=", 1) for t in l.split()[1:])
+                got.append((int(kv["freq"]), int(kv["idx"]), bytes.fromhex(kv["octets"]), int(kv["S"]), int(kv["L"]), int(kv["F"])))
+        assert sorted(got) == want and len(got) > 5, (batch, len(got), len(want))
+
+
 def test_dpp_primitives_behave_as_the_scan_assumes(vh):
     """The channeliser's wave scan (kernels.h) moves filter states between lanes with DPP controls: row_shr inside rows of 16 lanes
     (out-of-row sources read 0), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3, wave_shr:1 across the wavefront."""
