@@ -407,12 +407,13 @@ def test_weak_bursts_without_the_ppm_gate(vh, oracle_mod, pieces):
 
 
 @pytest.mark.parametrize("mode", ["plain", "again", "straddle_again", "straddle_mismatch"])
-@pytest.mark.parametrize("which,secs,chunks", [("config4", 3.0, (1_100_000, 1_500_000)), ("config3", 4.0, (700_000, 4_000_000))])
+@pytest.mark.parametrize("which,secs,chunks", [("config4", 3.0, (1_100_000, 1_500_000)), ("config3", 4.0, (700_000, 4_000_000)), ("config3", 3.0, (30_000, 1_500_000))])
 def test_walk_ahead_chosen_feed_by_feed(vh, oracle_mod, which, secs, chunks, mode):
     """Whether the next feed's walk goes ahead of a feed's check is decided per feed from its channel-samples (vdl2hip.hip:
     walk_ahead_of): a 256-channel receiver fed a second or so at a time - the drop-in adapter's collected blocks - walks ahead
     like a rank-sized one does on 16 s blocks.  `plain`: the library's own choice on pieces of 1.1-1.5 M samples (256 channels) /
-    0.7-4 M (64); `again`: the hook that flags every channel of every feed, so every second walk runs and is compared with what
+    0.7-4 M (64), and 30 000-1.5 M (64: short feeds - unsegmented, everything on the front stream - between the long ones);
+    `again`: the hook that flags every channel of every feed, so every second walk runs and is compared with what
     the next feed started from; `straddle_*`: the threshold moved into the range of the pieces (debug option walk_ahead_below), so
     feeds that let the next walk go ahead and feeds that do not alternate in one stream - with every channel walked again, and
     with every comparison forced to fail (every channel of the following feed stitched once more).  Frames, burst timing and the
