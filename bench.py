@@ -125,14 +125,19 @@ class Case:
         # the field below only reports it.
         env = os.environ.get("VDL2HIP_REF_PRESCAN")
         self.prescan = (env == "1") if env is not None else self.count <= 64
+        # N > 1: a rank of few channels is handed the exchanged blocks TWO per feed in the timed loops (dist.ShardedFeeder, pairs): the chain
+        # walk - scans - check is a cost per feed, and a rank's front is shorter than it (projected_scaling.two_blocks_per_feed measures the
+        # same on one GPU).  VDL2_BENCH_PAIR=0 / 1 overrides.
+        envp = os.environ.get("VDL2_BENCH_PAIR")
+        self.pair = world > 1 and not shard and ((envp == "1") if envp is not None else self.count <= 64)
         self.rx = vdl2hip.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vdl2hip.FMT_S16LE, cfg.rx_max_ppm,
-                                   device=local, max_block_bytes=self.nbytes, chan_first=self.first, chan_count=self.count)
+                                   device=local, max_block_bytes=self.nbytes * (2 if self.pair else 1), chan_first=self.first, chan_count=self.count)
         self.front = torch.cuda.ExternalStream(self.rx.stream(), device=self.device)
         self.host = torch.from_numpy(self.iq)
 
     def feeder(self, mode, source):
         return self.vdist.ShardedFeeder(self.rx, self.host, self.world, self.rank, mode=mode, source=source, device=self.device,
-                                        front_stream=self.front)
+                                        front_stream=self.front, pairs=self.pair)
 
     def frames_of_step(self, feeder):
         """one synchronous step: every frame this rank's channels produce for one block"""
@@ -177,7 +182,9 @@ class Case:
         t0 = time.perf_counter()
         nframes = 0
         for _ in range(steps):
-            nframes += feeder.step()[0]
+            nframes += feeder.step(pair=self.pair)[0]
+        if self.pair:
+            feeder.flush()                  # (an odd K: the last block has no partner)
         self.rx.set_drain_lag(0)
         nframes += self.rx.drain_packed()[0]
         feeder.finish()
@@ -573,6 +580,36 @@ def dropin_block_rate(case, torch, seconds=2.0, block=320000):
     return out
 
 
+def rank_two_blocks_per_feed(case, per, torch, local, steps, t_all_ms):
+    """rank-sized receivers (ranks 0, 3, 7 of 8) fed TWO 16 s blocks per feed, block resident, six feeds in flight: ms per 16 s block"""
+    vh = case.vdl2hip
+    cfg = case.cfg
+    dev2 = torch.from_numpy(np.concatenate([case.iq, case.iq])).to(f"cuda:{local}")
+    nbytes2 = 2 * case.nbytes
+    rows = []
+    try:
+        for r in (0, 3, 7):
+            rx = vh.Receiver(cfg.centerfreq, list(cfg.freqs), cfg.oversample, vh.FMT_S16LE, cfg.rx_max_ppm, device=local, max_block_bytes=nbytes2, chan_first=r * per, chan_count=per)
+            try:
+                rx.set_drain_lag(vh.MAX_DRAIN_LAG)
+                for _ in range(4):
+                    rx.feed_device(dev2.data_ptr(), nbytes2); rx.drain_packed()
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(steps):
+                    rx.feed_device(dev2.data_ptr(), nbytes2); rx.drain_packed()
+                rx.set_drain_lag(0); rx.drain_packed(); torch.cuda.synchronize()
+                rows.append({"rank": r, "ms_per_16s_block": round((time.perf_counter() - t0) / steps / 2 * 1e3, 4)})
+            finally:
+                rx.close()
+    finally:
+        del dev2
+    worst = max(x["ms_per_16s_block"] for x in rows)
+    return {"what": f"the same rank-sized receivers fed TWO 16 s blocks per feed ({steps} feeds in one timed region): the fixed chain walk - scans - check of a feed is paid "
+                    "once for 32 s of signal; what pairing the exchange's buffers would buy a rank (results one block later)",
+            "shards": rows, "t_rank_ms_per_block_max": worst, "t_all_channels_ms": round(t_all_ms, 4), "compute_ceiling_speedup_at_8": round(t_all_ms / worst, 3),
+            "note": "t_all_channels_ms is the 256-channel receiver on ONE block per feed (its front hides the chain: two per feed change nothing for it)"}
+
+
 def h2d_ms(torch, host_pinned, device, iters=3):
     """one plain H2D copy of the block from page-locked memory: this rank's PCIe link, nothing else running"""
     dst = torch.empty_like(host_pinned, device=device)
@@ -823,6 +860,12 @@ def main():
                                                   "allgather_into_each_gpu_over_7_links": round(case.nbytes * 7 / 8 / (7 * 76.5e9) * 1e3, 3),
                                                   "source": "spec link rates, not measured"},
                      "note": "projection from one GPU, not a measurement of 8; the driver's N = 8 run reports by_exchange / rank_ms_per_step"}
+        # The chain walk -> scans -> check is a fixed cost per FEED: a rank that takes two blocks per feed (the exchange's buffers in pairs) pays
+        # it once for 32 s of signal.  Timing only (the block twice in a row: what the second copy decodes is not looked at), its own try.
+        try:
+            projected["two_blocks_per_feed"] = rank_two_blocks_per_feed(case, per, torch, local, max(args.steps, 20), t_hbm_steady if t_hbm_steady is not None else t256)
+        except Exception as e:  # noqa: BLE001
+            projected["two_blocks_per_feed"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     except Exception as e:  # noqa: BLE001 - informational block: a failure here must not take the headline line with it
         projected = {"error": f"{type(e).__name__}: {str(e)[:400]}"}
 
@@ -888,6 +931,8 @@ def main():
                                        + (" [REHEARSAL: all ranks on one GPU over gloo - not a measurement]" if rehearsal else "")
                                        if world > 1 else "single GPU, all channels"),
                        "referee_scans_ahead_of_the_walk": case.prescan,
+                       # N > 1, ranks of <= 64 channels: the exchanged blocks go to the receiver two per feed in the timed loops (dist.ShardedFeeder)
+                       "blocks_per_feed": 2 if case.pair else 1,
                        "exchange": exchange_info,
                        "by_exchange": by_exchange,
                        "rank_ms_per_step": t_host.get("rank_ms_per_step"),

@@ -72,11 +72,17 @@ class ShardedFeeder:
     With one rank there is no exchange: the block is fed from host memory (`vdl2hip_feed_pinned`) or from the resident
     device copy.
 
+    `pairs`   the exchange buffers are laid out two by two, so that step(pair=True) can hand the receiver TWO consecutive blocks as
+              one feed: what a feed costs a rank-sized receiver beyond its channeliser - the chain walk, scans, check: 2-3 ms - is paid
+              per feed, not per block (32 of 256 channels: 1.3-2.0 ms per 16 s block one at a time, 1.1-1.25 two at a time: bench.py,
+              projected_scaling.two_blocks_per_feed).  The first block of a pair is only exchanged; the second step feeds both; flush()
+              feeds a block left without a partner.  Results come one block later.
+
     `rx` needs feed_tensor(t) (block resident on this rank's device), feed_pinned_tensor(t) (host, world 1 only) and
     drain_packed(); `front_stream` is the receiver's front stream as a torch stream (None on CPU)."""
 
     def __init__(self, rx, block_host, world: int, rank: int, mode: str = "broadcast", source: str = "host", src: int = 0,
-                 device=None, group=None, nbuf: int = 3, front_stream=None):
+                 device=None, group=None, nbuf: int = 3, front_stream=None, pairs: bool = False):
         import torch
         self.torch = torch
         self.rx, self.world, self.rank, self.mode, self.source, self.src, self.group = rx, world, rank, mode, source, src, group
@@ -99,7 +105,15 @@ class ShardedFeeder:
             self.bufs = []
             return
         self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
-        self.bufs = [torch.empty(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(nbuf)]
+        self.pairs = bool(pairs)
+        self.held = None                     # pair mode: the buffer index of a pair's first block, exchanged and not yet fed
+        if self.pairs:
+            # nbuf PAIRS: bufs[2p], bufs[2p + 1] are the two halves of one allocation
+            self.bufs2 = [torch.empty(2 * self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(nbuf)]
+            self.bufs = [b[h * self.nbytes:(h + 1) * self.nbytes] for b in self.bufs2 for h in (0, 1)]
+            nbuf = 2 * nbuf
+        else:
+            self.bufs = [torch.empty(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(nbuf)]
         self.ready = [None] * nbuf           # exchange of the block in bufs[k] complete
         self.consumed = [None] * nbuf        # channeliser that read bufs[k] complete
         if mode == "allgather":
@@ -114,6 +128,8 @@ class ShardedFeeder:
                 self.host_block = pin(host)
             else:
                 self.dev_block = host.to(self.device)
+                if self.pairs:
+                    self.dev_block2 = torch.cat([self.dev_block, self.dev_block])    # (the source rank reads its resident copy: twice in a row)
         self._start_exchange(0)
 
     # -- one exchange: block -> bufs[k] on every rank (asynchronous on GPUs: queued on the side stream) --
@@ -152,8 +168,9 @@ class ShardedFeeder:
             if self.cuda:
                 ctx.__exit__(None, None, None)
 
-    def step(self):
-        """Feed block i (every block carries the same bytes: a benchmark loop), start the exchange of block i+1, drain."""
+    def step(self, pair: bool = False):
+        """Feed block i (every block carries the same bytes: a benchmark loop), start the exchange of block i+1, drain.
+        pair=True (a feeder made with pairs=True): the first block of a pair is exchanged and held, the second step feeds both."""
         if self.world == 1:
             if self.source == "host":
                 self.rx.feed_pinned_tensor(self.host_block)
@@ -165,13 +182,44 @@ class ShardedFeeder:
         k = self.i % nb
         direct = getattr(self, "root_direct", False)
         self._start_exchange((self.i + 1) % nb)
+        pair = pair and self.pairs
+        if pair and self.held is None and k % 2 == 0:
+            self.held = k                    # the first half of a pair: wait for its partner
+            self.i += 1
+            return self.rx.drain_packed()
+        if self.held is not None and not (pair and k == self.held + 1):
+            self._feed_held()                # (pair mode was left between the two halves)
+        both = self.held is not None
+        ks = [self.held, k] if both else [k]
+        if self.cuda:
+            for j in ks:
+                if self.ready[j] is not None:
+                    self.front.wait_event(self.ready[j])
+        if both:
+            self.rx.feed_tensor(self.dev_block2 if (direct and self.dev_block is not None) else self.bufs2[k // 2])
+        else:
+            self.rx.feed_tensor(self.dev_block if (direct and self.dev_block is not None) else self.bufs[k])
+        if self.cuda:
+            ev = self.front.record_event()
+            for j in ks:
+                self.consumed[j] = ev
+        self.held = None
+        self.i += 1
+        return self.rx.drain_packed()
+
+    def _feed_held(self):
+        k, direct = self.held, getattr(self, "root_direct", False)
         if self.cuda and self.ready[k] is not None:
             self.front.wait_event(self.ready[k])
         self.rx.feed_tensor(self.dev_block if (direct and self.dev_block is not None) else self.bufs[k])
         if self.cuda:
             self.consumed[k] = self.front.record_event()
-        self.i += 1
-        return self.rx.drain_packed()
+        self.held = None
+
+    def flush(self):
+        """pair mode: feed a block that has been exchanged and is still waiting for its partner (before the last drain of a region)"""
+        if self.world > 1 and self.held is not None:
+            self._feed_held()
 
     def finish(self):
         """wait for the exchange left in flight by the last step (collectives must complete on every rank)"""

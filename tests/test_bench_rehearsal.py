@@ -13,10 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world", [2])
-def test_bench_multi_rank_rehearsal(world):
+@pytest.mark.parametrize("world,pair", [(2, None), (2, "1"), (8, None)])
+def test_bench_multi_rank_rehearsal(world, pair):
+    """pair "1": the ranks take the exchanged blocks two per feed in the timed loops (what ranks of <= 64 channels do by themselves: 8 GPUs;
+    here forced, VDL2_BENCH_PAIR=1, with K = 3 - a block left without a partner at the end of every region)"""
     import socket
     env = dict(os.environ, VDL2_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    env.pop("VDL2_BENCH_PAIR", None)
+    if pair:
+        env["VDL2_BENCH_PAIR"] = pair
     r = None
     for attempt in range(2):           # a rendezvous on a fresh box can fail once (port in TIME_WAIT, slow first import of torch)
         with socket.socket() as sk:
@@ -47,5 +52,5 @@ def test_bench_multi_rank_rehearsal(world):
     assert len(c["rank_ms_per_step"]) == world
     v = c["verified"]
     assert v["frames_and_integer_metadata_identical"] and v["oracle_parity_within_tolerance"] and v["channels_with_frames"] > 256 // world
-    assert "REHEARSAL" in c["parallelism"]
+    assert "REHEARSAL" in c["parallelism"] and c["blocks_per_feed"] == (2 if (pair or 256 // world <= 64) else 1)     # (world 8: ranks of 32 channels pair by themselves)
     assert j["roofline"]["bound"] == "valu" and j["roofline"]["hbm_algorithmic"]["frac"] > 0

@@ -73,6 +73,32 @@ def _worker(rank, world, port, q):
                 f._start_exchange((f.i + 1) % len(f.bufs)); f.i += 1
                 assert torch.equal(vd._u8(f.current_block()), vd._u8(host)), (mode, source)
             f.finish()
+    # blocks two at a time (ShardedFeeder(pairs=True), step(pair=True)): the first block of a pair is exchanged and held, the second step feeds
+    # both as ONE tensor of twice the length, flush() feeds a block left without a partner, and a step without `pair` in between feeds what
+    # is held on its own - whatever the exchange form, every byte fed is the capture's
+    class ByteRx:
+        def __init__(self): self.fed = []
+        def feed_tensor(self, t): self.fed.append(vd._u8(t).clone())
+        feed_pinned_tensor = feed_tensor
+        def drain_packed(self): return (0, None, None)
+    small = host[: 2 * 4096 * world].clone()
+    one = vd._u8(small)
+    for mode in ("broadcast", "allgather"):
+        for source in ("host", "hbm"):
+            mine = small if (mode == "allgather" or rank == 0) else torch.randint(-99, 99, small.shape, dtype=torch.int16)
+            rx = ByteRx()
+            f = vd.ShardedFeeder(rx, mine, world, rank, mode=mode, source=source, device=cpu, pairs=True)
+            f.step(pair=True); assert len(rx.fed) == 0 and f.held == 0
+            f.step(pair=True); assert len(rx.fed) == 1 and f.held is None
+            f.step(pair=True); f.step(pair=True)                      # the second pair
+            f.step(pair=True); assert f.held == 4                      # a first half ...
+            f.step()                                                   # ... then a step that does not pair: the held block goes on its own, then this one
+            f.step(pair=True); f.flush(); f.flush()                    # a block left without a partner (slot 0 again: the ring of 6 has wrapped)
+            f.step(); f.finish()
+            sizes = [t.numel() // one.numel() for t in rx.fed]
+            assert sizes == [2, 2, 1, 1, 1, 1], (mode, source, sizes)
+            for t in rx.fed:
+                assert torch.equal(t, one if t.numel() == one.numel() else torch.cat([one, one])), (mode, source)
     secs, ok = vd.time_exchange(host, world, rank, "allgather", "host", cpu, iters=2)
     assert ok and secs > 0
     secs, ok = vd.time_exchange(host, world, rank, "broadcast", "hbm", cpu, iters=2)
