@@ -864,6 +864,9 @@ def main():
         # it once for 32 s of signal.  Timing only (the block twice in a row: what the second copy decodes is not looked at), its own try.
         try:
             projected["two_blocks_per_feed"] = rank_two_blocks_per_feed(case, per, torch, local, max(args.steps, 20), t_hbm_steady if t_hbm_steady is not None else t256)
+            # `bench.py --gpus 8` hands its ranks (32 channels each) the exchanged blocks two per feed (Case.pair): the figure that goes with that run
+            projected["as_bench_gpus_8_feeds_its_ranks"] = {"blocks_per_feed": 2, "compute_ceiling_speedup_at_8": projected["two_blocks_per_feed"]["compute_ceiling_speedup_at_8"],
+                                                            "one_block_per_feed": projected["compute_ceiling_speedup_at_8"]}
         except Exception as e:  # noqa: BLE001
             projected["two_blocks_per_feed"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     except Exception as e:  # noqa: BLE001 - informational block: a failure here must not take the headline line with it
