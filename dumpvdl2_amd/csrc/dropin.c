@@ -22,7 +22,7 @@
  * sequential scan of the referee's.  A producer that comes back for the next block at
  * once (a file, a fast pipe) therefore has its blocks COLLECTED: process_buf_*() copies the block
  * into a staging buffer and returns; every `batch` blocks (as many as make a feed long enough to be
- * walked in segments and pipelined: 16 of the reference's s16 blocks at oversample 20, 5 of its u8
+ * walked in segments and pipelined: 16 of the reference's s16 blocks at oversample 20, 4 of its u8
  * blocks at 10; VDL2HIP_DROPIN_BATCH=<n> sets it, 1 = every block on its own as before) the buffer
  * goes to the GPU as one feed and the frames of the feed two before it are pushed (drain lag 2).  The
  * results are the same frames in the same order (any chunking gives the same answer:

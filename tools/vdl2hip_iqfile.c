@@ -5,7 +5,7 @@
  * (src/dumpvdl2.c:831-1099 option handling, :168-180 centre-frequency rule, :323-358 file loop):
  *   --iq-file <path|->            raw IQ file, read in FILE_BUFSIZE (320000-byte) blocks; sets oversample 10 and U8
  *   --blocks-per-feed <n>         how many of those blocks go to the GPU as one feed (default: as many as hold 64 000 decimated
- *                                 samples - 16 s16 blocks at oversample 20, 5 u8 blocks at 10; 1 = the reference's block by block).
+ *                                 samples - 16 s16 blocks at oversample 20, 4 u8 blocks at 10; 1 = the reference's block by block).
  *                                 A block is microseconds of GPU work behind a fixed chain of launches (and, now and then, a 2 ms
  *                                 scan of the referee's): collected blocks give the same frames at 5-7x the rate
  *   --sample-format U8|S16_LE     (the reference's token is S16_LE, src/dumpvdl2.c:849)
