@@ -432,7 +432,7 @@ static int feed_common(vdl2hip_ctx *c, const void *dev_in, size_t nbytes, bool i
 		// wavefronts of this feed's burst decoder: each owns kResSlots frame records of the output from the start, so a short block gets few
 		sl.k5_waves = (unsigned)std::min<int64_t>(2048, std::max<int64_t>(16, (D * (int64_t)c->C) >> 14));
 		sl.k5_waves = (sl.k5_waves + kBurstWaves - 1) / kBurstWaves * kBurstWaves;
-		// (a short feed - launch_back: `small` - asks the referee on the spot whatever the mode: its one walk sits on the front stream)
+		// (a short feed - launch_back: `small` - has no scans ahead of its walk: its one walk notes, the noted stretches are scanned side by side and checked on the front stream)
 		sl.prescan = c->referee && c->ref_prescan && !feed_is_small(c, D);
 		K3Args k3{ c->d_y, c->d_pf, c->d_cand, c->d_flag, c->d_tab, nbase, k1, c->cap, c->cap - 1, 1, sl.d_ctl, sl.k5_waves, ref_dst, refv, c->cfg.max_ppm, c->d_ppmthr, c->referee ? 1 : 0, sl.d_rqn, sl.d_rqflag, sl.d_rqbad, sl.prescan ? sl.d_pq : nullptr, kPreScans, sl.d_rqflag2 };
 		// The exact tier's stop event doubles as "front of this feed done" (what the walk stream waits for): one queue entry less
@@ -567,7 +567,7 @@ static int launch_back(vdl2hip_ctx *c, OutSlot &sl, hipEvent_t gate) {
 		sl.k4 = K4Args{ c->d_y, c->d_pf, c->d_cand, c->d_tab, c->d_ws, c->d_wcnt, sl.d_bursts, sl.d_nbchan, c->cap_bursts_chan, sl.d_ctl, c->d_freq,
 		           sl.d_log, sl.d_nlog, c->cap_log, k1, c->cfg.max_ppm, c->cap, c->cap - 1, c->chan_first, c->C, c->d_ppmthr, c->referee ? c->d_ref[sl.seq % kSlots] : nullptr, (uint32_t)(16 * sl.seq + 1),
 		           opt ? sl.d_rq : nullptr, sl.d_rqn, rq_cap, sl.d_rqflag, c->d_ws_snap[par], c->d_cnt_snap[par], sl.d_rqbad, sl.prescan ? 1 : 0, c->debug_force_again,
-		           c->d_ws_tmp, c->d_cnt_tmp, nullptr, nullptr, sl.d_rqflag2, nullptr, nullptr, c->debug_force_mismatch };   // (a short feed's one walk asks the referee on the spot: two launches fewer)
+		           c->d_ws_tmp, c->d_cnt_tmp, nullptr, nullptr, sl.d_rqflag2, nullptr, nullptr, c->debug_force_mismatch };   // (a short feed's walk notes and is checked like a long one's since round 6a: `opt`)
 		const K4Args &k4 = sl.k4;
 		sl.d_spec_of = c->d_spec[par];
 		if(nseg >= 2) {
